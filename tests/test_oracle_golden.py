@@ -1,0 +1,201 @@
+"""Pin the numpy oracle to the reference: every golden vector captured by
+tests/golden/make_golden.py (reference outputs + the reference tests' own known
+answers) must be reproduced exactly -- integers and positions equal, doubles
+bit-equal."""
+
+import numpy as np
+import pytest
+
+from conftest import load_golden, same_f64, stat_case_inputs, unhex
+from oracle import sai_oracle as O
+
+STATS = load_golden("stats_cases.json")
+
+
+@pytest.mark.parametrize("case", STATS, ids=[c["name"] for c in STATS])
+def test_stats_bit_exact(case):
+    a = stat_case_inputs(case)
+    out = case["out"]
+    raw = [O.allele_freq(a["ref_gts"], a["ploidy"][0]), O.allele_freq(a["tgt_gts"], a["ploidy"][1])] + [
+        O.allele_freq(s, p) for s, p in zip(a["src_gts_list"], a["ploidy"][2:])
+    ]
+    for got, exp in zip(raw, out["raw_freq"]):
+        assert all(same_f64(g, unhex(e)) for g, e in zip(got, exp))
+    rf, tf, cond = O.matching_loci(
+        a["ref_gts"], a["tgt_gts"], a["src_gts_list"], a["w"], a["y_list"], a["ploidy"], a["anc"]
+    )
+    assert all(same_f64(g, unhex(e)) for g, e in zip(rf, out["ref_freq"]))
+    assert all(same_f64(g, unhex(e)) for g, e in zip(tf, out["tgt_freq"]))
+    assert cond.tolist() == out["condition"]
+    kw = dict(
+        ref_gts=a["ref_gts"],
+        tgt_gts=a["tgt_gts"],
+        src_gts_list=a["src_gts_list"],
+        ref_ploidy=a["ploidy"][0],
+        tgt_ploidy=a["ploidy"][1],
+        src_ploidy_list=a["ploidy"][2:],
+    )
+    u = O.u_stat(**kw, pos=a["pos"], w=a["w"], x=a["x"], y_list=a["y_list"], anc_allele_available=a["anc"])
+    assert isinstance(u["value"], int) and u["value"] == out["U"]
+    assert u["cdd_pos"].tolist() == out["U_cdd_pos"]
+    q = O.q_stat(
+        **kw, pos=a["pos"], w=a["w"], y_list=a["y_list"], quantile=a["quantile"], anc_allele_available=a["anc"]
+    )
+    assert same_f64(q["value"], unhex(out["Q"]))
+    assert np.asarray(q["cdd_pos"]).astype(np.int64).tolist() == out["Q_cdd_pos"]
+    assert str(q["cdd_pos"].dtype) == out["Q_cdd_dtype"]
+
+
+def test_linear_quantile_matches_numpy_bitwise():
+    rng = np.random.default_rng(7)
+    for _ in range(400):
+        n = int(rng.integers(1, 40))
+        den = int(rng.integers(1, 50))
+        vals = np.sort(rng.integers(0, den + 1, size=n) / den)
+        for q in (0.0, 0.05, 0.25, 0.5, 0.9, 0.95, 0.99, 1.0, float(rng.random())):
+            assert same_f64(O.linear_quantile(vals, q), np.nanquantile(vals, q)), (vals, q)
+
+
+def test_errors_and_calc_freq():
+    g = load_golden("errors_and_freq.json")
+    A = np.array
+    ref, tgt = A([[0, 1, 0], [1, 1, 0], [0, 0, 1]]), A([[1, 1, 0], [0, 1, 1], [1, 1, 1]])
+    srcs = [A([[0, 0, 1], [1, 1, 0], [0, 1, 1]]), A([[1, 1, 0], [1, 0, 0], [1, 1, 0]])]
+    y2 = [("=", 0.5), ("=", 0.5)]
+    kw = dict(ref_gts=ref, tgt_gts=tgt, src_gts_list=srcs[:1], ref_ploidy=3, tgt_ploidy=1, src_ploidy_list=[2])
+    calls = {
+        "w_low": lambda: O.matching_loci(ref, tgt, srcs, -0.1, y2, [2, 2, 2], False),
+        "w_high": lambda: O.matching_loci(ref, tgt, srcs, 1.1, y2, [2, 2, 2], False),
+        "y_low": lambda: O.matching_loci(ref, tgt, srcs, 0.5, [("=", -0.1)], [2, 2, 2], False),
+        "y_high": lambda: O.matching_loci(ref, tgt, srcs, 0.5, [("=", 1.1)], [2, 2, 2], False),
+        "bad_op": lambda: O.matching_loci(ref, tgt, srcs, 0.5, [("invalid", 0.5)], [2, 2, 2], False),
+        "len_mismatch": lambda: O.matching_loci(ref, tgt, srcs, 0.5, [("=", 0.5)], [2, 2, 2], False),
+        "ploidy_none": lambda: O.allele_freq(ref, ploidy=None),
+        "ploidy_float": lambda: O.allele_freq(ref, ploidy=9.9),
+        "ploidy_neg": lambda: O.allele_freq(ref, ploidy=-100),
+        "u_missing_kw": lambda: O.u_stat(**kw, pos=A([0, 1, 2]), w=0.5, x=0.5, y_list=[("=", 0)]),
+        "q_missing_kw": lambda: O.q_stat(**kw, pos=A([0, 1, 2]), w=0.5, quantile=0.95, anc_allele_available=False),
+    }
+    for rec in g["errors"]:
+        assert rec["exc"] == "ValueError"
+        with pytest.raises(ValueError) as ei:
+            calls[rec["label"]]()
+        assert str(ei.value) == rec["msg"]
+    for rec in g["calc_freq"]:
+        got = O.allele_freq(A(rec["gts"]), ploidy=rec["ploidy"])
+        assert all(same_f64(a, unhex(b)) for a, b in zip(got, rec["freq"]))
+
+
+def test_window_grid():
+    g = load_golden("window_grid.json")
+    for c in g["split"]:
+        w = O.split_windows(np.array(c["pos"]), c["window_size"], c["step_size"], c["start"])
+        assert len(w) == c["n"]
+        assert [list(map(int, t)) for t in w[:6]] == c["head"]
+        assert [list(map(int, t)) for t in w[-3:]] == c["tail"]
+    for c in g["errors"]:
+        assert c["msg"] is not None
+        with pytest.raises(ValueError) as ei:
+            O.split_windows(np.array(c["pos"]), c["window_size"], c["step_size"])
+        assert str(ei.value) == c["msg"]
+    for c in g["chunks"]:
+        w = O.split_windows(np.array(c["pos"]), c["window_size"], c["step_size"])
+        assert [list(map(int, t)) for t in O.split_window_ranges(w, c["num_chunks"])] == c["chunks"]
+
+
+def _validated(stats):
+    """What StatConfig's validator leaves behind (stat_config.py:147-157)."""
+    out = {}
+    for name, prm in stats.items():
+        src = {}
+        for pop, expr in prm["src"].items():
+            op = next(o for o in ("<=", ">=", "=", "<", ">") if o in expr)
+            src[pop] = (op, float(expr[len(op):]))
+        out[name] = {"ref": prm["ref"], "tgt": prm["tgt"], "src": src}
+    return out
+
+
+PIPE = load_golden("pipeline.json")
+
+
+@pytest.mark.parametrize("sc", PIPE, ids=[s["name"] for s in PIPE])
+def test_pipeline_items_and_text(sc):
+    pos = np.array(sc["pos"], dtype=np.int32)
+    data = {
+        g: {k: O.Chrom(pos, np.array(v, dtype=np.int64).reshape(len(pos), -1)) for k, v in sc["gts"][g].items()}
+        for g in ("ref", "tgt", "src")
+    }
+    stats = _validated(sc["stats"])
+    items = O.run_chunk(
+        sc["chr_name"],
+        data["ref"],
+        data["tgt"],
+        data["src"],
+        sc["win_len"],
+        sc["win_step"],
+        stats,
+        sc["ploidies"],
+        sc["anc_allele_available"],
+        start=sc["start"],
+        end=sc["end"],
+    )
+    assert len(items) == len(sc["windows"])
+    for it, win, exp in zip(items, sc["windows"], sc["items"]):
+        assert [it["ref_pop"], it["tgt_pop"], list(it["src_pop_list"]), it["start"], it["end"], it["nsnps"]] == win[:6]
+        for k in ("U", "Q"):
+            if exp[k] is None:
+                assert k not in it
+                continue
+            if isinstance(exp[k], int):
+                assert it[k] == exp[k] and isinstance(it[k], int)
+            else:
+                assert same_f64(it[k], unhex(exp[k]))
+            assert np.asarray(it["cdd_pos"][k]).astype(np.int64).tolist() == exp[f"{k}_cdd"]
+    names = list(sc["stats"].keys())
+    assert "".join(O.score_lines(items, names)) == sc["text"]["tsv"]
+    for k in names:
+        assert "".join(O.log_lines(items, k)) == sc["text"][k]
+
+
+def test_feature_inline_and_example_vcf():
+    g = load_golden("feature_inline.json")
+    A = np.array
+    stats = _validated(
+        {
+            "U": {"ref": {"ref1": 0.3}, "tgt": {"tgt1": 0.5}, "src": {"src1": "=1", "src2": "=1"}},
+            "Q": {"ref": {"ref1": 0.3}, "tgt": {"tgt1": 0.95}, "src": {"src1": "=0.2", "src2": "=0.4"}},
+        }
+    )
+    pl = {"ref": {"ref1": 1}, "tgt": {"tgt1": 1}, "src": {"src1": 1}}
+    kw = dict(
+        chr_name="21", ref_pop="ref1", tgt_pop="tgt1", src_pop_list=["src1", "src2"], out_pop=None, start=1000,
+        end=2000, pos=A([100, 200, 300]), ref_gts=A([[0, 0, 1], [1, 1, 0], [0, 1, 1]]),
+        tgt_gts=A([[0, 1, 1], [1, 1, 1], [0, 0, 1]]),
+        src_gts_list=[A([[0, 0, 0], [1, 0, 0], [1, 1, 1]]), A([[1, 1, 1], [0, 1, 1], [0, 0, 1]])],
+    )  # fmt: skip
+    full = O.window_item(stats, pl, False, ploidy_config=pl, **kw)
+    assert full["U"] == g["full"]["U"] and same_f64(full["Q"], unhex(g["full"]["Q"]))
+    assert full["out_pop"] == "NA" and full["nsnps"] == 3
+    none = O.window_item(stats, pl, False, **dict(kw, ref_gts=None, tgt_gts=None, src_gts_list=None))
+    assert np.isnan(none["U"]) and np.isnan(none["Q"]) and none["cdd_pos"]["U"].size == 0
+    item = {"chr_name": "21", "start": 1000, "end": 2000, "ref_pop": "ref1", "tgt_pop": "tgt1", "out_pop": "NA",
+            "src_pop_list": ["src1", "src2"], "nsnps": 10, "U": 5, "Q": 0.8, "cdd_pos": {"U": A([]), "Q": A([])}}  # fmt: skip
+    assert O.score_lines([item], ["U", "Q"]) == [g["process_items_line"]]
+
+    ex = load_golden("example_vcf.json")
+    gt = np.array(ex["genotypes"]["gt"], dtype=np.int64)
+    pos = np.array(ex["genotypes"]["pos"], dtype=np.int32)
+    pl = {"ref": {"AFR": 2}, "tgt": {"CHB": 2}, "src": {"Nean": 2}}
+    for label in ("q_only", "u_and_q", "example_config"):
+        stats = _validated(ex[label]["stats"])
+        it = O.window_item(
+            stats, pl, False, chr_name="21", ref_pop="AFR", tgt_pop="CHB", src_pop_list=("Nean",), out_pop=None,
+            start=1, end=6666, pos=pos, ref_gts=gt[:, 0:5], tgt_gts=gt[:, 5:10], src_gts_list=[gt[:, 10:11]],
+            ploidy_config=pl,
+        )  # fmt: skip
+        names = list(stats.keys())
+        assert "".join(O.score_lines([it], names)) == ex[label]["text"]["tsv"]
+        for k in names:
+            assert "".join(O.log_lines([it], k)) == ex[label]["text"][k]
+    assert O.header_line(["U", "Q"]) == "Chrom\tStart\tEnd\tRef\tTgt\tSrc\tOutgroup\tN(Variants)\tU\tQ\n"
+    assert O.log_header_line("U") == "Chrom\tStart\tEnd\tU_SNP\n"
