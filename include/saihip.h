@@ -1,0 +1,179 @@
+/*
+ * saihip.h -- C ABI of libsaihip.so: sai's sliding-window U/Q statistics on MI355X (gfx950).
+ *
+ * The reference (xin-huang/sai 1.1.2) is pure Python and has no FFI; its plugin surface for this
+ * path is three Python protocols (statistic classes, generators, preprocessors).  This header is
+ * the one native boundary underneath the Python mirror of those protocols (package sai_amd): each
+ * entry point states which reference function(s) it replaces, file:line relative to the
+ * reference checkout.  INTEGRATION.md shows the ctypes binding a sai maintainer would add.
+ *
+ * Conventions
+ *   - every function returns an int status: 0 = ok, <0 = error class (enum sai_status);
+ *     sai_last_error() returns thread-local text for the last failure on the calling thread;
+ *   - the caller owns every buffer; all data pointers are DEVICE pointers unless the name ends in
+ *     _host; the library allocates nothing but the small sai_ctx;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); all work is enqueued on
+ *     it and no entry point synchronises unless documented;
+ *   - a ctx is bound to one device and is not thread-safe; distinct ctxs are independent;
+ *   - arguments are validated (sizes, NULLs, ranges); statistical parameters (w, x, y, quantile)
+ *     are assumed already validated by the caller the way stat_utils.py:99-111 does.
+ *
+ * Data layout in HBM ("tiled SoA")
+ *   A population's genotype block holds ALT-allele dosages as int8 (negative = missing call,
+ *   sai/utils/utils.py:389-410 sums the ploidy axis so "./." arrives as -2).  Sites are grouped
+ *   in tiles of SAI_TILE_SITES = 64 consecutive sites; inside a tile every individual owns one
+ *   contiguous 64-byte row:
+ *       byte(tile t, individual i, site-in-tile s) = tiles[(t * n_ind + i) * 64 + s]
+ *   so one wavefront instruction (64 lanes x 16 B) reads 16 individuals x 64 sites = 1 KiB of
+ *   contiguous memory and a tile is one contiguous n_ind * 64 byte run.  The last tile is padded
+ *   with zero bytes.  sai_tiled_bytes() gives the allocation size.
+ */
+#ifndef SAIHIP_H
+#define SAIHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SAI_ABI_VERSION 1
+#define SAI_TILE_SITES 64
+#define SAI_MAX_SRC 6   /* source populations per call */
+#define SAI_MAX_SETS 16 /* parameter sets per call */
+
+enum sai_status {
+  SAI_OK = 0,
+  SAI_ERR_ARG = -1,        /* bad argument (NULL, size, range) */
+  SAI_ERR_HIP = -2,        /* a HIP runtime call failed */
+  SAI_ERR_NO_DEVICE = -3,  /* no usable gfx950 device */
+  SAI_ERR_UNSUPPORTED = -4 /* valid request outside the built limits */
+};
+
+/* comparison operators of the source-frequency conditions (stat_utils.py:133-139) */
+enum sai_op { SAI_OP_EQ = 0, SAI_OP_LT = 1, SAI_OP_GT = 2, SAI_OP_LE = 3, SAI_OP_GE = 4 };
+
+typedef struct sai_ctx sai_ctx;
+
+/* One population block in the tiled SoA layout. */
+typedef struct sai_pop {
+  const int8_t* tiles; /* device pointer, sai_tiled_bytes(n_sites, n_ind) bytes */
+  int32_t n_ind;       /* individuals (columns of the reference's [sites][individuals] matrix) */
+  int32_t ploidy;      /* positive; calc_freq's `ploidy` argument (stat_utils.py:26) */
+} sai_pop;
+
+/* One parameter set = the arguments of compute_matching_loci (stat_utils.py:55-63) plus the
+ * statistic-specific thresholds: x of UStatistic.compute (u_statistic.py:92) and quantile of
+ * QStatistic.compute (q_statistic.py:100).  y[k]/op[k] pair with source population k;
+ * one_minus_y[k] must be the caller's f64 evaluation of 1 - y[k] (stat_utils.py:150). */
+typedef struct sai_params {
+  double w;
+  double x;
+  double quantile;
+  int32_t n_src;                /* must equal the number of source populations passed */
+  int32_t anc_allele_available; /* 0: also match 1-y and invert (stat_utils.py:146-160) */
+  int32_t op[SAI_MAX_SRC];      /* enum sai_op */
+  double y[SAI_MAX_SRC];
+  double one_minus_y[SAI_MAX_SRC];
+} sai_params;
+
+/* Per (parameter set, window) result: 24 bytes. */
+typedef struct sai_window_record {
+  int32_t n_sites; /* N(Variants): sites of the block inside [start, end] (feature_preprocessor.py:124) */
+  int32_t u_count; /* U value (u_statistic.py:96) */
+  int32_t n_cond;  /* sites passing compute_matching_loci's condition = size of the Q sample */
+  int32_t n_cdd_q; /* sites with tgt_freq >= Q (q_statistic.py:101) */
+  double q;        /* Q value, NaN when n_cond == 0 (q_statistic.py:96-100) */
+} sai_window_record;
+
+/* ---- library / context ------------------------------------------------------------------ */
+
+int sai_abi_version(void);            /* SAI_ABI_VERSION the library was built with */
+const char* sai_build_arch(void);     /* "gfx950" */
+const char* sai_last_error(void);     /* thread-local, never NULL */
+int sai_device_count(int* count_out); /* visible HIP devices */
+
+int sai_ctx_create(int device, sai_ctx** ctx_out);
+int sai_ctx_destroy(sai_ctx* ctx);
+
+/* ---- layout ----------------------------------------------------------------------------- */
+
+/* Bytes of a tiled SoA block: ceil(n_sites / 64) * n_ind * 64.  Returns -1 on bad arguments. */
+int64_t sai_tiled_bytes(int64_t n_sites, int32_t n_ind);
+
+/* Re-tile a reference-order block.  `src` is the reference's per-population matrix
+ * [site][individual] (window_generator.py:217-231 / utils.py:410) narrowed to int8 with
+ * `row_stride` bytes between sites; `dst` receives the tiled SoA block (padding zeroed). */
+int sai_tile_from_site_major(sai_ctx* ctx, const int8_t* src, int64_t n_sites, int32_t n_ind,
+                             int64_t row_stride, int8_t* dst, void* stream);
+
+/* ---- the hot path ----------------------------------------------------------------------- */
+
+/* Kernel 1 (HBM-bound): per site and population, the integer part of calc_freq
+ * (stat_utils.py:45-49): alt_sum = sum of non-negative dosages, n_called = individuals with a
+ * non-negative dosage.  pops[0] = ref, pops[1] = tgt, pops[2..] = sources.
+ * counts[(p * n_sites + site) * 2 + {0,1}] = {alt_sum, n_called}, uint32. */
+int sai_site_counts(sai_ctx* ctx, int64_t n_sites, int32_t n_pops, const sai_pop* pops,
+                    uint32_t* counts, void* stream);
+
+/* Kernel 2: calc_freq's f64 division (stat_utils.py:51-52) and compute_matching_loci
+ * (stat_utils.py:114-166) for every site and parameter set, plus U's final test
+ * (u_statistic.py:92).  tgt_freq[site] is the UNinverted target frequency (NaN when nothing is
+ * called); flags[set * n_sites + site] has bit0 = condition, bit1 = condition && tgt_freq > x,
+ * bit2 = site inverted (its effective target frequency is 1 - tgt_freq[site]).
+ * ploidy[p] pairs with population p of sai_site_counts.  adj_freq may be NULL; otherwise it
+ * receives compute_matching_loci's returned (possibly inverted) frequencies:
+ * adj_freq[(set * 2 + 0) * n_sites + site] = ref_freq, [(set * 2 + 1) * n_sites + site] = tgt_freq. */
+int sai_site_flags(sai_ctx* ctx, int64_t n_sites, int32_t n_pops, const int32_t* ploidy_host,
+                   const uint32_t* counts, int32_t n_sets, const sai_params* sets_host,
+                   double* tgt_freq, uint8_t* flags, double* adj_freq, void* stream);
+
+/* Kernel 3: window -> site-index range.  Replaces the per-window position masks of
+ * WindowGenerator._window_generator (window_generator.py:173-183) for a resident block with
+ * strictly increasing positions: lo[w] = first site with pos >= win_start[w], hi[w] = one past
+ * the last site with pos <= win_end[w] (inclusive windows, utils.py:607-610). */
+int sai_window_bounds(sai_ctx* ctx, const int32_t* pos, int64_t n_sites, int32_t n_windows,
+                      const int64_t* win_start, const int64_t* win_end, int32_t* lo, int32_t* hi,
+                      void* stream);
+
+/* Kernel 4: one record per (set, window): U count (u_statistic.py:94-96), numpy 'linear'
+ * nanquantile of the effective target frequency over condition sites (q_statistic.py:92-100),
+ * and both candidate lists (u_statistic.py:95, q_statistic.py:101) in ascending site order.
+ *   records[set * n_windows + w]
+ *   cdd_off[(set * n_windows + w) * 2 + {0,1}] = start of the window's U / Q list inside
+ *     cdd_u / cdd_q (placement order between windows is unspecified; lengths are u_count and
+ *     n_cdd_q);
+ *   list entries are pos[site] when `pos` is non-NULL, else block-relative site indices;
+ *   cdd_total[0..1] = entries needed for all U / Q lists.  When a total exceeds its capacity the
+ *     lists that did not fit are not written (their offset is -1): re-run with larger buffers.
+ * `quantile` is taken from sets_host[set].quantile. */
+int sai_window_stats(sai_ctx* ctx, int64_t n_sites, const double* tgt_freq, const uint8_t* flags,
+                     int32_t n_sets, const sai_params* sets_host, int32_t n_windows,
+                     const int32_t* lo, const int32_t* hi, const int32_t* pos,
+                     sai_window_record* records, int64_t* cdd_off, int32_t* cdd_u, int64_t cap_u,
+                     int32_t* cdd_q, int64_t cap_q, int64_t* cdd_total, void* stream);
+
+/* ---- synthetic data ("synth-v1") ---------------------------------- */
+
+/* Counter-based generator: every byte is a pure function of (seed, chrom, site, population
+ * stream, individual), so any shard on any GPU and the host produce identical data.
+ * pop_stream: 0 = ref, 1 = tgt, 2.. = sources.  missing_per_million: probability * 1e6 that a
+ * call is missing (-ploidy).  Fills the tiled SoA block for sites [site0, site0 + n_sites). */
+int sai_synth_fill(sai_ctx* ctx, uint64_t seed, int32_t chrom, int64_t site0, int64_t n_sites,
+                   int32_t pop_stream, int32_t n_ind, int32_t ploidy, int32_t missing_per_million,
+                   int8_t* tiles, void* stream);
+/* Same bytes on the host, in reference order [site][individual] (row stride = n_ind). */
+int sai_synth_fill_host(uint64_t seed, int32_t chrom, int64_t site0, int64_t n_sites,
+                        int32_t pop_stream, int32_t n_ind, int32_t ploidy,
+                        int32_t missing_per_million, int8_t* site_major_host);
+/* gaps_host[i] = pos[site0 + i] - pos[site0 + i - 1] (1..49); pos[-1] = 0. */
+int sai_synth_gaps_host(uint64_t seed, int32_t chrom, int64_t site0, int64_t n_sites,
+                        int32_t* gaps_host);
+int sai_synth_gaps(sai_ctx* ctx, uint64_t seed, int32_t chrom, int64_t site0, int64_t n_sites,
+                   int32_t* gaps, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SAIHIP_H */

@@ -1,0 +1,136 @@
+"""ctypes binding of libsaihip.so (include/saihip.h).
+
+There is no CPU fallback: if the shared library is missing or no gfx950 device
+is usable, the calls raise.  ``load()`` only needs the library file (and the HIP
+runtime it links against), so symbol checks work on a machine without a GPU.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+LIB_NAME = "libsaihip.so"
+LIB_PATH = Path(__file__).resolve().parent / "lib" / LIB_NAME
+
+SAI_TILE_SITES = 64
+SAI_MAX_SRC = 6
+SAI_MAX_SETS = 16
+SAI_ABI_VERSION = 1
+
+OPS = {"=": 0, "<": 1, ">": 2, "<=": 3, ">=": 4}
+
+
+class SaiHipError(RuntimeError):
+    """A libsaihip call returned a non-zero status."""
+
+    def __init__(self, status: int, message: str):
+        super().__init__(f"libsaihip error {status}: {message}")
+        self.status = status
+
+
+class SaiPop(C.Structure):
+    _fields_ = [("tiles", C.c_void_p), ("n_ind", C.c_int32), ("ploidy", C.c_int32)]
+
+
+class SaiParams(C.Structure):
+    _fields_ = [
+        ("w", C.c_double),
+        ("x", C.c_double),
+        ("quantile", C.c_double),
+        ("n_src", C.c_int32),
+        ("anc_allele_available", C.c_int32),
+        ("op", C.c_int32 * SAI_MAX_SRC),
+        ("y", C.c_double * SAI_MAX_SRC),
+        ("one_minus_y", C.c_double * SAI_MAX_SRC),
+    ]
+
+
+class SaiWindowRecord(C.Structure):
+    _fields_ = [
+        ("n_sites", C.c_int32),
+        ("u_count", C.c_int32),
+        ("n_cond", C.c_int32),
+        ("n_cdd_q", C.c_int32),
+        ("q", C.c_double),
+    ]
+
+
+_p = C.c_void_p
+_i32, _i64, _u64 = C.c_int32, C.c_int64, C.c_uint64
+
+# name -> (restype, argtypes); the single source of truth for the symbol check in tests
+SIGNATURES = {
+    "sai_abi_version": (C.c_int, []),
+    "sai_build_arch": (C.c_char_p, []),
+    "sai_last_error": (C.c_char_p, []),
+    "sai_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "sai_ctx_create": (C.c_int, [C.c_int, C.POINTER(_p)]),
+    "sai_ctx_destroy": (C.c_int, [_p]),
+    "sai_tiled_bytes": (_i64, [_i64, _i32]),
+    "sai_tile_from_site_major": (C.c_int, [_p, _p, _i64, _i32, _i64, _p, _p]),
+    "sai_site_counts": (C.c_int, [_p, _i64, _i32, C.POINTER(SaiPop), _p, _p]),
+    "sai_site_flags": (
+        C.c_int,
+        [_p, _i64, _i32, C.POINTER(_i32), _p, _i32, C.POINTER(SaiParams), _p, _p, _p, _p],
+    ),
+    "sai_window_bounds": (C.c_int, [_p, _p, _i64, _i32, _p, _p, _p, _p, _p]),
+    "sai_window_stats": (
+        C.c_int,
+        [_p, _i64, _p, _p, _i32, C.POINTER(SaiParams), _i32, _p, _p, _p, _p, _p, _p, _i64, _p, _i64, _p, _p],
+    ),
+    "sai_synth_fill": (C.c_int, [_p, _u64, _i32, _i64, _i64, _i32, _i32, _i32, _i32, _p, _p]),
+    "sai_synth_fill_host": (C.c_int, [_u64, _i32, _i64, _i64, _i32, _i32, _i32, _i32, _p]),
+    "sai_synth_gaps_host": (C.c_int, [_u64, _i32, _i64, _i64, _p]),
+    "sai_synth_gaps": (C.c_int, [_p, _u64, _i32, _i64, _i64, _p, _p]),
+}
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load libsaihip.so (once) and declare every prototype.  Raises if it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = Path(os.environ.get("SAI_AMD_LIB", LIB_PATH))
+    if not path.exists():
+        raise RuntimeError(
+            f"{path} not found: the HIP extension has not been built "
+            "(run `python -c 'import __graft_entry__ as g; g.build()'` at the repo root). "
+            "sai_amd has no CPU fallback."
+        )
+    lib = C.CDLL(str(path))
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    if lib.sai_abi_version() != SAI_ABI_VERSION:
+        raise RuntimeError(f"{path}: ABI {lib.sai_abi_version()} != expected {SAI_ABI_VERSION}")
+    _lib = lib
+    return lib
+
+
+def check(status: int) -> None:
+    if status != 0:
+        raise SaiHipError(status, load().sai_last_error().decode("utf-8", "replace"))
+
+
+def make_params(w, x, quantile, y_list, anc_allele_available, n_src=None) -> SaiParams:
+    """Pack one parameter set.  ``y_list`` = [(op, y), ...]; ``1 - y`` is evaluated here in
+    Python f64, exactly the value the reference compares with (stat_utils.py:150)."""
+    y_list = list(y_list)
+    if n_src is None:
+        n_src = len(y_list)
+    if n_src > SAI_MAX_SRC:
+        raise ValueError(f"at most {SAI_MAX_SRC} source populations are supported")
+    p = SaiParams()
+    p.w, p.x, p.quantile = float(w), float(x), float(quantile)
+    p.n_src = n_src
+    p.anc_allele_available = 1 if anc_allele_available else 0
+    for k, (op, y) in enumerate(y_list[:n_src]):
+        p.op[k] = OPS[op]
+        p.y[k] = float(y)
+        p.one_minus_y[k] = float(1 - y)
+    return p

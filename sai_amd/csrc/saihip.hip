@@ -1,0 +1,903 @@
+// libsaihip: sai's sliding-window U/Q statistics as hand-written HIP for MI355X (gfx950, CDNA4).
+//
+// Kernels (see DESIGN.md for the roofline of each):
+//   tile_from_site_major  ingest: reference-order [site][ind] int8 -> tiled SoA
+//   site_counts           HBM-bound byte reduction: per site/pop {alt_sum, n_called}
+//   site_flags            f64 frequencies + compute_matching_loci conditions per parameter set
+//   window_bounds         window (start,end) -> site index range (binary search)
+//   window_stats          U count, numpy-'linear' quantile (radix select), candidate lists
+//   synth_*               counter-based synthetic genotype / position generator
+//
+// Build: hipcc -O3 --offload-arch=gfx950 -ffp-contract=off -fPIC -shared (see __graft_entry__.py).
+// -ffp-contract=off is part of the contract: the f64 arithmetic must round exactly like numpy's
+// (separate multiply and add in the quantile lerp, IEEE division for the frequencies).
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <new>
+
+#include "saihip.h"
+
+// ------------------------------------------------------------------------------------------
+// errors / context
+// ------------------------------------------------------------------------------------------
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+#define SAI_HIP(call)                                                                     \
+  do {                                                                                    \
+    hipError_t e_ = (call);                                                               \
+    if (e_ != hipSuccess)                                                                 \
+      return fail(SAI_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_),     \
+                  __FILE__, __LINE__);                                                    \
+  } while (0)
+
+constexpr int kTile = SAI_TILE_SITES;
+constexpr int kMaxPops = 2 + SAI_MAX_SRC;
+
+}  // namespace
+
+struct sai_ctx {
+  int device;
+  int n_cu;
+};
+
+namespace {
+
+int enter(sai_ctx* ctx) {
+  if (!ctx) return fail(SAI_ERR_ARG, "ctx is NULL");
+  SAI_HIP(hipSetDevice(ctx->device));
+  return SAI_OK;
+}
+
+int check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(SAI_ERR_HIP, "launch of %s failed: %s", what, hipGetErrorString(e));
+  return SAI_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// ingest: [site][ind] -> tiled SoA.  One 256-thread workgroup moves a 64-site x 64-individual
+// block through LDS (the transpose of 64-byte rows).
+// ------------------------------------------------------------------------------------------
+
+__global__ __launch_bounds__(256) void tile_from_site_major_kernel(const int8_t* __restrict__ src,
+                                                                    int64_t n_sites, int32_t n_ind,
+                                                                    int64_t row_stride,
+                                                                    int8_t* __restrict__ dst) {
+  __shared__ int8_t blk[kTile][kTile + 4];
+  const int64_t tile = blockIdx.x;
+  const int ind0 = blockIdx.y * kTile;
+  const int tid = threadIdx.x;
+  {
+    const int s = tid >> 2;        // site in tile
+    const int part = tid & 3;      // 16 individuals
+    const int64_t site = tile * kTile + s;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const int ind = ind0 + part * 16 + k;
+      int8_t v = 0;
+      if (site < n_sites && ind < n_ind) v = src[site * row_stride + ind];
+      blk[s][part * 16 + k] = v;
+    }
+  }
+  __syncthreads();
+  {
+    const int i = tid >> 2;        // individual in block
+    const int part = tid & 3;      // 16 sites
+    const int ind = ind0 + i;
+    if (ind < n_ind) {
+      uint32_t w[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        uint32_t v = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          v |= static_cast<uint32_t>(static_cast<uint8_t>(blk[part * 16 + j * 4 + k][i])) << (8 * k);
+        w[j] = v;
+      }
+      uint4* out = reinterpret_cast<uint4*>(dst + (tile * n_ind + ind) * kTile + part * 16);
+      *out = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// site_counts: the HBM-bound kernel.
+//
+// One wavefront owns one 64-site tile and streams every population's rows of that tile.  A wave
+// instruction loads 16 rows x 64 B = 1 KiB contiguous: lane l holds individual (16*q + l/4),
+// sites (l%4)*16 .. +15 as four 32-bit words.  Bytes are accumulated SWAR-style into 16-bit
+// (dosage) and 8-bit (missing) fields, widened to 32 bit every <= 248 rows per lane, and the 16
+// row-groups are combined with a 4-step butterfly reduce-scatter so that lane l ends with the
+// totals of site (l%4)*16 + l/4.  No LDS, no barriers; occupancy and 4-8 KiB of loads in flight
+// per wave hide HBM latency.
+// ------------------------------------------------------------------------------------------
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+struct PopArg {
+  const int8_t* tiles;
+  int32_t n_ind;
+  int32_t pad;
+};
+
+struct CountsArgs {
+  int64_t n_sites;
+  int64_t n_tiles;
+  int32_t n_pops;
+  PopArg pop[kMaxPops];
+  uint2* counts;
+};
+
+__device__ __forceinline__ void acc_word(uint32_t w, uint32_t& lo, uint32_t& hi, uint32_t& ms) {
+  const uint32_t neg = w & 0x80808080u;   // sign bit of each byte
+  const uint32_t m1 = neg >> 7;           // 0x01 per missing call
+  ms += m1;
+  const uint32_t mask = (neg - m1) | neg; // 0xFF per missing call
+  const uint32_t val = w & ~mask;         // max(g, 0) per byte
+  lo += val & 0x00FF00FFu;                // sites 0,2 of the word -> 16-bit fields
+  hi += (val >> 8) & 0x00FF00FFu;         // sites 1,3
+}
+
+__device__ __forceinline__ void acc_vec(const u32x4& v, uint32_t (&lo)[4], uint32_t (&hi)[4],
+                                        uint32_t (&ms)[4]) {
+  acc_word(v.x, lo[0], hi[0], ms[0]);
+  acc_word(v.y, lo[1], hi[1], ms[1]);
+  acc_word(v.z, lo[2], hi[2], ms[2]);
+  acc_word(v.w, lo[3], hi[3], ms[3]);
+}
+
+template <int N, int MASK>
+__device__ __forceinline__ void reduce_scatter_step(uint32_t (&a)[16], int lane) {
+  constexpr int H = N / 2;
+  const bool up = (lane & MASK) != 0;
+#pragma unroll
+  for (int k = 0; k < H; ++k) {
+    const uint32_t send = up ? a[k] : a[k + H];
+    const uint32_t keep = up ? a[k + H] : a[k];
+    a[k] = keep + __shfl_xor(send, MASK, 64);
+  }
+}
+
+template <int UNROLL>
+__global__ __launch_bounds__(64) void site_counts_kernel(CountsArgs a) {
+  const int lane = threadIdx.x;
+  const int r = lane >> 2;
+  for (int64_t tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
+    for (int p = 0; p < a.n_pops; ++p) {
+      const int n_ind = a.pop[p].n_ind;
+      const u32x4* base =
+          reinterpret_cast<const u32x4*>(a.pop[p].tiles + tile * static_cast<int64_t>(n_ind) * kTile) + lane;
+      uint32_t sum32[16], miss32[16];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) sum32[j] = miss32[j] = 0;
+
+      const int n_full = n_ind >> 4;         // iterations in which all 16 rows exist
+      const int n_iter = (n_ind + 15) >> 4;  // plus at most one partial iteration
+      int it = 0;
+      while (it < n_iter) {
+        const int full_end = min(n_full, it + 248);
+        uint32_t lo[4] = {0, 0, 0, 0}, hi[4] = {0, 0, 0, 0}, ms[4] = {0, 0, 0, 0};
+        for (; it + UNROLL <= full_end; it += UNROLL) {
+          u32x4 v[UNROLL];
+#pragma unroll
+          for (int u = 0; u < UNROLL; ++u) v[u] = __builtin_nontemporal_load(base + (it + u) * 64);
+#pragma unroll
+          for (int u = 0; u < UNROLL; ++u) acc_vec(v[u], lo, hi, ms);
+        }
+        for (; it < full_end; ++it) {
+          const u32x4 v = __builtin_nontemporal_load(base + it * 64);
+          acc_vec(v, lo, hi, ms);
+        }
+        if (it == n_full && it < n_iter) {  // partial last group of rows
+          u32x4 v = {0u, 0u, 0u, 0u};
+          if (it * 16 + r < n_ind) v = __builtin_nontemporal_load(base + it * 64);
+          acc_vec(v, lo, hi, ms);
+          ++it;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          sum32[4 * j + 0] += lo[j] & 0xFFFFu;
+          sum32[4 * j + 1] += hi[j] & 0xFFFFu;
+          sum32[4 * j + 2] += lo[j] >> 16;
+          sum32[4 * j + 3] += hi[j] >> 16;
+          miss32[4 * j + 0] += ms[j] & 0xFFu;
+          miss32[4 * j + 1] += (ms[j] >> 8) & 0xFFu;
+          miss32[4 * j + 2] += (ms[j] >> 16) & 0xFFu;
+          miss32[4 * j + 3] += ms[j] >> 24;
+        }
+      }
+      reduce_scatter_step<16, 32>(sum32, lane);
+      reduce_scatter_step<8, 16>(sum32, lane);
+      reduce_scatter_step<4, 8>(sum32, lane);
+      reduce_scatter_step<2, 4>(sum32, lane);
+      reduce_scatter_step<16, 32>(miss32, lane);
+      reduce_scatter_step<8, 16>(miss32, lane);
+      reduce_scatter_step<4, 8>(miss32, lane);
+      reduce_scatter_step<2, 4>(miss32, lane);
+      const int64_t site = tile * kTile + (lane & 3) * 16 + r;
+      if (site < a.n_sites)
+        a.counts[static_cast<int64_t>(p) * a.n_sites + site] =
+            make_uint2(sum32[0], static_cast<uint32_t>(n_ind) - miss32[0]);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// site_flags: one thread per site; f64 exactly as numpy evaluates it.
+// ------------------------------------------------------------------------------------------
+
+struct FlagArgs {
+  int64_t n_sites;
+  int32_t n_pops;
+  int32_t n_sets;
+  int32_t ploidy[kMaxPops];
+  const uint2* counts;
+  double* tgt_freq;
+  uint8_t* flags;
+  double* adj_freq;
+  sai_params sets[SAI_MAX_SETS];
+};
+
+__device__ __forceinline__ bool cmp_op(int op, double f, double y) {
+  switch (op) {
+    case SAI_OP_EQ: return f == y;
+    case SAI_OP_LT: return f < y;
+    case SAI_OP_GT: return f > y;
+    case SAI_OP_LE: return f <= y;
+    default: return f >= y;
+  }
+}
+
+__global__ __launch_bounds__(256) void site_flags_kernel(FlagArgs a) {
+  const int64_t site = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (site >= a.n_sites) return;
+  double f[kMaxPops];
+  bool valid = true;
+#pragma unroll
+  for (int p = 0; p < kMaxPops; ++p) {
+    if (p < a.n_pops) {
+      const uint2 c = a.counts[static_cast<int64_t>(p) * a.n_sites + site];
+      const int64_t den = static_cast<int64_t>(c.y) * a.ploidy[p];
+      const double v = den > 0 ? static_cast<double>(c.x) / static_cast<double>(den)
+                               : std::numeric_limits<double>::quiet_NaN();
+      f[p] = v;
+      valid = valid && (v >= 0.0) && (v <= 1.0);  // false for NaN; the quotient is never inf
+    } else {
+      f[p] = 0.0;
+    }
+  }
+  a.tgt_freq[site] = f[1];
+  const int n_src = a.n_pops - 2;
+  for (int s = 0; s < a.n_sets; ++s) {
+    const sai_params& ps = a.sets[s];
+    bool hit_y = true, hit_m = true;
+#pragma unroll
+    for (int k = 0; k < SAI_MAX_SRC; ++k) {
+      if (k < n_src) {
+        hit_y = hit_y && cmp_op(ps.op[k], f[2 + k], ps.y[k]);
+        hit_m = hit_m && cmp_op(ps.op[k], f[2 + k], ps.one_minus_y[k]);
+      }
+    }
+    const bool anc = ps.anc_allele_available != 0;
+    const bool inverted = !anc && hit_m && valid;
+    const bool hit = anc ? hit_y : (hit_y || hit_m);
+    const double rf = inverted ? 1.0 - f[0] : f[0];
+    const double tf = inverted ? 1.0 - f[1] : f[1];
+    const bool cond = valid && hit && (rf < ps.w);
+    const bool ucand = cond && (tf > ps.x);
+    a.flags[static_cast<int64_t>(s) * a.n_sites + site] =
+        static_cast<uint8_t>((cond ? 1 : 0) | (ucand ? 2 : 0) | (inverted ? 4 : 0));
+    if (a.adj_freq) {
+      a.adj_freq[(static_cast<int64_t>(s) * 2 + 0) * a.n_sites + site] = rf;
+      a.adj_freq[(static_cast<int64_t>(s) * 2 + 1) * a.n_sites + site] = tf;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// window_bounds
+// ------------------------------------------------------------------------------------------
+
+__global__ __launch_bounds__(256) void window_bounds_kernel(const int32_t* __restrict__ pos,
+                                                             int64_t n_sites, int32_t n_windows,
+                                                             const int64_t* __restrict__ ws,
+                                                             const int64_t* __restrict__ we,
+                                                             int32_t* __restrict__ lo,
+                                                             int32_t* __restrict__ hi) {
+  const int w = blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= n_windows) return;
+  const int64_t s = ws[w], e = we[w];
+  int64_t a = 0, b = n_sites;  // first index with pos >= s
+  while (a < b) {
+    const int64_t m = (a + b) >> 1;
+    if (static_cast<int64_t>(pos[m]) < s) a = m + 1; else b = m;
+  }
+  const int64_t first = a;
+  b = n_sites;                 // first index with pos > e
+  while (a < b) {
+    const int64_t m = (a + b) >> 1;
+    if (static_cast<int64_t>(pos[m]) <= e) a = m + 1; else b = m;
+  }
+  lo[w] = static_cast<int32_t>(first);
+  hi[w] = static_cast<int32_t>(a < first ? first : a);
+}
+
+// ------------------------------------------------------------------------------------------
+// window_stats: one 256-thread workgroup per (window, parameter set).
+// ------------------------------------------------------------------------------------------
+
+struct WinArgs {
+  int64_t n_sites;
+  const double* tgt_freq;
+  const uint8_t* flags;
+  int32_t n_sets;
+  int32_t n_windows;
+  const int32_t* lo;
+  const int32_t* hi;
+  const int32_t* pos;
+  sai_window_record* records;
+  int64_t* cdd_off;
+  int32_t* cdd_u;
+  int64_t cap_u;
+  int32_t* cdd_q;
+  int64_t cap_q;
+  unsigned long long* cdd_total;
+  double quantile[SAI_MAX_SETS];
+};
+
+constexpr int kWinThreads = 256;
+constexpr int kSelCap = 4096;  // selected values kept in LDS (32 KiB); beyond that re-read HBM/L2
+
+struct WinShared {
+  double vals[kSelCap];
+  uint32_t hist[256];
+  uint32_t wave_tot[4];
+  uint32_t red[8];
+  uint32_t n_stored;
+  uint32_t digit;
+  uint32_t k_rem;
+  long long base_u;
+  long long base_q;
+};
+
+__device__ __forceinline__ uint32_t block_sum(uint32_t v, uint32_t* red, int tid) {
+  // wave reduce then 4 partials through LDS
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  __syncthreads();
+  if ((tid & 63) == 0) red[tid >> 6] = v;
+  __syncthreads();
+  return red[0] + red[1] + red[2] + red[3];
+}
+
+__device__ __forceinline__ double eff_freq(const double* tgt_freq, uint8_t f, int64_t i) {
+  const double v = tgt_freq[i];
+  return (f & 4) ? 1.0 - v : v;
+}
+
+// k-th smallest (0-based) of the selected values: MSB-first radix select on the f64 bit pattern
+// (all selected values are finite and >= 0, so the unsigned order of the bits is the numeric order).
+template <bool IN_LDS>
+__device__ double select_kth(WinShared& sh, const double* tgt_freq, const uint8_t* fl, int lo, int hi,
+                             uint32_t n_sel, uint32_t k, int tid) {
+  unsigned long long prefix = 0;
+  for (int shift = 56; shift >= 0; shift -= 8) {
+    sh.hist[tid] = 0;
+    __syncthreads();
+    const unsigned long long himask = shift == 56 ? 0ull : (~0ull << (shift + 8));
+    if (IN_LDS) {
+      for (uint32_t i = tid; i < n_sel; i += kWinThreads) {
+        const unsigned long long key = __double_as_longlong(sh.vals[i]);
+        if ((key & himask) == prefix) atomicAdd(&sh.hist[(key >> shift) & 255u], 1u);
+      }
+    } else {
+      for (int i = lo + tid; i < hi; i += kWinThreads) {
+        const uint8_t f = fl[i];
+        if (f & 1) {
+          const unsigned long long key = __double_as_longlong(eff_freq(tgt_freq, f, i));
+          if ((key & himask) == prefix) atomicAdd(&sh.hist[(key >> shift) & 255u], 1u);
+        }
+      }
+    }
+    __syncthreads();
+    // inclusive scan of the 256 bins: shuffles inside each wave, wave totals through LDS
+    const uint32_t h = sh.hist[tid];
+    uint32_t inc = h;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t t = __shfl_up(inc, o, 64);
+      if ((tid & 63) >= o) inc += t;
+    }
+    if ((tid & 63) == 63) sh.wave_tot[tid >> 6] = inc;
+    __syncthreads();
+    uint32_t before = 0;
+    for (int wv = 0; wv < (tid >> 6); ++wv) before += sh.wave_tot[wv];
+    inc += before;
+    const uint32_t exc = inc - h;
+    if (h != 0 && k >= exc && k < inc) {  // exactly one bin satisfies this
+      sh.digit = tid;
+      sh.k_rem = k - exc;
+    }
+    __syncthreads();
+    prefix |= static_cast<unsigned long long>(sh.digit) << shift;
+    k = sh.k_rem;
+    __syncthreads();
+  }
+  return __longlong_as_double(static_cast<long long>(prefix));
+}
+
+// ordered compaction of the sites of [lo, hi) whose predicate holds, written at out[base...]
+template <typename Pred>
+__device__ void write_list(WinShared& sh, int lo, int hi, const int32_t* pos, int32_t* out, long long base,
+                           int tid, Pred pred) {
+  long long running = base;
+  for (int i0 = lo; i0 < hi; i0 += kWinThreads) {
+    const int i = i0 + tid;
+    const bool p = i < hi && pred(i);
+    const unsigned long long bal = __ballot(p);
+    const int wave = tid >> 6;
+    __syncthreads();
+    if ((tid & 63) == 0) sh.wave_tot[wave] = __popcll(bal);
+    __syncthreads();
+    uint32_t before = 0;
+    for (int wv = 0; wv < wave; ++wv) before += sh.wave_tot[wv];
+    const uint32_t total = sh.wave_tot[0] + sh.wave_tot[1] + sh.wave_tot[2] + sh.wave_tot[3];
+    if (p) {
+      const uint32_t rank = before + __popcll(bal & ((1ull << (tid & 63)) - 1ull));
+      out[running + rank] = pos ? pos[i] : i;
+    }
+    running += total;
+  }
+}
+
+__global__ __launch_bounds__(kWinThreads) void window_stats_kernel(WinArgs a) {
+  __shared__ WinShared sh;
+  const int tid = threadIdx.x;
+  // XCD-aware order: consecutive blockIdx values round-robin over the 8 XCDs, so give each XCD a
+  // contiguous run of (overlapping) windows to keep their shared sites in one L2.
+  int w = blockIdx.x;
+  {
+    const int nw = a.n_windows;
+    const int per = nw >> 3;
+    if (per > 0 && w < per * 8) w = (w & 7) * per + (w >> 3);
+  }
+  const int set = blockIdx.y;
+  const int lo = a.lo[w], hi = a.hi[w];
+  const uint8_t* fl = a.flags + static_cast<int64_t>(set) * a.n_sites;
+  const int64_t ridx = static_cast<int64_t>(set) * a.n_windows + w;
+
+  if (tid == 0) sh.n_stored = 0;
+  __syncthreads();
+  uint32_t c_u = 0, c_c = 0;
+  for (int i = lo + tid; i < hi; i += kWinThreads) {
+    const uint8_t f = fl[i];
+    c_u += (f >> 1) & 1u;
+    if (f & 1u) {
+      ++c_c;
+      const uint32_t slot = atomicAdd(&sh.n_stored, 1u);
+      if (slot < kSelCap) sh.vals[slot] = eff_freq(a.tgt_freq, f, i);
+    }
+  }
+  const uint32_t n_u = block_sum(c_u, sh.red, tid);
+  const uint32_t n_c = block_sum(c_c, sh.red + 4, tid);
+
+  double q = std::numeric_limits<double>::quiet_NaN();
+  uint32_t n_q = 0;
+  if (n_c > 0) {
+    const bool in_lds = n_c <= kSelCap;
+    // numpy 'linear': virtual index (n-1)*q; at/after the last index -> the maximum
+    const double v = static_cast<double>(n_c - 1) * a.quantile[set];
+    if (v >= static_cast<double>(n_c - 1)) {
+      q = in_lds ? select_kth<true>(sh, a.tgt_freq, fl, lo, hi, n_c, n_c - 1, tid)
+                 : select_kth<false>(sh, a.tgt_freq, fl, lo, hi, n_c, n_c - 1, tid);
+    } else {
+      const double fl_v = floor(v);
+      const uint32_t k = static_cast<uint32_t>(fl_v);
+      const double g = v - fl_v;
+      const double x0 = in_lds ? select_kth<true>(sh, a.tgt_freq, fl, lo, hi, n_c, k, tid)
+                               : select_kth<false>(sh, a.tgt_freq, fl, lo, hi, n_c, k, tid);
+      const double x1 = in_lds ? select_kth<true>(sh, a.tgt_freq, fl, lo, hi, n_c, k + 1, tid)
+                               : select_kth<false>(sh, a.tgt_freq, fl, lo, hi, n_c, k + 1, tid);
+      const double d = x1 - x0;
+      q = (g >= 0.5) ? x1 - d * (1.0 - g) : x0 + d * g;
+    }
+    uint32_t c_q = 0;
+    for (int i = lo + tid; i < hi; i += kWinThreads) {
+      const uint8_t f = fl[i];
+      if ((f & 1u) && eff_freq(a.tgt_freq, f, i) >= q) ++c_q;
+    }
+    n_q = block_sum(c_q, sh.red, tid);
+  }
+
+  // reserve list space (placement between windows is arbitrary, the offsets say where)
+  if (tid == 0) {
+    const long long bu = static_cast<long long>(atomicAdd(a.cdd_total + 0, static_cast<unsigned long long>(n_u)));
+    const long long bq = static_cast<long long>(atomicAdd(a.cdd_total + 1, static_cast<unsigned long long>(n_q)));
+    sh.base_u = (bu + static_cast<long long>(n_u) <= a.cap_u) ? bu : -1;
+    sh.base_q = (bq + static_cast<long long>(n_q) <= a.cap_q) ? bq : -1;
+    sai_window_record rec;
+    rec.n_sites = hi - lo;
+    rec.u_count = static_cast<int32_t>(n_u);
+    rec.n_cond = static_cast<int32_t>(n_c);
+    rec.n_cdd_q = static_cast<int32_t>(n_q);
+    rec.q = q;
+    a.records[ridx] = rec;
+    a.cdd_off[ridx * 2 + 0] = sh.base_u;
+    a.cdd_off[ridx * 2 + 1] = sh.base_q;
+  }
+  __syncthreads();
+  const long long off_u = sh.base_u;
+  const long long off_q = sh.base_q;
+  __syncthreads();
+  if (n_u > 0 && off_u >= 0 && a.cdd_u)
+    write_list(sh, lo, hi, a.pos, a.cdd_u, off_u, tid, [&](int i) { return (fl[i] & 2u) != 0; });
+  if (n_q > 0 && off_q >= 0 && a.cdd_q)
+    write_list(sh, lo, hi, a.pos, a.cdd_q, off_q, tid, [&](int i) {
+      const uint8_t f = fl[i];
+      return (f & 1u) && eff_freq(a.tgt_freq, f, i) >= q;
+    });
+}
+
+// ------------------------------------------------------------------------------------------
+// synth-v1: counter-based synthetic data (identical on host and device)
+// ------------------------------------------------------------------------------------------
+
+#define SAI_HD __host__ __device__ __forceinline__
+
+SAI_HD uint64_t mix64(uint64_t z) {  // splitmix64 finaliser
+  z += 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+
+SAI_HD uint64_t stream_key(uint64_t seed, int32_t chrom, int32_t stream) {
+  return mix64(seed ^ (static_cast<uint64_t>(static_cast<uint32_t>(chrom)) << 40) ^
+               (static_cast<uint64_t>(static_cast<uint32_t>(stream)) << 32));
+}
+
+SAI_HD int32_t synth_gap(uint64_t seed, int32_t chrom, int64_t site) {
+  const uint64_t h = mix64(stream_key(seed, chrom, 0) + static_cast<uint64_t>(site));
+  return 1 + static_cast<int32_t>(static_cast<uint32_t>(h >> 32) % 49u);
+}
+
+struct SiteModel {
+  uint64_t key;        // per (site, population stream) hashing key
+  uint32_t threshold;  // allele is ALT when a 32-bit uniform < threshold
+  int32_t fixed;       // -1: draw; else dosage forced to this value
+};
+
+// pop_stream: 0 = ref, 1 = tgt, >= 2 = sources
+SAI_HD SiteModel site_model(uint64_t seed, int32_t chrom, int64_t site, int32_t pop_stream, int32_t ploidy) {
+  const uint64_t hs = mix64(stream_key(seed, chrom, 1) + static_cast<uint64_t>(site));
+  const bool intro = (static_cast<uint32_t>(hs >> 32) % 1000u) == 0u;
+  const double u = static_cast<double>(static_cast<uint32_t>(hs)) * (1.0 / 4294967296.0);
+  SiteModel m;
+  m.key = mix64(stream_key(seed, chrom, 2 + pop_stream) + static_cast<uint64_t>(site));
+  m.fixed = -1;
+  double p;
+  if (intro) {
+    if (pop_stream == 0) { m.fixed = 0; p = 0.0; }
+    else if (pop_stream == 1) { p = 0.2 + 0.7 * u; }
+    else { m.fixed = ploidy; p = 1.0; }
+  } else {
+    const double u2 = u * u;
+    p = u2 * u2;
+  }
+  m.threshold = static_cast<uint32_t>(p * 4294967296.0 >= 4294967295.0 ? 4294967295.0 : p * 4294967296.0);
+  return m;
+}
+
+SAI_HD int8_t synth_genotype(const SiteModel& m, int32_t ind, int32_t ploidy, uint32_t miss_thr) {
+  if (miss_thr != 0u) {
+    const uint64_t hm = mix64(m.key ^ 0xD1B54A32D192ED03ull ^ (static_cast<uint64_t>(static_cast<uint32_t>(ind)) << 1));
+    if (static_cast<uint32_t>(hm >> 32) < miss_thr) return static_cast<int8_t>(-ploidy);
+  }
+  if (m.fixed >= 0) return static_cast<int8_t>(m.fixed);
+  int d = 0;
+  for (int a = 0; a < ploidy; a += 2) {
+    const uint64_t h = mix64(m.key + static_cast<uint64_t>(static_cast<uint32_t>(ind)) +
+                             (static_cast<uint64_t>(a >> 1) << 32));
+    d += static_cast<uint32_t>(h) < m.threshold;
+    if (a + 1 < ploidy) d += static_cast<uint32_t>(h >> 32) < m.threshold;
+  }
+  return static_cast<int8_t>(d);
+}
+
+SAI_HD uint32_t miss_threshold(int32_t missing_per_million) {
+  return static_cast<uint32_t>((static_cast<uint64_t>(missing_per_million) << 32) / 1000000ull);
+}
+
+__global__ __launch_bounds__(256) void synth_fill_kernel(uint64_t seed, int32_t chrom, int64_t site0,
+                                                          int64_t n_sites, int32_t pop_stream, int32_t n_ind,
+                                                          int32_t ploidy, uint32_t miss_thr, int8_t* tiles) {
+  __shared__ SiteModel models[kTile];
+  const int64_t tile = blockIdx.x;
+  const int tid = threadIdx.x;
+  if (tid < kTile) models[tid] = site_model(seed, chrom, site0 + tile * kTile + tid, pop_stream, ploidy);
+  __syncthreads();
+  const int part = tid & 3;
+  for (int ind = tid >> 2; ind < n_ind; ind += 64) {
+    uint32_t w[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      uint32_t v = 0;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int s = part * 16 + j * 4 + k;
+        int8_t g = 0;
+        if (tile * kTile + s < n_sites) g = synth_genotype(models[s], ind, ploidy, miss_thr);
+        v |= static_cast<uint32_t>(static_cast<uint8_t>(g)) << (8 * k);
+      }
+      w[j] = v;
+    }
+    *reinterpret_cast<uint4*>(tiles + (tile * n_ind + ind) * kTile + part * 16) = make_uint4(w[0], w[1], w[2], w[3]);
+  }
+}
+
+__global__ __launch_bounds__(256) void synth_gaps_kernel(uint64_t seed, int32_t chrom, int64_t site0,
+                                                          int64_t n_sites, int32_t* gaps) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i < n_sites) gaps[i] = synth_gap(seed, chrom, site0 + i);
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------
+
+extern "C" {
+
+int sai_abi_version(void) { return SAI_ABI_VERSION; }
+const char* sai_build_arch(void) { return "gfx950"; }
+const char* sai_last_error(void) { return g_err; }
+
+int sai_device_count(int* count_out) {
+  if (!count_out) return fail(SAI_ERR_ARG, "count_out is NULL");
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) {
+    *count_out = 0;
+    return fail(SAI_ERR_NO_DEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e));
+  }
+  *count_out = n;
+  return SAI_OK;
+}
+
+int sai_ctx_create(int device, sai_ctx** ctx_out) {
+  if (!ctx_out) return fail(SAI_ERR_ARG, "ctx_out is NULL");
+  *ctx_out = nullptr;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+    return fail(SAI_ERR_NO_DEVICE, "no HIP device is visible; libsaihip has no CPU fallback");
+  if (device < 0 || device >= n) return fail(SAI_ERR_ARG, "device %d out of range (0..%d)", device, n - 1);
+  SAI_HIP(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  SAI_HIP(hipGetDeviceProperties(&prop, device));
+  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return fail(SAI_ERR_NO_DEVICE, "device %d is %s; this library is built for gfx950 only", device,
+                prop.gcnArchName);
+  sai_ctx* c = new (std::nothrow) sai_ctx;
+  if (!c) return fail(SAI_ERR_HIP, "out of host memory");
+  c->device = device;
+  c->n_cu = prop.multiProcessorCount;
+  *ctx_out = c;
+  return SAI_OK;
+}
+
+int sai_ctx_destroy(sai_ctx* ctx) {
+  delete ctx;
+  return SAI_OK;
+}
+
+int64_t sai_tiled_bytes(int64_t n_sites, int32_t n_ind) {
+  if (n_sites < 0 || n_ind < 0) return -1;
+  const int64_t n_tiles = (n_sites + kTile - 1) / kTile;
+  return n_tiles * static_cast<int64_t>(n_ind) * kTile;
+}
+
+int sai_tile_from_site_major(sai_ctx* ctx, const int8_t* src, int64_t n_sites, int32_t n_ind,
+                             int64_t row_stride, int8_t* dst, void* stream) {
+  if (int rc = enter(ctx)) return rc;
+  if (n_sites < 0 || n_ind < 0) return fail(SAI_ERR_ARG, "negative size");
+  if (n_sites == 0 || n_ind == 0) return SAI_OK;
+  if (!src || !dst) return fail(SAI_ERR_ARG, "NULL buffer");
+  if (row_stride < n_ind) return fail(SAI_ERR_ARG, "row_stride %lld < n_ind %d", (long long)row_stride, n_ind);
+  const int64_t n_tiles = (n_sites + kTile - 1) / kTile;
+  const int64_t n_blk = (static_cast<int64_t>(n_ind) + kTile - 1) / kTile;
+  if (n_tiles > 0x7FFFFFFFll || n_blk > 65535) return fail(SAI_ERR_UNSUPPORTED, "block too large for one launch");
+  dim3 grid(static_cast<unsigned>(n_tiles), static_cast<unsigned>(n_blk));
+  hipLaunchKernelGGL(tile_from_site_major_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream), src,
+                     n_sites, n_ind, row_stride, dst);
+  return check_launch("tile_from_site_major");
+}
+
+int sai_site_counts(sai_ctx* ctx, int64_t n_sites, int32_t n_pops, const sai_pop* pops, uint32_t* counts,
+                    void* stream) {
+  if (int rc = enter(ctx)) return rc;
+  if (n_sites < 0 || n_sites >= 0x7FFFFFFFll) return fail(SAI_ERR_ARG, "n_sites out of range");
+  if (n_pops < 1 || n_pops > kMaxPops) return fail(SAI_ERR_ARG, "n_pops must be 1..%d", kMaxPops);
+  if (!pops || !counts) return fail(SAI_ERR_ARG, "NULL buffer");
+  if (n_sites == 0) return SAI_OK;
+  CountsArgs a;
+  a.n_sites = n_sites;
+  a.n_tiles = (n_sites + kTile - 1) / kTile;
+  a.n_pops = n_pops;
+  for (int p = 0; p < n_pops; ++p) {
+    if (pops[p].n_ind < 0) return fail(SAI_ERR_ARG, "population %d: negative n_ind", p);
+    if (pops[p].n_ind > 0 && !pops[p].tiles) return fail(SAI_ERR_ARG, "population %d: NULL tiles", p);
+    if (pops[p].n_ind > (1 << 24)) return fail(SAI_ERR_UNSUPPORTED, "population %d: n_ind > 2^24", p);
+    if (reinterpret_cast<uintptr_t>(pops[p].tiles) & 15u)
+      return fail(SAI_ERR_ARG, "population %d: tiles must be 16-byte aligned", p);
+    a.pop[p].tiles = pops[p].tiles;
+    a.pop[p].n_ind = pops[p].n_ind;
+    a.pop[p].pad = 0;
+  }
+  a.counts = reinterpret_cast<uint2*>(counts);
+  const int64_t max_grid = static_cast<int64_t>(ctx->n_cu) * 64;  // grid-stride beyond this
+  const unsigned grid = static_cast<unsigned>(a.n_tiles < max_grid ? a.n_tiles : max_grid);
+  hipLaunchKernelGGL(site_counts_kernel<4>, dim3(grid), dim3(64), 0, static_cast<hipStream_t>(stream), a);
+  return check_launch("site_counts");
+}
+
+static int check_sets(int32_t n_sets, const sai_params* sets, int32_t n_src) {
+  if (n_sets < 1 || n_sets > SAI_MAX_SETS) return fail(SAI_ERR_ARG, "n_sets must be 1..%d", SAI_MAX_SETS);
+  if (!sets) return fail(SAI_ERR_ARG, "sets_host is NULL");
+  for (int s = 0; s < n_sets; ++s) {
+    if (n_src >= 0 && sets[s].n_src != n_src)
+      return fail(SAI_ERR_ARG, "set %d: n_src %d != source populations %d", s, sets[s].n_src, n_src);
+    for (int k = 0; k < sets[s].n_src && k < SAI_MAX_SRC; ++k)
+      if (sets[s].op[k] < SAI_OP_EQ || sets[s].op[k] > SAI_OP_GE)
+        return fail(SAI_ERR_ARG, "set %d: bad operator %d", s, sets[s].op[k]);
+  }
+  return SAI_OK;
+}
+
+int sai_site_flags(sai_ctx* ctx, int64_t n_sites, int32_t n_pops, const int32_t* ploidy_host,
+                   const uint32_t* counts, int32_t n_sets, const sai_params* sets_host, double* tgt_freq,
+                   uint8_t* flags, double* adj_freq, void* stream) {
+  if (int rc = enter(ctx)) return rc;
+  if (n_sites < 0 || n_sites >= 0x7FFFFFFFll) return fail(SAI_ERR_ARG, "n_sites out of range");
+  if (n_pops < 2 || n_pops > kMaxPops) return fail(SAI_ERR_ARG, "n_pops must be 2..%d (ref, tgt, sources)", kMaxPops);
+  if (!ploidy_host) return fail(SAI_ERR_ARG, "ploidy_host is NULL");
+  if (int rc = check_sets(n_sets, sets_host, n_pops - 2)) return rc;
+  if (n_sites == 0) return SAI_OK;
+  if (!counts || !tgt_freq || !flags) return fail(SAI_ERR_ARG, "NULL buffer");
+  FlagArgs a;
+  std::memset(&a, 0, sizeof(a));
+  a.n_sites = n_sites;
+  a.n_pops = n_pops;
+  a.n_sets = n_sets;
+  for (int p = 0; p < n_pops; ++p) {
+    if (ploidy_host[p] <= 0) return fail(SAI_ERR_ARG, "ploidy[%d] must be positive", p);
+    a.ploidy[p] = ploidy_host[p];
+  }
+  a.counts = reinterpret_cast<const uint2*>(counts);
+  a.tgt_freq = tgt_freq;
+  a.flags = flags;
+  a.adj_freq = adj_freq;
+  for (int s = 0; s < n_sets; ++s) a.sets[s] = sets_host[s];
+  const unsigned grid = static_cast<unsigned>((n_sites + 255) / 256);
+  hipLaunchKernelGGL(site_flags_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+  return check_launch("site_flags");
+}
+
+int sai_window_bounds(sai_ctx* ctx, const int32_t* pos, int64_t n_sites, int32_t n_windows,
+                      const int64_t* win_start, const int64_t* win_end, int32_t* lo, int32_t* hi, void* stream) {
+  if (int rc = enter(ctx)) return rc;
+  if (n_sites < 0 || n_sites >= 0x7FFFFFFFll || n_windows < 0) return fail(SAI_ERR_ARG, "size out of range");
+  if (n_windows == 0) return SAI_OK;
+  if ((n_sites > 0 && !pos) || !win_start || !win_end || !lo || !hi) return fail(SAI_ERR_ARG, "NULL buffer");
+  const unsigned grid = static_cast<unsigned>((n_windows + 255) / 256);
+  hipLaunchKernelGGL(window_bounds_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), pos, n_sites,
+                     n_windows, win_start, win_end, lo, hi);
+  return check_launch("window_bounds");
+}
+
+int sai_window_stats(sai_ctx* ctx, int64_t n_sites, const double* tgt_freq, const uint8_t* flags, int32_t n_sets,
+                     const sai_params* sets_host, int32_t n_windows, const int32_t* lo, const int32_t* hi,
+                     const int32_t* pos, sai_window_record* records, int64_t* cdd_off, int32_t* cdd_u, int64_t cap_u,
+                     int32_t* cdd_q, int64_t cap_q, int64_t* cdd_total, void* stream) {
+  if (int rc = enter(ctx)) return rc;
+  if (n_sites < 0 || n_sites >= 0x7FFFFFFFll || n_windows < 0) return fail(SAI_ERR_ARG, "size out of range");
+  if (int rc = check_sets(n_sets, sets_host, -1)) return rc;
+  if (!cdd_total) return fail(SAI_ERR_ARG, "cdd_total is NULL");
+  if (cap_u < 0 || cap_q < 0 || (cap_u > 0 && !cdd_u) || (cap_q > 0 && !cdd_q))
+    return fail(SAI_ERR_ARG, "candidate buffers do not match their capacities");
+  SAI_HIP(hipMemsetAsync(cdd_total, 0, 2 * sizeof(int64_t), static_cast<hipStream_t>(stream)));
+  if (n_windows == 0) return SAI_OK;
+  if ((n_sites > 0 && (!tgt_freq || !flags)) || !lo || !hi || !records || !cdd_off)
+    return fail(SAI_ERR_ARG, "NULL buffer");
+  WinArgs a;
+  std::memset(&a, 0, sizeof(a));
+  a.n_sites = n_sites;
+  a.tgt_freq = tgt_freq;
+  a.flags = flags;
+  a.n_sets = n_sets;
+  a.n_windows = n_windows;
+  a.lo = lo;
+  a.hi = hi;
+  a.pos = pos;
+  a.records = records;
+  a.cdd_off = cdd_off;
+  a.cdd_u = cdd_u;
+  a.cap_u = cap_u;
+  a.cdd_q = cdd_q;
+  a.cap_q = cap_q;
+  a.cdd_total = reinterpret_cast<unsigned long long*>(cdd_total);
+  for (int s = 0; s < n_sets; ++s) a.quantile[s] = sets_host[s].quantile;
+  dim3 grid(static_cast<unsigned>(n_windows), static_cast<unsigned>(n_sets));
+  hipLaunchKernelGGL(window_stats_kernel, grid, dim3(kWinThreads), 0, static_cast<hipStream_t>(stream), a);
+  return check_launch("window_stats");
+}
+
+int sai_synth_fill(sai_ctx* ctx, uint64_t seed, int32_t chrom, int64_t site0, int64_t n_sites, int32_t pop_stream,
+                   int32_t n_ind, int32_t ploidy, int32_t missing_per_million, int8_t* tiles, void* stream) {
+  if (int rc = enter(ctx)) return rc;
+  if (n_sites < 0 || site0 < 0 || n_ind < 0 || pop_stream < 0) return fail(SAI_ERR_ARG, "negative argument");
+  if (ploidy < 1 || ploidy > 8) return fail(SAI_ERR_ARG, "ploidy must be 1..8");
+  if (missing_per_million < 0 || missing_per_million > 1000000) return fail(SAI_ERR_ARG, "missing_per_million out of range");
+  if (n_sites == 0 || n_ind == 0) return SAI_OK;
+  if (!tiles) return fail(SAI_ERR_ARG, "NULL buffer");
+  const int64_t n_tiles = (n_sites + kTile - 1) / kTile;
+  if (n_tiles > 0x7FFFFFFFll) return fail(SAI_ERR_UNSUPPORTED, "too many tiles for one launch");
+  hipLaunchKernelGGL(synth_fill_kernel, dim3(static_cast<unsigned>(n_tiles)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), seed, chrom, site0, n_sites, pop_stream, n_ind, ploidy,
+                     miss_threshold(missing_per_million), tiles);
+  return check_launch("synth_fill");
+}
+
+int sai_synth_fill_host(uint64_t seed, int32_t chrom, int64_t site0, int64_t n_sites, int32_t pop_stream,
+                        int32_t n_ind, int32_t ploidy, int32_t missing_per_million, int8_t* out) {
+  if (n_sites < 0 || site0 < 0 || n_ind < 0 || pop_stream < 0) return fail(SAI_ERR_ARG, "negative argument");
+  if (ploidy < 1 || ploidy > 8) return fail(SAI_ERR_ARG, "ploidy must be 1..8");
+  if (missing_per_million < 0 || missing_per_million > 1000000) return fail(SAI_ERR_ARG, "missing_per_million out of range");
+  if (n_sites == 0 || n_ind == 0) return SAI_OK;
+  if (!out) return fail(SAI_ERR_ARG, "NULL buffer");
+  const uint32_t mt = miss_threshold(missing_per_million);
+  for (int64_t s = 0; s < n_sites; ++s) {
+    const SiteModel m = site_model(seed, chrom, site0 + s, pop_stream, ploidy);
+    int8_t* row = out + s * n_ind;
+    for (int32_t i = 0; i < n_ind; ++i) row[i] = synth_genotype(m, i, ploidy, mt);
+  }
+  return SAI_OK;
+}
+
+int sai_synth_gaps_host(uint64_t seed, int32_t chrom, int64_t site0, int64_t n_sites, int32_t* gaps) {
+  if (n_sites < 0 || site0 < 0) return fail(SAI_ERR_ARG, "negative argument");
+  if (n_sites > 0 && !gaps) return fail(SAI_ERR_ARG, "NULL buffer");
+  for (int64_t i = 0; i < n_sites; ++i) gaps[i] = synth_gap(seed, chrom, site0 + i);
+  return SAI_OK;
+}
+
+int sai_synth_gaps(sai_ctx* ctx, uint64_t seed, int32_t chrom, int64_t site0, int64_t n_sites, int32_t* gaps,
+                   void* stream) {
+  if (int rc = enter(ctx)) return rc;
+  if (n_sites < 0 || site0 < 0) return fail(SAI_ERR_ARG, "negative argument");
+  if (n_sites == 0) return SAI_OK;
+  if (!gaps) return fail(SAI_ERR_ARG, "NULL buffer");
+  const unsigned grid = static_cast<unsigned>((n_sites + 255) / 256);
+  hipLaunchKernelGGL(synth_gaps_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), seed, chrom,
+                     site0, n_sites, gaps);
+  return check_launch("synth_gaps");
+}
+
+}  // extern "C"

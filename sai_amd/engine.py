@@ -1,0 +1,287 @@
+"""Host-side driver of libsaihip: device buffers (torch), streams, and the launch order.
+
+torch is plumbing here (HBM allocations, the current HIP stream, H2D/D2H copies); every
+statistic is computed by the HIP kernels behind the C ABI (include/saihip.h).  Nothing in this
+module has a CPU path: without the built library or without a gfx950 device it raises.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Optional, Sequence
+
+import numpy as np
+
+from . import _ffi
+
+RECORD_DTYPE = np.dtype(
+    [("n_sites", "<i4"), ("u_count", "<i4"), ("n_cond", "<i4"), ("n_cdd_q", "<i4"), ("q", "<f8")]
+)
+assert RECORD_DTYPE.itemsize == C.sizeof(_ffi.SaiWindowRecord) == 24
+
+FLAG_COND, FLAG_UCAND, FLAG_INVERTED = 1, 2, 4
+
+
+def _torch():
+    import torch
+
+    return torch
+
+
+def to_int8_dosage(gts) -> np.ndarray:
+    """Narrow a reference-style genotype matrix ([sites][individuals], any integer dtype,
+    negative = missing; utils.py:410) to C-contiguous int8 without changing what calc_freq
+    (stat_utils.py:45-49) would compute: every negative value is a missing call, so values below
+    -128 are stored as -1; dosages above 127 cannot be represented and are rejected."""
+    g = np.asarray(gts)
+    if g.ndim != 2:
+        raise ValueError("genotype matrix must be 2-D [sites][individuals]")
+    if g.dtype == np.int8:
+        return np.ascontiguousarray(g)
+    if g.dtype == np.bool_:
+        return np.ascontiguousarray(g.astype(np.int8))
+    if not np.issubdtype(g.dtype, np.integer):
+        raise TypeError(f"genotype matrix must have an integer dtype, got {g.dtype}")
+    if g.size and g.max() > 127:
+        raise ValueError("dosage above 127 is not representable in the int8 device layout")
+    return np.ascontiguousarray(np.maximum(g, -1).astype(np.int8))
+
+
+@dataclass
+class TiledPop:
+    """One population block resident in HBM in the tiled SoA layout of saihip.h."""
+
+    tiles: "object"  # torch int8 tensor, 1-D
+    n_sites: int
+    n_ind: int
+
+
+@dataclass
+class WindowResults:
+    records: np.ndarray  # structured [n_sets][n_windows], RECORD_DTYPE
+    offsets: np.ndarray  # int64 [n_sets][n_windows][2]
+    cdd_u: np.ndarray  # int32 flat
+    cdd_q: np.ndarray  # int32 flat
+
+    def u_list(self, s: int, w: int) -> np.ndarray:
+        o = int(self.offsets[s, w, 0])
+        return self.cdd_u[o : o + int(self.records[s, w]["u_count"])]
+
+    def q_list(self, s: int, w: int) -> np.ndarray:
+        o = int(self.offsets[s, w, 1])
+        return self.cdd_q[o : o + int(self.records[s, w]["n_cdd_q"])]
+
+
+class Engine:
+    """One libsaihip context on one GPU of this process."""
+
+    _cache: dict[int, "Engine"] = {}
+
+    @classmethod
+    def get(cls, device: Optional[int] = None) -> "Engine":
+        torch = _torch()
+        if device is None:
+            device = torch.cuda.current_device() if torch.cuda.is_available() else 0
+        if device not in cls._cache:
+            cls._cache[device] = cls(device)
+        return cls._cache[device]
+
+    def __init__(self, device: int = 0):
+        self.lib = _ffi.load()
+        torch = _torch()
+        if not torch.cuda.is_available():
+            raise RuntimeError("no GPU visible to torch: sai_amd computes on MI355X only (no CPU fallback)")
+        self.device_index = int(device)
+        self.device = torch.device("cuda", self.device_index)
+        ctx = C.c_void_p()
+        _ffi.check(self.lib.sai_ctx_create(self.device_index, C.byref(ctx)))
+        self.ctx = ctx
+
+    def close(self) -> None:
+        if getattr(self, "ctx", None):
+            self.lib.sai_ctx_destroy(self.ctx)
+            self.ctx = None
+            Engine._cache.pop(self.device_index, None)
+
+    # -- helpers ---------------------------------------------------------------------------
+
+    def _stream(self):
+        return C.c_void_p(_torch().cuda.current_stream(self.device).cuda_stream)
+
+    def _empty(self, shape, dtype):
+        return _torch().empty(shape, dtype=dtype, device=self.device)
+
+    @staticmethod
+    def _ptr(t) -> C.c_void_p:
+        return C.c_void_p(t.data_ptr() if t is not None and t.numel() else 0)
+
+    def _params_array(self, sets: Sequence[_ffi.SaiParams]):
+        arr = (_ffi.SaiParams * len(sets))()
+        for i, s in enumerate(sets):
+            arr[i] = s
+        return arr
+
+    # -- layout ----------------------------------------------------------------------------
+
+    def tile(self, gts) -> TiledPop:
+        """Upload a [sites][individuals] matrix (host numpy, any int dtype, or a device int8
+        tensor) and re-tile it on the GPU."""
+        torch = _torch()
+        if isinstance(gts, torch.Tensor):
+            if gts.dtype != torch.int8 or gts.dim() != 2:
+                raise TypeError("device genotype matrix must be a 2-D int8 tensor")
+            src = gts.to(self.device).contiguous()
+        else:
+            src = torch.from_numpy(to_int8_dosage(gts)).to(self.device)
+        n_sites, n_ind = int(src.shape[0]), int(src.shape[1])
+        nbytes = self.lib.sai_tiled_bytes(n_sites, n_ind)
+        dst = self._empty((max(nbytes, 0),), torch.int8)
+        _ffi.check(
+            self.lib.sai_tile_from_site_major(
+                self.ctx, self._ptr(src), n_sites, n_ind, n_ind, self._ptr(dst), self._stream()
+            )
+        )
+        return TiledPop(dst, n_sites, n_ind)
+
+    # -- kernels ---------------------------------------------------------------------------
+
+    def site_counts(self, pops: Sequence[TiledPop], out=None):
+        """{alt_sum, n_called} per population and site: int32 tensor [P][n_sites][2]."""
+        torch = _torch()
+        n_sites = pops[0].n_sites
+        if any(p.n_sites != n_sites for p in pops):
+            raise ValueError("all populations of one call must cover the same sites")
+        arr = (_ffi.SaiPop * len(pops))()
+        for i, p in enumerate(pops):
+            arr[i].tiles = p.tiles.data_ptr() if p.tiles.numel() else 0
+            arr[i].n_ind = p.n_ind
+            arr[i].ploidy = 1
+        if out is None:
+            out = self._empty((len(pops), n_sites, 2), torch.int32)
+        _ffi.check(self.lib.sai_site_counts(self.ctx, n_sites, len(pops), arr, self._ptr(out), self._stream()))
+        return out
+
+    def site_flags(self, counts, ploidies: Sequence[int], sets: Sequence[_ffi.SaiParams], want_adj=False, out=None):
+        """(tgt_freq f64 [n], flags u8 [S][n], adj f64 [S][2][n] or None)."""
+        torch = _torch()
+        n_pops, n_sites = int(counts.shape[0]), int(counts.shape[1])
+        pl = (C.c_int32 * n_pops)(*[int(p) for p in ploidies])
+        n_sets = len(sets)
+        if out is None:
+            tgt_freq = self._empty((n_sites,), torch.float64)
+            flags = self._empty((n_sets, n_sites), torch.uint8)
+        else:
+            tgt_freq, flags = out
+        adj = self._empty((n_sets, 2, n_sites), torch.float64) if want_adj else None
+        for s0 in range(0, n_sets, _ffi.SAI_MAX_SETS):
+            chunk = sets[s0 : s0 + _ffi.SAI_MAX_SETS]
+            _ffi.check(
+                self.lib.sai_site_flags(
+                    self.ctx, n_sites, n_pops, pl, self._ptr(counts), len(chunk), self._params_array(chunk),
+                    self._ptr(tgt_freq), self._ptr(flags[s0:]), self._ptr(adj[s0:]) if want_adj else None,
+                    self._stream(),
+                )
+            )  # fmt: skip
+        return tgt_freq, flags, adj
+
+    def window_bounds(self, pos, win_start, win_end):
+        """Site-index ranges [lo, hi) of inclusive position windows; int32 device tensors."""
+        torch = _torch()
+        ws = torch.as_tensor(np.asarray(win_start, dtype=np.int64)).to(self.device)
+        we = torch.as_tensor(np.asarray(win_end, dtype=np.int64)).to(self.device)
+        n_w = int(ws.numel())
+        lo = self._empty((n_w,), torch.int32)
+        hi = self._empty((n_w,), torch.int32)
+        _ffi.check(
+            self.lib.sai_window_bounds(
+                self.ctx, self._ptr(pos), int(pos.numel()), n_w, self._ptr(ws), self._ptr(we), self._ptr(lo),
+                self._ptr(hi), self._stream(),
+            )
+        )  # fmt: skip
+        return lo, hi
+
+    def window_stats_async(self, tgt_freq, flags, sets, lo, hi, pos, bufs):
+        """Enqueue the window kernel into caller-held buffers (no sync).  ``bufs`` =
+        (records u8 [S*W*24], offsets i64 [S*W*2], cdd_u i32, cdd_q i32, totals i64 [2])."""
+        n_sets, n_sites = int(flags.shape[0]), int(flags.shape[1])
+        if n_sets > _ffi.SAI_MAX_SETS:
+            raise ValueError("window_stats_async handles at most SAI_MAX_SETS sets per call")
+        records, offsets, cdd_u, cdd_q, totals = bufs
+        _ffi.check(
+            self.lib.sai_window_stats(
+                self.ctx, n_sites, self._ptr(tgt_freq), self._ptr(flags), n_sets, self._params_array(sets),
+                int(lo.numel()), self._ptr(lo), self._ptr(hi), self._ptr(pos) if pos is not None else None,
+                self._ptr(records), self._ptr(offsets), self._ptr(cdd_u), int(cdd_u.numel()), self._ptr(cdd_q),
+                int(cdd_q.numel()), self._ptr(totals), self._stream(),
+            )
+        )  # fmt: skip
+
+    def alloc_window_bufs(self, n_sets, n_windows, cap_u, cap_q):
+        torch = _torch()
+        return (
+            self._empty((n_sets * n_windows * RECORD_DTYPE.itemsize,), torch.uint8),
+            self._empty((n_sets * n_windows * 2,), torch.int64),
+            self._empty((max(int(cap_u), 1),), torch.int32),
+            self._empty((max(int(cap_q), 1),), torch.int32),
+            self._empty((2,), torch.int64),
+        )
+
+    def window_stats(self, tgt_freq, flags, sets, lo, hi, pos=None, cap_hint=1 << 16) -> WindowResults:
+        """Records and candidate lists of every (set, window), copied to the host."""
+        n_sets, n_w = int(flags.shape[0]), int(lo.numel())
+        rec_parts, off_parts, u_parts, q_parts = [], [], [], []
+        base_u = base_q = 0
+        for s0 in range(0, n_sets, _ffi.SAI_MAX_SETS):
+            chunk = sets[s0 : s0 + _ffi.SAI_MAX_SETS]
+            fl = flags[s0 : s0 + len(chunk)]
+            cap_u = cap_q = cap_hint
+            while True:
+                bufs = self.alloc_window_bufs(len(chunk), n_w, cap_u, cap_q)
+                self.window_stats_async(tgt_freq, fl, chunk, lo, hi, pos, bufs)
+                need_u, need_q = (int(v) for v in bufs[4].cpu().tolist())
+                if need_u <= bufs[2].numel() and need_q <= bufs[3].numel():
+                    break
+                cap_u, cap_q = max(need_u, 1), max(need_q, 1)
+            rec = np.frombuffer(bufs[0].cpu().numpy().tobytes(), dtype=RECORD_DTYPE).reshape(len(chunk), n_w)
+            off = bufs[1].cpu().numpy().reshape(len(chunk), n_w, 2).copy()
+            off[:, :, 0] += base_u
+            off[:, :, 1] += base_q
+            rec_parts.append(rec)
+            off_parts.append(off)
+            u_parts.append(bufs[2][:need_u].cpu().numpy())
+            q_parts.append(bufs[3][:need_q].cpu().numpy())
+            base_u += need_u
+            base_q += need_q
+        return WindowResults(
+            np.concatenate(rec_parts, axis=0),
+            np.concatenate(off_parts, axis=0),
+            np.concatenate(u_parts) if u_parts else np.zeros(0, np.int32),
+            np.concatenate(q_parts) if q_parts else np.zeros(0, np.int32),
+        )
+
+    # -- synthetic data --------------------------------------------------------------------
+
+    def synth_population(self, seed, chrom, site0, n_sites, pop_stream, n_ind, ploidy=2, missing_per_million=0):
+        torch = _torch()
+        nbytes = self.lib.sai_tiled_bytes(n_sites, n_ind)
+        tiles = self._empty((nbytes,), torch.int8)
+        _ffi.check(
+            self.lib.sai_synth_fill(
+                self.ctx, seed, chrom, site0, n_sites, pop_stream, n_ind, ploidy, missing_per_million,
+                self._ptr(tiles), self._stream(),
+            )
+        )  # fmt: skip
+        return TiledPop(tiles, int(n_sites), int(n_ind))
+
+    def synth_positions(self, seed, chrom, n_sites, site0=0):
+        """int32 device positions of sites [site0, site0 + n_sites) (prefix sum of the gaps of
+        sites 0..site0+n_sites-1, so any shard sees the same coordinates)."""
+        torch = _torch()
+        total = site0 + n_sites
+        gaps = self._empty((total,), torch.int32)
+        _ffi.check(self.lib.sai_synth_gaps(self.ctx, seed, chrom, 0, total, self._ptr(gaps), self._stream()))
+        pos = torch.cumsum(gaps, dim=0, dtype=torch.int64)
+        if total and int(pos[-1]) >= 2**31:
+            raise ValueError("synthetic chromosome exceeds int32 coordinates")
+        return pos[site0:].to(torch.int32).contiguous()

@@ -1,0 +1,234 @@
+"""GPU parity tests of the HIP kernels, called through the C ABI (sai_amd._ffi / Engine),
+against the numpy oracle and the committed golden vectors.  Bit-exact everywhere: integer
+counts, candidate positions, and the f64 frequencies / Q values."""
+
+import numpy as np
+import pytest
+
+from conftest import load_golden, same_f64, stat_case_inputs, unhex
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    import torch
+
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    from sai_amd.engine import Engine
+
+    return Engine.get(0)
+
+
+def tile_numpy(g8: np.ndarray) -> np.ndarray:
+    n_sites, n_ind = g8.shape
+    n_tiles = (n_sites + 63) // 64
+    pad = np.zeros((n_tiles * 64, n_ind), dtype=np.int8)
+    pad[:n_sites] = g8
+    return pad.reshape(n_tiles, 64, n_ind).transpose(0, 2, 1).reshape(-1).copy()
+
+
+def counts_numpy(g):
+    present = g >= 0
+    return np.where(present, g, 0).sum(axis=1).astype(np.int64), present.sum(axis=1).astype(np.int64)
+
+
+@pytest.mark.parametrize("shape", [(1, 1), (63, 5), (64, 16), (65, 17), (200, 64), (130, 129), (1000, 3)])
+def test_tile_layout(eng, shape):
+    rng = np.random.default_rng(shape[0] * 1000 + shape[1])
+    g = rng.integers(-3, 5, size=shape).astype(np.int8)
+    t = eng.tile(g)
+    assert np.array_equal(t.tiles.cpu().numpy(), tile_numpy(g))
+    # a wider integer input is narrowed on the host: every negative (missing) value becomes -1
+    t2 = eng.tile(g.astype(np.int64))
+    assert np.array_equal(t2.tiles.cpu().numpy(), tile_numpy(np.maximum(g, -1)))
+
+
+@pytest.mark.parametrize("n_ind", [1, 2, 15, 16, 17, 31, 200, 1000, 1001, 4100])
+def test_site_counts_exact(eng, n_ind):
+    rng = np.random.default_rng(n_ind)
+    n_sites = 333
+    g = rng.integers(0, 3, size=(n_sites, n_ind)).astype(np.int8)
+    g[rng.random(g.shape) < 0.05] = -2
+    g[rng.random(g.shape) < 0.01] = -128
+    g[rng.random(g.shape) < 0.01] = 127
+    g[5] = 127  # worst case for the 16-bit accumulators
+    g[6] = -1  # everything missing
+    other = rng.integers(-1, 2, size=(n_sites, 7)).astype(np.int8)
+    counts = eng.site_counts([eng.tile(g), eng.tile(other), eng.tile(g)]).cpu().numpy().astype(np.int64)
+    for p, m in enumerate([g, other, g]):
+        s, c = counts_numpy(m.astype(np.int64))
+        assert np.array_equal(counts[p, :, 0], s)
+        assert np.array_equal(counts[p, :, 1], c)
+
+
+STATS = load_golden("stats_cases.json")
+
+
+@pytest.mark.parametrize("case", STATS, ids=[c["name"] for c in STATS])
+def test_golden_stats_through_plugin_api(eng, case):
+    from sai_amd.stats import QStatistic, UStatistic, calc_freq, compute_matching_loci
+
+    a = stat_case_inputs(case)
+    out = case["out"]
+    mats = [a["ref_gts"], a["tgt_gts"]] + a["src_gts_list"]
+    for m, p, exp in zip(mats, a["ploidy"], out["raw_freq"]):
+        got = calc_freq(m, p)
+        assert all(same_f64(g, unhex(e)) for g, e in zip(got, exp))
+    rf, tf, cond = compute_matching_loci(
+        a["ref_gts"], a["tgt_gts"], a["src_gts_list"], a["w"], a["y_list"], a["ploidy"], a["anc"]
+    )
+    assert all(same_f64(g, unhex(e)) for g, e in zip(rf, out["ref_freq"]))
+    assert all(same_f64(g, unhex(e)) for g, e in zip(tf, out["tgt_freq"]))
+    assert cond.tolist() == out["condition"]
+    kw = dict(
+        ref_gts=a["ref_gts"], tgt_gts=a["tgt_gts"], src_gts_list=a["src_gts_list"], ref_ploidy=a["ploidy"][0],
+        tgt_ploidy=a["ploidy"][1], src_ploidy_list=a["ploidy"][2:],
+    )  # fmt: skip
+    u = UStatistic(**kw).compute(pos=a["pos"], w=a["w"], x=a["x"], y_list=a["y_list"], anc_allele_available=a["anc"])
+    assert u["name"] == "U" and isinstance(u["value"], int) and u["value"] == out["U"]
+    assert u["cdd_pos"].tolist() == out["U_cdd_pos"]
+    q = QStatistic(**kw).compute(
+        pos=a["pos"], w=a["w"], y_list=a["y_list"], quantile=a["quantile"], anc_allele_available=a["anc"]
+    )
+    assert q["name"] == "Q" and same_f64(q["value"], unhex(out["Q"]))
+    assert np.asarray(q["cdd_pos"]).astype(np.int64).tolist() == out["Q_cdd_pos"]
+    assert str(q["cdd_pos"].dtype) == out["Q_cdd_dtype"]
+
+
+def test_plugin_errors_match_reference(eng):
+    from sai_amd.stats import QStatistic, UStatistic, calc_freq, compute_matching_loci
+
+    g = load_golden("errors_and_freq.json")
+    A = np.array
+    ref, tgt = A([[0, 1, 0], [1, 1, 0], [0, 0, 1]]), A([[1, 1, 0], [0, 1, 1], [1, 1, 1]])
+    srcs = [A([[0, 0, 1], [1, 1, 0], [0, 1, 1]]), A([[1, 1, 0], [1, 0, 0], [1, 1, 0]])]
+    y2 = [("=", 0.5), ("=", 0.5)]
+    kw = dict(ref_gts=ref, tgt_gts=tgt, src_gts_list=srcs[:1], ref_ploidy=3, tgt_ploidy=1, src_ploidy_list=[2])
+    calls = {
+        "w_low": lambda: compute_matching_loci(ref, tgt, srcs, -0.1, y2, [2, 2, 2], False),
+        "w_high": lambda: compute_matching_loci(ref, tgt, srcs, 1.1, y2, [2, 2, 2], False),
+        "y_low": lambda: compute_matching_loci(ref, tgt, srcs, 0.5, [("=", -0.1)], [2, 2, 2], False),
+        "y_high": lambda: compute_matching_loci(ref, tgt, srcs, 0.5, [("=", 1.1)], [2, 2, 2], False),
+        "bad_op": lambda: compute_matching_loci(ref, tgt, srcs, 0.5, [("invalid", 0.5)], [2, 2, 2], False),
+        "len_mismatch": lambda: compute_matching_loci(ref, tgt, srcs, 0.5, [("=", 0.5)], [2, 2, 2], False),
+        "ploidy_none": lambda: calc_freq(ref, ploidy=None),
+        "ploidy_float": lambda: calc_freq(ref, ploidy=9.9),
+        "ploidy_neg": lambda: calc_freq(ref, ploidy=-100),
+        "u_missing_kw": lambda: UStatistic(**kw).compute(pos=A([0, 1, 2]), w=0.5, x=0.5, y_list=[("=", 0)]),
+        "q_missing_kw": lambda: QStatistic(**kw).compute(pos=A([0, 1, 2]), w=0.5, quantile=0.95, anc_allele_available=False),
+    }  # fmt: skip
+    for rec in g["errors"]:
+        with pytest.raises(ValueError) as ei:
+            calls[rec["label"]]()
+        assert str(ei.value) == rec["msg"]
+
+
+def _window_pass(eng, mats, ploidy, sets, pos, starts, ends):
+    import torch
+
+    pops = [eng.tile(m) for m in mats]
+    counts = eng.site_counts(pops)
+    tgt_freq, flags, _ = eng.site_flags(counts, ploidy, sets)
+    pos_dev = torch.as_tensor(pos.astype(np.int32)).to(eng.device)
+    lo, hi = eng.window_bounds(pos_dev, starts, ends)
+    return eng.window_stats(tgt_freq, flags, sets, lo, hi, pos=pos_dev, cap_hint=8), lo.cpu().numpy(), hi.cpu().numpy()
+
+
+def test_batched_windows_vs_oracle(eng):
+    """Many overlapping windows, two parameter sets, missing data: records and candidate lists
+    equal the per-window oracle (the reference's structure) bit for bit."""
+    from oracle import sai_oracle as O
+    from sai_amd import _ffi
+
+    rng = np.random.default_rng(99)
+    n_sites = 6000
+    pos = np.cumsum(rng.integers(1, 50, n_sites)).astype(np.int64)
+    p = rng.random(n_sites) ** 4
+    intro = rng.random(n_sites) < 0.02
+    pr, pt = p.copy(), p.copy()
+    pr[intro] = 0.0
+    pt[intro] = 0.2 + 0.7 * rng.random(int(intro.sum()))
+    ref = rng.binomial(2, pr[:, None], size=(n_sites, 50)).astype(np.int64)
+    tgt = rng.binomial(2, pt[:, None], size=(n_sites, 37)).astype(np.int64)
+    src = rng.binomial(2, p[:, None], size=(n_sites, 2)).astype(np.int64)
+    src[intro] = 2
+    for m in (ref, tgt, src):
+        m[rng.random(m.shape) < 0.01] = -2
+    windows = O.split_windows(pos, 5000, 1000)
+    starts = np.array([w[0] for w in windows])
+    ends = np.array([w[1] for w in windows])
+    specs = [
+        dict(w=0.05, x=0.3, quantile=0.95, y_list=[("=", 1.0)], anc=True),
+        dict(w=0.5, x=0.1, quantile=0.5, y_list=[(">=", 0.5)], anc=False),
+        dict(w=1.0, x=0.0, quantile=1.0, y_list=[("<=", 1.0)], anc=True),  # nearly every site qualifies
+    ]
+    sets = [_ffi.make_params(s["w"], s["x"], s["quantile"], s["y_list"], s["anc"]) for s in specs]
+    res, lo, hi = _window_pass(eng, [ref, tgt, src], [2, 2, 2], sets, pos, starts, ends)
+    assert res.records.shape == (3, len(windows))
+    for si, s in enumerate(specs):
+        for wi, (ws, we) in enumerate(windows):
+            m = (pos >= ws) & (pos <= we)
+            assert (lo[wi], hi[wi]) == (np.searchsorted(pos, ws), np.searchsorted(pos, we, side="right"))
+            kw = dict(ref_gts=ref[m], tgt_gts=tgt[m], src_gts_list=[src[m]], ref_ploidy=2, tgt_ploidy=2,
+                      src_ploidy_list=[2], pos=pos[m], w=s["w"], y_list=s["y_list"], anc_allele_available=s["anc"])  # fmt: skip
+            eu = O.u_stat(x=s["x"], **kw)
+            eq = O.q_stat(quantile=s["quantile"], **kw)
+            rec = res.records[si, wi]
+            assert rec["n_sites"] == int(m.sum())
+            assert rec["u_count"] == eu["value"]
+            assert res.u_list(si, wi).tolist() == eu["cdd_pos"].tolist()
+            assert same_f64(rec["q"], eq["value"]), (si, wi, rec, eq["value"])
+            assert res.q_list(si, wi).tolist() == np.asarray(eq["cdd_pos"]).astype(np.int64).tolist()
+
+
+def test_quantile_beyond_lds_capacity(eng):
+    """More than 4096 qualifying sites in one window: the radix select falls back to re-reading
+    the per-site arrays; still numpy's 'linear' quantile bit for bit."""
+    from oracle import sai_oracle as O
+    from sai_amd import _ffi
+
+    rng = np.random.default_rng(3)
+    n_sites = 20000
+    ref = np.zeros((n_sites, 4), dtype=np.int64)
+    tgt = rng.integers(0, 3, size=(n_sites, 23)).astype(np.int64)
+    tgt[rng.random(tgt.shape) < 0.05] = -1
+    src = np.full((n_sites, 1), 2, dtype=np.int64)
+    pos = np.arange(1, n_sites + 1, dtype=np.int64) * 3
+    for quantile in (0.0, 0.3, 0.95, 1.0):
+        sets = [_ffi.make_params(0.5, 0.5, quantile, [("=", 1.0)], True)]
+        res, _, _ = _window_pass(eng, [ref, tgt, src], [2, 2, 2], sets, pos, np.array([1, 1]), np.array([10**9, 20000]))
+        for wi, we in enumerate([10**9, 20000]):
+            m = pos <= we
+            kw = dict(ref_gts=ref[m], tgt_gts=tgt[m], src_gts_list=[src[m]], ref_ploidy=2, tgt_ploidy=2,
+                      src_ploidy_list=[2], pos=pos[m], w=0.5, y_list=[("=", 1.0)], anc_allele_available=True)  # fmt: skip
+            eq = O.q_stat(quantile=quantile, **kw)
+            eu = O.u_stat(x=0.5, **kw)
+            rec = res.records[0, wi]
+            assert rec["n_cond"] == int(m.sum()) and rec["u_count"] == eu["value"]
+            assert same_f64(rec["q"], eq["value"])
+            assert res.q_list(0, wi).tolist() == eq["cdd_pos"].tolist()
+            assert res.u_list(0, wi).tolist() == eu["cdd_pos"].tolist()
+
+
+def test_synth_device_equals_host(eng):
+    import ctypes as C
+
+    from sai_amd import _ffi
+
+    lib = _ffi.load()
+    seed, chrom = 20260633, 3
+    for pop_stream, n_ind, ploidy, mpm in [(0, 37, 2, 0), (1, 64, 2, 1000), (2, 2, 2, 1000), (3, 5, 4, 50000), (1, 9, 1, 0)]:
+        n_sites, site0 = 1000, 12345
+        host = np.empty((n_sites, n_ind), dtype=np.int8)
+        _ffi.check(lib.sai_synth_fill_host(seed, chrom, site0, n_sites, pop_stream, n_ind, ploidy, mpm,
+                                           host.ctypes.data_as(C.c_void_p)))  # fmt: skip
+        dev = eng.synth_population(seed, chrom, site0, n_sites, pop_stream, n_ind, ploidy, mpm)
+        assert np.array_equal(dev.tiles.cpu().numpy(), tile_numpy(host))
+        assert host.max() <= ploidy and host.min() >= -ploidy
+    gaps = np.empty(5000, dtype=np.int32)
+    _ffi.check(lib.sai_synth_gaps_host(seed, chrom, 0, 5000, gaps.ctypes.data_as(C.c_void_p)))
+    pos = eng.synth_positions(seed, chrom, 5000).cpu().numpy()
+    assert np.array_equal(pos, np.cumsum(gaps)) and gaps.min() >= 1 and gaps.max() <= 49
+    part = eng.synth_positions(seed, chrom, 1000, site0=4000).cpu().numpy()
+    assert np.array_equal(part, pos[4000:])
