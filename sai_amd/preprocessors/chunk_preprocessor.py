@@ -1,0 +1,67 @@
+"""Chunk driver (mirror of sai/preprocessors/chunk_preprocessor.py:28-158): one chromosome
+region -> all its windows, computed in batched launches on the GPU."""
+
+from __future__ import annotations
+
+from typing import Any
+
+from ..generators.window_generator import WindowGenerator
+from ..utils.samples import parse_ind_file
+from .data_preprocessor import DataPreprocessor
+from .feature_preprocessor import FeaturePreprocessor
+
+
+class ChunkPreprocessor(DataPreprocessor):
+    def __init__(
+        self,
+        vcf_file: str,
+        ref_ind_file: str,
+        tgt_ind_file: str,
+        src_ind_file: str,
+        out_ind_file: str,
+        win_len: int,
+        win_step: int,
+        output_file: str,
+        ploidy_config,
+        stat_config,
+        anc_allele_file: str = None,
+        num_src: int = 1,
+    ):
+        self.vcf_file = vcf_file
+        self.ref_ind_file = ref_ind_file
+        self.tgt_ind_file = tgt_ind_file
+        self.src_ind_file = src_ind_file
+        self.out_ind_file = out_ind_file
+        self.win_len = win_len
+        self.win_step = win_step
+        self.ploidy_config = ploidy_config
+        self.anc_allele_file = anc_allele_file
+        # chunk_preprocessor.py:94-95: every population of the source file is used together
+        self.num_src = len(parse_ind_file(src_ind_file).keys())
+        self.feature_preprocessor = FeaturePreprocessor(
+            output_file=output_file,
+            stat_config=stat_config,
+            anc_allele_available=anc_allele_file is not None,
+        )
+
+    def run(self, chr_name: str, start: int, end: int) -> list[dict[str, Any]]:
+        """Items of all windows of [start, end] (chunk_preprocessor.py:105-147)."""
+        window_generator = WindowGenerator(
+            vcf_file=self.vcf_file,
+            chr_name=chr_name,
+            start=start,
+            end=end,
+            ref_ind_file=self.ref_ind_file,
+            tgt_ind_file=self.tgt_ind_file,
+            src_ind_file=self.src_ind_file,
+            out_ind_file=self.out_ind_file,
+            win_len=self.win_len,
+            win_step=self.win_step,
+            ploidy_config=self.ploidy_config,
+            anc_allele_file=self.anc_allele_file,
+            num_src=self.num_src,
+        )
+        return self.feature_preprocessor.run_windows(window_generator)
+
+    def process_items(self, items: list[dict[str, Any]]) -> None:
+        self.feature_preprocessor.process_items(items)

@@ -1,0 +1,107 @@
+"""``score`` -- the function behind ``sai score`` (mirror of sai/sai.py:33-151)."""
+
+from __future__ import annotations
+
+import os
+from pathlib import Path
+
+import yaml
+
+from .configs import GlobalConfig
+from .generators import ChunkGenerator
+from .preprocessors import ChunkPreprocessor
+from .utils import UniqueKeyLoader
+
+_POLARISED = ("fd", "df", "Danc", "Dplus")
+
+
+def load_config(config: str) -> GlobalConfig:
+    """YAML -> GlobalConfig with the reference's error behaviour (sai.py:65-73)."""
+    try:
+        with open(config, "r") as f:
+            config_dict = yaml.load(f, Loader=UniqueKeyLoader)
+    except FileNotFoundError:
+        raise FileNotFoundError(f"Configuration file '{config}' not found.")
+    except yaml.YAMLError as e:
+        raise ValueError(f"Error parsing YAML configuration file '{config}': {e}")
+    return GlobalConfig(**config_dict)
+
+
+def header_line(stat_config, ploidy_config) -> str:
+    """sai.py:107-131: fixed columns + one column per statistic in YAML order (U/Q always a
+    single column; a statistic set to False is left out)."""
+    cols = ["Chrom", "Start", "End", "Ref", "Tgt", "Src", "Outgroup", "N(Variants)"]
+    src_pops = list(ploidy_config.root["src"].keys())
+    for name, value in stat_config.root.items():
+        if name not in ("U", "Q") and value is False:
+            continue
+        if name in ("U", "Q") or len(src_pops) <= 1:
+            cols.append(name)
+        else:
+            cols.extend(f"{name}.{sp}" for sp in src_pops)
+    return "\t".join(cols) + "\n"
+
+
+def write_headers(output_file: str, stat_config, ploidy_config) -> None:
+    """Create the output directory, the TSV with its header and the .U.log/.Q.log files
+    (sai.py:133-144)."""
+    directory = os.path.dirname(output_file)
+    if directory:
+        os.makedirs(directory, exist_ok=True)
+    with open(output_file, "w") as f:
+        f.write(header_line(stat_config, ploidy_config))
+    for key in ("U", "Q"):
+        if key in stat_config.root:
+            with open(Path(output_file).with_suffix(f".{key}.log"), "w") as f:
+                f.write(f"Chrom\tStart\tEnd\t{key}_SNP\n")
+
+
+def score(
+    vcf_file: str,
+    chr_name: str,
+    win_len: int,
+    win_step: int,
+    anc_allele_file: str,
+    output_file: str,
+    config: str,
+    num_workers: int,
+) -> None:
+    """Sliding-window U/Q scores of one chromosome, written as the reference writes them
+    (TSV + ``.U.log`` + ``.Q.log``).  ``num_workers`` is accepted for signature compatibility;
+    the windows of the chromosome are computed in batched GPU launches by one process (use
+    ``sai_amd.distributed`` under torchrun to shard window ranges over several GPUs)."""
+    global_config = load_config(config)
+    stat_config = global_config.statistics
+    ploidy_config = global_config.ploidies
+    pop_config = global_config.populations
+
+    if anc_allele_file is None:  # sai.py:79-84
+        for stat_name in stat_config.root.keys():
+            if stat_name in _POLARISED:
+                raise ValueError(
+                    f"The {stat_name} statistic requires polarized data, please provide the ancestral allele information with `--anc-alleles`."
+                )
+
+    generator = ChunkGenerator(
+        vcf_file=vcf_file, chr_name=chr_name, window_size=win_len, step_size=win_step, num_chunks=1
+    )
+    preprocessor = ChunkPreprocessor(
+        vcf_file=vcf_file,
+        ref_ind_file=pop_config.get_population("ref"),
+        tgt_ind_file=pop_config.get_population("tgt"),
+        src_ind_file=pop_config.get_population("src"),
+        out_ind_file=pop_config.get_population("outgroup"),
+        win_len=win_len,
+        win_step=win_step,
+        output_file=output_file,
+        ploidy_config=ploidy_config,
+        stat_config=stat_config,
+        anc_allele_file=anc_allele_file,
+    )
+    preprocessor.feature_preprocessor._active_stats()  # reject statistics outside the U/Q path early
+    write_headers(output_file, stat_config, ploidy_config)
+
+    items = []
+    for params in generator.get():
+        items.extend(preprocessor.run(**params))
+    preprocessor.process_items(items)

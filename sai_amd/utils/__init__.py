@@ -1,0 +1,17 @@
+from .genomic_dataclasses import ChromosomeData
+from .read_data import read_data
+from .samples import parse_ind_file
+from .unique_key_loader import UniqueKeyLoader
+from .vcf import read_anc_allele
+from .windows import split_genome, split_index_ranges, split_windows_ranges
+
+__all__ = [
+    "ChromosomeData",
+    "UniqueKeyLoader",
+    "parse_ind_file",
+    "read_anc_allele",
+    "read_data",
+    "split_genome",
+    "split_index_ranges",
+    "split_windows_ranges",
+]

@@ -1,0 +1,358 @@
+"""CPU tests of the host side of sai_amd: window grid, chunking, VCF ingest and polarisation,
+configs, generators, output formatting -- against the golden vectors and the pins the
+reference's own tests hold (cited per test).  No GPU is touched."""
+
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import DATA, load_golden, unhex
+
+
+# ---- window grid (a9) --------------------------------------------------------------------
+
+
+def test_split_genome_golden():
+    from sai_amd.utils import split_genome, split_windows_ranges
+
+    g = load_golden("window_grid.json")
+    for c in g["split"]:
+        w = split_genome(np.array(c["pos"]), c["window_size"], c["step_size"], c["start"])
+        assert len(w) == c["n"]
+        assert [list(t) for t in w[:6]] == c["head"] and [list(t) for t in w[-3:]] == c["tail"]
+    for c in g["errors"]:
+        with pytest.raises(ValueError) as ei:
+            split_genome(np.array(c["pos"]), c["window_size"], c["step_size"])
+        assert str(ei.value) == c["msg"]
+    for c in g["chunks"]:
+        w = split_genome(np.array(c["pos"]), c["window_size"], c["step_size"])
+        assert [list(t) for t in split_windows_ranges(w, c["num_chunks"])] == c["chunks"]
+    # reference tests/utils/test_utils.py:423-431
+    assert split_genome(np.arange(0, 101, 10), 30, 20) == [(1, 30), (21, 50), (41, 70), (61, 90), (81, 110)]
+
+
+def test_split_genome_matches_oracle_on_a_sweep():
+    from oracle import sai_oracle as O
+    from sai_amd.utils import split_genome
+
+    rng = np.random.default_rng(0)
+    for _ in range(300):
+        a = int(rng.integers(0, 10**6))
+        b = a + int(rng.integers(0, 10**5))
+        step = int(rng.integers(1, 5000))
+        win = step + int(rng.integers(0, 20000))
+        start = None if rng.random() < 0.5 else int(rng.integers(1, a + 2))
+        assert split_genome([a, b], win, step, start) == O.split_windows([a, b], win, step, start)
+
+
+def test_chunk_generator_pins(in_repo_root):
+    # reference tests/generators/test_chunk_generator.py:25-51
+    from sai_amd.generators import ChunkGenerator
+
+    g = ChunkGenerator(vcf_file="tests/data/test.data.vcf", chr_name="21", step_size=5000, window_size=10000, num_chunks=2)
+    assert len(g) == 2 and g.chunks == [(1, 30000), (25001, 55000)]
+    assert list(g.get()) == [{"chr_name": "21", "start": 1, "end": 30000}, {"chr_name": "21", "start": 25001, "end": 55000}]
+    with pytest.raises(ValueError, match="Chromosome 1 not found in VCF."):
+        ChunkGenerator(vcf_file="tests/data/test.data.vcf", chr_name="1", step_size=10000, window_size=10000, num_chunks=2)
+
+
+# ---- ingest (a14, minimal) ---------------------------------------------------------------
+
+
+def test_vcf_reader_example_matches_golden_genotypes(in_repo_root):
+    from sai_amd.utils import parse_ind_file
+    from sai_amd.utils.vcf import dosage_matrices, read_region
+
+    ex = load_golden("example_vcf.json")["genotypes"]
+    names = [f"ind{i}" for i in range(1, 12)]
+    reg = read_region("tests/data/example.vcf", "21", names)
+    assert reg.pos.tolist() == ex["pos"] and reg.pos.dtype == np.int32
+    dos, fdos = dosage_matrices(reg, list(range(11)), 2)
+    assert dos.dtype == np.int8 and dos.tolist() == ex["gt"]
+    assert dos[11, 0] == -2 and fdos[11, 0] == 4  # ".|." flips to 2+2, as abs(g - 1) does (utils.py:555)
+    assert parse_ind_file("tests/data/example.ref.ind.list") == {"AFR": ["ind1", "ind2", "ind3", "ind4", "ind5"]}
+    sub = read_region("tests/data/example.vcf", "21", ["ind11", "ind6"], start=222, end=999)
+    assert sub.pos.tolist() == [222, 333, 444, 555, 666, 777, 888, 999] and sub.gt[0] == ["1|1", "0|1"]
+    with pytest.raises(ValueError, match="samples not found"):
+        read_region("tests/data/example.vcf", "21", ["nobody"])
+
+
+def test_read_data_and_polarisation_pins(in_repo_root):
+    """tests/utils/test_utils.py:204-209 (BED), :269-318 (polarised genotypes and positions)."""
+    from sai_amd.configs import PloidyConfig
+    from sai_amd.utils import read_anc_allele, read_data
+
+    assert read_anc_allele("tests/data/test.anc.allele.bed", "21") == {"21": {2309: "G", 7879: "A", 11484: "-", 48989: "C"}}
+    pc = PloidyConfig({"ref": {"ref1": 2}, "tgt": {"tgt1": 2, "tgt2": 2}, "src": {"src1": 2, "src2": 2}})
+    plain = read_data("tests/data/test.data.vcf", "21", pc, "tests/data/test.ref.ind.list", "tests/data/test.tgt.ind.list", None)
+    assert plain["src"] == (None, None) and plain["outgroup"] == (None, None)
+    assert len(plain["ref"][0]["ref1"].POS) == 19 and plain["ref"][0]["ref1"].GT.shape == (19, 2)
+    assert plain["tgt"][1] == {"tgt1": ["ind1", "ind2"], "tgt2": ["ind3", "ind4"]}
+    pol = read_data("tests/data/test.data.vcf", "21", pc, "tests/data/test.ref.ind.list", "tests/data/test.tgt.ind.list",
+                    None, anc_allele_file="tests/data/test.anc.allele.bed")  # fmt: skip
+    exp_pos = [2309, 7879, 48989]
+    # expected phased calls of the reference test, summed over the ploidy axis
+    assert pol["tgt"][0]["tgt1"].POS.tolist() == exp_pos and pol["tgt"][0]["tgt2"].POS.tolist() == exp_pos
+    assert pol["ref"][0]["ref1"].GT.tolist() == [[0, 0], [2, 2], [0, 0]]
+    assert pol["tgt"][0]["tgt1"].GT.tolist() == [[1, 0], [2, 1], [0, 1]]
+    assert pol["tgt"][0]["tgt2"].GT.tolist() == [[0, 0], [2, 2], [0, 0]]
+    with pytest.raises(ValueError, match="No ancestral allele is found for chromosome 21 in the region"):
+        read_anc_allele("tests/data/test.anc.allele.bed", "21", start=100, end=200)
+    with pytest.raises(ValueError, match="not found in sample file"):
+        read_data("tests/data/test.data.vcf", "21", PloidyConfig({"ref": {"nope": 2}, "tgt": {"tgt1": 2}, "src": {"s": 2}}),
+                  "tests/data/test.ref.ind.list", "tests/data/test.tgt.ind.list", None)  # fmt: skip
+
+
+def test_mixed_ploidy_gz_ingest(in_repo_root):
+    from sai_amd.configs import PloidyConfig
+    from sai_amd.utils import read_data
+
+    pc = PloidyConfig({"ref": {"ref1": 2}, "tgt": {"tgt1": 4, "tgt2": 4}, "src": {"src1": 4, "src2": 4}})
+    d = read_data("tests/data/test.mixed.ploidy.data.vcf.gz", "21", pc, "tests/data/test.ref.ind.list",
+                  "tests/data/test.tgt.ind.list", "tests/data/test.src.ind.list")  # fmt: skip
+    assert d["tgt"][0]["tgt1"].GT[0].tolist() == [2, 0]  # 1|0|1|0 and 0|0|0|0
+    assert d["ref"][0]["ref1"].GT[3].tolist() == [0, 1] and d["src"][0]["src2"].GT[3].tolist() == [4]
+
+
+# ---- generators (a8) ---------------------------------------------------------------------
+
+
+def test_window_generator_counts_and_none_branch(in_repo_root):
+    # reference tests/generators/test_window_generator.py:58-97 (380 windows; None generator)
+    from sai_amd.configs import PloidyConfig
+    from sai_amd.generators import WindowGenerator
+
+    pc = PloidyConfig({"ref": {"ref1": 2}, "tgt": {"tgt1": 2, "tgt2": 2}, "src": {"src1": 2, "src2": 2}})
+    kw = dict(vcf_file="tests/data/test.data.vcf", chr_name="21", ref_ind_file="tests/data/test.ref.ind.list",
+              tgt_ind_file="tests/data/test.tgt.ind.list", src_ind_file="tests/data/test.src.ind.list", out_ind_file=None,
+              win_len=1000, win_step=500, ploidy_config=pc)  # fmt: skip
+    g = WindowGenerator(**kw)
+    items = list(g.get())
+    assert len(items) == 380 == len(g)
+    first = items[0]
+    assert first["ref_pop"] == "ref1" and set(first) == {
+        "chr_name", "ref_pop", "tgt_pop", "src_pop_list", "out_pop", "start", "end", "pos", "ref_gts", "tgt_gts",
+        "src_gts_list", "out_gts", "ploidy_config"}  # fmt: skip
+    g.ref_data = None
+    none_items = list(g.get())
+    assert len(none_items) == 380 and none_items[0]["ref_gts"] is None and len(none_items[0]["pos"]) == 0
+    assert none_items[0]["ploidy_config"].get_ploidy("src")[0] == 2
+    g2 = WindowGenerator(**dict(kw, num_src=2))
+    items2 = list(g2.get())
+    assert len(items2) == 190 and all(len(i["src_pop_list"]) == 2 for i in items2)
+    with pytest.raises(ValueError, match="`win_len` must be greater than 0."):
+        WindowGenerator(**dict(kw, win_len=0))
+
+
+PIPE = load_golden("pipeline.json")
+
+
+def _from_scenario(sc):
+    from sai_amd.configs import PloidyConfig
+    from sai_amd.generators import WindowGenerator
+    from sai_amd.utils import ChromosomeData
+
+    pos = np.array(sc["pos"], dtype=np.int32)
+    start, end = sc["start"], sc["end"]
+    sel = np.ones(len(pos), bool) if start is None else (pos >= start) & (pos <= end)
+    data = {
+        g: {k: ChromosomeData(pos[sel], None, None, np.array(v, dtype=np.int8).reshape(len(pos), -1)[sel])
+            for k, v in sc["gts"][g].items()}
+        for g in ("ref", "tgt", "src")
+    }  # fmt: skip
+    return WindowGenerator.from_arrays(
+        sc["chr_name"], data["ref"], data["tgt"], data["src"], sc["win_len"], sc["win_step"],
+        PloidyConfig(sc["ploidies"]), start=start, end=end,
+    ), pos  # fmt: skip
+
+
+@pytest.mark.parametrize("sc", PIPE, ids=[s["name"] for s in PIPE])
+def test_window_generator_equals_reference_sequence(sc):
+    """Same ordered (ref, tgt, src, start, end, nsnps, first site) sequence as the reference's
+    WindowGenerator produced on the same resident arrays."""
+    wg, pos = _from_scenario(sc)
+    got = []
+    for it in wg.get():
+        p = it["pos"]
+        lo = int(np.searchsorted(pos, p[0])) if len(p) else -1
+        got.append([it["ref_pop"], it["tgt_pop"], list(it["src_pop_list"]), int(it["start"]), int(it["end"]), len(p), lo])
+        if len(p):
+            assert it["ref_gts"].shape[0] == len(p) == it["tgt_gts"].shape[0]
+    assert got == sc["windows"]
+
+
+# ---- configs (a12) -----------------------------------------------------------------------
+
+
+def test_configs_behaviour(in_repo_root):
+    from pydantic import ValidationError
+
+    from sai_amd.configs import GlobalConfig, PloidyConfig, PopConfig, StatConfig
+
+    sc = StatConfig({"U": {"ref": {"a": 0.01}, "tgt": {"b": 0.5}, "src": {"n": "=1", "d": ">=0.8"}}, "fd": False})
+    assert sc.get_parameters("U")["src"] == {"n": ("=", 1.0), "d": (">=", 0.8)}
+    assert sc.get_parameters("Q") is None and sc.get_parameters("fd") is False
+    for bad in (
+        {"X": True},
+        {"U": {"ref": {"a": 0.1}, "tgt": {"b": 0.5}}},
+        {"U": {"ref": {"a": 1.5}, "tgt": {"b": 0.5}, "src": {"n": "=1"}}},
+        {"U": {"ref": {"a": 0.5}, "tgt": {"b": 0.5}, "src": {"n": "1"}}},
+        {"Q": {"ref": {"a": 0.5}, "tgt": {"b": 0.5}, "src": {"n": "=1.5"}}},
+        {"Q": {"ref": {"a": 0.5}, "tgt": {"b": 0.5}, "src": {"n": "=abc"}}},
+    ):
+        with pytest.raises(ValueError):
+            StatConfig(bad)
+    pc = PloidyConfig({"ref": {"a": 2}, "tgt": {"b": 4}, "src": {"n": 2, "d": 1}})
+    assert pc.get_ploidy("src") == [2, 1] and pc.get_ploidy("tgt", "b") == 4 and pc.get_ploidy("outgroup") is None
+    with pytest.raises(KeyError):
+        pc.get_ploidy("ref", "zzz")
+    with pytest.raises(ValidationError, match="Missing required ploidy keys"):
+        PloidyConfig({"ref": {"a": 2}, "tgt": {"b": 2}})
+    with pytest.raises(ValidationError, match="Unsupported ploidy keys"):
+        PloidyConfig({"ref": {"a": 2}, "tgt": {"b": 2}, "src": {"c": 2}, "zzz": {"c": 2}})
+    with pytest.raises(ValidationError, match="must be a positive integer"):
+        PloidyConfig({"ref": {"a": 0}, "tgt": {"b": 2}, "src": {"c": 2}})
+    with pytest.raises(ValueError, match="Missing required population keys"):
+        PopConfig({"ref": "tests/data/example.ref.ind.list"})
+    with pytest.raises(ValueError, match="does not exist"):
+        PopConfig({"ref": "nope", "tgt": "nope", "src": "nope"})
+    import yaml
+
+    from sai_amd.utils import UniqueKeyLoader
+
+    cfg = yaml.load(open("tests/data/example.u_and_q.config.yaml"), Loader=UniqueKeyLoader)
+    gc = GlobalConfig(**cfg)
+    assert list(gc.statistics.root) == ["U", "Q"] and gc.populations.get_population("outgroup") is None
+    with pytest.raises(ValueError, match="Missing required fields in configuration: ploidies"):
+        GlobalConfig(**{k: v for k, v in cfg.items() if k != "ploidies"})
+    bad = json.loads(json.dumps(cfg))
+    bad["statistics"]["Q"]["tgt"] = {"popB": 0.9}
+    with pytest.raises(ValueError, match=r"Population 'popB' used in statistics\[Q\]\[tgt\] is not defined in ploidies\[tgt\]"):
+        GlobalConfig(**bad)
+    with pytest.raises(ValueError, match="Duplicate key in YAML"):
+        yaml.load("a: 1\na: 2\n", Loader=UniqueKeyLoader)
+
+
+# ---- output (a10) ------------------------------------------------------------------------
+
+
+def _items_from_golden(sc):
+    names = list(sc["stats"].keys())
+    items = []
+    for win, g in zip(sc["windows"], sc["items"]):
+        it = {"chr_name": sc["chr_name"], "ref_pop": win[0], "tgt_pop": win[1], "src_pop_list": tuple(win[2]),
+              "start": win[3], "end": win[4], "out_pop": "NA", "nsnps": g["nsnps"], "cdd_pos": {}}  # fmt: skip
+        for k in names:
+            v = g[k]
+            it[k] = v if isinstance(v, int) else np.float64(unhex(v))
+            if isinstance(v, str) and v == "nan":
+                it[k] = np.nan
+            it["cdd_pos"][k] = np.array(g[f"{k}_cdd"], dtype=np.int32) if g[f"{k}_cdd"] else np.array([])
+        items.append(it)
+    return items, names
+
+
+@pytest.mark.parametrize("sc", PIPE, ids=[s["name"] for s in PIPE])
+def test_process_items_text_equals_reference(sc, tmp_path):
+    from sai_amd.configs import PloidyConfig, StatConfig
+    from sai_amd.preprocessors import FeaturePreprocessor
+    from sai_amd.sai import write_headers
+
+    items, names = _items_from_golden(sc)
+    out = tmp_path / "sub" / "o.tsv"
+    stat_config = StatConfig(json.loads(json.dumps(sc["stats"])))
+    write_headers(str(out), stat_config, PloidyConfig(sc["ploidies"]))
+    fp = FeaturePreprocessor(str(out), stat_config, sc["anc_allele_available"])
+    fp.process_items(items)
+    head = "Chrom\tStart\tEnd\tRef\tTgt\tSrc\tOutgroup\tN(Variants)\t" + "\t".join(names) + "\n"
+    assert out.read_text() == head + sc["text"]["tsv"]
+    for k in names:
+        assert (tmp_path / "sub" / f"o.{k}.log").read_text() == f"Chrom\tStart\tEnd\t{k}_SNP\n" + sc["text"][k]
+
+
+def test_process_items_reference_line(tmp_path):
+    # reference tests/preprocessors/test_feature_preprocessor.py:128-159
+    from sai_amd.configs import StatConfig
+    from sai_amd.preprocessors import FeaturePreprocessor
+
+    sc = StatConfig({"DD": False,
+                     "U": {"ref": {"ref1": 0.3}, "tgt": {"tgt1": 0.5}, "src": {"src1": "=1", "src2": "=1"}},
+                     "Q": {"ref": {"ref1": 0.3}, "tgt": {"tgt1": 0.95}, "src": {"src1": "=0.2", "src2": "=0.4"}}})  # fmt: skip
+    out = tmp_path / "t.tsv"
+    fp = FeaturePreprocessor(str(out), sc)
+    item = {"chr_name": "21", "start": 1000, "end": 2000, "ref_pop": "ref1", "tgt_pop": "tgt1", "out_pop": "NA",
+            "src_pop_list": ["src1", "src2"], "nsnps": 10, "U": 5, "Q": 0.8, "cdd_pos": {"U": np.array([]), "Q": np.array([])}}  # fmt: skip
+    fp.process_items([item])
+    assert out.read_text() == load_golden("feature_inline.json")["process_items_line"]
+    assert (tmp_path / "t.U.log").read_text() == "21\t1000\t2000\tNA\n"
+    with pytest.raises(ValueError, match="outside the U/Q path"):
+        FeaturePreprocessor(str(out), StatConfig({"fd": True})).process_items([])
+
+
+def test_score_config_errors_without_gpu(in_repo_root, tmp_path):
+    # reference tests/test_sai.py:66-89, 113-124
+    from sai_amd.sai import score
+
+    kw = dict(vcf_file="tests/data/example.vcf", chr_name="21", win_len=6666, win_step=6666, anc_allele_file=None,
+              output_file=str(tmp_path / "o.tsv"), num_workers=1)  # fmt: skip
+    with pytest.raises(FileNotFoundError, match="not found"):
+        score(config="config.yaml", **kw)
+    with pytest.raises(ValueError, match="Error parsing YAML configuration file"):
+        score(config="tests/data/invalid.yaml", **kw)
+    with pytest.raises(ValueError, match="requires polarized data"):
+        score(config="tests/data/test_mixed_ploidy.config.yaml", **kw)
+
+
+def test_cli_parser(in_repo_root):
+    import argparse
+
+    from sai_amd.__main__ import _sai_cli_parser
+    from sai_amd.parsers.argument_validation import existed_file, positive_int
+
+    args = _sai_cli_parser().parse_args(
+        ["score", "--vcf", "tests/data/example.vcf", "--chr-name", "21", "--output", "o.tsv", "--config",
+         "tests/data/test_sai.config.yaml"]  # fmt: skip
+    )
+    assert (args.win_len, args.win_step, args.anc_alleles, args.chr_name) == (50000, 10000, None, "21")
+    with pytest.raises(argparse.ArgumentTypeError, match="0 is not a positive integer"):
+        positive_int("0")
+    with pytest.raises(argparse.ArgumentTypeError, match="abc is not a valid integer"):
+        positive_int("abc")
+    with pytest.raises(argparse.ArgumentTypeError, match="non_existent_file is not found"):
+        existed_file("non_existent_file")
+
+
+def test_registry_behaviour():
+    # reference tests/registries/test_registries.py
+    import sai_amd.stats  # noqa: F401
+    from sai_amd.registries import STAT_REGISTRY, GenericRegistry
+    from sai_amd.stats import QStatistic, UStatistic
+
+    assert STAT_REGISTRY.get("U") is UStatistic and STAT_REGISTRY.get("Q") is QStatistic
+    assert sorted(STAT_REGISTRY.list_registered()) == ["Q", "U"]
+    with pytest.raises(KeyError, match="No component registered under name 'nope'"):
+        STAT_REGISTRY.get("nope")
+
+    class R(GenericRegistry):
+        pass
+
+    r = R()
+    r.register("a")(int)
+    with pytest.raises(ValueError, match="'a' is already registered."):
+        r.register("a")(float)
+
+
+def test_to_int8_dosage():
+    from sai_amd.engine import to_int8_dosage
+
+    g = np.array([[0, 2, -2], [-300, 127, 1]], dtype=np.int64)
+    assert to_int8_dosage(g).tolist() == [[0, 2, -1], [-1, 127, 1]]
+    assert to_int8_dosage(g.astype(np.int8, casting="unsafe")[:1]).dtype == np.int8
+    with pytest.raises(ValueError, match="above 127"):
+        to_int8_dosage(np.array([[128]]))
+    with pytest.raises(TypeError):
+        to_int8_dosage(np.array([[0.5]]))
+    with pytest.raises(ValueError, match="2-D"):
+        to_int8_dosage(np.array([1, 2]))
