@@ -1,0 +1,282 @@
+#!/usr/bin/env python3
+"""Benchmark of the sliding-window U/Q hot path on MI355X.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[2], the configuration the metric is quoted on): one synthetic
+chromosome per GPU -- 1e7 sites, 1,000 ref / 1,000 tgt / 2 src diploids, 50 kb windows every
+25 kb, U (w=0.01, x=0.5, y "=1") and Q95 -- generated in place in HBM by the counter-based
+synth-v1 generator (rank r holds chromosome r+1: weak scaling, windows are independent).  One
+step = one pass of the whole path over the resident block: site_counts -> site_flags ->
+window_bounds -> window_stats -> copy of the per-window records to pinned host memory, plus, for
+N > 1, the RCCL gather of all records to rank 0.  Rank 0 prints one JSON line.
+
+`roofline` prices the dominant kernel (site_counts) with HIP events on the launch stream:
+algorithmic bytes = n_sites x (n_ref + n_tgt + n_src) genotype bytes per launch.
+`cpu_baseline` times the numpy oracle (the reference's per-window structure) on the host
+cores over a bounded site prefix of the same chromosome, before the GPU is initialised.
+"""
+
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+import numpy as np  # noqa: E402
+
+SEED = 20260633  # 20260630 + config number 3
+WIN_LEN, WIN_STEP = 50000, 25000
+U_Q_PARAMS = dict(w=0.01, x=0.5, quantile=0.95, y_list=[("=", 1.0)], anc=True)
+METRIC = "windows/sec (whole node) + achieved HBM GB/s, 50kb windows over 1e7 sites"
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+# ------------------------------------------------------------------------------------------
+# CPU baseline: the oracle under a process pool over ChunkGenerator-style chunks
+# ------------------------------------------------------------------------------------------
+
+_CPU = {}
+
+
+def usable_cores() -> int:
+    """Cores this process may really use: the affinity mask capped by the cgroup CPU quota (a
+    GPU box shows all host CPUs but grants a share of them)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = Path("/sys/fs/cgroup/cpu.max").read_text().split()
+        if quota != "max":
+            n = min(n, max(int(int(quota) / int(period)), 1))
+    except (OSError, ValueError):
+        try:
+            q = int(Path("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read_text())
+            per = int(Path("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read_text())
+            if q > 0:
+                n = min(n, max(q // per, 1))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
+def _cpu_chunk(bounds):
+    from oracle import sai_oracle as O
+
+    d = _CPU
+    return len(
+        O.run_chunk("1", {"ref": d["ref"]}, {"tgt": d["tgt"]}, {"src": d["src"]}, WIN_LEN, WIN_STEP, d["stats"],
+                    d["ploidies"], True, start=bounds[0], end=bounds[1])  # fmt: skip
+    )
+
+
+def cpu_baseline(n_sites: int, n_ref: int, n_tgt: int, n_src: int, workers: int) -> dict:
+    """windows/s of the numpy oracle on a site prefix of chromosome 1 (same seed and generator as
+    the GPU run).  Runs before any HIP call so that forking the pool is safe."""
+    import multiprocessing as mp
+    from concurrent.futures import ThreadPoolExecutor
+
+    from oracle import sai_oracle as O
+    from sai_amd import _ffi
+
+    lib = _ffi.load()
+
+    def host_block(stream, n_ind):
+        out = np.empty((n_sites, n_ind), dtype=np.int8)
+        step = max(n_sites // (workers * 4), 1)
+
+        def fill(s0):
+            n = min(step, n_sites - s0)
+            _ffi.check(lib.sai_synth_fill_host(SEED, 1, s0, n, stream, n_ind, 2, 0, out[s0:].ctypes.data_as(C.c_void_p)))
+
+        with ThreadPoolExecutor(workers) as ex:
+            list(ex.map(fill, range(0, n_sites, step)))
+        return out.astype(np.int64)  # the reference's resident layout (utils.py:410)
+
+    gaps = np.empty(n_sites, dtype=np.int32)
+    _ffi.check(lib.sai_synth_gaps_host(SEED, 1, 0, n_sites, gaps.ctypes.data_as(C.c_void_p)))
+    pos = np.cumsum(gaps).astype(np.int32)
+    _CPU.update(
+        ref=O.Chrom(pos, host_block(0, n_ref)),
+        tgt=O.Chrom(pos, host_block(1, n_tgt)),
+        src=O.Chrom(pos, host_block(2, n_src)),
+        stats={
+            "U": {"ref": {"ref": 0.01}, "tgt": {"tgt": 0.5}, "src": {"src": ("=", 1.0)}},
+            "Q": {"ref": {"ref": 0.01}, "tgt": {"tgt": 0.95}, "src": {"src": ("=", 1.0)}},
+        },
+        ploidies={"ref": {"ref": 2}, "tgt": {"tgt": 2}, "src": {"src": 2}},
+    )
+    windows = O.split_windows([int(pos[0]), int(pos[-1])], WIN_LEN, WIN_STEP)
+    windows = [w for w in windows if w[1] <= int(pos[-1])]  # only windows fully inside the prefix
+    chunks = O.split_window_ranges(windows, workers * 8)  # 8 chunks per worker (sai.py:91)
+    t0 = time.perf_counter()
+    with mp.get_context("fork").Pool(workers) as pool:
+        done = sum(pool.map(_cpu_chunk, chunks, chunksize=1))
+    dt = time.perf_counter() - t0
+    _CPU.clear()
+    assert done == len(windows), (done, len(windows))
+    return {
+        "value": round(len(windows) / dt, 2),
+        "unit": "windows/s",
+        "cores": workers,
+        "kind": "port",
+        "sample": f"first {n_sites} sites of chromosome 1 ({len(windows)} windows, {n_ref}/{n_tgt}/{n_src} diploids, "
+        f"int64 matrices, U+Q95), multiprocessing.Pool({workers}) over {len(chunks)} chunks, {dt:.1f} s",
+    }
+
+
+# ------------------------------------------------------------------------------------------
+# GPU run
+# ------------------------------------------------------------------------------------------
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--sites", type=float, default=1e7)
+    ap.add_argument("--ref", type=int, default=1000)
+    ap.add_argument("--tgt", type=int, default=1000)
+    ap.add_argument("--src", type=int, default=2)
+    ap.add_argument("--cpu-sites", type=float, default=4e5, help="site prefix timed on the CPU (0 = skip)")
+    ap.add_argument("--cpu-workers", type=int, default=0, help="0 = usable cores (affinity mask capped by the cgroup quota)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", 0))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+        args.gpus = world
+    n_sites = int(args.sites)
+
+    cpu = None
+    if rank == 0 and world == 1 and args.cpu_sites > 0:
+        # a one-GPU box grants a 16-CPU share of the host whatever nproc says
+        workers = args.cpu_workers or min(usable_cores(), 16)
+        cpu = cpu_baseline(int(args.cpu_sites), args.ref, args.tgt, args.src, workers)
+
+    import torch
+    import torch.distributed as dist
+
+    import __graft_entry__ as entry
+
+    entry.build()
+    from sai_amd import _ffi
+    from sai_amd.distributed import gather_padded
+    from sai_amd.engine import Engine
+    from sai_amd.resident import ResidentScorer, default_windows, synth_block
+
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world)
+    eng = Engine.get(local_rank)
+
+    chrom = rank + 1
+    block = synth_block(eng, SEED, chrom, n_sites, args.ref, args.tgt, [args.src])
+    p0, p1 = int(block.pos[0]), int(block.pos[-1])
+    windows = default_windows(p0, p1, WIN_LEN, WIN_STEP)
+    prm = _ffi.make_params(U_Q_PARAMS["w"], U_Q_PARAMS["x"], U_Q_PARAMS["quantile"], U_Q_PARAMS["y_list"], U_Q_PARAMS["anc"])
+    scorer = ResidentScorer(eng, block, windows, [prm], cap_u=1 << 22, cap_q=1 << 22)
+
+    sizes = [scorer.bufs[0].numel()]
+    if world > 1:
+        t = torch.tensor(sizes, dtype=torch.int64, device=eng.device)
+        all_sizes = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(all_sizes, t)
+        sizes = [int(s.item()) for s in all_sizes]
+
+    def step(timed: bool) -> None:
+        scorer.step(time_counts=timed)
+        if world > 1:
+            gather_padded(scorer.bufs[0], sizes)
+
+    def fence() -> None:
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step(False)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(True)
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=eng.device)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+        nw = torch.tensor([len(windows)], dtype=torch.int64, device=eng.device)
+        dist.all_reduce(nw, op=dist.ReduceOp.SUM)
+        total_windows = int(nw.item())
+    else:
+        total_windows = len(windows)
+
+    res = scorer.results()  # also checks the candidate buffers were large enough
+    kernel_ms = [a.elapsed_time(b) for a, b in scorer.count_events]
+    avg_ms = sum(kernel_ms) / len(kernel_ms)
+    achieved = block.genotype_bytes / (avg_ms * 1e-3) / 1e9
+
+    if rank == 0:
+        traffic = None
+        tfile = ROOT / "profiles" / "traffic.json"
+        if tfile.exists():
+            rec = json.loads(tfile.read_text())
+            key = f"{n_sites}x{args.ref}+{args.tgt}+{args.src}"
+            traffic = rec.get(key, {}).get("site_counts_hbm_bytes_per_launch")
+        line = {
+            "metric": METRIC,
+            "value": round(total_windows * args.steps / dt, 1),
+            "unit": "windows/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u8",
+            "data": "synthetic",
+            "config": {
+                "workload": f"synthetic chr: {n_sites:.0e} sites, {args.ref} ref/{args.tgt} tgt/{args.src} src diploids, "
+                "50kb/25kb windows, U+Q95 (BASELINE.json configs[2]); one chromosome per GPU",
+                "n_sites_per_gpu": n_sites,
+                "windows_per_gpu": len(windows),
+                "windows_total": total_windows,
+                "sharding": "windows sharded by chromosome, RCCL gather of records to rank 0" if world > 1 else "none",
+                "u_sum_rank0": int(res.records["u_count"].sum()),
+                "q_finite_rank0": int(np.isfinite(res.records["q"]).sum()),
+            },
+            "roofline": {
+                "kernel": "site_counts",
+                "bound": "hbm",
+                "achieved": round(achieved, 1),
+                "peak": HBM_PEAK_GBPS,
+                "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBPS, 4),
+                "traffic": traffic,
+                "algorithmic_bytes_per_launch": block.genotype_bytes,
+                "avg_launch_ms": round(avg_ms, 4),
+            },
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -101,6 +101,13 @@ def load() -> C.CDLL:
             "(run `python -c 'import __graft_entry__ as g; g.build()'` at the repo root). "
             "sai_amd has no CPU fallback."
         )
+    # torch ships its own libamdhip64.so (soname libamdhip64.so.7).  It must be in the process
+    # BEFORE libsaihip is loaded so that libsaihip's NEEDED libamdhip64.so.7 resolves to that
+    # already-loaded runtime: one HIP runtime per process, shared with the torch tensors and
+    # streams handed to the C ABI.  Loaded the other way round, torch would bring in a second
+    # runtime next to the system one and device pointers would cross runtimes.
+    import torch  # noqa: F401
+
     lib = C.CDLL(str(path))
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)

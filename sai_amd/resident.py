@@ -1,0 +1,114 @@
+"""A chromosome block resident in HBM and its repeated scoring (the path bench.py times and the
+multi-GPU driver shards): all buffers are allocated once, one ``step()`` enqueues the whole hot
+path -- site_counts -> site_flags -> window_bounds -> window_stats -> async copy of the records to
+pinned host memory -- on the current HIP stream without any host synchronisation.
+"""
+
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Optional, Sequence
+
+import numpy as np
+
+from . import _ffi
+from .engine import RECORD_DTYPE, Engine, TiledPop, WindowResults
+from .utils.windows import split_genome
+
+
+@dataclass
+class ResidentBlock:
+    """ref, tgt and source populations of one contiguous site range, plus positions."""
+
+    pops: list  # [ref, tgt, src...] TiledPop
+    ploidies: list  # same order
+    pos: "object"  # int32 device tensor [n_sites]
+
+    @property
+    def n_sites(self) -> int:
+        return self.pops[0].n_sites
+
+    @property
+    def genotype_bytes(self) -> int:
+        """Algorithmic bytes of one site_counts launch: every genotype byte once."""
+        return self.n_sites * sum(p.n_ind for p in self.pops)
+
+
+def synth_block(eng: Engine, seed: int, chrom: int, n_sites: int, n_ref: int, n_tgt: int, n_src_list: Sequence[int],
+                ploidy: int = 2, missing_per_million: int = 0, site0: int = 0) -> ResidentBlock:  # fmt: skip
+    """synth-v1 block generated in place on the GPU."""
+    sizes = [n_ref, n_tgt] + list(n_src_list)
+    pops = [
+        eng.synth_population(seed, chrom, site0, n_sites, stream, n, ploidy, missing_per_million)
+        for stream, n in enumerate(sizes)
+    ]
+    pos = eng.synth_positions(seed, chrom, n_sites, site0=site0)
+    return ResidentBlock(pops, [ploidy] * len(sizes), pos)
+
+
+class ResidentScorer:
+    def __init__(self, eng: Engine, block: ResidentBlock, windows: Sequence[tuple], sets: Sequence[_ffi.SaiParams],
+                 cap_u: int = 1 << 20, cap_q: int = 1 << 20):  # fmt: skip
+        import torch
+
+        if not 1 <= len(sets) <= _ffi.SAI_MAX_SETS:
+            raise ValueError(f"1..{_ffi.SAI_MAX_SETS} parameter sets per scorer")
+        self.eng, self.block, self.sets = eng, block, list(sets)
+        self.windows = list(windows)
+        n, n_w, n_s = block.n_sites, len(self.windows), len(self.sets)
+        self.n_windows, self.n_sets = n_w, n_s
+        dev = eng.device
+        self.win_start = torch.as_tensor(np.array([w[0] for w in self.windows], dtype=np.int64)).to(dev)
+        self.win_end = torch.as_tensor(np.array([w[1] for w in self.windows], dtype=np.int64)).to(dev)
+        self.counts = torch.empty((len(block.pops), n, 2), dtype=torch.int32, device=dev)
+        self.tgt_freq = torch.empty((n,), dtype=torch.float64, device=dev)
+        self.flags = torch.empty((n_s, n), dtype=torch.uint8, device=dev)
+        self.lo = torch.empty((n_w,), dtype=torch.int32, device=dev)
+        self.hi = torch.empty((n_w,), dtype=torch.int32, device=dev)
+        self.bufs = eng.alloc_window_bufs(n_s, n_w, cap_u, cap_q)
+        self.host_records = torch.empty((n_s * n_w * RECORD_DTYPE.itemsize,), dtype=torch.uint8).pin_memory()
+        self.host_offsets = torch.empty((n_s * n_w * 2,), dtype=torch.int64).pin_memory()
+        self.host_totals = torch.empty((2,), dtype=torch.int64).pin_memory()
+        self.count_events: list = []  # (start, end) torch events around site_counts, when requested
+
+    def step(self, time_counts: bool = False) -> None:
+        import torch
+
+        eng, b = self.eng, self.block
+        if time_counts:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        eng.site_counts(b.pops, out=self.counts)
+        if time_counts:
+            e1.record()
+            self.count_events.append((e0, e1))
+        eng.site_flags(self.counts, b.ploidies, self.sets, out=(self.tgt_freq, self.flags))
+        _ffi.check(
+            eng.lib.sai_window_bounds(
+                eng.ctx, eng._ptr(b.pos), b.n_sites, self.n_windows, eng._ptr(self.win_start), eng._ptr(self.win_end),
+                eng._ptr(self.lo), eng._ptr(self.hi), eng._stream(),
+            )
+        )  # fmt: skip
+        eng.window_stats_async(self.tgt_freq, self.flags, self.sets, self.lo, self.hi, b.pos, self.bufs)
+        self.host_records.copy_(self.bufs[0], non_blocking=True)
+        self.host_offsets.copy_(self.bufs[1], non_blocking=True)
+        self.host_totals.copy_(self.bufs[4], non_blocking=True)
+
+    def results(self) -> WindowResults:
+        """Synchronise and return the last step's records and candidate lists."""
+        import torch
+
+        torch.cuda.current_stream(self.eng.device).synchronize()
+        need_u, need_q = (int(v) for v in self.host_totals.tolist())
+        if need_u > self.bufs[2].numel() or need_q > self.bufs[3].numel():
+            raise RuntimeError(
+                f"candidate buffers too small (need {need_u}/{need_q}); rebuild the scorer with larger cap_u/cap_q"
+            )
+        rec = np.frombuffer(self.host_records.numpy().tobytes(), dtype=RECORD_DTYPE).reshape(self.n_sets, self.n_windows)
+        off = self.host_offsets.numpy().reshape(self.n_sets, self.n_windows, 2).copy()
+        return WindowResults(rec, off, self.bufs[2][:need_u].cpu().numpy(), self.bufs[3][:need_q].cpu().numpy())
+
+
+def default_windows(pos_first: int, pos_last: int, win_len: int, win_step: int) -> list[tuple]:
+    """The reference's window grid over a chromosome (ChunkGenerator, chunk_generator.py:78)."""
+    return split_genome([pos_first, pos_last], win_len, win_step)

@@ -1,0 +1,112 @@
+"""The N > 1 path on CPU: world_size-2 ``gloo`` process groups exercise the same sharding and
+gather code the GPUs run over RCCL (sai_amd.distributed).  The compute inside a chunk is a toy
+preprocessor here, exactly how the reference tests its executors
+(tests/multiprocessing/test_mp_pool.py:25-46)."""
+
+import json
+import os
+import socket
+
+import numpy as np
+import pytest
+
+
+def _free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank: int, world: int, port: int, out_dir: str) -> None:
+    import torch
+    import torch.distributed as dist
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))  # fmt: skip
+    from sai_amd.distributed import gather_padded, gather_window_records, init_process_group, my_chunk_indices, run_sharded
+    from sai_amd.generators import DataGenerator
+    from sai_amd.preprocessors import DataPreprocessor
+
+    r, w = init_process_group("gloo")
+    assert (r, w) == (rank, world)
+
+    class Gen(DataGenerator):
+        def get(self):
+            for i in range(7):
+                yield {"chr_name": "1", "start": i * 100 + 1, "end": i * 100 + 150}
+
+    class Pre(DataPreprocessor):
+        def __init__(self):
+            self.written = None
+
+        def run(self, chr_name, start, end):
+            return [{"chr": chr_name, "start": start, "end": end, "rank": dist.get_rank(), "k": k} for k in range(2)]
+
+        def process_items(self, items):
+            self.written = items
+
+    pre = Pre()
+    items = run_sharded(pre, Gen())
+    mine = list(my_chunk_indices(7, rank, world))
+    if rank == 0:
+        assert [it["start"] for it in items] == [i * 100 + 1 for i in range(7) for _ in range(2)]
+        assert [it["rank"] for it in items] == [0] * 8 + [1] * 6  # 4 chunks on rank 0, 3 on rank 1
+        assert pre.written is items and mine == [0, 1, 2, 3]
+    else:
+        assert items is None and pre.written is None and mine == [4, 5, 6]
+
+    # records of different lengths per rank -> rank 0, in rank order
+    local = torch.arange(10 + 5 * rank, dtype=torch.uint8) + 100 * rank
+    got = gather_window_records(local)
+    got2 = gather_padded(local.to(torch.int64), [10, 15])
+    if rank == 0:
+        assert [g.tolist() for g in got] == [list(range(10)), [100 + i for i in range(15)]]
+        assert [g.tolist() for g in got2] == [list(range(10)), [100 + i for i in range(15)]]
+    else:
+        assert got is None and got2 is None
+    dist.barrier()
+    with open(os.path.join(out_dir, f"ok{rank}"), "w") as f:
+        f.write("ok")
+    dist.destroy_process_group()
+
+
+def test_world_size_2_gloo(tmp_path):
+    import torch.multiprocessing as mp
+
+    mp.spawn(_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    assert (tmp_path / "ok0").exists() and (tmp_path / "ok1").exists()
+
+
+def test_chunk_assignment_covers_everything():
+    from sai_amd.distributed import my_chunk_indices
+
+    for n in (0, 1, 5, 8, 17, 110000):
+        for world in (1, 2, 3, 8):
+            got = [i for r in range(world) for i in my_chunk_indices(n, r, world)]
+            assert got == list(range(n))
+            sizes = [len(my_chunk_indices(n, r, world)) for r in range(world)]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_single_process_run_sharded_is_the_serial_loop():
+    from sai_amd.distributed import gather_window_records, run_sharded
+    from sai_amd.generators import DataGenerator
+    from sai_amd.preprocessors import DataPreprocessor
+
+    class Gen(DataGenerator):
+        def get(self):
+            return iter([{"x": 1}, {"x": 2}])
+
+    class Pre(DataPreprocessor):
+        def run(self, x):
+            return [x, x * 10]
+
+        def process_items(self, items):
+            self.items = items
+
+    p = Pre()
+    assert run_sharded(p, Gen()) == [1, 10, 2, 20] and p.items == [1, 10, 2, 20]
+    import torch
+
+    t = torch.arange(4)
+    assert gather_window_records(t)[0] is t

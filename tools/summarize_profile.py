@@ -1,0 +1,79 @@
+#!/usr/bin/env python3
+"""Condense a tools/profile.sh run (gpurun_out/prof_<tag>/) into the tracked files under
+profiles/: the rocprofv3 kernel-stats table, per-kernel duration of the timed steps, the two PMC
+passes, and profiles/traffic.json (HBM bytes per site_counts launch, corrected as
+MI355X_MICROARCH.md prescribes for gfx950: FETCH_SIZE counts 64 B per 128-B request of a wide
+coalesced read, so it is doubled; WRITE_SIZE is exact; both are in KiB)."""
+import csv, glob, json, shutil, sys
+from collections import defaultdict
+from pathlib import Path
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+workload_key = sys.argv[2] if len(sys.argv) > 2 else "10000000x1000+1000+2"
+warmup = int(sys.argv[3]) if len(sys.argv) > 3 else 2
+src = Path("gpurun_out") / f"prof_{tag}"
+dst = Path("profiles")
+dst.mkdir(exist_ok=True)
+
+
+def short(name):
+    for k in ("site_counts", "site_flags", "window_bounds", "window_stats", "synth_fill", "synth_gaps", "tile_from_site_major"):
+        if k in name:
+            return k
+    return name.split("(")[0][-60:]
+
+
+shutil.copy(glob.glob(str(src / "trace/*/*_kernel_stats.csv"))[0], dst / f"{tag}_kernel_stats.csv")
+# durations per kernel, all calls and timed calls (after the warm-up steps)
+per = defaultdict(list)
+for r in csv.DictReader(open(glob.glob(str(src / "trace/*/*_kernel_trace.csv"))[0])):
+    per[short(r["Kernel_Name"])].append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
+rows = []
+for k, v in per.items():
+    v.sort()
+    d = [x[1] for x in v]
+    timed = d[warmup:] if len(d) > warmup else d
+    rows.append((k, len(d), sum(d) / len(d) / 1e3, len(timed), sum(timed) / len(timed) / 1e3, min(d) / 1e3, max(d) / 1e3))
+rows.sort(key=lambda r: -r[1] * r[2])
+with open(dst / f"{tag}_kernel_durations.csv", "w") as f:
+    f.write("kernel,calls,avg_us_all_calls,timed_calls,avg_us_timed_steps,min_us,max_us\n")
+    for r in rows:
+        f.write(f"{r[0]},{r[1]},{r[2]:.2f},{r[3]},{r[4]:.2f},{r[5]:.2f},{r[6]:.2f}\n")
+# PMC passes
+pmc = defaultdict(dict)
+for pas, counter in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
+    files = glob.glob(str(src / pas / "*/*_counter_collection.csv"))
+    if not files:
+        continue
+    acc = defaultdict(list)
+    for r in csv.DictReader(open(files[0])):
+        if r["Counter_Name"] == counter:
+            acc[short(r["Kernel_Name"])].append(float(r["Counter_Value"]))
+    for k, v in acc.items():
+        pmc[k][counter] = (len(v), sum(v) / len(v))
+with open(dst / f"{tag}_pmc_summary.csv", "w") as f:
+    f.write("kernel,launches,FETCH_SIZE_KiB_raw_avg,WRITE_SIZE_KiB_avg,hbm_read_bytes_corrected_x2,hbm_write_bytes,hbm_bytes_per_launch\n")
+    for k, d in sorted(pmc.items()):
+        n, fs = d.get("FETCH_SIZE", (0, 0.0))
+        _, ws = d.get("WRITE_SIZE", (0, 0.0))
+        rd, wr = fs * 1024 * 2, ws * 1024
+        f.write(f"{k},{n},{fs:.3f},{ws:.3f},{rd:.0f},{wr:.0f},{rd + wr:.0f}\n")
+tfile = dst / "traffic.json"
+rec = json.loads(tfile.read_text()) if tfile.exists() else {}
+if "site_counts" in pmc:
+    fs = pmc["site_counts"]["FETCH_SIZE"][1]
+    ws = pmc["site_counts"].get("WRITE_SIZE", (0, 0.0))[1]
+    rec[workload_key] = {
+        "source": f"profiles/{tag}_pmc_summary.csv",
+        "site_counts_fetch_size_kib_raw": fs,
+        "site_counts_write_size_kib": ws,
+        "site_counts_hbm_bytes_per_launch": int(fs * 1024 * 2 + ws * 1024),
+    }
+    tfile.write_text(json.dumps(rec, indent=1) + "\n")
+for name in ("trace.log", "pmc_fetch.log", "pmc_write.log"):
+    lines = [l for l in (src / name).read_text().splitlines() if l.startswith('{"metric"')]
+    if lines:
+        (dst / f"{tag}_bench_under_{name.split('.')[0]}.json").write_text(lines[-1] + "\n")
+print(open(dst / f"{tag}_kernel_durations.csv").read())
+print(open(dst / f"{tag}_pmc_summary.csv").read())
+print(tfile.read_text())
