@@ -1,5 +1,5 @@
-"""``sai score`` sub-command (mirror of sai/parsers/score_parser.py:27-130): same flags,
-defaults and help; ``--gpus`` is this build's only addition."""
+"""``sai score`` sub-command (mirror of sai/parsers/score_parser.py:27-130): same flags and
+defaults."""
 
 from __future__ import annotations
 
