@@ -228,6 +228,8 @@ def main() -> None:
     kernel_ms = [a.elapsed_time(b) for a, b in scorer.count_events]
     avg_ms = sum(kernel_ms) / len(kernel_ms)
     achieved = block.genotype_bytes / (avg_ms * 1e-3) / 1e9
+    # on-box ceiling: plain 16-B-per-lane streaming read of the ref block (outside the timed region)
+    stream_read = eng.probe_stream_read(block.pops[0].tiles)
 
     if rank == 0:
         traffic = None
@@ -269,6 +271,8 @@ def main() -> None:
                 "traffic": traffic,
                 "algorithmic_bytes_per_launch": block.genotype_bytes,
                 "avg_launch_ms": round(avg_ms, 4),
+                "stream_read_probe_gbps": round(stream_read, 1),
+                "frac_of_stream_read_probe": round(achieved / stream_read, 4),
             },
             "cpu_baseline": cpu,
         }

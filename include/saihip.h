@@ -137,16 +137,18 @@ int sai_window_bounds(sai_ctx* ctx, const int32_t* pos, int64_t n_sites, int32_t
                       const int64_t* win_start, const int64_t* win_end, int32_t* lo, int32_t* hi,
                       void* stream);
 
-/* Kernel 4: one record per (set, window): U count (u_statistic.py:94-96), numpy 'linear'
- * nanquantile of the effective target frequency over condition sites (q_statistic.py:92-100),
- * and both candidate lists (u_statistic.py:95, q_statistic.py:101) in ascending site order.
+/* Kernel 4 (four launches): one record per (set, window): U count (u_statistic.py:94-96),
+ * numpy 'linear' nanquantile of the effective target frequency over condition sites
+ * (q_statistic.py:92-100), and both candidate lists (u_statistic.py:95, q_statistic.py:101) in
+ * ascending site order, laid out as a CSR in (set, window) order -- deterministic, so 1-GPU and
+ * sharded runs produce identical bytes.
  *   records[set * n_windows + w]
- *   cdd_off[(set * n_windows + w) * 2 + {0,1}] = start of the window's U / Q list inside
- *     cdd_u / cdd_q (placement order between windows is unspecified; lengths are u_count and
- *     n_cdd_q);
+ *   cdd_off[(set * n_windows + w) * 2 + {0,1}] = start of the record's U / Q list inside
+ *     cdd_u / cdd_q = exclusive prefix sum of u_count / n_cdd_q over the preceding records
+ *     (-1 when the list would end beyond the buffer's capacity; such lists are not written);
  *   list entries are pos[site] when `pos` is non-NULL, else block-relative site indices;
- *   cdd_total[0..1] = entries needed for all U / Q lists.  When a total exceeds its capacity the
- *     lists that did not fit are not written (their offset is -1): re-run with larger buffers.
+ *   cdd_total[0..1] = entries needed for all U / Q lists: when a total exceeds its capacity,
+ *     re-run with larger buffers.
  * `quantile` is taken from sets_host[set].quantile. */
 int sai_window_stats(sai_ctx* ctx, int64_t n_sites, const double* tgt_freq, const uint8_t* flags,
                      int32_t n_sets, const sai_params* sets_host, int32_t n_windows,
@@ -172,6 +174,14 @@ int sai_synth_gaps_host(uint64_t seed, int32_t chrom, int64_t site0, int64_t n_s
                         int32_t* gaps_host);
 int sai_synth_gaps(sai_ctx* ctx, uint64_t seed, int32_t chrom, int64_t site0, int64_t n_sites,
                    int32_t* gaps, void* stream);
+
+/* ---- measurement aid -------------------------------------------------------------------- */
+
+/* Plain streaming read of `n_bytes` (multiple of 16) with 16-byte loads, XOR-reduced into
+ * *xor_out (device).  No reference counterpart: bench.py times it to obtain the on-box read
+ * ceiling that the site_counts rate is compared with, next to the 8 TB/s datasheet peak. */
+int sai_probe_stream_read(sai_ctx* ctx, const void* buf, int64_t n_bytes, uint32_t* xor_out,
+                          void* stream);
 
 #ifdef __cplusplus
 }

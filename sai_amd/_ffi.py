@@ -84,6 +84,7 @@ SIGNATURES = {
     "sai_synth_fill_host": (C.c_int, [_u64, _i32, _i64, _i64, _i32, _i32, _i32, _i32, _p]),
     "sai_synth_gaps_host": (C.c_int, [_u64, _i32, _i64, _i64, _p]),
     "sai_synth_gaps": (C.c_int, [_p, _u64, _i32, _i64, _i64, _p, _p]),
+    "sai_probe_stream_read": (C.c_int, [_p, _p, _i64, _p, _p]),
 }
 
 _lib = None

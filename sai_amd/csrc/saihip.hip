@@ -17,6 +17,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <new>
@@ -175,53 +176,115 @@ __device__ __forceinline__ void reduce_scatter_step(uint32_t (&a)[16], int lane)
   }
 }
 
-template <int UNROLL>
-__global__ __launch_bounds__(64) void site_counts_kernel(CountsArgs a) {
-  const int lane = threadIdx.x;
+template <bool NT>
+__device__ __forceinline__ u32x4 load_rows(const u32x4* p) {
+  return NT ? __builtin_nontemporal_load(p) : *p;
+}
+
+constexpr int kChunkIters = 248;  // iterations (rows per lane) the 16-/8-bit fields can absorb
+
+// Accumulate iterations [it, full_end) of full 16-row groups plus, when it is the last one, the
+// partial group, into the packed fields lo/hi (16-bit dosage sums) and ms (8-bit missing counts).
+template <int UNROLL, bool PIPE, bool NT>
+__device__ __forceinline__ void accumulate_rows(const u32x4* base, int& it, int full_end, int n_full, int n_iter,
+                                                int n_ind, int r, uint32_t (&lo)[4], uint32_t (&hi)[4],
+                                                uint32_t (&ms)[4]) {
+  if (PIPE) {
+    u32x4 A[UNROLL], B[UNROLL];
+    const int n_groups = (full_end - it) / UNROLL;
+    if (n_groups > 0) {
+#pragma unroll
+      for (int u = 0; u < UNROLL; ++u) A[u] = load_rows<NT>(base + (it + u) * 64);
+    }
+    int g = 0;
+    for (; g + 2 <= n_groups; g += 2) {
+#pragma unroll
+      for (int u = 0; u < UNROLL; ++u) B[u] = load_rows<NT>(base + (it + UNROLL + u) * 64);
+#pragma unroll
+      for (int u = 0; u < UNROLL; ++u) acc_vec(A[u], lo, hi, ms);
+      if (g + 2 < n_groups) {
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) A[u] = load_rows<NT>(base + (it + 2 * UNROLL + u) * 64);
+      }
+#pragma unroll
+      for (int u = 0; u < UNROLL; ++u) acc_vec(B[u], lo, hi, ms);
+      it += 2 * UNROLL;
+    }
+    if (g < n_groups) {
+#pragma unroll
+      for (int u = 0; u < UNROLL; ++u) acc_vec(A[u], lo, hi, ms);
+      it += UNROLL;
+    }
+  } else {
+    for (; it + UNROLL <= full_end; it += UNROLL) {
+      u32x4 v[UNROLL];
+#pragma unroll
+      for (int u = 0; u < UNROLL; ++u) v[u] = load_rows<NT>(base + (it + u) * 64);
+#pragma unroll
+      for (int u = 0; u < UNROLL; ++u) acc_vec(v[u], lo, hi, ms);
+    }
+  }
+  for (; it < full_end; ++it) {
+    const u32x4 v = load_rows<NT>(base + it * 64);
+    acc_vec(v, lo, hi, ms);
+  }
+  if (it == n_full && it < n_iter) {  // partial last group of rows
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if (it * 16 + r < n_ind) v = load_rows<NT>(base + it * 64);
+    acc_vec(v, lo, hi, ms);
+    ++it;
+  }
+}
+
+__device__ __forceinline__ void widen_fields(const uint32_t (&lo)[4], const uint32_t (&hi)[4], const uint32_t (&ms)[4],
+                                             uint32_t (&sum32)[16], uint32_t (&miss32)[16]) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    sum32[4 * j + 0] += lo[j] & 0xFFFFu;
+    sum32[4 * j + 1] += hi[j] & 0xFFFFu;
+    sum32[4 * j + 2] += lo[j] >> 16;
+    sum32[4 * j + 3] += hi[j] >> 16;
+    miss32[4 * j + 0] += ms[j] & 0xFFu;
+    miss32[4 * j + 1] += (ms[j] >> 8) & 0xFFu;
+    miss32[4 * j + 2] += (ms[j] >> 16) & 0xFFu;
+    miss32[4 * j + 3] += ms[j] >> 24;
+  }
+}
+
+// UNROLL: wave loads in flight per group; PIPE: ping-pong two groups so the next group's loads are
+// issued before the current group is consumed; NT: non-temporal loads (the block is read once);
+// WAVES: independent waves (tiles) per workgroup; MULTI: some population has more than
+// 16 * kChunkIters individuals, so the packed fields are widened several times per population
+// (keeps 32 more registers live across the load loop).
+template <int UNROLL, bool PIPE, bool NT, int WAVES, bool MULTI, int MINW = 1>
+__global__ __launch_bounds__(64 * WAVES, MINW) void site_counts_kernel(CountsArgs a) {
+  const int lane = threadIdx.x & 63;
   const int r = lane >> 2;
-  for (int64_t tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
+  const int64_t tile0 = static_cast<int64_t>(blockIdx.x) * WAVES + (threadIdx.x >> 6);
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * WAVES;
+  for (int64_t tile = tile0; tile < a.n_tiles; tile += stride) {
     for (int p = 0; p < a.n_pops; ++p) {
       const int n_ind = a.pop[p].n_ind;
       const u32x4* base =
           reinterpret_cast<const u32x4*>(a.pop[p].tiles + tile * static_cast<int64_t>(n_ind) * kTile) + lane;
-      uint32_t sum32[16], miss32[16];
-#pragma unroll
-      for (int j = 0; j < 16; ++j) sum32[j] = miss32[j] = 0;
-
       const int n_full = n_ind >> 4;         // iterations in which all 16 rows exist
       const int n_iter = (n_ind + 15) >> 4;  // plus at most one partial iteration
+      uint32_t sum32[16], miss32[16];
       int it = 0;
-      while (it < n_iter) {
-        const int full_end = min(n_full, it + 248);
+      if (MULTI) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) sum32[j] = miss32[j] = 0;
+        while (it < n_iter) {
+          uint32_t lo[4] = {0, 0, 0, 0}, hi[4] = {0, 0, 0, 0}, ms[4] = {0, 0, 0, 0};
+          accumulate_rows<UNROLL, PIPE, NT>(base, it, min(n_full, it + kChunkIters), n_full, n_iter, n_ind, r, lo, hi, ms);
+          widen_fields(lo, hi, ms, sum32, miss32);
+        }
+      } else {  // n_iter <= kChunkIters + 1: one pass, widen once
         uint32_t lo[4] = {0, 0, 0, 0}, hi[4] = {0, 0, 0, 0}, ms[4] = {0, 0, 0, 0};
-        for (; it + UNROLL <= full_end; it += UNROLL) {
-          u32x4 v[UNROLL];
+        accumulate_rows<UNROLL, PIPE, NT>(base, it, n_full, n_full, n_iter, n_ind, r, lo, hi, ms);
 #pragma unroll
-          for (int u = 0; u < UNROLL; ++u) v[u] = __builtin_nontemporal_load(base + (it + u) * 64);
-#pragma unroll
-          for (int u = 0; u < UNROLL; ++u) acc_vec(v[u], lo, hi, ms);
-        }
-        for (; it < full_end; ++it) {
-          const u32x4 v = __builtin_nontemporal_load(base + it * 64);
-          acc_vec(v, lo, hi, ms);
-        }
-        if (it == n_full && it < n_iter) {  // partial last group of rows
-          u32x4 v = {0u, 0u, 0u, 0u};
-          if (it * 16 + r < n_ind) v = __builtin_nontemporal_load(base + it * 64);
-          acc_vec(v, lo, hi, ms);
-          ++it;
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          sum32[4 * j + 0] += lo[j] & 0xFFFFu;
-          sum32[4 * j + 1] += hi[j] & 0xFFFFu;
-          sum32[4 * j + 2] += lo[j] >> 16;
-          sum32[4 * j + 3] += hi[j] >> 16;
-          miss32[4 * j + 0] += ms[j] & 0xFFu;
-          miss32[4 * j + 1] += (ms[j] >> 8) & 0xFFu;
-          miss32[4 * j + 2] += (ms[j] >> 16) & 0xFFu;
-          miss32[4 * j + 3] += ms[j] >> 24;
-        }
+        for (int j = 0; j < 16; ++j) sum32[j] = miss32[j] = 0;
+        widen_fields(lo, hi, ms, sum32, miss32);
       }
       reduce_scatter_step<16, 32>(sum32, lane);
       reduce_scatter_step<8, 16>(sum32, lane);
@@ -340,7 +403,13 @@ __global__ __launch_bounds__(256) void window_bounds_kernel(const int32_t* __res
 }
 
 // ------------------------------------------------------------------------------------------
-// window_stats: one 256-thread workgroup per (window, parameter set).
+// window statistics.  Four launches, no atomics on shared words (a returning atomic on one
+// address saturates at ~90 per microsecond, which at one reservation per window was 85 % of the
+// old single-kernel version):
+//   window_stats_wave   one WAVEFRONT per (window, set): U count, condition count, Q, Q-list size
+//   window_stats_heavy  workgroup fallback for windows with > kWaveCap qualifying sites
+//   window_scan         exclusive prefix sums of the list sizes -> CSR offsets + totals
+//   window_lists        one wavefront per (window, set): candidate lists in ascending site order
 // ------------------------------------------------------------------------------------------
 
 struct WinArgs {
@@ -358,38 +427,133 @@ struct WinArgs {
   int64_t cap_u;
   int32_t* cdd_q;
   int64_t cap_q;
-  unsigned long long* cdd_total;
+  int64_t* cdd_total;
   double quantile[SAI_MAX_SETS];
 };
 
 constexpr int kWinThreads = 256;
-constexpr int kSelCap = 4096;  // selected values kept in LDS (32 KiB); beyond that re-read HBM/L2
+constexpr int kWaveCap = 256;       // qualifying sites a wave keeps in LDS; more -> heavy kernel
+constexpr int kSelCap = 4096;       // values the heavy kernel keeps in LDS (32 KiB); beyond: re-read
+constexpr int32_t kHeavyMark = -1;  // records[].n_cdd_q value that hands a window to the fallback
+
+__device__ __forceinline__ double eff_freq(const double* tgt_freq, uint8_t f, int64_t i) {
+  const double v = tgt_freq[i];
+  return (f & 4) ? 1.0 - v : v;
+}
+
+// numpy 'linear' quantile from the two neighbouring order statistics (numpy _quantile/_lerp):
+// virtual index v = (n-1)*q; a + (b-a)*g, or b - (b-a)*(1-g) when g >= 0.5.
+__device__ __forceinline__ double numpy_lerp(double x0, double x1, double v, double fl_v) {
+  const double g = v - fl_v;
+  const double d = x1 - x0;
+  return (g >= 0.5) ? x1 - d * (1.0 - g) : x0 + d * g;
+}
+
+__device__ __forceinline__ void wave_lds_fence() {
+  // LDS operations of one wave execute in order; this only stops the compiler from moving
+  // accesses across the point where lanes start reading what other lanes of the wave wrote.
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// XCD-aware block order: consecutive blockIdx values round-robin over the 8 XCDs; give each XCD a
+// contiguous run of (overlapping) windows so their shared sites stay in one L2.
+__device__ __forceinline__ int xcd_contiguous(int b, int n_blocks) {
+  const int per = n_blocks >> 3;
+  return (per > 0 && b < per * 8) ? (b & 7) * per + (b >> 3) : b;
+}
+
+__global__ __launch_bounds__(256) void window_stats_wave_kernel(WinArgs a) {
+  __shared__ double sh_vals[4][kWaveCap];
+  const int lane = threadIdx.x & 63;
+  const int wv = threadIdx.x >> 6;
+  const int w = xcd_contiguous(blockIdx.x, gridDim.x) * 4 + wv;
+  if (w >= a.n_windows) return;  // whole wave
+  const int set = blockIdx.y;
+  const int lo = a.lo[w], hi = a.hi[w];
+  const uint8_t* fl = a.flags + static_cast<int64_t>(set) * a.n_sites;
+  const int64_t ridx = static_cast<int64_t>(set) * a.n_windows + w;
+  double* vals = sh_vals[wv];
+  const unsigned long long lt_mask = (1ull << lane) - 1ull;
+
+  // pass 1: counts + compaction of the qualifying effective frequencies into LDS
+  uint32_t n_c = 0, n_u = 0;
+  for (int i0 = lo; i0 < hi; i0 += 64) {
+    const int i = i0 + lane;
+    const uint8_t f = i < hi ? fl[i] : static_cast<uint8_t>(0);
+    const bool c = (f & 1u) != 0;
+    const unsigned long long bc = __ballot(c);
+    if (c) {
+      const uint32_t slot = n_c + __popcll(bc & lt_mask);
+      if (slot < kWaveCap) vals[slot] = eff_freq(a.tgt_freq, f, i);
+    }
+    n_c += __popcll(bc);
+    n_u += __popcll(__ballot((f & 2u) != 0));
+  }
+  double q = std::numeric_limits<double>::quiet_NaN();
+  uint32_t n_q = 0;
+  if (n_c > kWaveCap) {
+    n_q = static_cast<uint32_t>(kHeavyMark);  // uniform: the workgroup kernel finishes this window
+  } else if (n_c > 0) {
+    wave_lds_fence();
+    const double v = static_cast<double>(n_c - 1) * a.quantile[set];
+    const bool take_max = v >= static_cast<double>(n_c - 1);  // at/after the last index: maximum
+    const double fl_v = floor(v);
+    const uint32_t k0 = take_max ? n_c - 1 : static_cast<uint32_t>(fl_v);
+    const uint32_t k1 = take_max ? n_c - 1 : k0 + 1;
+    double x0 = 0.0, x1 = 0.0;
+    // rank counting: rank(e) = #{j: v_j < v_e or (v_j == v_e and j < e)} is a permutation
+    for (uint32_t e0 = 0; e0 < n_c; e0 += 64) {
+      const uint32_t e = e0 + lane;
+      const bool act = e < n_c;
+      const double ve = act ? vals[e] : 0.0;
+      uint32_t rank = 0;
+      for (uint32_t j = 0; j < n_c; ++j) {
+        const double vj = vals[j];  // same address in every lane: LDS broadcast
+        rank += (vj < ve) || (vj == ve && j < e);
+      }
+      const unsigned long long h0 = __ballot(act && rank == k0);
+      const unsigned long long h1 = __ballot(act && rank == k1);
+      if (h0) x0 = __shfl(ve, __ffsll(static_cast<long long>(h0)) - 1, 64);
+      if (h1) x1 = __shfl(ve, __ffsll(static_cast<long long>(h1)) - 1, 64);
+    }
+    q = take_max ? x0 : numpy_lerp(x0, x1, v, fl_v);
+    for (uint32_t e0 = 0; e0 < n_c; e0 += 64) {
+      const uint32_t e = e0 + lane;
+      n_q += __popcll(__ballot(e < n_c && vals[e] >= q));
+    }
+  }
+  if (lane == 0) {
+    sai_window_record rec;
+    rec.n_sites = hi - lo;
+    rec.u_count = static_cast<int32_t>(n_u);
+    rec.n_cond = static_cast<int32_t>(n_c);
+    rec.n_cdd_q = static_cast<int32_t>(n_q);
+    rec.q = q;
+    a.records[ridx] = rec;
+  }
+}
+
+// ---- heavy fallback ------------------------------------------------------------------------
 
 struct WinShared {
   double vals[kSelCap];
   uint32_t hist[256];
   uint32_t wave_tot[4];
-  uint32_t red[8];
+  uint32_t red[4];
   uint32_t n_stored;
   uint32_t digit;
   uint32_t k_rem;
-  long long base_u;
-  long long base_q;
 };
 
 __device__ __forceinline__ uint32_t block_sum(uint32_t v, uint32_t* red, int tid) {
-  // wave reduce then 4 partials through LDS
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   __syncthreads();
   if ((tid & 63) == 0) red[tid >> 6] = v;
   __syncthreads();
   return red[0] + red[1] + red[2] + red[3];
-}
-
-__device__ __forceinline__ double eff_freq(const double* tgt_freq, uint8_t f, int64_t i) {
-  const double v = tgt_freq[i];
-  return (f & 4) ? 1.0 - v : v;
 }
 
 // k-th smallest (0-based) of the selected values: MSB-first radix select on the f64 bit pattern
@@ -443,116 +607,127 @@ __device__ double select_kth(WinShared& sh, const double* tgt_freq, const uint8_
   return __longlong_as_double(static_cast<long long>(prefix));
 }
 
-// ordered compaction of the sites of [lo, hi) whose predicate holds, written at out[base...]
-template <typename Pred>
-__device__ void write_list(WinShared& sh, int lo, int hi, const int32_t* pos, int32_t* out, long long base,
-                           int tid, Pred pred) {
-  long long running = base;
-  for (int i0 = lo; i0 < hi; i0 += kWinThreads) {
-    const int i = i0 + tid;
-    const bool p = i < hi && pred(i);
-    const unsigned long long bal = __ballot(p);
-    const int wave = tid >> 6;
-    __syncthreads();
-    if ((tid & 63) == 0) sh.wave_tot[wave] = __popcll(bal);
-    __syncthreads();
-    uint32_t before = 0;
-    for (int wv = 0; wv < wave; ++wv) before += sh.wave_tot[wv];
-    const uint32_t total = sh.wave_tot[0] + sh.wave_tot[1] + sh.wave_tot[2] + sh.wave_tot[3];
-    if (p) {
-      const uint32_t rank = before + __popcll(bal & ((1ull << (tid & 63)) - 1ull));
-      out[running + rank] = pos ? pos[i] : i;
+// The grid covers every window; those not marked by the wave kernel exit at once.
+__global__ __launch_bounds__(kWinThreads) void window_stats_heavy_kernel(WinArgs a) {
+  __shared__ WinShared sh;
+  const int tid = threadIdx.x;
+  const int w = blockIdx.x;
+  const int set = blockIdx.y;
+  const int64_t ridx = static_cast<int64_t>(set) * a.n_windows + w;
+  if (a.records[ridx].n_cdd_q != kHeavyMark) return;  // uniform over the workgroup
+  const int lo = a.lo[w], hi = a.hi[w];
+  const uint8_t* fl = a.flags + static_cast<int64_t>(set) * a.n_sites;
+  const uint32_t n_c = static_cast<uint32_t>(a.records[ridx].n_cond);
+  const bool in_lds = n_c <= kSelCap;
+  if (tid == 0) sh.n_stored = 0;
+  __syncthreads();
+  if (in_lds) {
+    for (int i = lo + tid; i < hi; i += kWinThreads) {
+      const uint8_t f = fl[i];
+      if (f & 1u) sh.vals[atomicAdd(&sh.n_stored, 1u)] = eff_freq(a.tgt_freq, f, i);
     }
-    running += total;
+  }
+  __syncthreads();
+  const double v = static_cast<double>(n_c - 1) * a.quantile[set];
+  double q;
+  if (v >= static_cast<double>(n_c - 1)) {
+    q = in_lds ? select_kth<true>(sh, a.tgt_freq, fl, lo, hi, n_c, n_c - 1, tid)
+               : select_kth<false>(sh, a.tgt_freq, fl, lo, hi, n_c, n_c - 1, tid);
+  } else {
+    const double fl_v = floor(v);
+    const uint32_t k = static_cast<uint32_t>(fl_v);
+    const double x0 = in_lds ? select_kth<true>(sh, a.tgt_freq, fl, lo, hi, n_c, k, tid)
+                             : select_kth<false>(sh, a.tgt_freq, fl, lo, hi, n_c, k, tid);
+    const double x1 = in_lds ? select_kth<true>(sh, a.tgt_freq, fl, lo, hi, n_c, k + 1, tid)
+                             : select_kth<false>(sh, a.tgt_freq, fl, lo, hi, n_c, k + 1, tid);
+    q = numpy_lerp(x0, x1, v, fl_v);
+  }
+  uint32_t c_q = 0;
+  for (int i = lo + tid; i < hi; i += kWinThreads) {
+    const uint8_t f = fl[i];
+    if ((f & 1u) && eff_freq(a.tgt_freq, f, i) >= q) ++c_q;
+  }
+  const uint32_t n_q = block_sum(c_q, sh.red, tid);
+  if (tid == 0) {
+    a.records[ridx].n_cdd_q = static_cast<int32_t>(n_q);
+    a.records[ridx].q = q;
   }
 }
 
-__global__ __launch_bounds__(kWinThreads) void window_stats_kernel(WinArgs a) {
-  __shared__ WinShared sh;
+// ---- CSR offsets ---------------------------------------------------------------------------
+
+// One 1024-thread workgroup: exclusive prefix sums of u_count and n_cdd_q over the records in
+// (set, window) order.  cdd_off[2r] / cdd_off[2r+1] = start of record r's U / Q list (or -1 when
+// the list would not fit its buffer); cdd_total[0..1] = entries needed in all.
+__global__ __launch_bounds__(1024) void window_scan_kernel(WinArgs a) {
+  __shared__ long long part[2][1024];
   const int tid = threadIdx.x;
-  // XCD-aware order: consecutive blockIdx values round-robin over the 8 XCDs, so give each XCD a
-  // contiguous run of (overlapping) windows to keep their shared sites in one L2.
-  int w = blockIdx.x;
-  {
-    const int nw = a.n_windows;
-    const int per = nw >> 3;
-    if (per > 0 && w < per * 8) w = (w & 7) * per + (w >> 3);
+  const int64_t n = static_cast<int64_t>(a.n_sets) * a.n_windows;
+  const int64_t per = (n + 1023) / 1024;
+  const int64_t r0 = min(n, tid * per), r1 = min(n, r0 + per);
+  long long su = 0, sq = 0;
+  for (int64_t r = r0; r < r1; ++r) {
+    su += a.records[r].u_count;
+    sq += a.records[r].n_cdd_q;
   }
+  part[0][tid] = su;
+  part[1][tid] = sq;
+  __syncthreads();
+  for (int o = 1; o < 1024; o <<= 1) {  // Hillis-Steele inclusive scan of the 1024 partial sums
+    const long long u = tid >= o ? part[0][tid - o] : 0;
+    const long long q = tid >= o ? part[1][tid - o] : 0;
+    __syncthreads();
+    part[0][tid] += u;
+    part[1][tid] += q;
+    __syncthreads();
+  }
+  long long ou = part[0][tid] - su, oq = part[1][tid] - sq;
+  for (int64_t r = r0; r < r1; ++r) {
+    const long long nu = a.records[r].u_count, nq = a.records[r].n_cdd_q;
+    a.cdd_off[2 * r + 0] = (ou + nu <= a.cap_u) ? ou : -1;
+    a.cdd_off[2 * r + 1] = (oq + nq <= a.cap_q) ? oq : -1;
+    ou += nu;
+    oq += nq;
+  }
+  if (tid == 1023) {
+    a.cdd_total[0] = part[0][1023];
+    a.cdd_total[1] = part[1][1023];
+  }
+}
+
+// ---- candidate lists -----------------------------------------------------------------------
+
+__global__ __launch_bounds__(256) void window_lists_kernel(WinArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int w = xcd_contiguous(blockIdx.x, gridDim.x) * 4 + (threadIdx.x >> 6);
+  if (w >= a.n_windows) return;
   const int set = blockIdx.y;
+  const int64_t ridx = static_cast<int64_t>(set) * a.n_windows + w;
+  const sai_window_record rec = a.records[ridx];
+  const long long off_u = a.cdd_off[2 * ridx + 0], off_q = a.cdd_off[2 * ridx + 1];
+  const bool write_u = rec.u_count > 0 && off_u >= 0 && a.cdd_u != nullptr;
+  const bool write_q = rec.n_cdd_q > 0 && off_q >= 0 && a.cdd_q != nullptr;
+  if (!write_u && !write_q) return;
   const int lo = a.lo[w], hi = a.hi[w];
   const uint8_t* fl = a.flags + static_cast<int64_t>(set) * a.n_sites;
-  const int64_t ridx = static_cast<int64_t>(set) * a.n_windows + w;
-
-  if (tid == 0) sh.n_stored = 0;
-  __syncthreads();
-  uint32_t c_u = 0, c_c = 0;
-  for (int i = lo + tid; i < hi; i += kWinThreads) {
-    const uint8_t f = fl[i];
-    c_u += (f >> 1) & 1u;
-    if (f & 1u) {
-      ++c_c;
-      const uint32_t slot = atomicAdd(&sh.n_stored, 1u);
-      if (slot < kSelCap) sh.vals[slot] = eff_freq(a.tgt_freq, f, i);
+  const unsigned long long lt_mask = (1ull << lane) - 1ull;
+  const double q = rec.q;
+  uint32_t done_u = 0, done_q = 0;
+  for (int i0 = lo; i0 < hi; i0 += 64) {
+    const int i = i0 + lane;
+    const uint8_t f = i < hi ? fl[i] : static_cast<uint8_t>(0);
+    const bool pu = (f & 2u) != 0;
+    const bool pq = write_q && (f & 1u) && eff_freq(a.tgt_freq, f, i) >= q;
+    const unsigned long long mu = __ballot(pu);
+    const unsigned long long mq = __ballot(pq);
+    if (mu | mq) {
+      const int32_t out = (pu || pq) ? (a.pos ? a.pos[i] : i) : 0;
+      if (write_u && pu) a.cdd_u[off_u + done_u + __popcll(mu & lt_mask)] = out;
+      if (pq) a.cdd_q[off_q + done_q + __popcll(mq & lt_mask)] = out;
+      done_u += __popcll(mu);
+      done_q += __popcll(mq);
     }
   }
-  const uint32_t n_u = block_sum(c_u, sh.red, tid);
-  const uint32_t n_c = block_sum(c_c, sh.red + 4, tid);
-
-  double q = std::numeric_limits<double>::quiet_NaN();
-  uint32_t n_q = 0;
-  if (n_c > 0) {
-    const bool in_lds = n_c <= kSelCap;
-    // numpy 'linear': virtual index (n-1)*q; at/after the last index -> the maximum
-    const double v = static_cast<double>(n_c - 1) * a.quantile[set];
-    if (v >= static_cast<double>(n_c - 1)) {
-      q = in_lds ? select_kth<true>(sh, a.tgt_freq, fl, lo, hi, n_c, n_c - 1, tid)
-                 : select_kth<false>(sh, a.tgt_freq, fl, lo, hi, n_c, n_c - 1, tid);
-    } else {
-      const double fl_v = floor(v);
-      const uint32_t k = static_cast<uint32_t>(fl_v);
-      const double g = v - fl_v;
-      const double x0 = in_lds ? select_kth<true>(sh, a.tgt_freq, fl, lo, hi, n_c, k, tid)
-                               : select_kth<false>(sh, a.tgt_freq, fl, lo, hi, n_c, k, tid);
-      const double x1 = in_lds ? select_kth<true>(sh, a.tgt_freq, fl, lo, hi, n_c, k + 1, tid)
-                               : select_kth<false>(sh, a.tgt_freq, fl, lo, hi, n_c, k + 1, tid);
-      const double d = x1 - x0;
-      q = (g >= 0.5) ? x1 - d * (1.0 - g) : x0 + d * g;
-    }
-    uint32_t c_q = 0;
-    for (int i = lo + tid; i < hi; i += kWinThreads) {
-      const uint8_t f = fl[i];
-      if ((f & 1u) && eff_freq(a.tgt_freq, f, i) >= q) ++c_q;
-    }
-    n_q = block_sum(c_q, sh.red, tid);
-  }
-
-  // reserve list space (placement between windows is arbitrary, the offsets say where)
-  if (tid == 0) {
-    const long long bu = static_cast<long long>(atomicAdd(a.cdd_total + 0, static_cast<unsigned long long>(n_u)));
-    const long long bq = static_cast<long long>(atomicAdd(a.cdd_total + 1, static_cast<unsigned long long>(n_q)));
-    sh.base_u = (bu + static_cast<long long>(n_u) <= a.cap_u) ? bu : -1;
-    sh.base_q = (bq + static_cast<long long>(n_q) <= a.cap_q) ? bq : -1;
-    sai_window_record rec;
-    rec.n_sites = hi - lo;
-    rec.u_count = static_cast<int32_t>(n_u);
-    rec.n_cond = static_cast<int32_t>(n_c);
-    rec.n_cdd_q = static_cast<int32_t>(n_q);
-    rec.q = q;
-    a.records[ridx] = rec;
-    a.cdd_off[ridx * 2 + 0] = sh.base_u;
-    a.cdd_off[ridx * 2 + 1] = sh.base_q;
-  }
-  __syncthreads();
-  const long long off_u = sh.base_u;
-  const long long off_q = sh.base_q;
-  __syncthreads();
-  if (n_u > 0 && off_u >= 0 && a.cdd_u)
-    write_list(sh, lo, hi, a.pos, a.cdd_u, off_u, tid, [&](int i) { return (fl[i] & 2u) != 0; });
-  if (n_q > 0 && off_q >= 0 && a.cdd_q)
-    write_list(sh, lo, hi, a.pos, a.cdd_q, off_q, tid, [&](int i) {
-      const uint8_t f = fl[i];
-      return (f & 1u) && eff_freq(a.tgt_freq, f, i) >= q;
-    });
 }
 
 // ------------------------------------------------------------------------------------------
@@ -658,6 +833,31 @@ __global__ __launch_bounds__(256) void synth_gaps_kernel(uint64_t seed, int32_t 
   if (i < n_sites) gaps[i] = synth_gap(seed, chrom, site0 + i);
 }
 
+
+// ------------------------------------------------------------------------------------------
+// stream_read probe: the plainest possible streaming read (16 B per lane, XOR-reduced, one
+// result word per wave) -- the on-box read ceiling the site_counts rate is compared with.
+// ------------------------------------------------------------------------------------------
+
+__global__ __launch_bounds__(256) void stream_read_kernel(const u32x4* __restrict__ src, int64_t n_vec,
+                                                           uint32_t* __restrict__ out) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  u32x4 acc = {0u, 0u, 0u, 0u};
+  for (; i + 3 * stride < n_vec; i += 4 * stride) {
+    const u32x4 a = __builtin_nontemporal_load(src + i);
+    const u32x4 b = __builtin_nontemporal_load(src + i + stride);
+    const u32x4 c = __builtin_nontemporal_load(src + i + 2 * stride);
+    const u32x4 d = __builtin_nontemporal_load(src + i + 3 * stride);
+    acc ^= a ^ b ^ c ^ d;
+  }
+  for (; i < n_vec; i += stride) acc ^= __builtin_nontemporal_load(src + i);
+  uint32_t v = acc.x ^ acc.y ^ acc.z ^ acc.w;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v ^= __shfl_xor(v, o, 64);
+  if ((threadIdx.x & 63) == 0) atomicXor(out, v);
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------------
@@ -752,9 +952,51 @@ int sai_site_counts(sai_ctx* ctx, int64_t n_sites, int32_t n_pops, const sai_pop
     a.pop[p].pad = 0;
   }
   a.counts = reinterpret_cast<uint2*>(counts);
-  const int64_t max_grid = static_cast<int64_t>(ctx->n_cu) * 64;  // grid-stride beyond this
-  const unsigned grid = static_cast<unsigned>(a.n_tiles < max_grid ? a.n_tiles : max_grid);
-  hipLaunchKernelGGL(site_counts_kernel<4>, dim3(grid), dim3(64), 0, static_cast<hipStream_t>(stream), a);
+  // SAI_COUNTS_VARIANT / SAI_COUNTS_GRID are tuning knobs for experiments
+  static const int variant = []() { const char* e = getenv("SAI_COUNTS_VARIANT"); return e ? atoi(e) : 0; }();
+  static const int grid_mult = []() { const char* e = getenv("SAI_COUNTS_GRID"); return e ? atoi(e) : 64; }();
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  bool multi = getenv("SAI_COUNTS_MULTI") != nullptr;  // tuning: force the general kernel
+  for (int p = 0; p < n_pops; ++p) multi = multi || pops[p].n_ind > 16 * kChunkIters;
+#define SAI_LAUNCH_COUNTS(U, PIPE, NT, WAVES)                                                         \
+  do {                                                                                                \
+    const int64_t blocks = (a.n_tiles + (WAVES) - 1) / (WAVES);                                       \
+    const int64_t cap = static_cast<int64_t>(ctx->n_cu) * grid_mult / (WAVES);                        \
+    const unsigned grid = static_cast<unsigned>(blocks < cap ? blocks : (cap > 0 ? cap : 1));         \
+    if (multi)                                                                                        \
+      hipLaunchKernelGGL((site_counts_kernel<U, PIPE, NT, WAVES, true>), dim3(grid), dim3(64 * (WAVES)), 0, st, a); \
+    else                                                                                              \
+      hipLaunchKernelGGL((site_counts_kernel<U, PIPE, NT, WAVES, false>), dim3(grid), dim3(64 * (WAVES)), 0, st, a); \
+  } while (0)
+  switch (variant) {
+    case 1: SAI_LAUNCH_COUNTS(8, false, true, 1); break;
+    case 2: SAI_LAUNCH_COUNTS(4, true, true, 1); break;
+    case 3: SAI_LAUNCH_COUNTS(4, false, false, 1); break;
+    case 4: SAI_LAUNCH_COUNTS(8, true, true, 1); break;
+    case 5: SAI_LAUNCH_COUNTS(4, false, true, 4); break;
+    case 6: SAI_LAUNCH_COUNTS(4, true, true, 4); break;
+    case 7: SAI_LAUNCH_COUNTS(2, true, true, 1); break;
+    case 8:  // single-chunk kernel squeezed to 64 VGPRs: 8 waves per SIMD
+      if (!multi) {
+        const int64_t cap8 = static_cast<int64_t>(ctx->n_cu) * grid_mult;
+        const unsigned g8 = static_cast<unsigned>(a.n_tiles < cap8 ? a.n_tiles : cap8);
+        hipLaunchKernelGGL((site_counts_kernel<4, false, true, 1, false, 8>), dim3(g8), dim3(64), 0, st, a);
+        break;
+      }
+      SAI_LAUNCH_COUNTS(4, false, true, 1);
+      break;
+    case 9:  // 6 waves per SIMD
+      if (!multi) {
+        const int64_t cap8 = static_cast<int64_t>(ctx->n_cu) * grid_mult;
+        const unsigned g8 = static_cast<unsigned>(a.n_tiles < cap8 ? a.n_tiles : cap8);
+        hipLaunchKernelGGL((site_counts_kernel<4, false, true, 1, false, 6>), dim3(g8), dim3(64), 0, st, a);
+        break;
+      }
+      SAI_LAUNCH_COUNTS(4, false, true, 1);
+      break;
+    default: SAI_LAUNCH_COUNTS(4, false, true, 1); break;
+  }
+#undef SAI_LAUNCH_COUNTS
   return check_launch("site_counts");
 }
 
@@ -822,8 +1064,11 @@ int sai_window_stats(sai_ctx* ctx, int64_t n_sites, const double* tgt_freq, cons
   if (!cdd_total) return fail(SAI_ERR_ARG, "cdd_total is NULL");
   if (cap_u < 0 || cap_q < 0 || (cap_u > 0 && !cdd_u) || (cap_q > 0 && !cdd_q))
     return fail(SAI_ERR_ARG, "candidate buffers do not match their capacities");
-  SAI_HIP(hipMemsetAsync(cdd_total, 0, 2 * sizeof(int64_t), static_cast<hipStream_t>(stream)));
-  if (n_windows == 0) return SAI_OK;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (n_windows == 0) {
+    SAI_HIP(hipMemsetAsync(cdd_total, 0, 2 * sizeof(int64_t), st));
+    return SAI_OK;
+  }
   if ((n_sites > 0 && (!tgt_freq || !flags)) || !lo || !hi || !records || !cdd_off)
     return fail(SAI_ERR_ARG, "NULL buffer");
   WinArgs a;
@@ -842,11 +1087,18 @@ int sai_window_stats(sai_ctx* ctx, int64_t n_sites, const double* tgt_freq, cons
   a.cap_u = cap_u;
   a.cdd_q = cdd_q;
   a.cap_q = cap_q;
-  a.cdd_total = reinterpret_cast<unsigned long long*>(cdd_total);
+  a.cdd_total = cdd_total;
   for (int s = 0; s < n_sets; ++s) a.quantile[s] = sets_host[s].quantile;
-  dim3 grid(static_cast<unsigned>(n_windows), static_cast<unsigned>(n_sets));
-  hipLaunchKernelGGL(window_stats_kernel, grid, dim3(kWinThreads), 0, static_cast<hipStream_t>(stream), a);
-  return check_launch("window_stats");
+  const dim3 wave_grid(static_cast<unsigned>((n_windows + 3) / 4), static_cast<unsigned>(n_sets));
+  const dim3 block_grid(static_cast<unsigned>(n_windows), static_cast<unsigned>(n_sets));
+  hipLaunchKernelGGL(window_stats_wave_kernel, wave_grid, dim3(256), 0, st, a);
+  if (int rc = check_launch("window_stats_wave")) return rc;
+  hipLaunchKernelGGL(window_stats_heavy_kernel, block_grid, dim3(kWinThreads), 0, st, a);
+  if (int rc = check_launch("window_stats_heavy")) return rc;
+  hipLaunchKernelGGL(window_scan_kernel, dim3(1), dim3(1024), 0, st, a);
+  if (int rc = check_launch("window_scan")) return rc;
+  hipLaunchKernelGGL(window_lists_kernel, wave_grid, dim3(256), 0, st, a);
+  return check_launch("window_lists");
 }
 
 int sai_synth_fill(sai_ctx* ctx, uint64_t seed, int32_t chrom, int64_t site0, int64_t n_sites, int32_t pop_stream,
@@ -898,6 +1150,19 @@ int sai_synth_gaps(sai_ctx* ctx, uint64_t seed, int32_t chrom, int64_t site0, in
   hipLaunchKernelGGL(synth_gaps_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), seed, chrom,
                      site0, n_sites, gaps);
   return check_launch("synth_gaps");
+}
+
+int sai_probe_stream_read(sai_ctx* ctx, const void* buf, int64_t n_bytes, uint32_t* xor_out, void* stream) {
+  if (int rc = enter(ctx)) return rc;
+  if (n_bytes < 0 || (n_bytes & 15)) return fail(SAI_ERR_ARG, "n_bytes must be a non-negative multiple of 16");
+  if (!xor_out || (n_bytes > 0 && !buf)) return fail(SAI_ERR_ARG, "NULL buffer");
+  if (reinterpret_cast<uintptr_t>(buf) & 15u) return fail(SAI_ERR_ARG, "buf must be 16-byte aligned");
+  SAI_HIP(hipMemsetAsync(xor_out, 0, sizeof(uint32_t), static_cast<hipStream_t>(stream)));
+  if (n_bytes == 0) return SAI_OK;
+  const unsigned grid = static_cast<unsigned>(ctx->n_cu) * 8;
+  hipLaunchKernelGGL(stream_read_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     static_cast<const u32x4*>(buf), n_bytes / 16, xor_out);
+  return check_launch("stream_read");
 }
 
 }  // extern "C"

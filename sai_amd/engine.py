@@ -260,6 +260,23 @@ class Engine:
             np.concatenate(q_parts) if q_parts else np.zeros(0, np.int32),
         )
 
+    # -- measurement aid ------------------------------------------------------------------
+
+    def probe_stream_read(self, buf, repeats: int = 5) -> float:
+        """GB/s of a plain 16-B-per-lane streaming read over ``buf`` (best of ``repeats``)."""
+        torch = _torch()
+        out = self._empty((1,), torch.int32)
+        n = (buf.numel() * buf.element_size()) & ~15
+        best = 0.0
+        for _ in range(repeats + 1):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            _ffi.check(self.lib.sai_probe_stream_read(self.ctx, self._ptr(buf), n, self._ptr(out), self._stream()))
+            e1.record()
+            e1.synchronize()
+            best = max(best, n / (e0.elapsed_time(e1) * 1e-3) / 1e9)
+        return best
+
     # -- synthetic data --------------------------------------------------------------------
 
     def synth_population(self, seed, chrom, site0, n_sites, pop_stream, n_ind, ploidy=2, missing_per_million=0):

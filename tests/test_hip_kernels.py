@@ -183,8 +183,9 @@ def test_batched_windows_vs_oracle(eng):
 
 
 def test_quantile_beyond_lds_capacity(eng):
-    """More than 4096 qualifying sites in one window: the radix select falls back to re-reading
-    the per-site arrays; still numpy's 'linear' quantile bit for bit."""
+    """All selection paths of window_stats: <= 256 qualifying sites (wave kernel, rank counting),
+    <= 4096 (workgroup kernel, radix select in LDS) and more (radix select re-reading the
+    per-site arrays); always numpy's 'linear' quantile bit for bit."""
     from oracle import sai_oracle as O
     from sai_amd import _ffi
 
@@ -197,8 +198,10 @@ def test_quantile_beyond_lds_capacity(eng):
     pos = np.arange(1, n_sites + 1, dtype=np.int64) * 3
     for quantile in (0.0, 0.3, 0.95, 1.0):
         sets = [_ffi.make_params(0.5, 0.5, quantile, [("=", 1.0)], True)]
-        res, _, _ = _window_pass(eng, [ref, tgt, src], [2, 2, 2], sets, pos, np.array([1, 1]), np.array([10**9, 20000]))
-        for wi, we in enumerate([10**9, 20000]):
+        ends = [10**9, 20000, 3000, 600, 768, 771, 3]
+        res, _, _ = _window_pass(eng, [ref, tgt, src], [2, 2, 2], sets, pos, np.ones(len(ends), dtype=np.int64), np.array(ends))
+        assert res.records[0]["n_cond"].tolist() == [20000, 6666, 1000, 200, 256, 257, 1]
+        for wi, we in enumerate(ends):
             m = pos <= we
             kw = dict(ref_gts=ref[m], tgt_gts=tgt[m], src_gts_list=[src[m]], ref_ploidy=2, tgt_ploidy=2,
                       src_ploidy_list=[2], pos=pos[m], w=0.5, y_list=[("=", 1.0)], anc_allele_available=True)  # fmt: skip

@@ -44,7 +44,4 @@ print(f"window_bounds (incl. H2D of {len(starts)} windows) min {mn:.3f} ms")
 bufs = eng.alloc_window_bufs(1, len(starts), 1 << 22, 1 << 22)
 mn, av = timeit(lambda: eng.window_stats_async(out[0], out[1], sets, lo, hi, pos, bufs))
 print(f"window_stats min {mn:.3f} ms avg {av:.3f}; totals {bufs[4].cpu().tolist()} windows {len(starts)}")
-# a plain streaming read for comparison (torch reduction over the same bytes)
-big = pops[0].tiles
-mn, av = timeit(lambda: big.view(torch.int32).sum())
-print(f"torch int32 sum over ref block: {big.numel() / mn / 1e6:.1f} GB/s")
+print(f"stream-read probe over the ref block: {eng.probe_stream_read(pops[0].tiles):.1f} GB/s")

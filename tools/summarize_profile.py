@@ -17,10 +17,12 @@ dst.mkdir(exist_ok=True)
 
 
 def short(name):
-    for k in ("site_counts", "site_flags", "window_bounds", "window_stats", "synth_fill", "synth_gaps", "tile_from_site_major"):
-        if k in name:
-            return k
-    return name.split("(")[0][-60:]
+    import re
+
+    m = re.search(r"(\w+)_kernel\b", name)
+    if m and "::" in name and "anonymous namespace" in name:
+        return m.group(1)
+    return name.split("<")[0].split("(")[0].strip()[-60:] or name[:60]
 
 
 shutil.copy(glob.glob(str(src / "trace/*/*_kernel_stats.csv"))[0], dst / f"{tag}_kernel_stats.csv")
