@@ -6,6 +6,7 @@ import argparse
 
 import sai_amd.stats  # noqa: F401  (registers U and Q)
 from sai_amd import __version__
+from sai_amd.parsers.outlier_parser import add_outlier_parser
 from sai_amd.parsers.score_parser import add_score_parser
 
 
@@ -23,6 +24,7 @@ def _sai_cli_parser() -> argparse.ArgumentParser:
     subparsers = top_parser.add_subparsers(dest="subcommand")
     subparsers.required = True
     add_score_parser(subparsers)
+    add_outlier_parser(subparsers)
     return top_parser
 
 

@@ -1,8 +1,10 @@
-"""``score`` -- the function behind ``sai score`` (mirror of sai/sai.py:33-151)."""
+"""``score`` and ``outlier`` -- the functions behind ``sai score`` / ``sai outlier`` (mirror of
+sai/sai.py:33-230)."""
 
 from __future__ import annotations
 
 import os
+import warnings
 from pathlib import Path
 
 import yaml
@@ -105,3 +107,42 @@ def score(
     for params in generator.get():
         items.extend(preprocessor.run(**params))
     preprocessor.process_items(items)
+
+
+def outlier(score_file: str, output_prefix: str, quantile: float) -> None:
+    """Per statistic column of a score table, write the rows beyond the ``quantile`` of that
+    column to ``{output_prefix}.{column}.{quantile}.outliers.tsv`` (sai.py:154-230): columns
+    after ``N(Variants)`` are statistics; ``U*`` columns keep rows strictly above the threshold,
+    the others rows at or above it; a column without numbers, or with a single distinct value,
+    gives a header-only file and a UserWarning; rows are naturally sorted by Chrom/Start/End.
+    Host-side post-processing of a small table (pandas, like the reference); no GPU involved."""
+    import pandas as pd
+
+    from .utils import natsorted_df
+
+    df = pd.read_csv(score_file, sep="\t", na_values=["nan"], index_col=False)
+    cols = list(df.columns)
+    if "N(Variants)" in cols:
+        metric_cols = cols[cols.index("N(Variants)") + 1 :]
+    else:  # sai.py:188-194
+        skip = {"Chrom", "Start", "End", "Ref", "Tgt", "Src"}
+        metric_cols = [c for c in cols if c not in skip and pd.to_numeric(df[c], errors="coerce").notna().any()]
+    if not metric_cols:
+        raise ValueError("No metric columns found.")
+    for col in metric_cols:
+        numeric = pd.to_numeric(df[col], errors="coerce")
+        present = numeric.dropna()
+        if present.empty:
+            warnings.warn(f"Column '{col}' has no numeric values; writing empty result.", UserWarning)
+            out = pd.DataFrame(columns=df.columns)
+        elif present.nunique() == 1:
+            warnings.warn(
+                f"Column '{col}' has only one unique value ({present.iloc[0]}); writing empty result.", UserWarning
+            )
+            out = pd.DataFrame(columns=df.columns)
+        else:
+            thr = present.quantile(quantile)
+            out = df[numeric > thr] if col.startswith("U") else df[numeric >= thr]
+            if not out.empty:
+                out = natsorted_df(out.reset_index(drop=True))
+        out.astype(str).to_csv(f"{output_prefix}.{col}.{quantile}.outliers.tsv", index=False, sep="\t")

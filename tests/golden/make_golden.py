@@ -514,3 +514,39 @@ if __name__ == "__main__":
     make_windows_grid()
     make_pipeline()
     make_example_vcf()
+
+
+# ---------------------------------------------------------------------------
+# 6. `sai outlier` (sai/sai.py:154-230) on single-chromosome score tables, where the
+#    `natsorted = sorted` import stub orders rows exactly like natsort would
+# ---------------------------------------------------------------------------
+
+
+def make_outlier():
+    import warnings
+
+    from sai.sai import outlier
+
+    tables = {"test.q.scores": (Path(REF) / "tests" / "data" / "test.q.scores").read_text()}
+    for sc in json.loads((OUT / "pipeline.json").read_text()):
+        names = list(sc["stats"].keys())
+        head = "Chrom\tStart\tEnd\tRef\tTgt\tSrc\tOutgroup\tN(Variants)\t" + "\t".join(names) + "\n"
+        tables[sc["name"]] = head + sc["text"]["tsv"]
+    out = []
+    for name, text in tables.items():
+        for quantile in (0.25, 0.5, 0.75, 0.99):
+            with tempfile.TemporaryDirectory() as td:
+                src = os.path.join(td, "scores.tsv")
+                Path(src).write_text(text)
+                with warnings.catch_warnings(record=True) as wl:
+                    warnings.simplefilter("always")
+                    outlier(score_file=src, output_prefix=os.path.join(td, "o"), quantile=quantile)
+                files = {f[2:]: Path(td, f).read_text() for f in sorted(os.listdir(td)) if f.startswith("o.")}
+                out.append(dict(table=name, quantile=quantile, files=files,
+                                warnings=[str(w.message).replace(td, "") for w in wl if w.category is UserWarning]))
+    (OUT / "outlier.json").write_text(json.dumps(dict(tables=tables, runs=out), separators=(",", ":")) + "\n")
+    print("outlier.json", len(out))
+
+
+if __name__ == "__main__" and os.path.isdir(REF):
+    make_outlier()

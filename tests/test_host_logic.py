@@ -356,3 +356,47 @@ def test_to_int8_dosage():
         to_int8_dosage(np.array([[0.5]]))
     with pytest.raises(ValueError, match="2-D"):
         to_int8_dosage(np.array([1, 2]))
+
+
+# ---- outlier --------------------------------------------------------------
+
+
+def test_outlier_equals_reference(tmp_path):
+    """`sai outlier` output files and warnings, byte for byte, against the capture of the
+    reference's outlier() (tests/golden/outlier.json; includes tests/data/test.q.scores)."""
+    import warnings
+
+    from sai_amd.sai import outlier
+
+    g = load_golden("outlier.json")
+    for run in g["runs"]:
+        d = tmp_path / f"{run['table']}_{run['quantile']}"
+        d.mkdir()
+        (d / "scores.tsv").write_text(g["tables"][run["table"]])
+        with warnings.catch_warnings(record=True) as wl:
+            warnings.simplefilter("always")
+            outlier(score_file=str(d / "scores.tsv"), output_prefix=str(d / "o"), quantile=run["quantile"])
+        files = {f.name[2:]: f.read_text() for f in sorted(d.iterdir()) if f.name.startswith("o.")}
+        assert files == run["files"]
+        assert [str(w.message) for w in wl if w.category is UserWarning] == run["warnings"]
+
+
+def test_outlier_reference_pins_and_natural_order(in_repo_root, tmp_path):
+    # reference tests/test_sai.py:154-173 and tests/utils/test_utils.py:450-511
+    import pandas as pd
+
+    from sai_amd.__main__ import main
+    from sai_amd.utils import natsorted_df
+
+    (tmp_path / "q.scores").write_text(load_golden("outlier.json")["tables"]["test.q.scores"])
+    main(["outlier", "--score", str(tmp_path / "q.scores"), "--output-prefix", str(tmp_path / "outliers"), "--quantile", "0.25"])
+    df = pd.read_csv(tmp_path / "outliers.Q.0.25.outliers.tsv", sep="\t")
+    assert df["Q"].iloc[0] == 0.7
+    df = pd.DataFrame({"Chrom": ["1", "10", "2", "X", "1"], "Start": [300, 50, 150, 10, 100], "End": [400, 100, 200, 50, 200]})
+    s = natsorted_df(df)
+    assert s["Chrom"].tolist() == ["1", "1", "2", "10", "X"] and s["Start"].tolist() == [100, 300, 150, 50, 10]
+    with pytest.raises(ValueError, match="Missing required columns: End"):
+        natsorted_df(pd.DataFrame({"Chrom": ["1"], "Start": [1]}))
+    assert natsorted_df(pd.DataFrame(columns=["Chrom", "Start", "End"])).empty
+    t = natsorted_df(pd.DataFrame({"Chrom": ["1", "2", "X"], "Start": ["100", "200", "300"], "End": ["150", "250", "350"]}))
+    assert t["Start"].dtype == int and t["End"].dtype == int
