@@ -175,6 +175,33 @@ int sai_synth_gaps_host(uint64_t seed, int32_t chrom, int64_t site0, int64_t n_s
 int sai_synth_gaps(sai_ctx* ctx, uint64_t seed, int32_t chrom, int64_t site0, int64_t n_sites,
                    int32_t* gaps, void* stream);
 
+/* ---- ingest (host side, no GPU involved) ------------------------------------------------- */
+
+/* First and last POS of the first contiguous run of `chrom` records; -1/-1 when the chromosome
+ * is absent.  Replaces the pysam scan of ChunkGenerator.__init__ (chunk_generator.py:64-73).
+ * Plain, gzip and bgzip files are accepted. */
+int sai_vcf_scan(const char* path, const char* chrom, int64_t* first_pos, int64_t* last_pos);
+
+/* One pass over a VCF: for the records of `chrom` with start <= POS <= end (either bound -1 =
+ * open), the unphased ALT dosage of the selected samples as int8 [record][sample] plus int32
+ * positions.  Replaces read_geno_data + reshape_genotypes (utils.py:78-186, 389-410): first ALT
+ * only, '.' allele = -1, each call padded / cut to ploidy[sample] alleles, alleles summed.  With
+ * `anc_bed_path` (columns chrom, start, pos, allele) it also applies check_anc_allele
+ * (utils.py:492-555): only listed sites are kept, sites whose ancestral allele is neither REF nor
+ * ALT are dropped, and where ALT is ancestral every allele call a becomes |a - 1|.  Lines are
+ * tokenised by `n_threads` threads.  The block is owned by the library until
+ * sai_vcf_block_free. */
+typedef struct sai_vcf_block sai_vcf_block;
+int sai_vcf_load(const char* path, const char* chrom, int64_t start, int64_t end, int32_t n_samples,
+                 const char* const* sample_names, const int32_t* ploidy, const char* anc_bed_path,
+                 int32_t n_threads, sai_vcf_block** block_out);
+/* n_records = rows held; n_matched = records of the chromosome/region before polarisation;
+ * n_anc_entries = ancestral-allele entries found for the chromosome/region. */
+int sai_vcf_block_info(const sai_vcf_block* block, int64_t* n_records, int64_t* n_matched,
+                       int64_t* n_anc_entries);
+int sai_vcf_block_copy(const sai_vcf_block* block, int32_t* pos_host, int8_t* dosage_host);
+int sai_vcf_block_free(sai_vcf_block* block);
+
 /* ---- measurement aid -------------------------------------------------------------------- */
 
 /* Plain streaming read of `n_bytes` (multiple of 16) with 16-byte loads, XOR-reduced into

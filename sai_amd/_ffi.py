@@ -85,6 +85,14 @@ SIGNATURES = {
     "sai_synth_gaps_host": (C.c_int, [_u64, _i32, _i64, _i64, _p]),
     "sai_synth_gaps": (C.c_int, [_p, _u64, _i32, _i64, _i64, _p, _p]),
     "sai_probe_stream_read": (C.c_int, [_p, _p, _i64, _p, _p]),
+    "sai_vcf_scan": (C.c_int, [C.c_char_p, C.c_char_p, C.POINTER(_i64), C.POINTER(_i64)]),
+    "sai_vcf_load": (
+        C.c_int,
+        [C.c_char_p, C.c_char_p, _i64, _i64, _i32, C.POINTER(C.c_char_p), C.POINTER(_i32), C.c_char_p, _i32, C.POINTER(_p)],
+    ),
+    "sai_vcf_block_info": (C.c_int, [_p, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)]),
+    "sai_vcf_block_copy": (C.c_int, [_p, _p, _p]),
+    "sai_vcf_block_free": (C.c_int, [_p]),
 }
 
 _lib = None

@@ -866,6 +866,15 @@ __global__ __launch_bounds__(256) void stream_read_kernel(const u32x4* __restric
 
 extern "C" {
 
+// shared with vcf_ingest.cpp (not part of the public header)
+int sai_set_error(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
 int sai_abi_version(void) { return SAI_ABI_VERSION; }
 const char* sai_build_arch(void) { return "gfx950"; }
 const char* sai_last_error(void) { return g_err; }

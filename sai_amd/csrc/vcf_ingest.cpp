@@ -1,0 +1,442 @@
+// Host-side VCF ingest for libsaihip (first "next" row): one pass over a
+// plain or gzip/bgzip VCF, multithreaded tokenising of the record lines, output = unphased ALT
+// dosage as int8 [record][sample] in the reference's matrix order plus int32 positions -- what
+// sai/utils/utils.py:78-186 + 389-410 obtain from scikit-allel (GT of the selected samples,
+// first ALT, region filter, '.' = -1, calls padded / cut to the population's ploidy, ploidy axis
+// summed) -- and, when an ancestral-allele BED is given, the polarisation of utils.py:435-555
+// (keep only listed sites whose ancestral allele is REF or ALT; where ALT is ancestral every
+// allele call a becomes |a - 1|, so a missing allele becomes 2 exactly as in the reference).
+// The Python reader sai_amd/utils/vcf.py is the readable statement of the same rules; the two are
+// tested against each other and against the reference tests' expectations.
+
+#include <zlib.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <thread>
+#include <unordered_map>
+#include <vector>
+
+#include "saihip.h"
+
+extern "C" int sai_set_error(int code, const char* fmt, ...);  // defined in saihip.hip
+
+namespace {
+
+struct GzReader {
+  gzFile f = nullptr;
+  explicit GzReader(const char* path) { f = gzopen(path, "rb"); if (f) gzbuffer(f, 1 << 20); }
+  ~GzReader() { if (f) gzclose(f); }
+};
+
+inline const char* find_tab(const char* p, const char* end) {
+  const void* t = memchr(p, '\t', static_cast<size_t>(end - p));
+  return t ? static_cast<const char*>(t) : end;
+}
+
+struct Selection {
+  std::vector<int32_t> slot_of_col;  // sample column (0-based after FORMAT) -> output slot or -1
+  std::vector<int32_t> ploidy;       // per output slot
+  int32_t n_out = 0;
+  int32_t max_col = -1;
+};
+
+struct AncMap {
+  bool active = false;
+  std::unordered_map<int64_t, std::string> allele;
+};
+
+struct ThreadOut {
+  std::vector<int32_t> pos;
+  std::vector<int8_t> dosage;
+  int64_t matched = 0;  // records of the chromosome inside the region, before polarisation
+  int64_t first = -1, last = -1;
+  std::string error;
+};
+
+// one-character alleles: value ('.' = -1, digits) and value after flipping |a - 1|
+constexpr int kBadAllele = 64;
+struct AlleleLut {
+  int8_t v[256];
+  int8_t f[256];
+  constexpr AlleleLut() : v(), f() {
+    for (int i = 0; i < 256; ++i) { v[i] = kBadAllele; f[i] = 0; }
+    v[static_cast<unsigned char>('.')] = -1;
+    f[static_cast<unsigned char>('.')] = 2;
+    for (int dgt = 0; dgt < 10; ++dgt) {
+      v['0' + dgt] = static_cast<int8_t>(dgt);
+      f['0' + dgt] = static_cast<int8_t>(dgt >= 1 ? dgt - 1 : 1);
+    }
+  }
+};
+constexpr AlleleLut kAllele;
+
+// Parse the record lines of [begin, end) (whole lines).
+void parse_lines(const char* begin, const char* end, const std::string& chrom, int64_t start, int64_t stop,
+                 const Selection& sel, const AncMap& anc, bool want_rows, ThreadOut& out) {
+  const char* p = begin;
+  std::vector<int8_t> row(static_cast<size_t>(sel.n_out)), frow(static_cast<size_t>(sel.n_out));
+  while (p < end) {
+    const char* eol = static_cast<const char*>(memchr(p, '\n', static_cast<size_t>(end - p)));
+    if (!eol) eol = end;
+    const char* line = p;
+    p = eol + 1;
+    const char* le = eol;
+    if (le > line && le[-1] == '\r') --le;
+    if (le == line || *line == '#') continue;
+    const char* t1 = find_tab(line, le);
+    if (static_cast<size_t>(t1 - line) != chrom.size() || memcmp(line, chrom.data(), chrom.size()) != 0) continue;
+    if (t1 >= le) continue;
+    const char* f = t1 + 1;
+    int64_t pos = 0;
+    while (f < le && *f >= '0' && *f <= '9') pos = pos * 10 + (*f++ - '0');
+    if (out.first < 0) out.first = pos;
+    out.last = pos;
+    if ((start >= 0 && pos < start) || (stop >= 0 && pos > stop)) continue;
+    ++out.matched;
+    if (!want_rows) continue;
+    // columns: 0 CHROM 1 POS 2 ID 3 REF 4 ALT 5 QUAL 6 FILTER 7 INFO 8 FORMAT 9.. samples
+    const char* col[10];
+    col[0] = line;
+    col[1] = t1 + 1;
+    const char* q = find_tab(f, le);
+    bool ok = true;
+    for (int c = 2; c <= 9; ++c) {
+      if (q >= le) { ok = false; break; }
+      col[c] = q + 1;
+      q = find_tab(col[c], le);
+    }
+    if (!ok) { out.error = "record with fewer than 10 columns at " + chrom + ":" + std::to_string(pos); return; }
+    bool flip = false;
+    if (anc.active) {
+      auto it = anc.allele.find(pos);
+      if (it == anc.allele.end()) continue;
+      const char* ref = col[3];
+      const size_t ref_len = static_cast<size_t>(col[4] - 1 - col[3]);
+      const char* alt = col[4];
+      const char* alt_end = col[5] - 1;
+      const void* comma = memchr(alt, ',', static_cast<size_t>(alt_end - alt));
+      const size_t alt_len = static_cast<size_t>((comma ? static_cast<const char*>(comma) : alt_end) - alt);
+      const std::string& a = it->second;
+      if (a.size() == alt_len && memcmp(a.data(), alt, alt_len) == 0) flip = true;
+      else if (!(a.size() == ref_len && memcmp(a.data(), ref, ref_len) == 0)) continue;
+    }
+    // FORMAT: index of GT
+    int gi = -1;
+    {
+      const char* fs = col[8];
+      const char* fe = col[9] - 1;
+      int k = 0;
+      while (fs <= fe) {
+        const void* c = memchr(fs, ':', static_cast<size_t>(fe - fs));
+        const char* ce = c ? static_cast<const char*>(c) : fe;
+        if (ce - fs == 2 && fs[0] == 'G' && fs[1] == 'T') { gi = k; break; }
+        if (!c) break;
+        fs = ce + 1;
+        ++k;
+      }
+    }
+    if (gi < 0) { out.error = "record " + chrom + ":" + std::to_string(pos) + " has no GT field"; return; }
+    // one forward scan over the sample columns (byte loops: the fields are 3-4 bytes long, so
+    // memchr calls would cost more than they save)
+    const char* s = col[9];
+    for (int c = 0; c <= sel.max_col; ++c) {
+      if (s > le) { out.error = "record " + chrom + ":" + std::to_string(pos) + " has too few sample columns"; return; }
+      const int slot = sel.slot_of_col[static_cast<size_t>(c)];
+      const char* g = s;
+      if (slot >= 0) {
+        for (int k = 0; k < gi; ++k) {  // skip to the GT sub-field
+          while (g < le && *g != ':' && *g != '\t') ++g;
+          if (g < le && *g == ':') ++g;
+        }
+        const int pl = sel.ploidy[static_cast<size_t>(slot)];
+        int n = 0, d = 0, fd = 0;
+        // fast path, branch-free in the data: a diploid call of two one-character alleles
+        if (pl == 2 && g + 3 <= le) {
+          const int a0 = kAllele.v[static_cast<unsigned char>(g[0])];
+          const int a1 = kAllele.v[static_cast<unsigned char>(g[2])];
+          const char sep = g[1];
+          const char term = g + 3 < le ? g[3] : '\t';
+          if (a0 != kBadAllele && a1 != kBadAllele && (sep == '|' || sep == '/') && (term == '\t' || term == ':')) {
+            row[static_cast<size_t>(slot)] = static_cast<int8_t>(a0 + a1);
+            frow[static_cast<size_t>(slot)] = static_cast<int8_t>(kAllele.f[static_cast<unsigned char>(g[0])] +
+                                                                   kAllele.f[static_cast<unsigned char>(g[2])]);
+            g += 3;
+            while (g < le && *g != '\t') ++g;
+            s = g + 1;
+            continue;
+          }
+        }
+        for (;;) {
+          const char ch = g < le ? *g : '\t';
+          int a;
+          if (ch == '.') {
+            a = -1;
+            ++g;
+          } else if (ch >= '0' && ch <= '9') {
+            a = 0;
+            do { a = a * 10 + (*g++ - '0'); } while (g < le && *g >= '0' && *g <= '9');
+          } else if (ch == '|' || ch == '/' || ch == ':' || ch == '\t') {
+            a = -1;  // empty allele
+          } else {
+            out.error = "unparsable genotype at " + chrom + ":" + std::to_string(pos);
+            return;
+          }
+          if (n < pl) {  // alleles beyond the ploidy asked for are ignored
+            d += a;
+            fd += a >= 1 ? a - 1 : 1 - a;
+            ++n;
+          }
+          if (g < le && (*g == '|' || *g == '/')) { ++g; continue; }
+          break;
+        }
+        for (; n < pl; ++n) {  // fewer alleles than the ploidy asked for: padded with missing
+          d -= 1;
+          fd += 2;
+        }
+        if (d > 127 || fd > 127 || d < -128) { out.error = "dosage outside the int8 range at " + chrom + ":" + std::to_string(pos); return; }
+        row[static_cast<size_t>(slot)] = static_cast<int8_t>(d);
+        frow[static_cast<size_t>(slot)] = static_cast<int8_t>(fd);
+      }
+      while (g < le && *g != '\t') ++g;
+      s = g + 1;
+    }
+    out.pos.push_back(static_cast<int32_t>(pos));
+    const std::vector<int8_t>& src = flip ? frow : row;
+    out.dosage.insert(out.dosage.end(), src.begin(), src.end());
+  }
+}
+
+int load_anc(const char* path, const std::string& chrom, int64_t start, int64_t stop, AncMap& anc, int64_t* n_entries) {
+  GzReader r(path);
+  if (!r.f) return sai_set_error(SAI_ERR_ARG, "cannot open ancestral-allele file %s", path);
+  std::vector<char> line(1 << 16);
+  while (gzgets(r.f, line.data(), static_cast<int>(line.size()))) {
+    // columns: chrom, start, pos, allele (whitespace separated)
+    char* save = nullptr;
+    const char* c0 = strtok_r(line.data(), " \t\r\n", &save);
+    const char* c1 = c0 ? strtok_r(nullptr, " \t\r\n", &save) : nullptr;
+    const char* c2 = c1 ? strtok_r(nullptr, " \t\r\n", &save) : nullptr;
+    const char* c3 = c2 ? strtok_r(nullptr, " \t\r\n", &save) : nullptr;
+    if (!c0) continue;
+    if (!c3) return sai_set_error(SAI_ERR_ARG, "%s: line with fewer than 4 columns", path);
+    if (chrom != c0) continue;
+    const int64_t p = strtoll(c2, nullptr, 10);
+    if ((start >= 0 && p < start) || (stop >= 0 && p > stop)) continue;
+    anc.allele[p] = c3;
+  }
+  anc.active = true;
+  if (n_entries) *n_entries = static_cast<int64_t>(anc.allele.size());
+  return SAI_OK;
+}
+
+// Streams the file in blocks of whole lines and hands each block to `consume(begin, end)`.
+// Returns 0, or a negative status after sai_set_error.
+template <typename F>
+int for_each_block(const char* path, F&& consume) {
+  GzReader r(path);
+  if (!r.f) return sai_set_error(SAI_ERR_ARG, "cannot open VCF %s", path);
+  std::vector<char> buf(size_t(8) << 20);
+  size_t have = 0;
+  for (;;) {
+    if (have == buf.size()) buf.resize(buf.size() * 2);  // one line longer than the buffer
+    const int got = gzread(r.f, buf.data() + have, static_cast<unsigned>(std::min<size_t>(buf.size() - have, size_t(1) << 30)));
+    if (got < 0) return sai_set_error(SAI_ERR_ARG, "read error in %s", path);
+    have += static_cast<size_t>(got);
+    const bool eof = got == 0;
+    size_t usable = have;
+    if (!eof) {
+      usable = 0;
+      for (size_t i = have; i > 0; --i)
+        if (buf[i - 1] == '\n') { usable = i; break; }
+      if (usable == 0) continue;  // no complete line yet
+    }
+    if (usable) {
+      const int rc = consume(buf.data(), buf.data() + usable);
+      if (rc < 0) return rc;
+      if (rc > 0) return SAI_OK;  // consumer has seen enough
+    }
+    const size_t rest = have - usable;
+    if (rest) memmove(buf.data(), buf.data() + usable, rest);
+    have = rest;
+    if (eof) break;
+  }
+  return SAI_OK;
+}
+
+int parse_header(const char* p, const char* eol, const char* path, int32_t n_samples, const char* const* sample_names,
+                 const int32_t* ploidy, Selection& sel) {
+  const char* le = eol;
+  if (le > p && le[-1] == '\r') --le;
+  std::vector<std::string> names;
+  const char* q = p;
+  int c = 0;
+  while (q <= le) {
+    const char* t = find_tab(q, le);
+    if (c >= 9) names.emplace_back(q, static_cast<size_t>(t - q));
+    q = t + 1;
+    ++c;
+  }
+  sel.slot_of_col.assign(names.size(), -1);
+  sel.ploidy.assign(static_cast<size_t>(n_samples), 1);
+  sel.n_out = n_samples;
+  std::unordered_map<std::string, int32_t> index;
+  for (size_t i = 0; i < names.size(); ++i) index.emplace(names[i], static_cast<int32_t>(i));
+  for (int32_t s = 0; s < n_samples; ++s) {
+    auto it = index.find(sample_names[s]);
+    if (it == index.end()) return sai_set_error(SAI_ERR_ARG, "samples not found in %s: %s", path, sample_names[s]);
+    if (sel.slot_of_col[static_cast<size_t>(it->second)] >= 0)
+      return sai_set_error(SAI_ERR_ARG, "sample %s requested twice", sample_names[s]);
+    sel.slot_of_col[static_cast<size_t>(it->second)] = s;
+    sel.ploidy[static_cast<size_t>(s)] = ploidy[s];
+    sel.max_col = std::max(sel.max_col, it->second);
+  }
+  return SAI_OK;
+}
+
+}  // namespace
+
+struct sai_vcf_block {
+  int32_t n_samples = 0;
+  int64_t n_matched = 0;      // records of the chromosome inside the region
+  int64_t n_anc_entries = 0;  // ancestral-allele entries loaded for the chromosome/region
+  std::vector<int32_t> pos;
+  std::vector<int8_t> dosage;  // [record][sample]
+};
+
+extern "C" {
+
+int sai_vcf_scan(const char* path, const char* chrom, int64_t* first_pos, int64_t* last_pos) {
+  if (!path || !chrom || !first_pos || !last_pos) return sai_set_error(SAI_ERR_ARG, "NULL argument");
+  const std::string c(chrom);
+  int64_t first = -1, last = -1;
+  bool header_seen = false;
+  const int rc = for_each_block(path, [&](const char* p, const char* end) -> int {
+    while (p < end) {
+      const char* eol = static_cast<const char*>(memchr(p, '\n', static_cast<size_t>(end - p)));
+      if (!eol) eol = end;
+      if (*p == '#') {
+        if (eol - p > 6 && memcmp(p, "#CHROM", 6) == 0) header_seen = true;
+      } else if (eol > p) {
+        const char* t1 = find_tab(p, eol);
+        if (static_cast<size_t>(t1 - p) == c.size() && memcmp(p, c.data(), c.size()) == 0 && t1 < eol) {
+          int64_t v = 0;
+          for (const char* f = t1 + 1; f < eol && *f >= '0' && *f <= '9'; ++f) v = v * 10 + (*f - '0');
+          if (first < 0) first = v;
+          last = v;
+        } else if (first >= 0) {
+          return 1;  // the first contiguous run of the chromosome is over (chunk_generator.py:66-73)
+        }
+      }
+      p = eol + 1;
+    }
+    return 0;
+  });
+  if (rc) return rc;
+  if (!header_seen && first < 0) return sai_set_error(SAI_ERR_ARG, "%s: not a VCF (no #CHROM header)", path);
+  *first_pos = first;
+  *last_pos = last;
+  return SAI_OK;
+}
+
+int sai_vcf_load(const char* path, const char* chrom, int64_t start, int64_t end, int32_t n_samples,
+                 const char* const* sample_names, const int32_t* ploidy, const char* anc_bed_path, int32_t n_threads,
+                 sai_vcf_block** block_out) {
+  if (!path || !chrom || !block_out) return sai_set_error(SAI_ERR_ARG, "NULL argument");
+  *block_out = nullptr;
+  if (n_samples < 1 || !sample_names || !ploidy) return sai_set_error(SAI_ERR_ARG, "empty sample selection");
+  for (int32_t s = 0; s < n_samples; ++s)
+    if (ploidy[s] < 1 || ploidy[s] > 64) return sai_set_error(SAI_ERR_ARG, "ploidy of sample %d out of range", s);
+  if (n_threads < 1) n_threads = 1;
+  const std::string c(chrom);
+  sai_vcf_block* blk = new (std::nothrow) sai_vcf_block;
+  if (!blk) return sai_set_error(SAI_ERR_HIP, "out of host memory");
+  blk->n_samples = n_samples;
+  AncMap anc;
+  if (anc_bed_path) {
+    if (int rc = load_anc(anc_bed_path, c, start, end, anc, &blk->n_anc_entries)) { delete blk; return rc; }
+  }
+  Selection sel;
+  bool header_seen = false;
+  // per-thread scratch lives across blocks: clear() keeps the capacity, so the allocator (and the
+  // page-fault cost of fresh memory) is paid once, not per block
+  std::vector<ThreadOut> outs(static_cast<size_t>(n_threads));
+  const int rc = for_each_block(path, [&](const char* p, const char* endp) -> int {
+    while (!header_seen && p < endp) {  // header lines (serial)
+      const char* eol = static_cast<const char*>(memchr(p, '\n', static_cast<size_t>(endp - p)));
+      if (!eol) eol = endp;
+      if (*p != '#') return sai_set_error(SAI_ERR_ARG, "%s: no #CHROM header line before the records", path);
+      if (eol - p > 6 && memcmp(p, "#CHROM", 6) == 0) {
+        if (int hrc = parse_header(p, eol, path, n_samples, sample_names, ploidy, sel)) return hrc;
+        header_seen = true;
+      }
+      p = eol + 1;
+    }
+    if (p >= endp) return 0;
+    // split [p, endp) into n_threads pieces at line boundaries
+    std::vector<const char*> cut(static_cast<size_t>(n_threads) + 1, endp);
+    cut[0] = p;
+    const size_t total = static_cast<size_t>(endp - p);
+    for (int t = 1; t < n_threads; ++t) {
+      const char* guess = p + total * static_cast<size_t>(t) / static_cast<size_t>(n_threads);
+      if (guess < cut[static_cast<size_t>(t) - 1]) guess = cut[static_cast<size_t>(t) - 1];
+      const char* nl = static_cast<const char*>(memchr(guess, '\n', static_cast<size_t>(endp - guess)));
+      cut[static_cast<size_t>(t)] = nl ? nl + 1 : endp;
+    }
+    for (auto& o : outs) {
+      o.pos.clear();
+      o.dosage.clear();
+      o.matched = 0;
+    }
+    std::vector<std::thread> th;
+    for (int t = 1; t < n_threads; ++t) {
+      if (cut[static_cast<size_t>(t)] >= cut[static_cast<size_t>(t) + 1]) continue;
+      th.emplace_back(parse_lines, cut[static_cast<size_t>(t)], cut[static_cast<size_t>(t) + 1], std::cref(c), start, end,
+                      std::cref(sel), std::cref(anc), true, std::ref(outs[static_cast<size_t>(t)]));
+    }
+    if (cut[0] < cut[1]) parse_lines(cut[0], cut[1], c, start, end, sel, anc, true, outs[0]);  // this thread works too
+    for (auto& x : th) x.join();
+    for (auto& o : outs) {
+      if (!o.error.empty()) return sai_set_error(SAI_ERR_ARG, "%s: %s", path, o.error.c_str());
+      blk->n_matched += o.matched;
+      blk->pos.insert(blk->pos.end(), o.pos.begin(), o.pos.end());
+      blk->dosage.insert(blk->dosage.end(), o.dosage.begin(), o.dosage.end());
+    }
+    return 0;
+  });
+  if (rc) { delete blk; return rc; }
+  if (!header_seen) { delete blk; return sai_set_error(SAI_ERR_ARG, "%s: not a VCF (no #CHROM header)", path); }
+  *block_out = blk;
+  return SAI_OK;
+}
+
+int sai_vcf_block_info(const sai_vcf_block* block, int64_t* n_records, int64_t* n_matched, int64_t* n_anc_entries) {
+  if (!block) return sai_set_error(SAI_ERR_ARG, "block is NULL");
+  if (n_records) *n_records = static_cast<int64_t>(block->pos.size());
+  if (n_matched) *n_matched = block->n_matched;
+  if (n_anc_entries) *n_anc_entries = block->n_anc_entries;
+  return SAI_OK;
+}
+
+int sai_vcf_block_copy(const sai_vcf_block* block, int32_t* pos_host, int8_t* dosage_host) {
+  if (!block) return sai_set_error(SAI_ERR_ARG, "block is NULL");
+  if (!block->pos.empty() && (!pos_host || !dosage_host)) return sai_set_error(SAI_ERR_ARG, "NULL output buffer");
+  if (!block->pos.empty()) {
+    memcpy(pos_host, block->pos.data(), block->pos.size() * sizeof(int32_t));
+    memcpy(dosage_host, block->dosage.data(), block->dosage.size());
+  }
+  return SAI_OK;
+}
+
+int sai_vcf_block_free(sai_vcf_block* block) {
+  delete block;
+  return SAI_OK;
+}
+
+}  // extern "C"

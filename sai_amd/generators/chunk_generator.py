@@ -4,7 +4,7 @@ from __future__ import annotations
 
 from typing import Iterator
 
-from ..utils.vcf import first_last_pos
+from ..utils.native_vcf import scan_first_last
 from ..utils.windows import split_genome, split_windows_ranges
 from .data_generator import DataGenerator
 
@@ -17,7 +17,7 @@ class ChunkGenerator(DataGenerator):
 
     def __init__(self, vcf_file: str, chr_name: str, step_size: int, window_size: int, num_chunks: int):
         chr_name = str(chr_name)
-        first, last = first_last_pos(vcf_file, chr_name)
+        first, last = scan_first_last(vcf_file, chr_name)
         if first is None:
             raise ValueError(f"Chromosome {chr_name} not found in VCF.")  # chunk_generator.py:75-76
         self.windows = split_genome([first, last], window_size, step_size)

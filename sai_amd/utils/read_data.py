@@ -4,12 +4,14 @@ WindowGenerator: unphased, no fixed-variant or missing-data filtering)."""
 
 from __future__ import annotations
 
+import os
 import warnings
 from typing import Optional
 
+import numpy as np
+
 from .genomic_dataclasses import ChromosomeData
 from .samples import parse_ind_file
-from .vcf import dosage_matrices, polarisation_masks, read_anc_allele, read_region
 
 
 def read_data(
@@ -23,14 +25,18 @@ def read_data(
     anc_allele_file: Optional[str] = None,
     start: int = None,
     end: int = None,
+    engine: str = "native",
 ) -> dict[str, tuple[Optional[dict[str, ChromosomeData]], Optional[dict[str, list[str]]]]]:
     """{"ref": (data, samples), "tgt": ..., "src": ..., "outgroup": (None, None)}.
 
     ``data`` maps population -> ChromosomeData for the populations that have a ploidy entry
     (others are skipped with the reference's RuntimeWarning, utils.py:722-728); a population
     with a ploidy but no samples is a ValueError (:713-718); ``data`` is None when the region
-    holds no record.  The VCF is parsed once for all groups (the reference re-reads it per
-    population); outgroups are outside this path."""
+    holds no record.  The VCF is parsed once per distinct ploidy for all groups (the reference
+    re-reads it per population) by the native tokenizer of libsaihip (``engine="native"``) or by
+    the Python statement of the same rules (``engine="python"``, used by the tests as the
+    cross-check); REF/ALT are not kept (the U/Q path never reads them after polarisation);
+    outgroups are outside this path."""
     chr_name = str(chr_name)
     groups = [("ref", ref_ind_file), ("tgt", tgt_ind_file), ("src", src_ind_file)]
     samples_by_group: dict[str, Optional[dict[str, list[str]]]] = {}
@@ -58,17 +64,31 @@ def read_data(
             results[group] = (None, samples_by_group[group])
         return results
 
-    try:
-        region = read_region(vcf_file, chr_name, wanted, start, end)
-    except Exception as e:  # utils.py:139-140
-        where = chr_name if start is None and end is None else f"{chr_name}:{start}-{end}"
-        raise ValueError(f"Failed to read VCF file {vcf_file} from {where}: {e}") from e
-    column = {name: i for i, name in enumerate(region.samples)}
-
-    keep = flip = None
-    if anc_allele_file and len(region):
-        anc = read_anc_allele(anc_allele_file, chr_name, start, end)
-        keep, flip = polarisation_masks(region, anc.get(chr_name, {}))
+    loader = _load_python if engine == "python" else _load_native
+    where = chr_name if start is None and end is None else f"{chr_name}:{start}-{end}"
+    # one pass per distinct ploidy (normally one or two), each over the samples that need it
+    by_ploidy: dict[int, list[str]] = {}
+    for group, _ in groups:
+        samples = samples_by_group[group]
+        if samples is None:
+            continue
+        for population, names in samples.items():
+            if population in ploidy_config.root[group]:
+                bucket = by_ploidy.setdefault(ploidy_config.root[group][population], [])
+                bucket.extend(n for n in names if n not in bucket)
+    loaded = {}
+    for ploidy, names in by_ploidy.items():
+        try:
+            pos, dos, n_matched, n_anc = loader(vcf_file, chr_name, names, ploidy, start, end, anc_allele_file)
+        except FileNotFoundError:
+            raise
+        except Exception as e:  # utils.py:139-140
+            raise ValueError(f"Failed to read VCF file {vcf_file} from {where}: {e}") from e
+        if anc_allele_file and n_matched and n_anc == 0:  # read_anc_allele, utils.py:480-487
+            if start is not None or end is not None:
+                raise ValueError(f"No ancestral allele is found for chromosome {chr_name} in the region {start}-{end}.")
+            raise ValueError(f"No ancestral allele is found for chromosome {chr_name}.")
+        loaded[ploidy] = (pos, dos, {n: i for i, n in enumerate(names)}, n_matched)
 
     for group, _ in groups:
         samples = samples_by_group[group]
@@ -83,17 +103,39 @@ def read_data(
                     RuntimeWarning,
                 )
                 continue
-            if len(region) == 0:
+            pos, dos, column, n_matched = loaded[ploidy_config.root[group][population]]
+            if n_matched == 0:  # no record in the region: the reference's "vcf_data is None" case
                 continue
-            ploidy = ploidy_config.root[group][population]
-            dos, fdos = dosage_matrices(region, [column[n] for n in names], ploidy)
-            pos, ref, alt = region.pos, region.ref, region.alt
-            if keep is not None:
-                dos[flip] = fdos[flip]
-                dos = dos[keep]
-                pos = pos[keep]
-                ref = [r for r, k in zip(ref, keep) if k]
-                alt = [a for a, k in zip(alt, keep) if k]
-            data[population] = ChromosomeData(POS=pos.copy(), REF=list(ref), ALT=list(alt), GT=dos)
+            gt = np.ascontiguousarray(dos[:, [column[n] for n in names]])
+            data[population] = ChromosomeData(POS=pos.copy(), REF=None, ALT=None, GT=gt)
         results[group] = (data if data else None, samples)
     return results
+
+
+def _load_native(vcf_file, chr_name, names, ploidy, start, end, anc_allele_file):
+    """libsaihip's multithreaded tokenizer (sai_amd/csrc/vcf_ingest.cpp)."""
+    from .native_vcf import load_dosage
+
+    if not os.path.exists(vcf_file):
+        raise ValueError(f"cannot open VCF {vcf_file}")
+    return load_dosage(vcf_file, chr_name, names, [ploidy] * len(names), start, end, anc_allele_file)
+
+
+def _load_python(vcf_file, chr_name, names, ploidy, start, end, anc_allele_file):
+    """The readable statement of the same rules (sai_amd/utils/vcf.py); tests compare the two."""
+    from .vcf import dosage_matrices, polarisation_masks, read_anc_allele, read_region
+
+    region = read_region(vcf_file, chr_name, names, start, end)
+    dos, fdos = dosage_matrices(region, list(range(len(names))), ploidy)
+    pos, n_matched, n_anc = region.pos, len(region), 0
+    if anc_allele_file and len(region):
+        try:
+            anc = read_anc_allele(anc_allele_file, chr_name, start, end)
+        except ValueError:
+            anc = {}
+        table = anc.get(chr_name, {})
+        n_anc = len(table)
+        keep, flip = polarisation_masks(region, table)
+        dos[flip] = fdos[flip]
+        dos, pos = dos[keep], pos[keep]
+    return pos, dos, n_matched, n_anc

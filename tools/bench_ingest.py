@@ -1,0 +1,33 @@
+"""Throughput of the native VCF tokenizer vs the Python reader on a synthetic VCF (host only)."""
+import os, sys, time, tempfile
+import numpy as np
+sys.path.insert(0, ".")
+from sai_amd.utils.native_vcf import load_dosage, default_threads
+from sai_amd.utils.read_data import _load_python
+
+n_sites = int(float(sys.argv[1])) if len(sys.argv) > 1 else 20000
+n_samples = int(sys.argv[2]) if len(sys.argv) > 2 else 2002
+rng = np.random.default_rng(1)
+d = tempfile.mkdtemp(dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+path = os.path.join(d, "synth.vcf")
+names = [f"i{k}" for k in range(n_samples)]
+calls = np.array(["0|0", "0|1", "1|0", "1|1", ".|."])
+with open(path, "w") as f:
+    f.write("##fileformat=VCFv4.2\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t" + "\t".join(names) + "\n")
+    pos = 0
+    for s in range(n_sites):
+        pos += int(rng.integers(1, 50))
+        row = calls[rng.choice(5, size=n_samples, p=[0.7, 0.1, 0.1, 0.095, 0.005])]
+        f.write(f"1\t{pos}\t.\tA\tT\t100\tPASS\t.\tGT\t" + "\t".join(row) + "\n")
+size = os.path.getsize(path)
+print(f"VCF: {n_sites} sites x {n_samples} samples, {size / 1e6:.1f} MB")
+load_dosage(path, "1", names[:1], [2], n_threads=1)  # loads the library (and torch) once
+for th in (1, 4, default_threads()):
+    t0 = time.perf_counter(); pos_n, dos_n, _, _ = load_dosage(path, "1", names, [2] * n_samples, n_threads=th); dt = time.perf_counter() - t0
+    print(f"native, {th:2d} threads: {dt:.3f} s  {size / dt / 1e6:8.1f} MB/s  {n_sites * n_samples / dt / 1e6:8.1f} M genotypes/s")
+sub = min(n_sites, 1500)
+t0 = time.perf_counter(); pos_p, dos_p, _, _ = _load_python(path, "1", names, 2, None, int(pos_n[sub - 1]), None); dt = time.perf_counter() - t0
+frac = sub / n_sites
+print(f"python reader on the first {sub} sites: {dt:.3f} s  {size * frac / dt / 1e6:8.1f} MB/s")
+assert np.array_equal(dos_p, dos_n[:sub])
+os.remove(path); os.rmdir(d)
