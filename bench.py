@@ -170,15 +170,19 @@ def main() -> None:
 
     import __graft_entry__ as entry
 
-    entry.build()
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world)
+    # one process per node builds (a no-op when the in-tree library is current); the others wait
+    if local_rank == 0:
+        entry.build()
+    if world > 1:
+        dist.barrier()
     from sai_amd import _ffi
     from sai_amd.distributed import gather_padded
     from sai_amd.engine import Engine
     from sai_amd.resident import ResidentScorer, default_windows, synth_block
 
-    torch.cuda.set_device(local_rank)
-    if world > 1:
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world)
     eng = Engine.get(local_rank)
 
     chrom = rank + 1

@@ -117,6 +117,15 @@ int sai_tile_from_site_major(sai_ctx* ctx, const int8_t* src, int64_t n_sites, i
 int sai_site_counts(sai_ctx* ctx, int64_t n_sites, int32_t n_pops, const sai_pop* pops,
                     uint32_t* counts, void* stream);
 
+/* Kernels 1+2 fused (the fast path when there are at most 4 parameter sets): one pass over the
+ * genotypes that also evaluates sai_site_flags' per-site decision for each set at the end of every
+ * tile, while the counts are still on chip.  `counts` may be NULL (then the 8 bytes per site and
+ * population are neither written nor re-read); pops[p].ploidy is used.  Results are identical to
+ * sai_site_counts followed by sai_site_flags. */
+int sai_site_pass(sai_ctx* ctx, int64_t n_sites, int32_t n_pops, const sai_pop* pops,
+                  uint32_t* counts, int32_t n_sets, const sai_params* sets_host, double* tgt_freq,
+                  uint8_t* flags, void* stream);
+
 /* Kernel 2: calc_freq's f64 division (stat_utils.py:51-52) and compute_matching_loci
  * (stat_utils.py:114-166) for every site and parameter set, plus U's final test
  * (u_statistic.py:92).  tgt_freq[site] is the UNinverted target frequency (NaN when nothing is

@@ -17,6 +17,7 @@ LIB_PATH = Path(__file__).resolve().parent / "lib" / LIB_NAME
 SAI_TILE_SITES = 64
 SAI_MAX_SRC = 6
 SAI_MAX_SETS = 16
+SAI_FUSED_SETS = 4
 SAI_ABI_VERSION = 1
 
 OPS = {"=": 0, "<": 1, ">": 2, "<=": 3, ">=": 4}
@@ -71,6 +72,10 @@ SIGNATURES = {
     "sai_tiled_bytes": (_i64, [_i64, _i32]),
     "sai_tile_from_site_major": (C.c_int, [_p, _p, _i64, _i32, _i64, _p, _p]),
     "sai_site_counts": (C.c_int, [_p, _i64, _i32, C.POINTER(SaiPop), _p, _p]),
+    "sai_site_pass": (
+        C.c_int,
+        [_p, _i64, _i32, C.POINTER(SaiPop), _p, _i32, C.POINTER(SaiParams), _p, _p, _p],
+    ),
     "sai_site_flags": (
         C.c_int,
         [_p, _i64, _i32, C.POINTER(_i32), _p, _i32, C.POINTER(SaiParams), _p, _p, _p, _p],

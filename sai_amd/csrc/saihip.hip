@@ -119,6 +119,100 @@ __global__ __launch_bounds__(256) void tile_from_site_major_kernel(const int8_t*
 }
 
 // ------------------------------------------------------------------------------------------
+// Per-site decision: calc_freq's f64 division and compute_matching_loci for every parameter set,
+// exactly as numpy evaluates it.  One device function, used by the stand-alone site_flags kernel
+// (counts read back from HBM) and by the fused tail of site_counts (counts still in LDS).
+// ------------------------------------------------------------------------------------------
+
+__device__ __forceinline__ bool cmp_op(int op, double f, double y) {
+  switch (op) {
+    case SAI_OP_EQ: return f == y;
+    case SAI_OP_LT: return f < y;
+    case SAI_OP_GT: return f > y;
+    case SAI_OP_LE: return f <= y;
+    default: return f >= y;
+  }
+}
+
+// get(p) -> uint2 {alt_sum, n_called} of population p at this site.
+template <typename GetCounts>
+__device__ __forceinline__ void eval_site(int n_pops, const int32_t* ploidy, GetCounts get, int n_sets,
+                                          const sai_params* sets, int64_t site, int64_t n_sites, double* tgt_freq,
+                                          uint8_t* flags, double* adj_freq) {
+  double f[kMaxPops];
+  bool valid = true;
+#pragma unroll
+  for (int p = 0; p < kMaxPops; ++p) {
+    if (p < n_pops) {
+      const uint2 c = get(p);
+      const int64_t den = static_cast<int64_t>(c.y) * ploidy[p];
+      const double v = den > 0 ? static_cast<double>(c.x) / static_cast<double>(den)
+                               : std::numeric_limits<double>::quiet_NaN();
+      f[p] = v;
+      valid = valid && (v >= 0.0) && (v <= 1.0);  // false for NaN; the quotient is never inf
+    } else {
+      f[p] = 0.0;
+    }
+  }
+  tgt_freq[site] = f[1];
+  const int n_src = n_pops - 2;
+  for (int s = 0; s < n_sets; ++s) {
+    const sai_params& ps = sets[s];
+    bool hit_y = true, hit_m = true;
+#pragma unroll
+    for (int k = 0; k < SAI_MAX_SRC; ++k) {
+      if (k < n_src) {
+        hit_y = hit_y && cmp_op(ps.op[k], f[2 + k], ps.y[k]);
+        hit_m = hit_m && cmp_op(ps.op[k], f[2 + k], ps.one_minus_y[k]);
+      }
+    }
+    const bool anc = ps.anc_allele_available != 0;
+    const bool inverted = !anc && hit_m && valid;
+    const bool hit = anc ? hit_y : (hit_y || hit_m);
+    const double rf = inverted ? 1.0 - f[0] : f[0];
+    const double tf = inverted ? 1.0 - f[1] : f[1];
+    const bool cond = valid && hit && (rf < ps.w);
+    const bool ucand = cond && (tf > ps.x);
+    flags[static_cast<int64_t>(s) * n_sites + site] =
+        static_cast<uint8_t>((cond ? 1 : 0) | (ucand ? 2 : 0) | (inverted ? 4 : 0));
+    if (adj_freq) {
+      adj_freq[(static_cast<int64_t>(s) * 2 + 0) * n_sites + site] = rf;
+      adj_freq[(static_cast<int64_t>(s) * 2 + 1) * n_sites + site] = tf;
+    }
+  }
+}
+
+struct FlagArgs {
+  int64_t n_sites;
+  int32_t n_pops;
+  int32_t n_sets;
+  int32_t ploidy[kMaxPops];
+  const uint2* counts;
+  double* tgt_freq;
+  uint8_t* flags;
+  double* adj_freq;
+  sai_params sets[SAI_MAX_SETS];
+};
+
+__global__ __launch_bounds__(256) void site_flags_kernel(FlagArgs a) {
+  const int64_t site = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (site >= a.n_sites) return;
+  eval_site(
+      a.n_pops, a.ploidy, [&](int p) { return a.counts[static_cast<int64_t>(p) * a.n_sites + site]; }, a.n_sets, a.sets,
+      site, a.n_sites, a.tgt_freq, a.flags, a.adj_freq);
+}
+
+constexpr int kFusedSets = 4;  // parameter sets the fused tail of site_counts can carry in its arguments
+
+struct FusedArgs {
+  int32_t n_sets;  // 0 = plain site_counts
+  int32_t ploidy[kMaxPops];
+  double* tgt_freq;
+  uint8_t* flags;
+  sai_params sets[kFusedSets];
+};
+
+// ------------------------------------------------------------------------------------------
 // site_counts: the HBM-bound kernel.
 //
 // One wavefront owns one 64-site tile and streams every population's rows of that tile.  A wave
@@ -176,61 +270,35 @@ __device__ __forceinline__ void reduce_scatter_step(uint32_t (&a)[16], int lane)
   }
 }
 
-template <bool NT>
-__device__ __forceinline__ u32x4 load_rows(const u32x4* p) {
-  return NT ? __builtin_nontemporal_load(p) : *p;
-}
-
 constexpr int kChunkIters = 248;  // iterations (rows per lane) the 16-/8-bit fields can absorb
 
 // Accumulate iterations [it, full_end) of full 16-row groups plus, when it is the last one, the
 // partial group, into the packed fields lo/hi (16-bit dosage sums) and ms (8-bit missing counts).
-template <int UNROLL, bool PIPE, bool NT>
+constexpr int kUnroll = 4;  // wave loads (1 KiB each) in flight per group
+
+// Accumulate iterations [it, full_end) of full 16-row groups plus, when it is the last one, the
+// partial group, into the packed fields lo/hi (16-bit dosage sums) and ms (8-bit missing counts).
+// Loads are non-temporal: every genotype byte is read exactly once.  (Measured alternatives --
+// 8 loads per group, ping-pong prefetch of the next group, default cache policy, 4 waves per
+// workgroup, 64-register builds with 8 waves per SIMD -- all landed within 2 % of this form: the
+// kernel sits at the rate a plain streaming read reaches on the same box.)
 __device__ __forceinline__ void accumulate_rows(const u32x4* base, int& it, int full_end, int n_full, int n_iter,
                                                 int n_ind, int r, uint32_t (&lo)[4], uint32_t (&hi)[4],
                                                 uint32_t (&ms)[4]) {
-  if (PIPE) {
-    u32x4 A[UNROLL], B[UNROLL];
-    const int n_groups = (full_end - it) / UNROLL;
-    if (n_groups > 0) {
+  for (; it + kUnroll <= full_end; it += kUnroll) {
+    u32x4 v[kUnroll];
 #pragma unroll
-      for (int u = 0; u < UNROLL; ++u) A[u] = load_rows<NT>(base + (it + u) * 64);
-    }
-    int g = 0;
-    for (; g + 2 <= n_groups; g += 2) {
+    for (int u = 0; u < kUnroll; ++u) v[u] = __builtin_nontemporal_load(base + (it + u) * 64);
 #pragma unroll
-      for (int u = 0; u < UNROLL; ++u) B[u] = load_rows<NT>(base + (it + UNROLL + u) * 64);
-#pragma unroll
-      for (int u = 0; u < UNROLL; ++u) acc_vec(A[u], lo, hi, ms);
-      if (g + 2 < n_groups) {
-#pragma unroll
-        for (int u = 0; u < UNROLL; ++u) A[u] = load_rows<NT>(base + (it + 2 * UNROLL + u) * 64);
-      }
-#pragma unroll
-      for (int u = 0; u < UNROLL; ++u) acc_vec(B[u], lo, hi, ms);
-      it += 2 * UNROLL;
-    }
-    if (g < n_groups) {
-#pragma unroll
-      for (int u = 0; u < UNROLL; ++u) acc_vec(A[u], lo, hi, ms);
-      it += UNROLL;
-    }
-  } else {
-    for (; it + UNROLL <= full_end; it += UNROLL) {
-      u32x4 v[UNROLL];
-#pragma unroll
-      for (int u = 0; u < UNROLL; ++u) v[u] = load_rows<NT>(base + (it + u) * 64);
-#pragma unroll
-      for (int u = 0; u < UNROLL; ++u) acc_vec(v[u], lo, hi, ms);
-    }
+    for (int u = 0; u < kUnroll; ++u) acc_vec(v[u], lo, hi, ms);
   }
   for (; it < full_end; ++it) {
-    const u32x4 v = load_rows<NT>(base + it * 64);
+    const u32x4 v = __builtin_nontemporal_load(base + it * 64);
     acc_vec(v, lo, hi, ms);
   }
   if (it == n_full && it < n_iter) {  // partial last group of rows
     u32x4 v = {0u, 0u, 0u, 0u};
-    if (it * 16 + r < n_ind) v = load_rows<NT>(base + it * 64);
+    if (it * 16 + r < n_ind) v = __builtin_nontemporal_load(base + it * 64);
     acc_vec(v, lo, hi, ms);
     ++it;
   }
@@ -251,18 +319,18 @@ __device__ __forceinline__ void widen_fields(const uint32_t (&lo)[4], const uint
   }
 }
 
-// UNROLL: wave loads in flight per group; PIPE: ping-pong two groups so the next group's loads are
-// issued before the current group is consumed; NT: non-temporal loads (the block is read once);
-// WAVES: independent waves (tiles) per workgroup; MULTI: some population has more than
-// 16 * kChunkIters individuals, so the packed fields are widened several times per population
-// (keeps 32 more registers live across the load loop).
-template <int UNROLL, bool PIPE, bool NT, int WAVES, bool MULTI, int MINW = 1>
-__global__ __launch_bounds__(64 * WAVES, MINW) void site_counts_kernel(CountsArgs a) {
-  const int lane = threadIdx.x & 63;
+// MULTI: some population has more than 16 * kChunkIters individuals, so the packed fields are
+// widened several times per population (keeps 32 more registers live across the load loop).
+// FUSED: evaluate the parameter sets at the end of each tile (site_flags folded in).
+template <bool MULTI, bool FUSED>
+__global__ __launch_bounds__(64) void site_counts_kernel(CountsArgs a, FusedArgs fa) {
+  // FUSED: each lane parks its site's {alt_sum, n_called} per population here and evaluates the
+  // parameter sets itself once all populations of the tile are done (only the lane that wrote a
+  // slot reads it back, so no synchronisation is involved)
+  __shared__ uint2 stash[FUSED ? kMaxPops : 1][FUSED ? 64 : 1];
+  const int lane = threadIdx.x;
   const int r = lane >> 2;
-  const int64_t tile0 = static_cast<int64_t>(blockIdx.x) * WAVES + (threadIdx.x >> 6);
-  const int64_t stride = static_cast<int64_t>(gridDim.x) * WAVES;
-  for (int64_t tile = tile0; tile < a.n_tiles; tile += stride) {
+  for (int64_t tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
     for (int p = 0; p < a.n_pops; ++p) {
       const int n_ind = a.pop[p].n_ind;
       const u32x4* base =
@@ -276,12 +344,12 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void site_counts_kernel(CountsArg
         for (int j = 0; j < 16; ++j) sum32[j] = miss32[j] = 0;
         while (it < n_iter) {
           uint32_t lo[4] = {0, 0, 0, 0}, hi[4] = {0, 0, 0, 0}, ms[4] = {0, 0, 0, 0};
-          accumulate_rows<UNROLL, PIPE, NT>(base, it, min(n_full, it + kChunkIters), n_full, n_iter, n_ind, r, lo, hi, ms);
+          accumulate_rows(base, it, min(n_full, it + kChunkIters), n_full, n_iter, n_ind, r, lo, hi, ms);
           widen_fields(lo, hi, ms, sum32, miss32);
         }
       } else {  // n_iter <= kChunkIters + 1: one pass, widen once
         uint32_t lo[4] = {0, 0, 0, 0}, hi[4] = {0, 0, 0, 0}, ms[4] = {0, 0, 0, 0};
-        accumulate_rows<UNROLL, PIPE, NT>(base, it, n_full, n_full, n_iter, n_ind, r, lo, hi, ms);
+        accumulate_rows(base, it, n_full, n_full, n_iter, n_ind, r, lo, hi, ms);
 #pragma unroll
         for (int j = 0; j < 16; ++j) sum32[j] = miss32[j] = 0;
         widen_fields(lo, hi, ms, sum32, miss32);
@@ -295,81 +363,16 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void site_counts_kernel(CountsArg
       reduce_scatter_step<4, 8>(miss32, lane);
       reduce_scatter_step<2, 4>(miss32, lane);
       const int64_t site = tile * kTile + (lane & 3) * 16 + r;
+      const uint2 cnt = make_uint2(sum32[0], static_cast<uint32_t>(n_ind) - miss32[0]);
+      if (a.counts && site < a.n_sites) a.counts[static_cast<int64_t>(p) * a.n_sites + site] = cnt;
+      if (FUSED) stash[p][lane] = cnt;
+    }
+    if (FUSED) {
+      const int64_t site = tile * kTile + (lane & 3) * 16 + r;
       if (site < a.n_sites)
-        a.counts[static_cast<int64_t>(p) * a.n_sites + site] =
-            make_uint2(sum32[0], static_cast<uint32_t>(n_ind) - miss32[0]);
-    }
-  }
-}
-
-// ------------------------------------------------------------------------------------------
-// site_flags: one thread per site; f64 exactly as numpy evaluates it.
-// ------------------------------------------------------------------------------------------
-
-struct FlagArgs {
-  int64_t n_sites;
-  int32_t n_pops;
-  int32_t n_sets;
-  int32_t ploidy[kMaxPops];
-  const uint2* counts;
-  double* tgt_freq;
-  uint8_t* flags;
-  double* adj_freq;
-  sai_params sets[SAI_MAX_SETS];
-};
-
-__device__ __forceinline__ bool cmp_op(int op, double f, double y) {
-  switch (op) {
-    case SAI_OP_EQ: return f == y;
-    case SAI_OP_LT: return f < y;
-    case SAI_OP_GT: return f > y;
-    case SAI_OP_LE: return f <= y;
-    default: return f >= y;
-  }
-}
-
-__global__ __launch_bounds__(256) void site_flags_kernel(FlagArgs a) {
-  const int64_t site = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-  if (site >= a.n_sites) return;
-  double f[kMaxPops];
-  bool valid = true;
-#pragma unroll
-  for (int p = 0; p < kMaxPops; ++p) {
-    if (p < a.n_pops) {
-      const uint2 c = a.counts[static_cast<int64_t>(p) * a.n_sites + site];
-      const int64_t den = static_cast<int64_t>(c.y) * a.ploidy[p];
-      const double v = den > 0 ? static_cast<double>(c.x) / static_cast<double>(den)
-                               : std::numeric_limits<double>::quiet_NaN();
-      f[p] = v;
-      valid = valid && (v >= 0.0) && (v <= 1.0);  // false for NaN; the quotient is never inf
-    } else {
-      f[p] = 0.0;
-    }
-  }
-  a.tgt_freq[site] = f[1];
-  const int n_src = a.n_pops - 2;
-  for (int s = 0; s < a.n_sets; ++s) {
-    const sai_params& ps = a.sets[s];
-    bool hit_y = true, hit_m = true;
-#pragma unroll
-    for (int k = 0; k < SAI_MAX_SRC; ++k) {
-      if (k < n_src) {
-        hit_y = hit_y && cmp_op(ps.op[k], f[2 + k], ps.y[k]);
-        hit_m = hit_m && cmp_op(ps.op[k], f[2 + k], ps.one_minus_y[k]);
-      }
-    }
-    const bool anc = ps.anc_allele_available != 0;
-    const bool inverted = !anc && hit_m && valid;
-    const bool hit = anc ? hit_y : (hit_y || hit_m);
-    const double rf = inverted ? 1.0 - f[0] : f[0];
-    const double tf = inverted ? 1.0 - f[1] : f[1];
-    const bool cond = valid && hit && (rf < ps.w);
-    const bool ucand = cond && (tf > ps.x);
-    a.flags[static_cast<int64_t>(s) * a.n_sites + site] =
-        static_cast<uint8_t>((cond ? 1 : 0) | (ucand ? 2 : 0) | (inverted ? 4 : 0));
-    if (a.adj_freq) {
-      a.adj_freq[(static_cast<int64_t>(s) * 2 + 0) * a.n_sites + site] = rf;
-      a.adj_freq[(static_cast<int64_t>(s) * 2 + 1) * a.n_sites + site] = tf;
+        eval_site(
+            a.n_pops, fa.ploidy, [&](int p) { return stash[p][lane]; }, fa.n_sets, fa.sets, site,
+            a.n_sites, fa.tgt_freq, fa.flags, nullptr);
     }
   }
 }
@@ -939,17 +942,23 @@ int sai_tile_from_site_major(sai_ctx* ctx, const int8_t* src, int64_t n_sites, i
   return check_launch("tile_from_site_major");
 }
 
-int sai_site_counts(sai_ctx* ctx, int64_t n_sites, int32_t n_pops, const sai_pop* pops, uint32_t* counts,
-                    void* stream) {
-  if (int rc = enter(ctx)) return rc;
+static int check_sets(int32_t n_sets, const sai_params* sets, int32_t n_src);
+
+// shared by sai_site_counts (n_sets == 0) and sai_site_pass
+static int launch_site_counts(sai_ctx* ctx, int64_t n_sites, int32_t n_pops, const sai_pop* pops, uint32_t* counts,
+                              int32_t n_sets, const sai_params* sets_host, double* tgt_freq, uint8_t* flags,
+                              void* stream) {
   if (n_sites < 0 || n_sites >= 0x7FFFFFFFll) return fail(SAI_ERR_ARG, "n_sites out of range");
   if (n_pops < 1 || n_pops > kMaxPops) return fail(SAI_ERR_ARG, "n_pops must be 1..%d", kMaxPops);
-  if (!pops || !counts) return fail(SAI_ERR_ARG, "NULL buffer");
+  if (!pops) return fail(SAI_ERR_ARG, "pops is NULL");
   if (n_sites == 0) return SAI_OK;
   CountsArgs a;
+  FusedArgs fa;
+  std::memset(&fa, 0, sizeof(fa));
   a.n_sites = n_sites;
   a.n_tiles = (n_sites + kTile - 1) / kTile;
   a.n_pops = n_pops;
+  bool multi = false;
   for (int p = 0; p < n_pops; ++p) {
     if (pops[p].n_ind < 0) return fail(SAI_ERR_ARG, "population %d: negative n_ind", p);
     if (pops[p].n_ind > 0 && !pops[p].tiles) return fail(SAI_ERR_ARG, "population %d: NULL tiles", p);
@@ -959,54 +968,47 @@ int sai_site_counts(sai_ctx* ctx, int64_t n_sites, int32_t n_pops, const sai_pop
     a.pop[p].tiles = pops[p].tiles;
     a.pop[p].n_ind = pops[p].n_ind;
     a.pop[p].pad = 0;
+    multi = multi || pops[p].n_ind > 16 * kChunkIters;
+    fa.ploidy[p] = pops[p].ploidy;
   }
   a.counts = reinterpret_cast<uint2*>(counts);
-  // SAI_COUNTS_VARIANT / SAI_COUNTS_GRID are tuning knobs for experiments
-  static const int variant = []() { const char* e = getenv("SAI_COUNTS_VARIANT"); return e ? atoi(e) : 0; }();
-  static const int grid_mult = []() { const char* e = getenv("SAI_COUNTS_GRID"); return e ? atoi(e) : 64; }();
+  fa.n_sets = n_sets;
+  fa.tgt_freq = tgt_freq;
+  fa.flags = flags;
+  for (int s = 0; s < n_sets; ++s) fa.sets[s] = sets_host[s];
+  const int64_t max_grid = static_cast<int64_t>(ctx->n_cu) * 64;  // grid-stride beyond this
+  const dim3 grid(static_cast<unsigned>(a.n_tiles < max_grid ? a.n_tiles : max_grid));
   hipStream_t st = static_cast<hipStream_t>(stream);
-  bool multi = getenv("SAI_COUNTS_MULTI") != nullptr;  // tuning: force the general kernel
-  for (int p = 0; p < n_pops; ++p) multi = multi || pops[p].n_ind > 16 * kChunkIters;
-#define SAI_LAUNCH_COUNTS(U, PIPE, NT, WAVES)                                                         \
-  do {                                                                                                \
-    const int64_t blocks = (a.n_tiles + (WAVES) - 1) / (WAVES);                                       \
-    const int64_t cap = static_cast<int64_t>(ctx->n_cu) * grid_mult / (WAVES);                        \
-    const unsigned grid = static_cast<unsigned>(blocks < cap ? blocks : (cap > 0 ? cap : 1));         \
-    if (multi)                                                                                        \
-      hipLaunchKernelGGL((site_counts_kernel<U, PIPE, NT, WAVES, true>), dim3(grid), dim3(64 * (WAVES)), 0, st, a); \
-    else                                                                                              \
-      hipLaunchKernelGGL((site_counts_kernel<U, PIPE, NT, WAVES, false>), dim3(grid), dim3(64 * (WAVES)), 0, st, a); \
-  } while (0)
-  switch (variant) {
-    case 1: SAI_LAUNCH_COUNTS(8, false, true, 1); break;
-    case 2: SAI_LAUNCH_COUNTS(4, true, true, 1); break;
-    case 3: SAI_LAUNCH_COUNTS(4, false, false, 1); break;
-    case 4: SAI_LAUNCH_COUNTS(8, true, true, 1); break;
-    case 5: SAI_LAUNCH_COUNTS(4, false, true, 4); break;
-    case 6: SAI_LAUNCH_COUNTS(4, true, true, 4); break;
-    case 7: SAI_LAUNCH_COUNTS(2, true, true, 1); break;
-    case 8:  // single-chunk kernel squeezed to 64 VGPRs: 8 waves per SIMD
-      if (!multi) {
-        const int64_t cap8 = static_cast<int64_t>(ctx->n_cu) * grid_mult;
-        const unsigned g8 = static_cast<unsigned>(a.n_tiles < cap8 ? a.n_tiles : cap8);
-        hipLaunchKernelGGL((site_counts_kernel<4, false, true, 1, false, 8>), dim3(g8), dim3(64), 0, st, a);
-        break;
-      }
-      SAI_LAUNCH_COUNTS(4, false, true, 1);
-      break;
-    case 9:  // 6 waves per SIMD
-      if (!multi) {
-        const int64_t cap8 = static_cast<int64_t>(ctx->n_cu) * grid_mult;
-        const unsigned g8 = static_cast<unsigned>(a.n_tiles < cap8 ? a.n_tiles : cap8);
-        hipLaunchKernelGGL((site_counts_kernel<4, false, true, 1, false, 6>), dim3(g8), dim3(64), 0, st, a);
-        break;
-      }
-      SAI_LAUNCH_COUNTS(4, false, true, 1);
-      break;
-    default: SAI_LAUNCH_COUNTS(4, false, true, 1); break;
+  if (n_sets > 0) {
+    if (multi) hipLaunchKernelGGL((site_counts_kernel<true, true>), grid, dim3(64), 0, st, a, fa);
+    else hipLaunchKernelGGL((site_counts_kernel<false, true>), grid, dim3(64), 0, st, a, fa);
+  } else {
+    if (multi) hipLaunchKernelGGL((site_counts_kernel<true, false>), grid, dim3(64), 0, st, a, fa);
+    else hipLaunchKernelGGL((site_counts_kernel<false, false>), grid, dim3(64), 0, st, a, fa);
   }
-#undef SAI_LAUNCH_COUNTS
   return check_launch("site_counts");
+}
+
+int sai_site_counts(sai_ctx* ctx, int64_t n_sites, int32_t n_pops, const sai_pop* pops, uint32_t* counts,
+                    void* stream) {
+  if (int rc = enter(ctx)) return rc;
+  if (!counts && n_sites > 0) return fail(SAI_ERR_ARG, "counts is NULL");
+  return launch_site_counts(ctx, n_sites, n_pops, pops, counts, 0, nullptr, nullptr, nullptr, stream);
+}
+
+int sai_site_pass(sai_ctx* ctx, int64_t n_sites, int32_t n_pops, const sai_pop* pops, uint32_t* counts,
+                  int32_t n_sets, const sai_params* sets_host, double* tgt_freq, uint8_t* flags, void* stream) {
+  if (int rc = enter(ctx)) return rc;
+  if (n_pops < 2) return fail(SAI_ERR_ARG, "n_pops must be >= 2 (ref, tgt, sources)");
+  if (n_sets > kFusedSets)
+    return fail(SAI_ERR_UNSUPPORTED, "sai_site_pass carries at most %d parameter sets; use sai_site_counts + sai_site_flags",
+                kFusedSets);
+  if (int rc = check_sets(n_sets, sets_host, n_pops - 2)) return rc;
+  if (pops)
+    for (int p = 0; p < n_pops && p < kMaxPops; ++p)
+      if (pops[p].ploidy <= 0) return fail(SAI_ERR_ARG, "ploidy[%d] must be positive", p);
+  if (n_sites > 0 && (!tgt_freq || !flags)) return fail(SAI_ERR_ARG, "NULL buffer");
+  return launch_site_counts(ctx, n_sites, n_pops, pops, counts, n_sets, sets_host, tgt_freq, flags, stream);
 }
 
 static int check_sets(int32_t n_sets, const sai_params* sets, int32_t n_src) {

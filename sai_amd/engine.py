@@ -162,6 +162,32 @@ class Engine:
         _ffi.check(self.lib.sai_site_counts(self.ctx, n_sites, len(pops), arr, self._ptr(out), self._stream()))
         return out
 
+    def site_pass(self, pops: Sequence[TiledPop], ploidies: Sequence[int], sets: Sequence[_ffi.SaiParams], out=None,
+                  counts=None):
+        """Fused site_counts + site_flags (at most SAI_FUSED_SETS parameter sets): one launch,
+        the per-population counts stay on chip unless a ``counts`` tensor is passed.  Returns
+        (tgt_freq, flags) exactly as ``site_flags(site_counts(pops), ...)`` would."""
+        torch = _torch()
+        n_sites = pops[0].n_sites
+        if any(p.n_sites != n_sites for p in pops):
+            raise ValueError("all populations of one call must cover the same sites")
+        if len(sets) > _ffi.SAI_FUSED_SETS:
+            raise ValueError(f"site_pass carries at most {_ffi.SAI_FUSED_SETS} parameter sets")
+        arr = (_ffi.SaiPop * len(pops))()
+        for i, p in enumerate(pops):
+            arr[i].tiles = p.tiles.data_ptr() if p.tiles.numel() else 0
+            arr[i].n_ind = p.n_ind
+            arr[i].ploidy = int(ploidies[i])
+        if out is None:
+            out = (self._empty((n_sites,), torch.float64), self._empty((len(sets), n_sites), torch.uint8))
+        _ffi.check(
+            self.lib.sai_site_pass(
+                self.ctx, n_sites, len(pops), arr, self._ptr(counts) if counts is not None else None, len(sets),
+                self._params_array(sets), self._ptr(out[0]), self._ptr(out[1]), self._stream(),
+            )
+        )  # fmt: skip
+        return out
+
     def site_flags(self, counts, ploidies: Sequence[int], sets: Sequence[_ffi.SaiParams], want_adj=False, out=None):
         """(tgt_freq f64 [n], flags u8 [S][n], adj f64 [S][2][n] or None)."""
         torch = _torch()

@@ -1,7 +1,7 @@
 """A chromosome block resident in HBM and its repeated scoring (the path bench.py times and the
 multi-GPU driver shards): all buffers are allocated once, one ``step()`` enqueues the whole hot
-path -- site_counts -> site_flags -> window_bounds -> window_stats -> async copy of the records to
-pinned host memory -- on the current HIP stream without any host synchronisation.
+path -- site_counts (+ fused per-site decision) -> window_bounds -> window_stats -> async copy of
+the records to pinned host memory -- on the current HIP stream without any host synchronisation.
 """
 
 from __future__ import annotations
@@ -60,7 +60,9 @@ class ResidentScorer:
         dev = eng.device
         self.win_start = torch.as_tensor(np.array([w[0] for w in self.windows], dtype=np.int64)).to(dev)
         self.win_end = torch.as_tensor(np.array([w[1] for w in self.windows], dtype=np.int64)).to(dev)
-        self.counts = torch.empty((len(block.pops), n, 2), dtype=torch.int32, device=dev)
+        # at most SAI_FUSED_SETS sets: one fused launch, the per-population counts never leave the chip
+        self.fused = n_s <= _ffi.SAI_FUSED_SETS
+        self.counts = None if self.fused else torch.empty((len(block.pops), n, 2), dtype=torch.int32, device=dev)
         self.tgt_freq = torch.empty((n,), dtype=torch.float64, device=dev)
         self.flags = torch.empty((n_s, n), dtype=torch.uint8, device=dev)
         self.lo = torch.empty((n_w,), dtype=torch.int32, device=dev)
@@ -78,11 +80,15 @@ class ResidentScorer:
         if time_counts:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        eng.site_counts(b.pops, out=self.counts)
+        if self.fused:
+            eng.site_pass(b.pops, b.ploidies, self.sets, out=(self.tgt_freq, self.flags))
+        else:
+            eng.site_counts(b.pops, out=self.counts)
         if time_counts:
             e1.record()
             self.count_events.append((e0, e1))
-        eng.site_flags(self.counts, b.ploidies, self.sets, out=(self.tgt_freq, self.flags))
+        if not self.fused:
+            eng.site_flags(self.counts, b.ploidies, self.sets, out=(self.tgt_freq, self.flags))
         _ffi.check(
             eng.lib.sai_window_bounds(
                 eng.ctx, eng._ptr(b.pos), b.n_sites, self.n_windows, eng._ptr(self.win_start), eng._ptr(self.win_end),

@@ -73,7 +73,7 @@ def check_identities(eng, block, scorer, res):
     """Conservation + prefix-sum identities, everything recomputed with plain torch ops."""
     import torch
 
-    counts = scorer.counts.to(torch.int64)
+    counts = eng.site_counts(block.pops).to(torch.int64)  # the scorer itself runs the fused pass
     for p, pop in enumerate(block.pops):
         total, called = 0, 0
         step = 1 << 30  # bytes per slice, keeps the torch temporaries small

@@ -235,3 +235,35 @@ def test_synth_device_equals_host(eng):
     assert np.array_equal(pos, np.cumsum(gaps)) and gaps.min() >= 1 and gaps.max() <= 49
     part = eng.synth_positions(seed, chrom, 1000, site0=4000).cpu().numpy()
     assert np.array_equal(part, pos[4000:])
+
+
+def test_fused_site_pass_equals_two_kernels(eng):
+    """sai_site_pass (counts kept on chip) == sai_site_counts + sai_site_flags, bit for bit, with
+    and without the optional counts output, for 1..4 parameter sets and 1..3 sources."""
+    import torch
+
+    from sai_amd import _ffi
+
+    rng = np.random.default_rng(17)
+    n_sites = 1500
+    for n_src in (1, 3):
+        mats = [rng.integers(-2, 3, size=(n_sites, n)).astype(np.int8) for n in [33, 4100, *([2] * n_src)]]
+        pl = [2, 2] + [int(rng.integers(1, 4)) for _ in range(n_src)]
+        pops = [eng.tile(m) for m in mats]
+        for n_sets in (1, 4):
+            sets = [
+                _ffi.make_params(float(rng.choice([0.1, 0.5, 1.0])), float(rng.choice([0.0, 0.4])), 0.9,
+                                 [(str(rng.choice(["=", ">=", "<"])), float(rng.choice([0.0, 0.5, 1.0]))) for _ in range(n_src)],
+                                 bool(s % 2))
+                for s in range(n_sets)
+            ]  # fmt: skip
+            counts = eng.site_counts(pops)
+            tf, fl, _ = eng.site_flags(counts, pl, sets)
+            tf2, fl2 = eng.site_pass(pops, pl, sets)
+            c3 = torch.zeros_like(counts)
+            tf3, fl3 = eng.site_pass(pops, pl, sets, counts=c3)
+            for a, b in ((tf, tf2), (tf, tf3)):
+                assert a.cpu().numpy().tobytes() == b.cpu().numpy().tobytes()
+            assert torch.equal(fl, fl2) and torch.equal(fl, fl3) and torch.equal(counts, c3)
+    with pytest.raises(ValueError, match="at most"):
+        eng.site_pass(pops, pl, sets * 2)
