@@ -291,34 +291,39 @@ def iter_windows(
     start=None,
     end=None,
     num_src: Optional[int] = None,
+    out_data: Optional[dict[str, Chrom]] = None,
 ) -> Iterator[dict[str, Any]]:
     """The reference's per-window dicts, in its order, built its way: full-length
     inclusive position masks (:173-183), intersect1d chain (:193-197), empty
     window (:199-215), ``isin`` + ``compress`` per population (:217-231).
-    Population order = dict order (product over ref, tgt, src combinations,
-    :164-166).  Outgroups are outside this path."""
+    Population order = dict order (product over ref, tgt, src combinations and
+    outgroups, :162-166); the outgroup's positions join the intersection (:196-197)."""
     if num_src is None:
         num_src = len(src_data)
     src_combos = list(itertools.combinations(src_data.keys(), num_src))
     windows = {
         t: target_windows(tgt_data[t].POS, win_len, win_step, start, end) for t in tgt_data
     }
-    for ref_pop, tgt_pop, combo in itertools.product(ref_data, tgt_data, src_combos):
+    out_pops = list(out_data) if out_data else [None]
+    for ref_pop, tgt_pop, combo, out_pop in itertools.product(ref_data, tgt_data, src_combos, out_pops):
         r = ref_data[ref_pop]
         t = tgt_data[tgt_pop]
         srcs = [src_data[s] for s in combo]
+        o = None if out_pop is None else out_data[out_pop]
         for w_start, w_end in windows[tgt_pop]:
             r_pos = r.POS[(r.POS >= w_start) & (r.POS <= w_end)]
             t_pos = t.POS[(t.POS >= w_start) & (t.POS <= w_end)]
             common = np.intersect1d(r_pos, t_pos)
             for s in srcs:
                 common = np.intersect1d(common, s.POS[(s.POS >= w_start) & (s.POS <= w_end)])
+            if o is not None:
+                common = np.intersect1d(common, o.POS[(o.POS >= w_start) & (o.POS <= w_end)])
             item = {
                 "chr_name": chr_name,
                 "ref_pop": ref_pop,
                 "tgt_pop": tgt_pop,
                 "src_pop_list": combo,
-                "out_pop": None,
+                "out_pop": out_pop,
                 "start": w_start,
                 "end": w_end,
                 "out_gts": None,
@@ -333,6 +338,8 @@ def iter_windows(
                     tgt_gts=t.GT.compress(np.isin(t.POS, common), axis=0),
                     src_gts_list=[s.GT.compress(np.isin(s.POS, common), axis=0) for s in srcs],
                 )
+                if o is not None:
+                    item["out_gts"] = o.GT.compress(np.isin(o.POS, common), axis=0)
             yield item
 
 
@@ -382,11 +389,26 @@ def window_item(
         "cdd_pos": {},
     }
     if ref_gts is None or tgt_gts is None or src_gts_list is None or ploidy_config is None:
-        for name in stat_params:
-            item[name] = np.nan
-            item["cdd_pos"][name] = np.array([])
+        for name, prm in stat_params.items():
+            if name in ("U", "Q"):
+                item[name] = np.nan
+                item["cdd_pos"][name] = np.array([])
+            elif prm is True:  # feature_preprocessor.py:137-141
+                item[name] = [np.nan] * len(src_pop_list) if len(src_pop_list) > 1 else np.nan
         return item
+    four = None
     for name, prm in stat_params.items():
+        if name not in ("U", "Q"):
+            if prm is not True:  # feature_preprocessor.py:147-151
+                continue
+            if name not in ("fd", "df", "Danc", "Dplus"):
+                raise ValueError(f"statistic {name} is outside the oracle")
+            if four is None:
+                out_ploidy = None if out_pop is None or "outgroup" not in ploidies else ploidies["outgroup"][out_pop]
+                four = four_pop_stats(ref_gts, tgt_gts, src_gts_list, out_gts, ploidies["ref"][ref_pop],
+                                      ploidies["tgt"][tgt_pop], list(ploidies["src"].values()), out_ploidy)  # fmt: skip
+            item[name] = four[name]
+            continue
         common = dict(
             ref_gts=ref_gts,
             tgt_gts=tgt_gts,
@@ -415,10 +437,16 @@ def window_item(
 # ---------------------------------------------------------------------------
 
 
-def header_line(stat_names: Sequence[str]) -> str:
-    """sai.py:109-131 for U/Q-only configurations (one column per statistic)."""
+def header_line(stat_names: Sequence[str], src_pops: Sequence[str] = ()) -> str:
+    """sai.py:109-131: U/Q are one column each; the other statistics one column per source
+    population (``stat.src``) when there is more than one source."""
     cols = ["Chrom", "Start", "End", "Ref", "Tgt", "Src", "Outgroup", "N(Variants)"]
-    return "\t".join(cols + list(stat_names)) + "\n"
+    for name in stat_names:
+        if name in ("U", "Q") or len(src_pops) <= 1:
+            cols.append(name)
+        else:
+            cols.extend(f"{name}.{sp}" for sp in src_pops)
+    return "\t".join(cols) + "\n"
 
 
 def log_header_line(key: str) -> str:
@@ -430,7 +458,14 @@ def score_lines(items: Sequence[dict], stat_names: Sequence[str]) -> list[str]:
     """TSV rows (feature_preprocessor.py:206-237): values through ``str()``."""
     out = []
     for it in items:
-        vals = "\t".join(str(it.get(s)) for s in stat_names)
+        parts = []
+        for s in stat_names:  # feature_preprocessor.py:217-228
+            v = it.get(s)
+            if isinstance(v, list) and len(v) == len(it["src_pop_list"]):
+                parts.extend(str(x) for x in v)
+            else:
+                parts.append(str(v[0] if isinstance(v, list) and v else v))
+        vals = "\t".join(parts)
         out.append(
             f"{it['chr_name']}\t{it['start']}\t{it['end']}\t{it['ref_pop']}\t{it['tgt_pop']}\t"
             f"{','.join(it['src_pop_list'])}\t{it['out_pop']}\t{it['nsnps']}\t{vals}\n"
@@ -466,6 +501,7 @@ def run_chunk(
     anc_allele_available,
     start=None,
     end=None,
+    out_data=None,
 ) -> list[dict]:
     """All windows of one chunk through ``iter_windows`` + ``window_item``.  When a
     chunk is bounded the resident arrays are first cut to ``[start, end]`` the way
@@ -480,6 +516,7 @@ def run_chunk(
             return out
 
         ref_data, tgt_data, src_data = cut(ref_data), cut(tgt_data), cut(src_data)
+        out_data = cut(out_data) if out_data else out_data
     items = []
     for win in iter_windows(
         chr_name,
@@ -491,6 +528,102 @@ def run_chunk(
         ploidy_config=ploidies,
         start=start,
         end=end,
+        out_data=out_data,
     ):
         items.append(window_item(stat_params, ploidies, anc_allele_available, **win))
     return items
+
+
+# ---------------------------------------------------------------------------
+# ABBA-BABA family: fd, df, Danc, Dplus
+#   calc_four_pops_freq / calc_pattern_sum        sai/stats/stat_utils.py:171-272
+#   FdStatistic / DfStatistic / DancStatistic / DplusStatistic
+#                                                 sai/stats/{fd,df,danc,dplus}_statistic.py
+# ---------------------------------------------------------------------------
+
+
+def four_pops_freq(ref_gts, tgt_gts, src_gts, out_gts=None, ref_ploidy=1, tgt_ploidy=1, src_ploidy=1, out_ploidy=1):
+    """stat_utils.py:209-217: the outgroup frequency is 0 everywhere when there is no outgroup."""
+    ref = allele_freq(ref_gts, ref_ploidy)
+    out = np.zeros_like(ref) if out_gts is None else allele_freq(out_gts, out_ploidy)
+    return ref, allele_freq(tgt_gts, tgt_ploidy), allele_freq(src_gts, src_ploidy), out
+
+
+def pattern_sum(ref_freq, tgt_freq, src_freq, out_freq, pattern: str) -> float:
+    """stat_utils.py:255-272: product over the four populations of f ('b') or 1 - f ('a'),
+    multiplied in population order starting from 1.0, then np.sum (NaN sites poison the sum)."""
+    if len(pattern) != 4:
+        raise ValueError("Pattern must be a four-character string.")
+    prod = np.ones_like(ref_freq)
+    for f, c in zip((ref_freq, tgt_freq, src_freq, out_freq), pattern.lower()):
+        if c == "a":
+            prod *= 1 - f
+        elif c == "b":
+            prod *= f
+        else:
+            raise ValueError(f"Invalid character '{c}' in pattern. Only 'a' and 'b' allowed.")
+    return float(np.sum(prod))
+
+
+def _ratio(num: float, den: float) -> float:
+    return num / den if den != 0 else np.nan
+
+
+def four_pop_stats(ref_gts, tgt_gts, src_gts_list, out_gts, ref_ploidy, tgt_ploidy, src_ploidy_list, out_ploidy):
+    """{"fd": [...], "df": [...], "Danc": [...], "Dplus": [...]}, one value per source
+    (fd_statistic.py:61-89, df_statistic.py:60-84, danc_statistic.py:59-83,
+    dplus_statistic.py:60-86)."""
+    res = {"fd": [], "df": [], "Danc": [], "Dplus": []}
+    for i in range(len(src_gts_list)):
+        r, t, s, o = four_pops_freq(ref_gts, tgt_gts, src_gts_list[i], out_gts, ref_ploidy, tgt_ploidy,
+                                    src_ploidy_list[i], out_ploidy)  # fmt: skip
+        abba, baba = pattern_sum(r, t, s, o, "abba"), pattern_sum(r, t, s, o, "baba")
+        bbaa, baaa, abaa = pattern_sum(r, t, s, o, "bbaa"), pattern_sum(r, t, s, o, "baaa"), pattern_sum(r, t, s, o, "abaa")
+        d = np.maximum(t, s)
+        abba_d, baba_d = pattern_sum(r, d, d, o, "abba"), pattern_sum(r, d, d, o, "baba")
+        res["fd"].append(_ratio(abba - baba, abba_d - baba_d))
+        res["df"].append(_ratio(abba - baba, abba + baba + 2 * bbaa))
+        res["Danc"].append(_ratio(baaa - abaa, baaa + abaa))
+        res["Dplus"].append(_ratio(abba - baba + baaa - abaa, abba + baba + baaa + abaa))
+    return res
+
+
+def numpy_pairwise_sum(a) -> float:
+    """numpy's float add.reduce order for a contiguous 1-D array (numpy/_core/src/umath/
+    loops_utils.h.src, *_pairwise_sum): plain loop below 8 elements; up to 128 elements eight
+    running sums combined as ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)) plus a tail loop; above that the
+    array is halved (first half rounded down to a multiple of 8) recursively.  The HIP kernel
+    sums in exactly this order; tests check this function bit-for-bit against np.sum."""
+    a = np.asarray(a, dtype=np.float64)
+    n = len(a)
+    if n < 8:
+        res = np.float64(0.0)
+        for v in a:
+            res = res + v
+        return float(res)
+    if n <= 128:
+        r = [np.float64(a[j]) for j in range(8)]
+        i = 8
+        while i < n - (n % 8):
+            for j in range(8):
+                r[j] = r[j] + a[i + j]
+            i += 8
+        res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]))
+        while i < n:
+            res = res + a[i]
+            i += 1
+        return float(res)
+    n2 = n // 2
+    n2 -= n2 % 8
+    return float(np.float64(numpy_pairwise_sum(a[:n2])) + np.float64(numpy_pairwise_sum(a[n2:])))
+
+
+def numpy_sum(a) -> float:
+    """np.sum of a contiguous f64 array, operation by operation: the reduction runs over the
+    ufunc buffer size (8192 elements) at a time, each piece pairwise-summed as above and added to
+    the running total in order.  Checked bit-for-bit against np.sum in the tests."""
+    a = np.asarray(a, dtype=np.float64)
+    res = np.float64(0.0)
+    for i in range(0, len(a), 8192):
+        res = res + np.float64(numpy_pairwise_sum(a[i : i + 8192]))
+    return float(res)

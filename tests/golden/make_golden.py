@@ -550,3 +550,120 @@ def make_outlier():
 
 if __name__ == "__main__" and os.path.isdir(REF):
     make_outlier()
+
+
+# ---------------------------------------------------------------------------
+# 7. ABBA-BABA family: fd / df / Danc / Dplus (sai/stats/*_statistic.py)
+# ---------------------------------------------------------------------------
+
+FOURPOP_SEEDED = [
+    # name, seed, n_sites, n_ref, n_tgt, src_sizes, n_out, ploidies [ref, tgt, [src], out], missing rate
+    ("small_out", 1, 40, 6, 5, [2], 2, [2, 2, [2], 2], 0.0),
+    ("small_noout", 2, 40, 6, 5, [2], 0, [2, 2, [2], 2], 0.0),
+    ("two_src_missing", 3, 200, 9, 7, [1, 3], 2, [2, 2, [2, 1], 2], 0.05),
+    ("nan_sites", 4, 60, 3, 3, [1], 1, [2, 2, [2], 2], 0.5),
+    ("mixed_ploidy", 5, 130, 4, 6, [2, 2], 3, [4, 1, [2, 3], 2], 0.01),
+    ("blocks_129", 6, 129, 5, 5, [2], 2, [2, 2, [2], 2], 0.0),
+    ("blocks_1000", 7, 1000, 5, 5, [2], 2, [2, 2, [2], 2], 0.0),
+    ("beyond_buffer_9000", 8, 9000, 4, 4, [1], 1, [2, 2, [2], 2], 0.0),
+    ("seven_sites", 9, 7, 5, 5, [2], 2, [2, 2, [2], 2], 0.0),
+]
+
+
+def make_fourpop():
+    sys.path.insert(0, str(OUT))
+    from seeded import fourpop_inputs
+    from sai.stats import DancStatistic, DfStatistic, DplusStatistic, FdStatistic
+
+    A = np.array
+    classes = {"fd": FdStatistic, "df": DfStatistic, "Danc": DancStatistic, "Dplus": DplusStatistic}
+    cases = []
+
+    def run(name, ref, tgt, srcs, out, pl, inline):
+        kw = dict(ref_gts=ref, tgt_gts=tgt, src_gts_list=srcs, out_gts=out, ref_ploidy=pl[0], tgt_ploidy=pl[1],
+                  src_ploidy_list=pl[2], out_ploidy=pl[3])
+        res = {k: [hx(v) for v in cls(**kw).compute()["value"]] for k, cls in classes.items()}
+        rec = dict(name=name, ploidies=pl, out=res)
+        if inline:
+            rec.update(ref_gts=ints(ref), tgt_gts=ints(tgt), src_gts_list=[ints(s) for s in srcs],
+                       out_gts=None if out is None else ints(out))
+        cases.append(rec)
+        return res
+
+    # the reference tests' inputs and published answers
+    r = run("fd_test", A([[0, 1], [1, 0], [0, 1]]), A([[1, 0], [0, 1], [1, 0]]), [A([[1, 1], [1, 1], [1, 1]])], None,
+            [1, 1, [1], None], True)
+    assert np.isclose(float.fromhex(r["fd"][0]), 0)  # tests/stats/test_fd_statistic.py
+    ref, tgt, src = A([[0, 0], [0, 0], [1, 1]]), A([[1, 0], [0, 1], [0, 1]]), A([[0, 1], [1, 0], [1, 0]])
+    r = run("df_danc_dplus_test", ref, tgt, [src], None, [1, 1, [1], None], True)
+    assert np.isclose(float.fromhex(r["df"][0]), 0.2)  # test_df_statistic.py:71
+    assert np.isclose(float.fromhex(r["Danc"][0]), -1 / 3)  # test_danc_statistic.py:48
+    assert np.isclose(float.fromhex(r["Dplus"][0]), 0)  # test_dplus_statistic.py:77
+    run("with_out_ploidy1", ref, tgt, [src], A([[0, 0], [1, 0], [0, 0]]), [1, 1, [1], 1], True)
+    run("zero_denominators", A([[0, 0]]), A([[0, 0]]), [A([[0, 0]])], None, [1, 1, [1], None], True)
+    for name, seed, n_sites, n_ref, n_tgt, src_sizes, n_out, pl, miss in FOURPOP_SEEDED:
+        ref, tgt, srcs, out = fourpop_inputs(seed, n_sites, n_ref, n_tgt, src_sizes, n_out, pl, miss)
+        cases.append(dict(run(name, ref, tgt, srcs, out, pl, False) and cases.pop(), seeded=[seed, n_sites, n_ref, n_tgt, src_sizes, n_out, miss]))
+    (OUT / "fourpop_cases.json").write_text(json.dumps(cases, separators=(",", ":")) + "\n")
+    print("fourpop_cases.json", len(cases))
+
+
+def make_pipeline_outgroup():
+    """WindowGenerator + FeaturePreprocessor + process_items with an outgroup, two sources and the
+    four ABBA-BABA statistics next to U and Q (multi-source column expansion, header rule)."""
+    sys.path.insert(0, str(OUT))
+    from itertools import combinations
+
+    from seeded import fourpop_inputs
+    from sai.configs import PloidyConfig, StatConfig
+    from sai.generators import WindowGenerator
+    from sai.preprocessors import FeaturePreprocessor
+    from sai.utils import split_genome
+    from sai.utils.genomic_dataclasses import ChromosomeData
+
+    out = []
+    for name, seed, n_src, with_out in (("outgroup_two_src", 21, 2, True), ("no_outgroup_one_src", 22, 1, False)):
+        n_sites = 700
+        pl = [2, 2, [2] * n_src, 2]
+        ref, tgt, srcs, og = fourpop_inputs(seed, n_sites, 8, 6, [1] * n_src, 2 if with_out else 0, pl, 0.02)
+        rng = np.random.default_rng(seed + 100)
+        pos = (np.cumsum(rng.integers(1, 40, size=n_sites)) + 500).astype(np.int32)
+        ploidies = {"ref": {"R": 2}, "tgt": {"T": 2}, "src": {f"S{i}": 2 for i in range(n_src)}}
+        if with_out:
+            ploidies["outgroup"] = {"O": 2}
+        stats = {"fd": True, "DD": False, "U": {"ref": {"R": 0.4}, "tgt": {"T": 0.3}, "src": {f"S{i}": ">=0.5" for i in range(n_src)}},
+                 "df": True, "Danc": True, "Q": {"ref": {"R": 0.4}, "tgt": {"T": 0.9}, "src": {f"S{i}": ">=0.5" for i in range(n_src)}},
+                 "Dplus": True}
+        wg = object.__new__(WindowGenerator)
+        wg.win_len, wg.win_step, wg.chr_name, wg.ploidy_config = 3000, 1500, "9", PloidyConfig(ploidies)
+        mk = lambda g: ChromosomeData(POS=pos.copy(), REF=None, ALT=None, GT=g.copy())
+        wg.ref_data, wg.ref_samples = {"R": mk(ref)}, {"R": []}
+        wg.tgt_data, wg.tgt_samples = {"T": mk(tgt)}, {"T": []}
+        wg.src_data = {f"S{i}": mk(s) for i, s in enumerate(srcs)}
+        wg.src_samples = {f"S{i}": [] for i in range(n_src)}
+        wg.out_data, wg.out_samples = ({"O": mk(og)}, {"O": []}) if with_out else (None, None)
+        wg.num_src = n_src
+        wg.src_combinations = list(combinations(wg.src_samples.keys(), n_src))
+        wg.tgt_windows = {"T": split_genome(pos=pos, window_size=3000, step_size=1500)}
+        sc = StatConfig(json.loads(json.dumps(stats)))
+        with tempfile.TemporaryDirectory() as td:
+            tsv = os.path.join(td, "o.tsv")
+            fp = FeaturePreprocessor(output_file=tsv, stat_config=sc, anc_allele_available=True)
+            items = []
+            for item in wg.get():
+                items.extend(fp.run(**item))
+            fp.process_items(items)
+            text = {"tsv": open(tsv).read(), "U": open(os.path.join(td, "o.U.log")).read(),
+                    "Q": open(os.path.join(td, "o.Q.log")).read()}
+        out.append(dict(name=name, seed=seed, n_src=n_src, with_out=with_out, n_sites=n_sites, ploidies=ploidies,
+                        stats=stats, pos=ints(pos), n_windows=len(items), text=text,
+                        items=[{k: ([hx(v) for v in it[k]] if isinstance(it[k], list) else hx(it[k]))
+                                for k in ("fd", "df", "Danc", "Dplus")} | {"out_pop": it["out_pop"], "nsnps": it["nsnps"]}
+                               for it in items]))
+        print(name, len(items), "windows")
+    (OUT / "pipeline_outgroup.json").write_text(json.dumps(out, separators=(",", ":")) + "\n")
+
+
+if __name__ == "__main__" and os.path.isdir(REF):
+    make_fourpop()
+    make_pipeline_outgroup()

@@ -199,3 +199,81 @@ def test_feature_inline_and_example_vcf():
             assert "".join(O.log_lines([it], k)) == ex[label]["text"][k]
     assert O.header_line(["U", "Q"]) == "Chrom\tStart\tEnd\tRef\tTgt\tSrc\tOutgroup\tN(Variants)\tU\tQ\n"
     assert O.log_header_line("U") == "Chrom\tStart\tEnd\tU_SNP\n"
+
+
+# ---- ABBA-BABA family -------------------------------------------------------
+
+import sys  # noqa: E402
+
+sys.path.insert(0, str((__import__("pathlib").Path(__file__).parent / "golden")))
+from seeded import fourpop_inputs  # noqa: E402
+
+FOURPOP = load_golden("fourpop_cases.json")
+
+
+def fourpop_case_inputs(c):
+    if "seeded" in c:
+        seed, n_sites, n_ref, n_tgt, src_sizes, n_out, miss = c["seeded"]
+        return fourpop_inputs(seed, n_sites, n_ref, n_tgt, src_sizes, n_out, c["ploidies"], miss)
+    A = lambda v: None if v is None else np.array(v, dtype=np.int64).reshape(len(v), -1)  # noqa: E731
+    return A(c["ref_gts"]), A(c["tgt_gts"]), [A(s) for s in c["src_gts_list"]], A(c["out_gts"])
+
+
+@pytest.mark.parametrize("case", FOURPOP, ids=[c["name"] for c in FOURPOP])
+def test_fourpop_bit_exact(case):
+    ref, tgt, srcs, out = fourpop_case_inputs(case)
+    pl = case["ploidies"]
+    got = O.four_pop_stats(ref, tgt, srcs, out, pl[0], pl[1], pl[2], pl[3])
+    for k, exp in case["out"].items():
+        assert len(got[k]) == len(exp)
+        assert all(same_f64(g, unhex(e)) for g, e in zip(got[k], exp)), (k, got[k], exp)
+
+
+def test_numpy_sum_order_restatement():
+    """The summation order the HIP kernel follows == np.sum, bit for bit (incl. > 8192 elements)."""
+    rng = np.random.default_rng(5)
+    for n in list(range(0, 140)) + [255, 256, 1000, 2001, 8191, 8192, 8193, 12345, 30000]:
+        a = rng.random(n) * rng.choice([1e-3, 1.0, 1e3], n)
+        assert same_f64(O.numpy_sum(a), np.sum(a)), n
+    a = np.array([1.0, np.nan, 2.0] * 50)
+    assert np.isnan(O.numpy_sum(a))
+    with pytest.raises(ValueError, match="four-character"):
+        O.pattern_sum(a, a, a, a, "abb")
+    with pytest.raises(ValueError, match="Invalid character"):
+        O.pattern_sum(a, a, a, a, "abcx")
+
+
+PIPE_OUT = load_golden("pipeline_outgroup.json")
+
+
+def outgroup_scenario_data(sc):
+    n_src = sc["n_src"]
+    pl = [2, 2, [2] * n_src, 2]
+    ref, tgt, srcs, og = fourpop_inputs(sc["seed"], sc["n_sites"], 8, 6, [1] * n_src, 2 if sc["with_out"] else 0, pl, 0.02)
+    pos = np.array(sc["pos"], dtype=np.int32)
+    return pos, ref, tgt, srcs, og
+
+
+@pytest.mark.parametrize("sc", PIPE_OUT, ids=[s["name"] for s in PIPE_OUT])
+def test_pipeline_with_outgroup_items_and_text(sc):
+    pos, ref, tgt, srcs, og = outgroup_scenario_data(sc)
+    stats = {}
+    for name, prm in sc["stats"].items():
+        stats[name] = _validated({name: prm})[name] if name in ("U", "Q") else prm
+    items = O.run_chunk(
+        "9", {"R": O.Chrom(pos, ref)}, {"T": O.Chrom(pos, tgt)}, {f"S{i}": O.Chrom(pos, s) for i, s in enumerate(srcs)},
+        3000, 1500, stats, sc["ploidies"], True, out_data=({"O": O.Chrom(pos, og)} if sc["with_out"] else None),
+    )  # fmt: skip
+    assert len(items) == sc["n_windows"]
+    for it, exp in zip(items, sc["items"]):
+        assert it["out_pop"] == exp["out_pop"] and it["nsnps"] == exp["nsnps"]
+        for k in ("fd", "df", "Danc", "Dplus"):
+            assert all(same_f64(g, unhex(e)) for g, e in zip(it[k], exp[k]))
+    names = [n for n, p in sc["stats"].items() if n in ("U", "Q") or p is True]
+    assert "".join(O.score_lines(items, names)) == sc["text"]["tsv"]
+    for k in ("U", "Q"):
+        assert "".join(O.log_lines(items, k)) == sc["text"][k]
+    src_pops = list(sc["ploidies"]["src"])
+    head = O.header_line(names, src_pops)
+    assert head.startswith("Chrom\tStart\tEnd\tRef\tTgt\tSrc\tOutgroup\tN(Variants)\tfd")
+    assert ("fd.S0\tfd.S1" in head) == (sc["n_src"] == 2)
