@@ -165,6 +165,26 @@ int sai_window_stats(sai_ctx* ctx, int64_t n_sites, const double* tgt_freq, cons
                      sai_window_record* records, int64_t* cdd_off, int32_t* cdd_u, int64_t cap_u,
                      int32_t* cdd_q, int64_t cap_q, int64_t* cdd_total, void* stream);
 
+/* ---- ABBA-BABA family: fd, df, Danc, Dplus --------------------- */
+
+/* calc_freq's f64 division for every population of a counts tensor (stat_utils.py:48-52;
+ * what calc_four_pops_freq, stat_utils.py:209-217, asks for): freqs[p * n_sites + site], NaN
+ * where no individual is called.  Up to 9 populations (ref, tgt, 6 sources, outgroup). */
+int sai_site_freqs(sai_ctx* ctx, int64_t n_sites, int32_t n_pops, const int32_t* ploidy_host,
+                   const uint32_t* counts, double* freqs, void* stream);
+
+/* Per (window, source): the pattern sums of calc_pattern_sum (stat_utils.py:220-272) for abba,
+ * baba, bbaa, baaa, abaa and fd's two denominators -- products formed in population order, sums
+ * taken in numpy's np.sum order, so they are the reference's doubles bit for bit -- and the four
+ * statistics formed from them (fd_statistic.py:85-88, df_statistic.py:79-82,
+ * danc_statistic.py:78-81, dplus_statistic.py:81-84; NaN on a zero denominator).
+ * freqs = [ref, tgt, src_0..src_{n_src-1} (, outgroup)] as written by sai_site_freqs; without an
+ * outgroup its frequency is 0 everywhere (stat_utils.py:213-214).
+ * sums[(w * n_src + s) * 7 + k], stats[(w * n_src + s) * 4 + {fd, df, Danc, Dplus}]. */
+int sai_window_fourpop(sai_ctx* ctx, int64_t n_sites, int32_t n_src, int32_t has_outgroup,
+                       const double* freqs, int32_t n_windows, const int32_t* lo, const int32_t* hi,
+                       double* sums, double* stats, void* stream);
+
 /* ---- synthetic data ("synth-v1") ---------------------------------- */
 
 /* Counter-based generator: every byte is a pure function of (seed, chrom, site, population

@@ -211,6 +211,30 @@ class Engine:
             )  # fmt: skip
         return tgt_freq, flags, adj
 
+    def site_freqs(self, counts, ploidies: Sequence[int]):
+        """f64 frequency per population and site ([P][n_sites], NaN where nothing is called)."""
+        torch = _torch()
+        n_pops, n_sites = int(counts.shape[0]), int(counts.shape[1])
+        pl = (C.c_int32 * n_pops)(*[int(p) for p in ploidies])
+        freqs = self._empty((n_pops, n_sites), torch.float64)
+        _ffi.check(self.lib.sai_site_freqs(self.ctx, n_sites, n_pops, pl, self._ptr(counts), self._ptr(freqs), self._stream()))
+        return freqs
+
+    def window_fourpop(self, freqs, n_src: int, has_outgroup: bool, lo, hi):
+        """fd, df, Danc, Dplus per (window, source): f64 tensor [n_windows][n_src][4]; ``freqs`` =
+        [ref, tgt, sources..., (outgroup)] from ``site_freqs``."""
+        torch = _torch()
+        n_w = int(lo.numel())
+        sums = self._empty((n_w, n_src, 7), torch.float64)
+        stats = self._empty((n_w, n_src, 4), torch.float64)
+        _ffi.check(
+            self.lib.sai_window_fourpop(
+                self.ctx, int(freqs.shape[1]), n_src, 1 if has_outgroup else 0, self._ptr(freqs), n_w, self._ptr(lo),
+                self._ptr(hi), self._ptr(sums), self._ptr(stats), self._stream(),
+            )
+        )  # fmt: skip
+        return stats
+
     def window_bounds(self, pos, win_start, win_end):
         """Site-index ranges [lo, hi) of inclusive position windows; int32 device tensors."""
         torch = _torch()

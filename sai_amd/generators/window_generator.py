@@ -57,7 +57,8 @@ class WindowGenerator(DataGenerator):
             anc_allele_file=anc_allele_file,
         )
         self._setup(
-            chr_name, win_len, win_step, ploidy_config, results["ref"], results["tgt"], results["src"], start, end, num_src
+            chr_name, win_len, win_step, ploidy_config, results["ref"], results["tgt"], results["src"], start, end, num_src,
+            results["outgroup"],
         )
 
     @classmethod
@@ -73,6 +74,7 @@ class WindowGenerator(DataGenerator):
         start: int = None,
         end: int = None,
         num_src: Optional[int] = None,
+        out_data: Optional[dict] = None,
     ) -> "WindowGenerator":
         """Build from in-memory ``{population: ChromosomeData}`` dictionaries (synthetic data,
         tests); sample names are synthesised."""
@@ -84,17 +86,18 @@ class WindowGenerator(DataGenerator):
         self._setup(
             chr_name, win_len, win_step, ploidy_config, (ref_data, names(ref_data)), (tgt_data, names(tgt_data)),
             (src_data, names(src_data)), start, end, len(src_data) if num_src is None else num_src,
+            (out_data, names(out_data)) if out_data else (None, None),
         )  # fmt: skip
         return self
 
-    def _setup(self, chr_name, win_len, win_step, ploidy_config, ref, tgt, src, start, end, num_src):
+    def _setup(self, chr_name, win_len, win_step, ploidy_config, ref, tgt, src, start, end, num_src, out=(None, None)):
         self.win_len, self.win_step, self.num_src = win_len, win_step, num_src
         self.chr_name, self.ploidy_config = chr_name, ploidy_config
         self.start, self.end = start, end
         self.ref_data, self.ref_samples = ref
         self.tgt_data, self.tgt_samples = tgt
         self.src_data, self.src_samples = src
-        self.out_data = self.out_samples = None
+        self.out_data, self.out_samples = out
         # window_generator.py:129-131: combinations of the populations of the source file
         self.src_combinations = list(combinations(self.src_samples.keys(), self.num_src))
         # :132-144: the grid comes from the target's positions, or from the chunk bounds
@@ -117,14 +120,16 @@ class WindowGenerator(DataGenerator):
         return self.ref_data is not None and self.tgt_data is not None and self.src_data is not None
 
     def combinations(self) -> Iterator[tuple]:
-        """(ref_pop, tgt_pop, src_comb, out_pop) in the reference's product order (:164-166)."""
-        return product(self.ref_samples, self.tgt_samples, self.src_combinations, [None])
+        """(ref_pop, tgt_pop, src_comb, out_pop) in the reference's product order (:162-166)."""
+        return product(self.ref_samples, self.tgt_samples, self.src_combinations, self.out_samples or [None])
 
-    def common_positions(self, ref_pop, tgt_pop, src_comb) -> np.ndarray:
+    def common_positions(self, ref_pop, tgt_pop, src_comb, out_pop=None) -> np.ndarray:
         """Positions shared by the populations of one combination.  All populations come from
         the same VCF region (and the same polarisation), so their site sets are identical; that
         is what the resident, index-range design relies on and it is checked here."""
         blocks = [self.ref_data[ref_pop], self.tgt_data[tgt_pop]] + [self.src_data[s] for s in src_comb]
+        if out_pop is not None:
+            blocks.append(self.out_data[out_pop])
         pos = blocks[0].POS
         for b in blocks[1:]:
             if b.POS.shape != pos.shape or not np.array_equal(b.POS, pos):
@@ -149,7 +154,7 @@ class WindowGenerator(DataGenerator):
 
     def _window_generator(self) -> Iterator[dict[str, Any]]:
         for ref_pop, tgt_pop, src_comb, out_pop in self.combinations():
-            pos = self.common_positions(ref_pop, tgt_pop, src_comb)
+            pos = self.common_positions(ref_pop, tgt_pop, src_comb, out_pop)
             for start, end in self.tgt_windows[tgt_pop]:
                 lo, hi = self.window_range(pos, start, end)
                 if hi <= lo:  # window_generator.py:199-215
@@ -161,6 +166,7 @@ class WindowGenerator(DataGenerator):
                     ref_gts=self.ref_data[ref_pop].GT[lo:hi],
                     tgt_gts=self.tgt_data[tgt_pop].GT[lo:hi],
                     src_gts_list=[self.src_data[s].GT[lo:hi] for s in src_comb],
+                    out_gts=None if out_pop is None else self.out_data[out_pop].GT[lo:hi],
                 )
                 yield item
 

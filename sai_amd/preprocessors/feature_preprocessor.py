@@ -19,6 +19,7 @@ from ..registries.stat_registry import STAT_REGISTRY
 from .data_preprocessor import DataPreprocessor
 
 _HIP_STATS = ("U", "Q")
+_FOURPOP = ("fd", "df", "Danc", "Dplus")
 
 
 class FeaturePreprocessor(DataPreprocessor):
@@ -30,15 +31,16 @@ class FeaturePreprocessor(DataPreprocessor):
     # -- helpers ---------------------------------------------------------------------------
 
     def _active_stats(self) -> list[str]:
-        """Statistic names in config order; a non-U/Q entry set to True is outside this build."""
+        """Statistic names in config order: U/Q always, the ABBA-BABA family when set to True
+        (feature_preprocessor.py:146-151); DD is the one statistic this build does not compute."""
         names = []
         for name, value in self.stat_config.root.items():
-            if name in _HIP_STATS:
+            if name in _HIP_STATS or (name in _FOURPOP and value is True):
                 names.append(name)
             elif value is True:
                 raise ValueError(
-                    f"The {name} statistic is outside the U/Q path this build accelerates; "
-                    "disable it in the configuration."
+                    f"The {name} statistic is outside the path this build accelerates "
+                    "(U, Q, fd, df, Danc, Dplus); disable it in the configuration."
                 )
         return names
 
@@ -59,9 +61,13 @@ class FeaturePreprocessor(DataPreprocessor):
 
     def _fill_missing(self, item: dict, names) -> None:
         # feature_preprocessor.py:131-144
+        n_src = len(item["src_pop_list"])
         for name in names:
-            item[name] = np.nan
-            item["cdd_pos"][name] = np.array([])
+            if name in _HIP_STATS:
+                item[name] = np.nan
+                item["cdd_pos"][name] = np.array([])
+            else:
+                item[name] = [np.nan for _ in range(n_src)] if n_src > 1 else np.nan
 
     def _stat_kwargs(self, name: str, ref_pop: str, tgt_pop: str) -> dict:
         # feature_preprocessor.py:164-185: thresholds per (ref_pop, tgt_pop), sources by position
@@ -111,8 +117,11 @@ class FeaturePreprocessor(DataPreprocessor):
                 src_ploidy_list=ploidy_config.get_ploidy("src"),
                 out_ploidy=ploidy_config.get_ploidy("outgroup", out_pop),
             )
-            res = stat.compute(pos=pos, **self._stat_kwargs(name, ref_pop, tgt_pop))
-            item["cdd_pos"][name] = res["cdd_pos"]
+            if name in _HIP_STATS:
+                res = stat.compute(pos=pos, **self._stat_kwargs(name, ref_pop, tgt_pop))
+                item["cdd_pos"][name] = res["cdd_pos"]
+            else:
+                res = stat.compute()
             item[name] = res["value"]
         return [item]
 
@@ -140,7 +149,10 @@ class FeaturePreprocessor(DataPreprocessor):
         pc = wg.ploidy_config
         # upload + reduce every population block once
         blocks = {}
-        for group, data in (("ref", wg.ref_data), ("tgt", wg.tgt_data), ("src", wg.src_data)):
+        groups = [("ref", wg.ref_data), ("tgt", wg.tgt_data), ("src", wg.src_data)]
+        if wg.out_data:
+            groups.append(("outgroup", wg.out_data))
+        for group, data in groups:
             for pop, cd in data.items():
                 blocks[(group, pop)] = eng.tile(cd.GT)
         keys = list(blocks)
@@ -155,13 +167,15 @@ class FeaturePreprocessor(DataPreprocessor):
 
         pos_dev_cache = {}
         for ref_pop, tgt_pop, src_comb, out_pop in wg.combinations():
-            pos = wg.common_positions(ref_pop, tgt_pop, src_comb)
+            pos = wg.common_positions(ref_pop, tgt_pop, src_comb, out_pop)
             windows = wg.tgt_windows[tgt_pop]
             src_ploidies = pc.get_ploidy("src")
             ploidy = [pc.get_ploidy("ref", ref_pop), pc.get_ploidy("tgt", tgt_pop)] + list(src_ploidies)
             n_eff = min(len(src_comb), len(src_ploidies))
+            uq_names = [n for n in names if n in _HIP_STATS]
+            four_names = [n for n in names if n in _FOURPOP]
             sets, kwargs = [], {}
-            for name in names:
+            for name in uq_names:
                 kw = self._stat_kwargs(name, ref_pop, tgt_pop)
                 validate_thresholds(kw["w"], kw["y_list"], len(src_comb))
                 kwargs[name] = kw
@@ -172,31 +186,45 @@ class FeaturePreprocessor(DataPreprocessor):
             for p in ploidy[: 2 + len(src_comb)]:
                 _check_ploidy(p)
             n_sites = int(pos.size)
-            res = None
+            res = four = nsnps_all = None
             if names and windows and n_sites:
-                counts = torch.stack(
-                    [counts_rows[("ref", ref_pop)], counts_rows[("tgt", tgt_pop)]]
-                    + [counts_rows[("src", s)] for s in src_comb[:n_eff]]
-                )
-                tgt_freq, flags, _ = eng.site_flags(counts, ploidy[: 2 + n_eff], sets)
                 pid = id(pos)
                 if pid not in pos_dev_cache:
                     pos_dev_cache[pid] = torch.as_tensor(np.ascontiguousarray(pos, dtype=np.int32)).to(eng.device)
                 pos_dev = pos_dev_cache[pid]
                 lo, hi = eng.window_bounds(pos_dev, [w[0] for w in windows], [w[1] for w in windows])
-                res = eng.window_stats(tgt_freq, flags, sets, lo, hi, pos=pos_dev)
+                nsnps_all = (hi - lo).cpu().numpy()
+                if uq_names:
+                    counts = torch.stack(
+                        [counts_rows[("ref", ref_pop)], counts_rows[("tgt", tgt_pop)]]
+                        + [counts_rows[("src", s)] for s in src_comb[:n_eff]]
+                    )
+                    tgt_freq, flags, _ = eng.site_flags(counts, ploidy[: 2 + n_eff], sets)
+                    res = eng.window_stats(tgt_freq, flags, sets, lo, hi, pos=pos_dev)
+                if four_names:  # every source of the combination, with its own ploidy (fd_statistic.py:63-74)
+                    if len(src_ploidies) < len(src_comb):
+                        raise IndexError("list index out of range")
+                    rows = [counts_rows[("ref", ref_pop)], counts_rows[("tgt", tgt_pop)]] + [
+                        counts_rows[("src", s)] for s in src_comb
+                    ]
+                    pl4 = [ploidy[0], ploidy[1]] + list(src_ploidies[: len(src_comb)])
+                    if out_pop is not None:
+                        rows.append(counts_rows[("outgroup", out_pop)])
+                        pl4.append(pc.get_ploidy("outgroup", out_pop))
+                    for p in pl4:
+                        _check_ploidy(p)
+                    freqs = eng.site_freqs(torch.stack(rows), pl4)
+                    four = eng.window_fourpop(freqs, len(src_comb), out_pop is not None, lo, hi).cpu().numpy()
             for wi, (start, end) in enumerate(windows):
-                if res is not None:
-                    nsnps = int(res.records[0, wi]["n_sites"])
-                else:
-                    w_lo, w_hi = wg.window_range(pos, start, end)
-                    nsnps = max(w_hi - w_lo, 0)
+                nsnps = int(nsnps_all[wi]) if nsnps_all is not None else 0
                 item = self._new_item(wg.chr_name, start, end, ref_pop, tgt_pop, src_comb, out_pop, nsnps)
                 if nsnps == 0:  # window without sites: the reference's None-matrix branch
                     self._fill_missing(item, names)
                     items.append(item)
                     continue
-                for si, name in enumerate(names):
+                for name in four_names:  # one value per source, Python floats like the reference
+                    item[name] = [float(v) for v in four[wi, :, _FOURPOP.index(name)]]
+                for si, name in enumerate(uq_names):
                     rec = res.records[si, wi]
                     if name == "U":
                         item["cdd_pos"][name] = res.u_list(si, wi).astype(pos.dtype, copy=True)
@@ -219,9 +247,14 @@ class FeaturePreprocessor(DataPreprocessor):
         with open(self.output_file, "a") as f:
             for item in items:
                 vals = []
-                for name in names:
+                for name in names:  # feature_preprocessor.py:217-228
                     v = item.get(name)
-                    vals.append("" if v is None else str(v))
+                    if isinstance(v, list) and len(v) == len(item["src_pop_list"]):
+                        vals.extend("" if x is None else str(x) for x in v)
+                    else:
+                        if isinstance(v, list):
+                            v = v[0] if len(v) > 0 else ""
+                        vals.append("" if v is None else str(v))
                 f.write(
                     f"{item['chr_name']}\t{item['start']}\t{item['end']}\t{item['ref_pop']}\t{item['tgt_pop']}\t"
                     f"{','.join(item['src_pop_list'])}\t{item['out_pop']}\t{item['nsnps']}\t" + "\t".join(vals) + "\n"

@@ -27,7 +27,7 @@ def read_data(
     end: int = None,
     engine: str = "native",
 ) -> dict[str, tuple[Optional[dict[str, ChromosomeData]], Optional[dict[str, list[str]]]]]:
-    """{"ref": (data, samples), "tgt": ..., "src": ..., "outgroup": (None, None)}.
+    """{"ref": (data, samples), "tgt": ..., "src": ..., "outgroup": (data, samples) or (None, None)}.
 
     ``data`` maps population -> ChromosomeData for the populations that have a ploidy entry
     (others are skipped with the reference's RuntimeWarning, utils.py:722-728); a population
@@ -35,10 +35,12 @@ def read_data(
     holds no record.  The VCF is parsed once per distinct ploidy for all groups (the reference
     re-reads it per population) by the native tokenizer of libsaihip (``engine="native"``) or by
     the Python statement of the same rules (``engine="python"``, used by the tests as the
-    cross-check); REF/ALT are not kept (the U/Q path never reads them after polarisation);
-    outgroups are outside this path."""
+    cross-check); REF/ALT are not kept (nothing reads them after polarisation)."""
     chr_name = str(chr_name)
     groups = [("ref", ref_ind_file), ("tgt", tgt_ind_file), ("src", src_ind_file)]
+    # utils.py:331-337: an outgroup file only counts when the ploidy section names outgroups
+    if out_ind_file is not None and "outgroup" in ploidy_config.root:
+        groups.append(("outgroup", out_ind_file))
     samples_by_group: dict[str, Optional[dict[str, list[str]]]] = {}
     wanted: list[str] = []
     for group, ind_file in groups:

@@ -132,10 +132,17 @@ def test_score_mixed_ploidy_with_anc_alleles(in_repo_root, tmp_path):
     rows = [ln.split("\t") for ln in out.read_text().splitlines()]
     assert rows[0] == ["Chrom", "Start", "End", "Ref", "Tgt", "Src", "Outgroup", "N(Variants)", "U"]
     assert [r[8] for r in rows[1:]] == ["0", "1"] and rows[1][5] == "src1,src2"
-    with pytest.raises(ValueError, match="outside the U/Q path"):
-        score(vcf_file="tests/data/test.mixed.ploidy.data.vcf.gz", chr_name="21", win_len=50000, win_step=50000,
-              anc_allele_file="tests/data/test.mixed.ploidy.data.anc.alleles", output_file=str(out),
-              config="tests/data/test_mixed_ploidy.config.yaml", num_workers=1)  # fmt: skip
+    # the reference's own config of that test (df: True, fd: False): tests/test_sai.py:140-151
+    import pandas as pd
+
+    score(vcf_file="tests/data/test.mixed.ploidy.data.vcf.gz", chr_name="21", win_len=50000, win_step=50000,
+          anc_allele_file="tests/data/test.mixed.ploidy.data.anc.alleles", output_file=str(out),
+          config="tests/data/test_mixed_ploidy.config.yaml", num_workers=1)  # fmt: skip
+    df = pd.read_csv(out, sep="\t")
+    assert "fd" not in df.columns and "fd.src1" not in df.columns and "fd.src2" not in df.columns
+    assert np.isclose(df["df.src1"].iloc[0], -0.6086956521739131)
+    assert np.isclose(df["df.src2"].iloc[1], -0.45454545454545453)
+    assert df["U"].iloc[0] == 0 and df["U"].iloc[1] == 1
 
 
 def test_cli_main(in_repo_root, tmp_path):
@@ -149,3 +156,82 @@ def test_cli_main(in_repo_root, tmp_path):
           "--anc-alleles", "tests/data/test.anc.allele.bed", "--output", str(out), "--config",
           "tests/data/test_mixed_ploidy.u_only.config.yaml"])  # fmt: skip
     assert len(out.read_text().splitlines()) == 1 + 2 * 10  # 10 windows x 2 target populations
+
+
+# ---- ABBA-BABA family: fd, df, Danc, Dplus ----------------------------------
+
+from test_oracle_golden import FOURPOP, PIPE_OUT, fourpop_case_inputs, outgroup_scenario_data  # noqa: E402
+
+
+@pytest.mark.parametrize("case", FOURPOP, ids=[c["name"] for c in FOURPOP])
+def test_fourpop_classes_bit_exact(case):
+    """FdStatistic / DfStatistic / DancStatistic / DplusStatistic against the reference capture:
+    every value bit-equal (products in population order, sums in np.sum order)."""
+    from sai_amd.registries import STAT_REGISTRY
+
+    ref, tgt, srcs, out = fourpop_case_inputs(case)
+    pl = case["ploidies"]
+    for name, exp in case["out"].items():
+        stat = STAT_REGISTRY.get(name)(ref_gts=ref, tgt_gts=tgt, src_gts_list=srcs, out_gts=out, ref_ploidy=pl[0],
+                                       tgt_ploidy=pl[1], src_ploidy_list=pl[2], out_ploidy=pl[3])  # fmt: skip
+        res = stat.compute()
+        assert res["name"] == name and isinstance(res["value"], list) and len(res["value"]) == len(exp)
+        assert all(isinstance(v, float) and same_f64(v, unhex(e)) for v, e in zip(res["value"], exp)), (name, res, exp)
+
+
+@pytest.mark.parametrize("sc", PIPE_OUT, ids=[s["name"] for s in PIPE_OUT])
+def test_run_windows_with_outgroup_equals_reference(sc, tmp_path):
+    from sai_amd.configs import PloidyConfig, StatConfig
+    from sai_amd.generators import WindowGenerator
+    from sai_amd.preprocessors import FeaturePreprocessor
+    from sai_amd.sai import write_headers
+    from sai_amd.utils import ChromosomeData
+
+    pos, ref, tgt, srcs, og = outgroup_scenario_data(sc)
+    mk = lambda g: ChromosomeData(pos, None, None, g.astype(np.int8))  # noqa: E731
+    pc = PloidyConfig(sc["ploidies"])
+    wg = WindowGenerator.from_arrays(
+        "9", {"R": mk(ref)}, {"T": mk(tgt)}, {f"S{i}": mk(s) for i, s in enumerate(srcs)}, 3000, 1500, pc,
+        out_data=({"O": mk(og)} if sc["with_out"] else None),
+    )  # fmt: skip
+    stat_config = StatConfig(json.loads(json.dumps(sc["stats"])))
+    out = tmp_path / "o.tsv"
+    fp = FeaturePreprocessor(str(out), stat_config, anc_allele_available=True)
+    items = fp.run_windows(wg)
+    assert len(items) == sc["n_windows"]
+    for it, exp in zip(items, sc["items"]):
+        assert it["out_pop"] == exp["out_pop"] and it["nsnps"] == exp["nsnps"]
+        for k in ("fd", "df", "Danc", "Dplus"):
+            assert all(same_f64(g, unhex(e)) for g, e in zip(it[k], exp[k]))
+    write_headers(str(out), stat_config, pc)
+    fp.process_items(items)
+    lines = out.read_text().splitlines(keepends=True)
+    cols = lines[0].rstrip("\n").split("\t")
+    if sc["n_src"] == 2:
+        assert cols[8:] == ["fd.S0", "fd.S1", "U", "df.S0", "df.S1", "Danc.S0", "Danc.S1", "Q", "Dplus.S0", "Dplus.S1"]
+    else:
+        assert cols[8:] == ["fd", "U", "df", "Danc", "Q", "Dplus"]
+    assert "".join(lines[1:]) == sc["text"]["tsv"]
+    for k in ("U", "Q"):
+        assert (tmp_path / f"o.{k}.log").read_text() == f"Chrom\tStart\tEnd\t{k}_SNP\n" + sc["text"][k]
+    # per-window plugin path gives the same values
+    single = [fp.run(**w)[0] for w in wg.get()]
+    for a, b in zip(single, items):
+        for k in ("fd", "df", "Danc", "Dplus"):
+            assert all(same_f64(x, y) for x, y in zip(a[k], b[k]))
+
+
+def test_score_with_outgroup_matches_reference_tsv(in_repo_root, tmp_path):
+    """tests/test_sai.py:92-110: the reference's own expected table for the 373-site, 1 513-sample
+    outgroup VCF -- reproduced as text, digit for digit."""
+    from sai_amd.sai import score
+
+    out = tmp_path / "og.tsv"
+    score(vcf_file="tests/data/test.with.outgroup.vcf.gz", chr_name="1", win_len=40000, win_step=40000,
+          anc_allele_file="tests/data/test.with.outgroup.anc.alleles", output_file=str(out),
+          config="tests/data/test.with.outgroup.config.yaml", num_workers=1)  # fmt: skip
+    assert out.read_text() == open("tests/data/test.with.outgroup.res.tsv").read()
+    with pytest.raises(ValueError, match="requires polarized data"):
+        score(vcf_file="tests/data/test.with.outgroup.vcf.gz", chr_name="1", win_len=40000, win_step=40000,
+              anc_allele_file=None, output_file=str(out), config="tests/data/test.with.outgroup.config.yaml",
+              num_workers=1)  # fmt: skip

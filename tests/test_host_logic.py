@@ -287,8 +287,8 @@ def test_process_items_reference_line(tmp_path):
     fp.process_items([item])
     assert out.read_text() == load_golden("feature_inline.json")["process_items_line"]
     assert (tmp_path / "t.U.log").read_text() == "21\t1000\t2000\tNA\n"
-    with pytest.raises(ValueError, match="outside the U/Q path"):
-        FeaturePreprocessor(str(out), StatConfig({"fd": True})).process_items([])
+    with pytest.raises(ValueError, match="outside the path this build accelerates"):
+        FeaturePreprocessor(str(out), StatConfig({"DD": True})).process_items([])
 
 
 def test_score_config_errors_without_gpu(in_repo_root, tmp_path):
@@ -331,7 +331,7 @@ def test_registry_behaviour():
     from sai_amd.stats import QStatistic, UStatistic
 
     assert STAT_REGISTRY.get("U") is UStatistic and STAT_REGISTRY.get("Q") is QStatistic
-    assert sorted(STAT_REGISTRY.list_registered()) == ["Q", "U"]
+    assert sorted(STAT_REGISTRY.list_registered()) == ["Danc", "Dplus", "Q", "U", "df", "fd"]
     with pytest.raises(KeyError, match="No component registered under name 'nope'"):
         STAT_REGISTRY.get("nope")
 
