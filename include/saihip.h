@@ -185,6 +185,23 @@ int sai_window_fourpop(sai_ctx* ctx, int64_t n_sites, int32_t n_src, int32_t has
                        const double* freqs, int32_t n_windows, const int32_t* lo, const int32_t* hi,
                        double* sums, double* stats, void* stream);
 
+/* ---- DD --------------------------------------------------------- */
+
+/* Per site and source individual a: out[a * n_sites + site] = sum over the individuals b of `pop`
+ * of |src[a][site] - pop[b][site]| on the raw int8 dosages (negative = missing enters as that
+ * number): the per-site terms of scipy's cdist(src.T, pop.T, "cityblock") (dd_statistic.py:64-66).
+ * One streaming pass over `pop` per two source individuals. */
+int sai_site_absdiff(sai_ctx* ctx, int64_t n_sites, const sai_pop* pop, const sai_pop* src,
+                     uint32_t* out, void* stream);
+
+/* Per window the DD value of one source population (dd_statistic.py:68-74): with
+ * T_ref[a] / T_tgt[a] the window sums of the per-site terms above,
+ * dd = mean_a( T_ref[a] / n_ref_ind - T_tgt[a] / n_tgt_ind ), summed in numpy's order.
+ * scratch: n_windows * n_src_ind doubles. */
+int sai_window_dd(sai_ctx* ctx, int64_t n_sites, int32_t n_src_ind, const uint32_t* ad_ref,
+                  int32_t n_ref_ind, const uint32_t* ad_tgt, int32_t n_tgt_ind, int32_t n_windows,
+                  const int32_t* lo, const int32_t* hi, double* scratch, double* dd, void* stream);
+
 /* ---- synthetic data ("synth-v1") ---------------------------------- */
 
 /* Counter-based generator: every byte is a pure function of (seed, chrom, site, population

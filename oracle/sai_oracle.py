@@ -401,6 +401,9 @@ def window_item(
         if name not in ("U", "Q"):
             if prm is not True:  # feature_preprocessor.py:147-151
                 continue
+            if name == "DD":
+                item[name] = dd_stat(ref_gts, tgt_gts, src_gts_list)
+                continue
             if name not in ("fd", "df", "Danc", "Dplus"):
                 raise ValueError(f"statistic {name} is outside the oracle")
             if four is None:
@@ -627,3 +630,24 @@ def numpy_sum(a) -> float:
     for i in range(0, len(a), 8192):
         res = res + np.float64(numpy_pairwise_sum(a[i : i + 8192]))
     return float(res)
+
+
+# ---------------------------------------------------------------------------
+# DD                    sai/stats/dd_statistic.py:40-77
+# ---------------------------------------------------------------------------
+
+
+def dd_stat(ref_gts, tgt_gts, src_gts_list) -> list[float]:
+    """Per source population: mean over its individuals of (mean city-block distance to the
+    reference individuals - mean city-block distance to the target individuals), distances taken
+    over the window's sites on the raw dosage values (missing calls enter as their negative
+    numbers, as scipy's cdist sees them; dd_statistic.py:62-75)."""
+    ref = np.asarray(ref_gts, dtype=np.float64)
+    tgt = np.asarray(tgt_gts, dtype=np.float64)
+    out = []
+    for src in src_gts_list:
+        s = np.asarray(src, dtype=np.float64)
+        d_tgt = np.abs(s.T[:, None, :] - tgt.T[None, :, :]).sum(axis=2)  # == cdist(s.T, tgt.T, "cityblock")
+        d_ref = np.abs(s.T[:, None, :] - ref.T[None, :, :]).sum(axis=2)
+        out.append(np.mean(np.mean(d_ref, axis=1) - np.mean(d_tgt, axis=1)))
+    return out

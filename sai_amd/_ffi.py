@@ -87,6 +87,8 @@ SIGNATURES = {
     ),
     "sai_site_freqs": (C.c_int, [_p, _i64, _i32, C.POINTER(_i32), _p, _p, _p]),
     "sai_window_fourpop": (C.c_int, [_p, _i64, _i32, _i32, _p, _i32, _p, _p, _p, _p, _p]),
+    "sai_site_absdiff": (C.c_int, [_p, _i64, C.POINTER(SaiPop), C.POINTER(SaiPop), _p, _p]),
+    "sai_window_dd": (C.c_int, [_p, _i64, _i32, _p, _i32, _p, _i32, _i32, _p, _p, _p, _p, _p]),
     "sai_synth_fill": (C.c_int, [_p, _u64, _i32, _i64, _i64, _i32, _i32, _i32, _i32, _p, _p]),
     "sai_synth_fill_host": (C.c_int, [_u64, _i32, _i64, _i64, _i32, _i32, _i32, _i32, _p]),
     "sai_synth_gaps_host": (C.c_int, [_u64, _i32, _i64, _i64, _p]),

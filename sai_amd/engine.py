@@ -31,9 +31,10 @@ def _torch():
 
 def to_int8_dosage(gts) -> np.ndarray:
     """Narrow a reference-style genotype matrix ([sites][individuals], any integer dtype,
-    negative = missing; utils.py:410) to C-contiguous int8 without changing what calc_freq
-    (stat_utils.py:45-49) would compute: every negative value is a missing call, so values below
-    -128 are stored as -1; dosages above 127 cannot be represented and are rejected."""
+    negative = missing; utils.py:410) to C-contiguous int8.  Values inside the int8 range are kept
+    as they are (DD works on the raw numbers); a value below -128 can only be a missing call for
+    calc_freq (stat_utils.py:45-49) and is stored as -128; dosages above 127 cannot be represented
+    and are rejected."""
     g = np.asarray(gts)
     if g.ndim != 2:
         raise ValueError("genotype matrix must be 2-D [sites][individuals]")
@@ -45,7 +46,7 @@ def to_int8_dosage(gts) -> np.ndarray:
         raise TypeError(f"genotype matrix must have an integer dtype, got {g.dtype}")
     if g.size and g.max() > 127:
         raise ValueError("dosage above 127 is not representable in the int8 device layout")
-    return np.ascontiguousarray(np.maximum(g, -1).astype(np.int8))
+    return np.ascontiguousarray(np.maximum(g, -128).astype(np.int8))
 
 
 @dataclass
@@ -234,6 +235,34 @@ class Engine:
             )
         )  # fmt: skip
         return stats
+
+    def site_absdiff(self, pop: TiledPop, src: TiledPop):
+        """int32 [src.n_ind][n_sites]: per site, sum over pop's individuals of |src - g| (DD's
+        per-site city-block terms)."""
+        torch = _torch()
+        if pop.n_sites != src.n_sites:
+            raise ValueError("populations must cover the same sites")
+        a, b = _ffi.SaiPop(), _ffi.SaiPop()
+        a.tiles, a.n_ind, a.ploidy = (pop.tiles.data_ptr() if pop.tiles.numel() else 0), pop.n_ind, 1
+        b.tiles, b.n_ind, b.ploidy = (src.tiles.data_ptr() if src.tiles.numel() else 0), src.n_ind, 1
+        out = self._empty((src.n_ind, pop.n_sites), torch.int32)
+        _ffi.check(self.lib.sai_site_absdiff(self.ctx, pop.n_sites, C.byref(a), C.byref(b), self._ptr(out), self._stream()))
+        return out
+
+    def window_dd(self, ad_ref, n_ref_ind: int, ad_tgt, n_tgt_ind: int, lo, hi):
+        """f64 [n_windows]: DD of one source population from its per-site terms."""
+        torch = _torch()
+        n_src_ind, n_sites = int(ad_ref.shape[0]), int(ad_ref.shape[1])
+        n_w = int(lo.numel())
+        scratch = self._empty((n_w, n_src_ind), torch.float64)
+        dd = self._empty((n_w,), torch.float64)
+        _ffi.check(
+            self.lib.sai_window_dd(
+                self.ctx, n_sites, n_src_ind, self._ptr(ad_ref), n_ref_ind, self._ptr(ad_tgt), n_tgt_ind, n_w,
+                self._ptr(lo), self._ptr(hi), self._ptr(scratch), self._ptr(dd), self._stream(),
+            )
+        )  # fmt: skip
+        return dd
 
     def window_bounds(self, pos, win_start, win_end):
         """Site-index ranges [lo, hi) of inclusive position windows; int32 device tensors."""

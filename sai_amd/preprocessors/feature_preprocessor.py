@@ -20,6 +20,7 @@ from .data_preprocessor import DataPreprocessor
 
 _HIP_STATS = ("U", "Q")
 _FOURPOP = ("fd", "df", "Danc", "Dplus")
+_LIST_STATS = _FOURPOP + ("DD",)  # one value per source population
 
 
 class FeaturePreprocessor(DataPreprocessor):
@@ -31,18 +32,13 @@ class FeaturePreprocessor(DataPreprocessor):
     # -- helpers ---------------------------------------------------------------------------
 
     def _active_stats(self) -> list[str]:
-        """Statistic names in config order: U/Q always, the ABBA-BABA family when set to True
-        (feature_preprocessor.py:146-151); DD is the one statistic this build does not compute."""
-        names = []
-        for name, value in self.stat_config.root.items():
-            if name in _HIP_STATS or (name in _FOURPOP and value is True):
-                names.append(name)
-            elif value is True:
-                raise ValueError(
-                    f"The {name} statistic is outside the path this build accelerates "
-                    "(U, Q, fd, df, Danc, Dplus); disable it in the configuration."
-                )
-        return names
+        """Statistic names in config order: U/Q always, the others when set to True
+        (feature_preprocessor.py:146-151)."""
+        return [
+            name
+            for name, value in self.stat_config.root.items()
+            if name in _HIP_STATS or (name in _LIST_STATS and value is True)
+        ]
 
     @staticmethod
     def _new_item(chr_name, start, end, ref_pop, tgt_pop, src_pop_list, out_pop, nsnps) -> dict[str, Any]:
@@ -163,6 +159,7 @@ class FeaturePreprocessor(DataPreprocessor):
             counts = eng.site_counts([blocks[k] for k in part])
             for j, k in enumerate(part):
                 counts_rows[k] = counts[j]
+        tiled = blocks if "DD" in names else None  # DD streams the genotype blocks again
         del blocks
 
         pos_dev_cache = {}
@@ -174,6 +171,7 @@ class FeaturePreprocessor(DataPreprocessor):
             n_eff = min(len(src_comb), len(src_ploidies))
             uq_names = [n for n in names if n in _HIP_STATS]
             four_names = [n for n in names if n in _FOURPOP]
+            want_dd = "DD" in names
             sets, kwargs = [], {}
             for name in uq_names:
                 kw = self._stat_kwargs(name, ref_pop, tgt_pop)
@@ -186,7 +184,7 @@ class FeaturePreprocessor(DataPreprocessor):
             for p in ploidy[: 2 + len(src_comb)]:
                 _check_ploidy(p)
             n_sites = int(pos.size)
-            res = four = nsnps_all = None
+            res = four = dd = nsnps_all = None
             if names and windows and n_sites:
                 pid = id(pos)
                 if pid not in pos_dev_cache:
@@ -215,6 +213,18 @@ class FeaturePreprocessor(DataPreprocessor):
                         _check_ploidy(p)
                     freqs = eng.site_freqs(torch.stack(rows), pl4)
                     four = eng.window_fourpop(freqs, len(src_comb), out_pop is not None, lo, hi).cpu().numpy()
+                if want_dd:  # per source population: two streaming passes per pair of its individuals
+                    dd = np.stack(
+                        [
+                            eng.window_dd(
+                                eng.site_absdiff(tiled[("ref", ref_pop)], tiled[("src", s)]), tiled[("ref", ref_pop)].n_ind,
+                                eng.site_absdiff(tiled[("tgt", tgt_pop)], tiled[("src", s)]), tiled[("tgt", tgt_pop)].n_ind,
+                                lo, hi,
+                            ).cpu().numpy()
+                            for s in src_comb
+                        ],
+                        axis=1,
+                    )  # fmt: skip
             for wi, (start, end) in enumerate(windows):
                 nsnps = int(nsnps_all[wi]) if nsnps_all is not None else 0
                 item = self._new_item(wg.chr_name, start, end, ref_pop, tgt_pop, src_comb, out_pop, nsnps)
@@ -224,6 +234,8 @@ class FeaturePreprocessor(DataPreprocessor):
                     continue
                 for name in four_names:  # one value per source, Python floats like the reference
                     item[name] = [float(v) for v in four[wi, :, _FOURPOP.index(name)]]
+                if want_dd:  # np.float64 values, as np.mean returns them (dd_statistic.py:74)
+                    item["DD"] = [np.float64(v) for v in dd[wi]]
                 for si, name in enumerate(uq_names):
                     rec = res.records[si, wi]
                     if name == "U":

@@ -1,7 +1,7 @@
 """Statistics on the HIP path; importing this package registers "U", "Q" and the ABBA-BABA
-family "fd", "df", "Danc", "Dplus" (mirror of sai/stats/__init__.py; "DD" is not built)."""
+family "fd", "df", "Danc", "Dplus" and "DD" (mirror of sai/stats/__init__.py)."""
 
-from .fourpop import DancStatistic, DfStatistic, DplusStatistic, FdStatistic
+from .fourpop import DancStatistic, DdStatistic, DfStatistic, DplusStatistic, FdStatistic
 from .generic_statistic import GenericStatistic
 from .q_statistic import QStatistic
 from .stat_utils import calc_freq, compute_matching_loci
@@ -15,6 +15,7 @@ __all__ = [
     "DfStatistic",
     "DancStatistic",
     "DplusStatistic",
+    "DdStatistic",
     "calc_freq",
     "compute_matching_loci",
 ]

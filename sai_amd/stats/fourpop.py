@@ -82,3 +82,31 @@ class DplusStatistic(_FourPopStatistic):
     """D+ (Lopez Fang et al. 2024): (abba - baba + baaa - abaa) / (abba + baba + baaa + abaa)."""
 
     STAT_NAME = "Dplus"
+
+
+@STAT_REGISTRY.register("DD")
+class DdStatistic(GenericStatistic):
+    """DD (mirror of sai/stats/dd_statistic.py:28-77): per source population, the mean over its
+    individuals of (mean city-block distance to the reference individuals - mean city-block
+    distance to the target individuals) over the window's sites, on the raw dosage values."""
+
+    STAT_NAME = "DD"
+
+    def compute(self, **kwargs) -> Dict[str, Any]:
+        import torch
+
+        from ..engine import Engine
+
+        eng = Engine.get()
+        ref, tgt = eng.tile(self.ref_gts), eng.tile(self.tgt_gts)
+        n_sites = ref.n_sites
+        lo = torch.zeros(1, dtype=torch.int32, device=eng.device)
+        hi = torch.full((1,), n_sites, dtype=torch.int32, device=eng.device)
+        values = []
+        for src_gts in self.src_gts_list:
+            src = eng.tile(src_gts)
+            if src.n_sites != n_sites or tgt.n_sites != n_sites:
+                raise ValueError("genotype matrices must have the same number of sites")
+            dd = eng.window_dd(eng.site_absdiff(ref, src), ref.n_ind, eng.site_absdiff(tgt, src), tgt.n_ind, lo, hi)
+            values.append(np.float64(dd[0].item()))
+        return {"name": self.STAT_NAME, "value": values}

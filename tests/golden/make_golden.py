@@ -631,7 +631,7 @@ def make_pipeline_outgroup():
         ploidies = {"ref": {"R": 2}, "tgt": {"T": 2}, "src": {f"S{i}": 2 for i in range(n_src)}}
         if with_out:
             ploidies["outgroup"] = {"O": 2}
-        stats = {"fd": True, "DD": False, "U": {"ref": {"R": 0.4}, "tgt": {"T": 0.3}, "src": {f"S{i}": ">=0.5" for i in range(n_src)}},
+        stats = {"fd": True, "DD": not with_out, "U": {"ref": {"R": 0.4}, "tgt": {"T": 0.3}, "src": {f"S{i}": ">=0.5" for i in range(n_src)}},
                  "df": True, "Danc": True, "Q": {"ref": {"R": 0.4}, "tgt": {"T": 0.9}, "src": {f"S{i}": ">=0.5" for i in range(n_src)}},
                  "Dplus": True}
         wg = object.__new__(WindowGenerator)
@@ -658,8 +658,8 @@ def make_pipeline_outgroup():
         out.append(dict(name=name, seed=seed, n_src=n_src, with_out=with_out, n_sites=n_sites, ploidies=ploidies,
                         stats=stats, pos=ints(pos), n_windows=len(items), text=text,
                         items=[{k: ([hx(v) for v in it[k]] if isinstance(it[k], list) else hx(it[k]))
-                                for k in ("fd", "df", "Danc", "Dplus")} | {"out_pop": it["out_pop"], "nsnps": it["nsnps"]}
-                               for it in items]))
+                                for k in ("fd", "df", "Danc", "Dplus", "DD") if k in it}
+                               | {"out_pop": it["out_pop"], "nsnps": it["nsnps"]} for it in items]))
         print(name, len(items), "windows")
     (OUT / "pipeline_outgroup.json").write_text(json.dumps(out, separators=(",", ":")) + "\n")
 
@@ -667,3 +667,43 @@ def make_pipeline_outgroup():
 if __name__ == "__main__" and os.path.isdir(REF):
     make_fourpop()
     make_pipeline_outgroup()
+
+
+# ---------------------------------------------------------------------------
+# 8. DD (sai/stats/dd_statistic.py; needs scipy, which this image has)
+# ---------------------------------------------------------------------------
+
+DD_SEEDED = [
+    # name, seed, n_sites, n_ref, n_tgt, src_sizes, missing rate, ploidies
+    ("dd_small", 31, 50, 6, 5, [2], 0.0, [2, 2, [2], 2]),
+    ("dd_missing", 32, 300, 9, 7, [1, 3], 0.1, [2, 2, [2, 2], 2]),
+    ("dd_many_src_individuals", 33, 120, 5, 4, [11, 150], 0.02, [2, 2, [2, 1], 2]),
+    ("dd_tetraploid", 34, 80, 3, 8, [2], 0.05, [4, 4, [4], 2]),
+    ("dd_long", 35, 5000, 4, 3, [2], 0.01, [2, 2, [2], 2]),
+]
+
+
+def make_dd():
+    sys.path.insert(0, str(OUT))
+    from seeded import fourpop_inputs
+    from sai.stats import DdStatistic
+
+    A = np.array
+    cases = []
+    r = DdStatistic(ref_gts=A([[1, 1], [0, 0]]), tgt_gts=A([[1, 0], [0, 1]]), src_gts_list=[A([[0, 1], [1, 1]])],
+                    ref_ploidy=1, tgt_ploidy=1, src_ploidy_list=[1]).compute()
+    assert r["name"] == "DD" and np.isclose(r["value"][0], 0.5)  # tests/stats/test_dd_statistic.py:40
+    cases.append(dict(name="dd_test", ref_gts=[[1, 1], [0, 0]], tgt_gts=[[1, 0], [0, 1]], src_gts_list=[[[0, 1], [1, 1]]],
+                      out=[hx(v) for v in r["value"]]))
+    for name, seed, n_sites, n_ref, n_tgt, src_sizes, miss, pl in DD_SEEDED:
+        ref, tgt, srcs, _ = fourpop_inputs(seed, n_sites, n_ref, n_tgt, src_sizes, 0, pl, miss)
+        r = DdStatistic(ref_gts=ref, tgt_gts=tgt, src_gts_list=srcs, ref_ploidy=pl[0], tgt_ploidy=pl[1],
+                        src_ploidy_list=pl[2]).compute()
+        cases.append(dict(name=name, seeded=[seed, n_sites, n_ref, n_tgt, src_sizes, miss], ploidies=pl,
+                          out=[hx(v) for v in r["value"]]))
+    (OUT / "dd_cases.json").write_text(json.dumps(cases, separators=(",", ":")) + "\n")
+    print("dd_cases.json", len(cases))
+
+
+if __name__ == "__main__" and os.path.isdir(REF):
+    make_dd()

@@ -201,8 +201,9 @@ def test_run_windows_with_outgroup_equals_reference(sc, tmp_path):
     assert len(items) == sc["n_windows"]
     for it, exp in zip(items, sc["items"]):
         assert it["out_pop"] == exp["out_pop"] and it["nsnps"] == exp["nsnps"]
-        for k in ("fd", "df", "Danc", "Dplus"):
-            assert all(same_f64(g, unhex(e)) for g, e in zip(it[k], exp[k]))
+        for k in ("fd", "df", "Danc", "Dplus", "DD"):
+            if k in exp:
+                assert all(same_f64(g, unhex(e)) for g, e in zip(it[k], exp[k]))
     write_headers(str(out), stat_config, pc)
     fp.process_items(items)
     lines = out.read_text().splitlines(keepends=True)
@@ -210,15 +211,16 @@ def test_run_windows_with_outgroup_equals_reference(sc, tmp_path):
     if sc["n_src"] == 2:
         assert cols[8:] == ["fd.S0", "fd.S1", "U", "df.S0", "df.S1", "Danc.S0", "Danc.S1", "Q", "Dplus.S0", "Dplus.S1"]
     else:
-        assert cols[8:] == ["fd", "U", "df", "Danc", "Q", "Dplus"]
+        assert cols[8:] == ["fd", "DD", "U", "df", "Danc", "Q", "Dplus"]
     assert "".join(lines[1:]) == sc["text"]["tsv"]
     for k in ("U", "Q"):
         assert (tmp_path / f"o.{k}.log").read_text() == f"Chrom\tStart\tEnd\t{k}_SNP\n" + sc["text"][k]
     # per-window plugin path gives the same values
     single = [fp.run(**w)[0] for w in wg.get()]
     for a, b in zip(single, items):
-        for k in ("fd", "df", "Danc", "Dplus"):
-            assert all(same_f64(x, y) for x, y in zip(a[k], b[k]))
+        for k in ("fd", "df", "Danc", "Dplus", "DD"):
+            if k in b:
+                assert all(same_f64(x, y) for x, y in zip(a[k], b[k]))
 
 
 def test_score_with_outgroup_matches_reference_tsv(in_repo_root, tmp_path):
@@ -235,3 +237,33 @@ def test_score_with_outgroup_matches_reference_tsv(in_repo_root, tmp_path):
         score(vcf_file="tests/data/test.with.outgroup.vcf.gz", chr_name="1", win_len=40000, win_step=40000,
               anc_allele_file=None, output_file=str(out), config="tests/data/test.with.outgroup.config.yaml",
               num_workers=1)  # fmt: skip
+
+
+# ---- DD ---------------------------------------------------------------------
+
+from test_oracle_golden import DD_CASES, dd_case_inputs  # noqa: E402
+
+
+@pytest.mark.parametrize("case", DD_CASES, ids=[c["name"] for c in DD_CASES])
+def test_dd_class_bit_exact(case):
+    from sai_amd.stats import DdStatistic
+
+    ref, tgt, srcs = dd_case_inputs(case)
+    res = DdStatistic(ref_gts=ref, tgt_gts=tgt, src_gts_list=srcs, ref_ploidy=2, tgt_ploidy=2,
+                      src_ploidy_list=[2] * len(srcs)).compute()  # fmt: skip
+    assert res["name"] == "DD" and len(res["value"]) == len(case["out"])
+    assert all(same_f64(v, unhex(e)) for v, e in zip(res["value"], case["out"])), (res, case["out"])
+
+
+def test_site_absdiff_exact_at_extremes(_gpu):
+    """Raw int8 values over the whole range, partial row groups, > 248 rows per lane."""
+    from sai_amd.engine import Engine
+
+    eng = Engine.get(0)
+    rng = np.random.default_rng(8)
+    for n_ind, n_src in ((1, 1), (17, 3), (4100, 2)):
+        g = rng.integers(-128, 128, size=(200, n_ind)).astype(np.int8)
+        s = rng.integers(-128, 128, size=(200, n_src)).astype(np.int8)
+        got = eng.site_absdiff(eng.tile(g), eng.tile(s)).cpu().numpy()
+        exp = np.abs(s.astype(np.int64).T[:, :, None] - g.astype(np.int64)[None, :, :]).sum(axis=2)
+        assert np.array_equal(got, exp)

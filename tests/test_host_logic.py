@@ -287,8 +287,7 @@ def test_process_items_reference_line(tmp_path):
     fp.process_items([item])
     assert out.read_text() == load_golden("feature_inline.json")["process_items_line"]
     assert (tmp_path / "t.U.log").read_text() == "21\t1000\t2000\tNA\n"
-    with pytest.raises(ValueError, match="outside the path this build accelerates"):
-        FeaturePreprocessor(str(out), StatConfig({"DD": True})).process_items([])
+    assert FeaturePreprocessor(str(out), StatConfig({"DD": True, "fd": False}))._active_stats() == ["DD"]
 
 
 def test_score_config_errors_without_gpu(in_repo_root, tmp_path):
@@ -331,7 +330,7 @@ def test_registry_behaviour():
     from sai_amd.stats import QStatistic, UStatistic
 
     assert STAT_REGISTRY.get("U") is UStatistic and STAT_REGISTRY.get("Q") is QStatistic
-    assert sorted(STAT_REGISTRY.list_registered()) == ["Danc", "Dplus", "Q", "U", "df", "fd"]
+    assert sorted(STAT_REGISTRY.list_registered()) == ["DD", "Danc", "Dplus", "Q", "U", "df", "fd"]
     with pytest.raises(KeyError, match="No component registered under name 'nope'"):
         STAT_REGISTRY.get("nope")
 
@@ -348,7 +347,7 @@ def test_to_int8_dosage():
     from sai_amd.engine import to_int8_dosage
 
     g = np.array([[0, 2, -2], [-300, 127, 1]], dtype=np.int64)
-    assert to_int8_dosage(g).tolist() == [[0, 2, -1], [-1, 127, 1]]
+    assert to_int8_dosage(g).tolist() == [[0, 2, -2], [-128, 127, 1]]
     assert to_int8_dosage(g.astype(np.int8, casting="unsafe")[:1]).dtype == np.int8
     with pytest.raises(ValueError, match="above 127"):
         to_int8_dosage(np.array([[128]]))

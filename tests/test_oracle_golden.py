@@ -267,8 +267,9 @@ def test_pipeline_with_outgroup_items_and_text(sc):
     assert len(items) == sc["n_windows"]
     for it, exp in zip(items, sc["items"]):
         assert it["out_pop"] == exp["out_pop"] and it["nsnps"] == exp["nsnps"]
-        for k in ("fd", "df", "Danc", "Dplus"):
-            assert all(same_f64(g, unhex(e)) for g, e in zip(it[k], exp[k]))
+        for k in ("fd", "df", "Danc", "Dplus", "DD"):
+            if k in exp:
+                assert all(same_f64(g, unhex(e)) for g, e in zip(it[k], exp[k]))
     names = [n for n, p in sc["stats"].items() if n in ("U", "Q") or p is True]
     assert "".join(O.score_lines(items, names)) == sc["text"]["tsv"]
     for k in ("U", "Q"):
@@ -277,3 +278,24 @@ def test_pipeline_with_outgroup_items_and_text(sc):
     head = O.header_line(names, src_pops)
     assert head.startswith("Chrom\tStart\tEnd\tRef\tTgt\tSrc\tOutgroup\tN(Variants)\tfd")
     assert ("fd.S0\tfd.S1" in head) == (sc["n_src"] == 2)
+
+
+# ---- DD ---------------------------------------------------------------------
+
+DD_CASES = load_golden("dd_cases.json")
+
+
+def dd_case_inputs(c):
+    if "seeded" in c:
+        seed, n_sites, n_ref, n_tgt, src_sizes, miss = c["seeded"]
+        ref, tgt, srcs, _ = fourpop_inputs(seed, n_sites, n_ref, n_tgt, src_sizes, 0, c["ploidies"], miss)
+        return ref, tgt, srcs
+    A = lambda v: np.array(v, dtype=np.int64)  # noqa: E731
+    return A(c["ref_gts"]), A(c["tgt_gts"]), [A(s) for s in c["src_gts_list"]]
+
+
+@pytest.mark.parametrize("case", DD_CASES, ids=[c["name"] for c in DD_CASES])
+def test_dd_bit_exact(case):
+    ref, tgt, srcs = dd_case_inputs(case)
+    got = O.dd_stat(ref, tgt, srcs)
+    assert len(got) == len(case["out"]) and all(same_f64(g, unhex(e)) for g, e in zip(got, case["out"]))
