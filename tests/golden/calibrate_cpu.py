@@ -1,4 +1,4 @@
-"""Container-only calibration: oracle (oracle/sai_oracle.py) vs the real reference on the same
+"""Container-only calibration (test infrastructure, like make_golden.py; run from the repo root): oracle (oracle/sai_oracle.py) vs the real reference on the same
 in-memory synthetic input, one process.  The reference never leaves this container; only the
 measured ratio is recorded."""
 import sys, time, types, ctypes as C

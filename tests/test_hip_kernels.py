@@ -267,3 +267,58 @@ def test_fused_site_pass_equals_two_kernels(eng):
             assert torch.equal(fl, fl2) and torch.equal(fl, fl3) and torch.equal(counts, c3)
     with pytest.raises(ValueError, match="at most"):
         eng.site_pass(pops, pl, sets * 2)
+
+
+def test_randomized_windows_against_oracle(eng):
+    """Fuzz: random population sizes, ploidies, missing rates, operators, thresholds, window
+    grids; every record and candidate list against the per-window oracle."""
+    from oracle import sai_oracle as O
+    from sai_amd import _ffi
+
+    rng = np.random.default_rng(2026)
+    ops = ["=", "<", ">", "<=", ">="]
+    for trial in range(25):
+        n_sites = int(rng.integers(1, 900))
+        n_src = int(rng.integers(1, 4))
+        sizes = [int(rng.integers(1, 70)), int(rng.integers(1, 70))] + [int(rng.integers(1, 4)) for _ in range(n_src)]
+        pl = [int(rng.integers(1, 5)) for _ in range(2 + n_src)]
+        miss = float(rng.choice([0.0, 0.01, 0.3]))
+        p = rng.random(n_sites) ** float(rng.choice([1, 2, 4]))
+        mats = []
+        for n, ploidy in zip(sizes, pl):
+            g = rng.binomial(ploidy, np.broadcast_to(p[:, None], (n_sites, n))).astype(np.int64)
+            if rng.random() < 0.5:
+                g[rng.random(n_sites) < 0.3] = ploidy  # fixed sites so "= 1" matches
+            g[rng.random(g.shape) < miss] = -ploidy
+            mats.append(g)
+        pos = np.cumsum(rng.integers(1, 80, n_sites)).astype(np.int64)
+        win = int(rng.integers(50, 5000))
+        step = int(rng.integers(1, win + 1))
+        windows = O.split_windows(pos, win, step)[:400]
+        specs = []
+        for _ in range(int(rng.integers(1, 4))):
+            specs.append(dict(
+                w=float(rng.choice([0.0, 0.05, 0.3, 1.0])), x=float(rng.choice([0.0, 0.3, 0.9])),
+                quantile=float(rng.choice([0.0, 0.5, 0.95, 1.0, rng.random()])),
+                y_list=[(str(rng.choice(ops)), float(rng.choice([0.0, 0.25, 0.5, 1.0]))) for _ in range(n_src)],
+                anc=bool(rng.random() < 0.5),
+            ))  # fmt: skip
+        sets = [_ffi.make_params(s["w"], s["x"], s["quantile"], s["y_list"], s["anc"]) for s in specs]
+        res, lo, hi = _window_pass(eng, mats, pl, sets, pos, np.array([w[0] for w in windows]), np.array([w[1] for w in windows]))
+        for si, s in enumerate(specs):
+            for wi, (ws, we) in enumerate(windows):
+                m = (pos >= ws) & (pos <= we)
+                rec = res.records[si, wi]
+                assert rec["n_sites"] == int(m.sum())
+                if not m.any():
+                    assert rec["u_count"] == 0 and np.isnan(rec["q"])
+                    continue
+                kw = dict(ref_gts=mats[0][m], tgt_gts=mats[1][m], src_gts_list=[g[m] for g in mats[2:]], ref_ploidy=pl[0],
+                          tgt_ploidy=pl[1], src_ploidy_list=pl[2:], pos=pos[m], w=s["w"], y_list=s["y_list"],
+                          anc_allele_available=s["anc"])  # fmt: skip
+                eu = O.u_stat(x=s["x"], **kw)
+                eq = O.q_stat(quantile=s["quantile"], **kw)
+                assert rec["u_count"] == eu["value"], (trial, si, wi)
+                assert res.u_list(si, wi).tolist() == eu["cdd_pos"].tolist()
+                assert same_f64(rec["q"], eq["value"]), (trial, si, wi, rec["q"], eq["value"])
+                assert res.q_list(si, wi).tolist() == np.asarray(eq["cdd_pos"]).astype(np.int64).tolist()
