@@ -146,6 +146,9 @@ def main() -> None:
     ap.add_argument("--ref", type=int, default=1000)
     ap.add_argument("--tgt", type=int, default=1000)
     ap.add_argument("--src", type=int, default=2)
+    ap.add_argument("--layout", choices=["int8", "packed2"], default="int8",
+                    help="int8 = the SoA int8 block the metric is defined on (default); packed2 = the optional "
+                    "2-bit layout (4x fewer genotype bytes; reported with its own algorithmic bytes)")
     ap.add_argument("--cpu-sites", type=float, default=4e5, help="site prefix timed on the CPU (0 = skip)")
     ap.add_argument("--cpu-workers", type=int, default=0, help="0 = usable cores (affinity mask capped by the cgroup quota)")
     args = ap.parse_args()
@@ -190,7 +193,8 @@ def main() -> None:
     p0, p1 = int(block.pos[0]), int(block.pos[-1])
     windows = default_windows(p0, p1, WIN_LEN, WIN_STEP)
     prm = _ffi.make_params(U_Q_PARAMS["w"], U_Q_PARAMS["x"], U_Q_PARAMS["quantile"], U_Q_PARAMS["y_list"], U_Q_PARAMS["anc"])
-    scorer = ResidentScorer(eng, block, windows, [prm], cap_u=1 << 22, cap_q=1 << 22)
+    scorer = ResidentScorer(eng, block, windows, [prm], cap_u=1 << 22, cap_q=1 << 22, layout=args.layout)
+    alg_bytes = block.genotype_bytes if args.layout == "int8" else block.packed2_bytes
 
     sizes = [scorer.bufs[0].numel()]
     if world > 1:
@@ -231,7 +235,7 @@ def main() -> None:
     res = scorer.results()  # also checks the candidate buffers were large enough
     kernel_ms = [a.elapsed_time(b) for a, b in scorer.count_events]
     avg_ms = sum(kernel_ms) / len(kernel_ms)
-    achieved = block.genotype_bytes / (avg_ms * 1e-3) / 1e9
+    achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
     # on-box ceiling: plain 16-B-per-lane streaming read of the ref block (outside the timed region)
     stream_read = eng.probe_stream_read(block.pops[0].tiles)
 
@@ -240,7 +244,7 @@ def main() -> None:
         tfile = ROOT / "profiles" / "traffic.json"
         if tfile.exists():
             rec = json.loads(tfile.read_text())
-            key = f"{n_sites}x{args.ref}+{args.tgt}+{args.src}"
+            key = f"{n_sites}x{args.ref}+{args.tgt}+{args.src}" + ("" if args.layout == "int8" else f":{args.layout}")
             traffic = rec.get(key, {}).get("site_counts_hbm_bytes_per_launch")
         line = {
             "metric": METRIC,
@@ -258,6 +262,7 @@ def main() -> None:
             "config": {
                 "workload": f"synthetic chr: {n_sites:.0e} sites, {args.ref} ref/{args.tgt} tgt/{args.src} src diploids, "
                 "50kb/25kb windows, U+Q95 (BASELINE.json configs[2]); one chromosome per GPU",
+                "layout": args.layout,
                 "n_sites_per_gpu": n_sites,
                 "windows_per_gpu": len(windows),
                 "windows_total": total_windows,
@@ -266,14 +271,14 @@ def main() -> None:
                 "q_finite_rank0": int(np.isfinite(res.records["q"]).sum()),
             },
             "roofline": {
-                "kernel": "site_counts",
+                "kernel": "site_counts" if args.layout == "int8" else "site_counts_packed2",
                 "bound": "hbm",
                 "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 4),
                 "traffic": traffic,
-                "algorithmic_bytes_per_launch": block.genotype_bytes,
+                "algorithmic_bytes_per_launch": alg_bytes,
                 "avg_launch_ms": round(avg_ms, 4),
                 "stream_read_probe_gbps": round(stream_read, 1),
                 "frac_of_stream_read_probe": round(achieved / stream_read, 4),

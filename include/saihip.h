@@ -202,6 +202,27 @@ int sai_window_dd(sai_ctx* ctx, int64_t n_sites, int32_t n_src_ind, const uint32
                   int32_t n_ref_ind, const uint32_t* ad_tgt, int32_t n_tgt_ind, int32_t n_windows,
                   const int32_t* lo, const int32_t* hi, double* scratch, double* dd, void* stream);
 
+/* ---- packed2: optional 2-bit layout ----------------------------- */
+
+/* For dosages in {0, 1, 2} plus missing (unphased diploid or haploid biallelic calls) a block can
+ * be held 4x denser: site-major, 2 bits per individual (0, 1, 2 = dosage, 3 = missing), every
+ * site's row padded to 16 * 2^k bytes, whole 64-site tiles allocated:
+ *   field(site, ind) = bits [2 * (ind % 16), +2) of uint32 word [site * row_words + ind / 16].
+ * At most 16 384 individuals per population.  The byte count of a launch is 4x smaller, so
+ * throughput figures on this layout are always reported separately from the int8 ones. */
+int64_t sai_packed2_bytes(int64_t n_sites, int32_t n_ind); /* -1 on bad arguments */
+
+/* Convert a tiled int8 block; *n_unrepresentable (device) receives the number of words holding a
+ * dosage above 2 -- the caller must not use the packed block when it is non-zero. */
+int sai_pack2_from_tiles(sai_ctx* ctx, const int8_t* tiles, int64_t n_sites, int32_t n_ind,
+                         uint8_t* packed, int32_t* n_unrepresentable, void* stream);
+
+/* sai_site_pass on packed2 blocks (pops[p].tiles points at the packed block); n_sets may be 0 to
+ * obtain only the counts.  Results are identical to the int8 entry points. */
+int sai_site_pass_packed2(sai_ctx* ctx, int64_t n_sites, int32_t n_pops, const sai_pop* pops,
+                          uint32_t* counts, int32_t n_sets, const sai_params* sets_host,
+                          double* tgt_freq, uint8_t* flags, void* stream);
+
 /* ---- synthetic data ("synth-v1") ---------------------------------- */
 
 /* Counter-based generator: every byte is a pure function of (seed, chrom, site, population

@@ -89,6 +89,12 @@ SIGNATURES = {
     "sai_window_fourpop": (C.c_int, [_p, _i64, _i32, _i32, _p, _i32, _p, _p, _p, _p, _p]),
     "sai_site_absdiff": (C.c_int, [_p, _i64, C.POINTER(SaiPop), C.POINTER(SaiPop), _p, _p]),
     "sai_window_dd": (C.c_int, [_p, _i64, _i32, _p, _i32, _p, _i32, _i32, _p, _p, _p, _p, _p]),
+    "sai_packed2_bytes": (_i64, [_i64, _i32]),
+    "sai_pack2_from_tiles": (C.c_int, [_p, _p, _i64, _i32, _p, _p, _p]),
+    "sai_site_pass_packed2": (
+        C.c_int,
+        [_p, _i64, _i32, C.POINTER(SaiPop), _p, _i32, C.POINTER(SaiParams), _p, _p, _p],
+    ),
     "sai_synth_fill": (C.c_int, [_p, _u64, _i32, _i64, _i64, _i32, _i32, _i32, _i32, _p, _p]),
     "sai_synth_fill_host": (C.c_int, [_u64, _i32, _i64, _i64, _i32, _i32, _i32, _i32, _p]),
     "sai_synth_gaps_host": (C.c_int, [_u64, _i32, _i64, _i64, _p]),

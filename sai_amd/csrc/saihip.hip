@@ -378,6 +378,148 @@ __global__ __launch_bounds__(64) void site_counts_kernel(CountsArgs a, FusedArgs
 }
 
 // ------------------------------------------------------------------------------------------
+// packed2: an optional 4x denser layout for dosages in {0, 1, 2} (+ missing), i.e. unphased
+// diploid (or haploid) biallelic calls -- SURVEY.md section 8f #4.  Site-major, 2 bits per
+// individual (0, 1, 2 = dosage, 3 = missing), each site's row padded to 16 * 2^k bytes:
+//     field(site, ind) = bits [2*(ind%16), +2) of word  packed32[site * row_words + ind / 16]
+// One wave still owns a 64-site tile; a wave instruction reads 1 KiB = 64 / 2^k whole rows, the
+// three codes are counted with v_bcnt_u32_b32 (popcount with accumulate), partial sums of the
+// 2^k lanes of a site are combined by xor-shuffles, and the per-site counts meet in the same LDS
+// stash / eval_site tail as the int8 kernel.  Results are identical to the int8 path; the
+// algorithmic bytes are 4x fewer, so this is reported as a separate roofline, never mixed with
+// the int8 numbers.
+// ------------------------------------------------------------------------------------------
+
+__host__ __device__ __forceinline__ int packed2_row_chunks(int n_ind) {  // 16-byte chunks per site row
+  const int c = (n_ind + 63) / 64;
+  int p = 1;
+  while (p < c) p <<= 1;
+  return p;
+}
+
+constexpr int kPackedMaxInd = 16384;  // sum and missing count of one site share a 32-bit word
+
+// tiled int8 -> packed2.  One workgroup per (tile, 64 individuals); n_bad counts bytes above 2.
+__global__ __launch_bounds__(256) void pack2_from_tiles_kernel(const int8_t* __restrict__ tiles, int64_t n_sites,
+                                                                int32_t n_ind, int32_t row_chunks,
+                                                                uint32_t* __restrict__ packed, int32_t* n_bad) {
+  __shared__ int8_t blk[kTile][kTile + 4];  // [individual][site]
+  const int64_t tile = blockIdx.x;
+  const int ind0 = blockIdx.y * kTile;
+  const int tid = threadIdx.x;
+  {
+    const int i = tid >> 2, part = tid & 3;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (ind0 + i < n_ind) v = *reinterpret_cast<const uint4*>(tiles + (tile * n_ind + ind0 + i) * kTile + part * 16);
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) blk[i][part * 16 + j * 4 + k] = static_cast<int8_t>((w[j] >> (8 * k)) & 0xFF);
+  }
+  __syncthreads();
+  const int s = tid >> 2, j = tid & 3;  // site in tile, 16-individual word of this 64-individual chunk
+  const int64_t site = tile * kTile + s;
+  if (site >= n_sites) return;
+  uint32_t w = 0;
+  bool bad = false;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const int g = blk[j * 16 + k][s];
+    bad = bad || g > 2;
+    w |= static_cast<uint32_t>(g < 0 ? 3 : (g & 3)) << (2 * k);
+  }
+  packed[(site * row_chunks + blockIdx.y) * 4 + j] = w;
+  if (bad) atomicAdd(n_bad, 1);
+}
+
+struct PackedPop {
+  const u32x4* data;
+  int32_t n_ind;
+  int32_t lg;  // log2 of the 16-byte chunks per site row
+};
+
+struct PackedArgs {
+  int64_t n_sites;
+  int64_t n_tiles;
+  int32_t n_pops;
+  PackedPop pop[kMaxPops];
+  uint2* counts;
+};
+
+__device__ __forceinline__ void count_codes(const u32x4& v, uint32_t& ones, uint32_t& twos, uint32_t& miss) {
+  const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const uint32_t lo = w[j] & 0x55555555u, hi = (w[j] >> 1) & 0x55555555u;
+    ones += __popc(lo & ~hi);
+    twos += __popc(hi & ~lo);
+    miss += __popc(lo & hi);
+  }
+}
+
+__device__ __forceinline__ void wave_lds_fence_counts() {
+  // single-wave workgroup: LDS operations execute in order; only the compiler needs the fence
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <bool FUSED>
+__global__ __launch_bounds__(64) void site_counts_packed2_kernel(PackedArgs a, FusedArgs fa) {
+  __shared__ uint2 stash[kMaxPops][64];
+  const int lane = threadIdx.x;
+  for (int64_t tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
+    for (int p = 0; p < a.n_pops; ++p) {
+      const int lg = a.pop[p].lg;
+      const uint32_t n_ind = static_cast<uint32_t>(a.pop[p].n_ind);
+      const u32x4* base = a.pop[p].data + (tile * kTile << lg);  // the tile's rows are contiguous
+      if (lg <= 6) {
+        const int n_loads = 1 << lg;  // each wave load covers 64 >> lg whole rows
+        for (int i0 = 0; i0 < n_loads; i0 += 4) {
+          u32x4 v[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+            v[u] = (i0 + u < n_loads) ? __builtin_nontemporal_load(base + (i0 + u) * 64 + lane) : u32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            if (i0 + u < n_loads) {
+              uint32_t ones = 0, twos = 0, miss = 0;
+              count_codes(v[u], ones, twos, miss);
+              uint32_t val = (ones + 2 * twos) | (miss << 16);
+              for (int o = (1 << lg) >> 1; o > 0; o >>= 1) val += __shfl_xor(val, o, 64);
+              if ((lane & ((1 << lg) - 1)) == 0)
+                stash[p][((i0 + u) << (6 - lg)) + (lane >> lg)] = make_uint2(val & 0xFFFFu, n_ind - (val >> 16));
+            }
+          }
+        }
+      } else {  // more than 4096 individuals: several wave loads per site
+        const int per_site = 1 << (lg - 6);
+        for (int s = 0; s < kTile; ++s) {
+          uint32_t ones = 0, twos = 0, miss = 0;
+          for (int j = 0; j < per_site; ++j) count_codes(__builtin_nontemporal_load(base + (s * per_site + j) * 64 + lane), ones, twos, miss);
+          uint32_t val = (ones + 2 * twos) | (miss << 16);
+#pragma unroll
+          for (int o = 32; o > 0; o >>= 1) val += __shfl_xor(val, o, 64);
+          if (lane == 0) stash[p][s] = make_uint2(val & 0xFFFFu, n_ind - (val >> 16));
+        }
+      }
+    }
+    wave_lds_fence_counts();
+    const int64_t site = tile * kTile + lane;
+    if (site < a.n_sites) {
+      if (a.counts)
+        for (int p = 0; p < a.n_pops; ++p) a.counts[static_cast<int64_t>(p) * a.n_sites + site] = stash[p][lane];
+      if (FUSED)
+        eval_site(
+            a.n_pops, fa.ploidy, [&](int p) { return stash[p][lane]; }, fa.n_sets, fa.sets, site, a.n_sites, fa.tgt_freq,
+            fa.flags, nullptr);
+    }
+    wave_lds_fence_counts();  // the next tile overwrites the stash
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // window_bounds
 // ------------------------------------------------------------------------------------------
 
@@ -1575,6 +1717,77 @@ int sai_window_dd(sai_ctx* ctx, int64_t n_sites, int32_t n_src_ind, const uint32
   hipLaunchKernelGGL(window_dd_kernel, dim3(static_cast<unsigned>((n_windows + 3) / 4)), dim3(256), 0,
                      static_cast<hipStream_t>(stream), a);
   return check_launch("window_dd");
+}
+
+int64_t sai_packed2_bytes(int64_t n_sites, int32_t n_ind) {
+  if (n_sites < 0 || n_ind < 0 || n_ind > kPackedMaxInd) return -1;
+  const int64_t n_tiles = (n_sites + kTile - 1) / kTile;
+  return n_tiles * kTile * packed2_row_chunks(n_ind) * 16;  // whole tiles, so the kernel never reads past the end
+}
+
+int sai_pack2_from_tiles(sai_ctx* ctx, const int8_t* tiles, int64_t n_sites, int32_t n_ind, uint8_t* packed,
+                         int32_t* n_unrepresentable, void* stream) {
+  if (int rc = enter(ctx)) return rc;
+  if (n_sites < 0 || n_sites >= 0x7FFFFFFFll) return fail(SAI_ERR_ARG, "n_sites out of range");
+  if (n_ind < 1 || n_ind > kPackedMaxInd) return fail(SAI_ERR_UNSUPPORTED, "packed2 supports 1..%d individuals", kPackedMaxInd);
+  if (!n_unrepresentable) return fail(SAI_ERR_ARG, "n_unrepresentable is NULL");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  SAI_HIP(hipMemsetAsync(n_unrepresentable, 0, sizeof(int32_t), st));
+  if (n_sites == 0) return SAI_OK;
+  if (!tiles || !packed) return fail(SAI_ERR_ARG, "NULL buffer");
+  SAI_HIP(hipMemsetAsync(packed, 0, static_cast<size_t>(sai_packed2_bytes(n_sites, n_ind)), st));
+  const int64_t n_tiles = (n_sites + kTile - 1) / kTile;
+  const dim3 grid(static_cast<unsigned>(n_tiles), static_cast<unsigned>((n_ind + kTile - 1) / kTile));
+  hipLaunchKernelGGL(pack2_from_tiles_kernel, grid, dim3(256), 0, st, tiles, n_sites, n_ind, packed2_row_chunks(n_ind),
+                     reinterpret_cast<uint32_t*>(packed), n_unrepresentable);
+  return check_launch("pack2_from_tiles");
+}
+
+int sai_site_pass_packed2(sai_ctx* ctx, int64_t n_sites, int32_t n_pops, const sai_pop* pops, uint32_t* counts,
+                          int32_t n_sets, const sai_params* sets_host, double* tgt_freq, uint8_t* flags, void* stream) {
+  if (int rc = enter(ctx)) return rc;
+  if (n_sites < 0 || n_sites >= 0x7FFFFFFFll) return fail(SAI_ERR_ARG, "n_sites out of range");
+  if (n_pops < 1 || n_pops > kMaxPops) return fail(SAI_ERR_ARG, "n_pops must be 1..%d", kMaxPops);
+  if (!pops) return fail(SAI_ERR_ARG, "pops is NULL");
+  if (n_sets < 0 || n_sets > kFusedSets) return fail(SAI_ERR_UNSUPPORTED, "at most %d parameter sets", kFusedSets);
+  if (n_sets > 0) {
+    if (n_pops < 2) return fail(SAI_ERR_ARG, "n_pops must be >= 2 (ref, tgt, sources)");
+    if (int rc = check_sets(n_sets, sets_host, n_pops - 2)) return rc;
+    if (n_sites > 0 && (!tgt_freq || !flags)) return fail(SAI_ERR_ARG, "NULL buffer");
+  } else if (!counts && n_sites > 0) {
+    return fail(SAI_ERR_ARG, "nothing to compute: no parameter sets and counts is NULL");
+  }
+  if (n_sites == 0) return SAI_OK;
+  PackedArgs a;
+  FusedArgs fa;
+  std::memset(&fa, 0, sizeof(fa));
+  a.n_sites = n_sites;
+  a.n_tiles = (n_sites + kTile - 1) / kTile;
+  a.n_pops = n_pops;
+  for (int p = 0; p < n_pops; ++p) {
+    if (pops[p].n_ind < 1 || pops[p].n_ind > kPackedMaxInd)
+      return fail(SAI_ERR_UNSUPPORTED, "population %d: packed2 supports 1..%d individuals", p, kPackedMaxInd);
+    if (!pops[p].tiles || (reinterpret_cast<uintptr_t>(pops[p].tiles) & 15u))
+      return fail(SAI_ERR_ARG, "population %d: packed block must be a 16-byte aligned device pointer", p);
+    if (n_sets > 0 && pops[p].ploidy <= 0) return fail(SAI_ERR_ARG, "ploidy[%d] must be positive", p);
+    a.pop[p].data = reinterpret_cast<const u32x4*>(pops[p].tiles);
+    a.pop[p].n_ind = pops[p].n_ind;
+    int lg = 0;
+    while ((1 << lg) < packed2_row_chunks(pops[p].n_ind)) ++lg;
+    a.pop[p].lg = lg;
+    fa.ploidy[p] = pops[p].ploidy;
+  }
+  a.counts = reinterpret_cast<uint2*>(counts);
+  fa.n_sets = n_sets;
+  fa.tgt_freq = tgt_freq;
+  fa.flags = flags;
+  for (int s = 0; s < n_sets; ++s) fa.sets[s] = sets_host[s];
+  const int64_t max_grid = static_cast<int64_t>(ctx->n_cu) * 64;
+  const dim3 grid(static_cast<unsigned>(a.n_tiles < max_grid ? a.n_tiles : max_grid));
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (n_sets > 0) hipLaunchKernelGGL((site_counts_packed2_kernel<true>), grid, dim3(64), 0, st, a, fa);
+  else hipLaunchKernelGGL((site_counts_packed2_kernel<false>), grid, dim3(64), 0, st, a, fa);
+  return check_launch("site_counts_packed2");
 }
 
 }  // extern "C"

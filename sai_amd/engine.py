@@ -59,6 +59,15 @@ class TiledPop:
 
 
 @dataclass
+class PackedPop:
+    """One population block in the optional packed2 layout of saihip.h (2 bits per call)."""
+
+    data: "object"  # torch uint8 tensor, 1-D
+    n_sites: int
+    n_ind: int
+
+
+@dataclass
 class WindowResults:
     records: np.ndarray  # structured [n_sets][n_windows], RECORD_DTYPE
     offsets: np.ndarray  # int64 [n_sets][n_windows][2]
@@ -185,6 +194,47 @@ class Engine:
             self.lib.sai_site_pass(
                 self.ctx, n_sites, len(pops), arr, self._ptr(counts) if counts is not None else None, len(sets),
                 self._params_array(sets), self._ptr(out[0]), self._ptr(out[1]), self._stream(),
+            )
+        )  # fmt: skip
+        return out
+
+    def pack2(self, pop: TiledPop) -> PackedPop:
+        """Re-encode a tiled int8 block (dosages 0..2, negative = missing) as packed2.  Raises if a
+        dosage above 2 is present (polyploid data stay on the int8 path)."""
+        torch = _torch()
+        nbytes = self.lib.sai_packed2_bytes(pop.n_sites, pop.n_ind)
+        if nbytes < 0:
+            raise ValueError("packed2 supports at most 16384 individuals per population")
+        data = self._empty((nbytes,), torch.uint8)
+        bad = self._empty((1,), torch.int32)
+        _ffi.check(
+            self.lib.sai_pack2_from_tiles(
+                self.ctx, self._ptr(pop.tiles), pop.n_sites, pop.n_ind, self._ptr(data), self._ptr(bad), self._stream()
+            )
+        )
+        if int(bad.item()) != 0:
+            raise ValueError("dosage above 2: this block cannot be held in the packed2 layout")
+        return PackedPop(data, pop.n_sites, pop.n_ind)
+
+    def site_pass_packed2(self, pops: Sequence[PackedPop], ploidies: Sequence[int], sets: Sequence[_ffi.SaiParams],
+                          out=None, counts=None):
+        """``site_pass`` on packed2 blocks; with ``sets == []`` only the counts are produced."""
+        torch = _torch()
+        n_sites = pops[0].n_sites
+        if any(p.n_sites != n_sites for p in pops):
+            raise ValueError("all populations of one call must cover the same sites")
+        arr = (_ffi.SaiPop * len(pops))()
+        for i, p in enumerate(pops):
+            arr[i].tiles = p.data.data_ptr() if p.data.numel() else 0
+            arr[i].n_ind = p.n_ind
+            arr[i].ploidy = int(ploidies[i])
+        if out is None and sets:
+            out = (self._empty((n_sites,), torch.float64), self._empty((len(sets), n_sites), torch.uint8))
+        _ffi.check(
+            self.lib.sai_site_pass_packed2(
+                self.ctx, n_sites, len(pops), arr, self._ptr(counts) if counts is not None else None, len(sets),
+                self._params_array(sets) if sets else None, self._ptr(out[0]) if out else None,
+                self._ptr(out[1]) if out else None, self._stream(),
             )
         )  # fmt: skip
         return out

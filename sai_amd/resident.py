@@ -33,6 +33,12 @@ class ResidentBlock:
         """Algorithmic bytes of one site_counts launch: every genotype byte once."""
         return self.n_sites * sum(p.n_ind for p in self.pops)
 
+    @property
+    def packed2_bytes(self) -> int:
+        """Algorithmic bytes of one packed2 launch: two bits per genotype, each site's row rounded
+        up to whole bytes (the layout's power-of-two row padding is not counted)."""
+        return self.n_sites * sum((p.n_ind + 3) // 4 for p in self.pops)
+
 
 def synth_block(eng: Engine, seed: int, chrom: int, n_sites: int, n_ref: int, n_tgt: int, n_src_list: Sequence[int],
                 ploidy: int = 2, missing_per_million: int = 0, site0: int = 0) -> ResidentBlock:  # fmt: skip
@@ -48,8 +54,15 @@ def synth_block(eng: Engine, seed: int, chrom: int, n_sites: int, n_ref: int, n_
 
 class ResidentScorer:
     def __init__(self, eng: Engine, block: ResidentBlock, windows: Sequence[tuple], sets: Sequence[_ffi.SaiParams],
-                 cap_u: int = 1 << 20, cap_q: int = 1 << 20):  # fmt: skip
+                 cap_u: int = 1 << 20, cap_q: int = 1 << 20, layout: str = "int8"):  # fmt: skip
+        """``layout="packed2"`` re-encodes the block once into the 2-bit layout (dosages 0..2 only)
+        and streams that instead: 4x fewer genotype bytes per step, identical results."""
         import torch
+
+        if layout not in ("int8", "packed2"):
+            raise ValueError("layout must be 'int8' or 'packed2'")
+        self.layout = layout
+        self.packed = [eng.pack2(p) for p in block.pops] if layout == "packed2" else None
 
         if not 1 <= len(sets) <= _ffi.SAI_MAX_SETS:
             raise ValueError(f"1..{_ffi.SAI_MAX_SETS} parameter sets per scorer")
@@ -80,7 +93,12 @@ class ResidentScorer:
         if time_counts:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        if self.fused:
+        if self.packed is not None:
+            if self.fused:
+                eng.site_pass_packed2(self.packed, b.ploidies, self.sets, out=(self.tgt_freq, self.flags))
+            else:
+                eng.site_pass_packed2(self.packed, b.ploidies, [], counts=self.counts)
+        elif self.fused:
             eng.site_pass(b.pops, b.ploidies, self.sets, out=(self.tgt_freq, self.flags))
         else:
             eng.site_counts(b.pops, out=self.counts)

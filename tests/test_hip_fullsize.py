@@ -217,3 +217,22 @@ def test_c5_two_sources_sweep(eng):
     s.lo, s.hi = lo, hi
     hot = np.argsort(-res.records[8]["u_count"])[:3].tolist()
     check_sampled_windows_against_oracle(block, windows, s, res, specs, sorted(set(hot + [7, 5000])))
+
+
+def test_c3_packed2_equals_int8(eng):
+    """configs[2] once more on the optional 2-bit layout: every record and candidate list equal to
+    the int8 run."""
+    from sai_amd import _ffi
+    from sai_amd.resident import ResidentScorer, default_windows, synth_block
+
+    block = synth_block(eng, SEED + 3, 1, 10_000_000, 1000, 1000, [2], missing_per_million=1000)
+    windows = default_windows(int(block.pos[0]), int(block.pos[-1]), 50000, 25000)
+    sets = [_ffi.make_params(s["w"], s["x"], s["quantile"], s["y_list"], s["anc"]) for s in C3_SPECS]
+    a = ResidentScorer(eng, block, windows, sets, cap_u=1 << 22, cap_q=1 << 22)
+    b = ResidentScorer(eng, block, windows, sets, cap_u=1 << 22, cap_q=1 << 22, layout="packed2")
+    a.step()
+    b.step()
+    ra, rb = a.results(), b.results()
+    assert ra.records.tobytes() == rb.records.tobytes()
+    assert np.array_equal(ra.offsets, rb.offsets) and np.array_equal(ra.cdd_u, rb.cdd_u) and np.array_equal(ra.cdd_q, rb.cdd_q)
+    assert sum(p.data.numel() for p in b.packed) * 3.5 < sum(p.tiles.numel() for p in block.pops)

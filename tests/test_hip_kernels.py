@@ -322,3 +322,49 @@ def test_randomized_windows_against_oracle(eng):
                 assert res.u_list(si, wi).tolist() == eu["cdd_pos"].tolist()
                 assert same_f64(rec["q"], eq["value"]), (trial, si, wi, rec["q"], eq["value"])
                 assert res.q_list(si, wi).tolist() == np.asarray(eq["cdd_pos"]).astype(np.int64).tolist()
+
+
+@pytest.mark.parametrize("sizes", [[1, 1, 1], [64, 65, 2], [200, 129, 1, 3], [1000, 1008, 2], [4097, 513, 2]])
+def test_packed2_layout_equals_int8_path(eng, sizes):
+    """The optional 2-bit layout: packing is exact, the packed site pass gives the same counts,
+    frequencies and flags as the int8 kernels, and blocks with dosages above 2 are refused."""
+    import torch
+
+    from sai_amd import _ffi
+
+    rng = np.random.default_rng(sum(sizes))
+    n_sites = 777
+    mats = []
+    for n in sizes:
+        g = rng.integers(0, 3, size=(n_sites, n)).astype(np.int8)
+        g[rng.random(g.shape) < 0.03] = -2
+        g[rng.random(g.shape) < 0.01] = -1
+        mats.append(g)
+    mats[0][5] = 2
+    mats[1][6] = -1
+    pl = [2] * len(sizes)
+    tiled = [eng.tile(m) for m in mats]
+    packed = [eng.pack2(t) for t in tiled]
+    for m, pk in zip(mats, packed):  # the documented bit layout
+        chunks = 1
+        while chunks < (m.shape[1] + 63) // 64:
+            chunks *= 2
+        words = pk.data.cpu().numpy().view(np.uint32).reshape(-1, chunks * 4)[:n_sites]
+        codes = np.where(m < 0, 3, m).astype(np.uint32)
+        for ind in (0, m.shape[1] // 2, m.shape[1] - 1):
+            assert np.array_equal((words[:, ind // 16] >> (2 * (ind % 16))) & 3, codes[:, ind])
+    n_src = len(sizes) - 2
+    sets = [_ffi.make_params(0.4, 0.3, 0.9, [(">=", 0.5)] * n_src, False), _ffi.make_params(1.0, 0.0, 0.5, [("<=", 1.0)] * n_src, True)]
+    counts = eng.site_counts(tiled)
+    tf, fl, _ = eng.site_flags(counts, pl, sets)
+    c2 = torch.zeros_like(counts)
+    tf2, fl2 = eng.site_pass_packed2(packed, pl, sets, counts=c2)
+    assert torch.equal(counts, c2) and torch.equal(fl, fl2)
+    assert tf.cpu().numpy().tobytes() == tf2.cpu().numpy().tobytes()
+    c3 = torch.zeros_like(counts)
+    eng.site_pass_packed2(packed, pl, [], counts=c3)
+    assert torch.equal(counts, c3)
+    bad = mats[0].copy()
+    bad[3, 0] = 3
+    with pytest.raises(ValueError, match="dosage above 2"):
+        eng.pack2(eng.tile(bad))
