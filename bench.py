@@ -155,6 +155,8 @@ def main() -> None:
 
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    if "SAI_BENCH_DEVICE" in os.environ:  # rehearsal knob: every rank on one device of a 1-GPU box
+        local_rank = int(os.environ["SAI_BENCH_DEVICE"])
     world = int(os.environ.get("WORLD_SIZE", 1))
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
@@ -174,8 +176,12 @@ def main() -> None:
     import __graft_entry__ as entry
 
     torch.cuda.set_device(local_rank)
+    backend = os.environ.get("SAI_BENCH_BACKEND", "nccl")  # "gloo" only for rehearsals on a 1-GPU box
     if world > 1:
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world)
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
     # one process per node builds (a no-op when the in-tree library is current); the others wait
     if local_rank == 0:
         entry.build()
@@ -196,9 +202,10 @@ def main() -> None:
     scorer = ResidentScorer(eng, block, windows, [prm], cap_u=1 << 22, cap_q=1 << 22, layout=args.layout)
     alg_bytes = block.genotype_bytes if args.layout == "int8" else block.packed2_bytes
 
+    cdev = eng.device if backend == "nccl" else torch.device("cpu")  # where the small collectives live
     sizes = [scorer.bufs[0].numel()]
     if world > 1:
-        t = torch.tensor(sizes, dtype=torch.int64, device=eng.device)
+        t = torch.tensor(sizes, dtype=torch.int64, device=cdev)
         all_sizes = [torch.zeros_like(t) for _ in range(world)]
         dist.all_gather(all_sizes, t)
         sizes = [int(s.item()) for s in all_sizes]
@@ -223,10 +230,10 @@ def main() -> None:
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=eng.device)
+        tmax = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
-        nw = torch.tensor([len(windows)], dtype=torch.int64, device=eng.device)
+        nw = torch.tensor([len(windows)], dtype=torch.int64, device=cdev)
         dist.all_reduce(nw, op=dist.ReduceOp.SUM)
         total_windows = int(nw.item())
     else:

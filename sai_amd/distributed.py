@@ -29,12 +29,14 @@ def init_process_group(backend: Optional[str] = None) -> tuple[int, int]:
 
     rank, local_rank, world = env_rank_world()
     if world > 1 and not dist.is_initialized():
-        if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend is None:  # SAI_AMD_DIST_BACKEND=gloo: several ranks on one GPU (tests, rehearsals)
+            backend = os.environ.get("SAI_AMD_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
             torch.cuda.set_device(local_rank)
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+            dist.init_process_group(backend=backend, rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world
 
 
@@ -93,6 +95,8 @@ def gather_padded(local, sizes: Sequence[int], group=None):
     import torch.distributed as dist
 
     rank, world = dist.get_rank(group), dist.get_world_size(group)
+    if local.is_cuda and dist.get_backend(group) == "gloo":
+        local = local.cpu()  # gloo gathers host tensors (CPU tests, single-GPU rehearsals)
     cap = max(sizes)
     padded = local
     if local.numel() != cap:
