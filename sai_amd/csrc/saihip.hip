@@ -803,40 +803,56 @@ __global__ __launch_bounds__(kWinThreads) void window_stats_heavy_kernel(WinArgs
 
 // One 1024-thread workgroup: exclusive prefix sums of u_count and n_cdd_q over the records in
 // (set, window) order.  cdd_off[2r] / cdd_off[2r+1] = start of record r's U / Q list (or -1 when
-// the list would not fit its buffer); cdd_total[0..1] = entries needed in all.
+// the list would not fit its buffer); cdd_total[0..1] = entries needed in all.  Records are taken
+// 4 x 1024 at a time (coalesced, all loads of a batch in flight together); each row of 1024 is
+// scanned with wave shuffles + one LDS hop, the running totals carry over in registers.
 __global__ __launch_bounds__(1024) void window_scan_kernel(WinArgs a) {
-  __shared__ long long part[2][1024];
-  const int tid = threadIdx.x;
+  __shared__ long long wave_tot[2][16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int64_t n = static_cast<int64_t>(a.n_sets) * a.n_windows;
-  const int64_t per = (n + 1023) / 1024;
-  const int64_t r0 = min(n, tid * per), r1 = min(n, r0 + per);
-  long long su = 0, sq = 0;
-  for (int64_t r = r0; r < r1; ++r) {
-    su += a.records[r].u_count;
-    sq += a.records[r].n_cdd_q;
+  long long carry_u = 0, carry_q = 0;
+  constexpr int kBatch = 4;
+  for (int64_t base = 0; base < n; base += 1024 * kBatch) {
+    long long nu[kBatch], nq[kBatch];
+#pragma unroll
+    for (int k = 0; k < kBatch; ++k) {
+      const int64_t r = base + k * 1024 + tid;
+      nu[k] = r < n ? a.records[r].u_count : 0;
+      nq[k] = r < n ? a.records[r].n_cdd_q : 0;
+    }
+#pragma unroll
+    for (int k = 0; k < kBatch; ++k) {
+      if (base + k * 1024 >= n) break;  // uniform
+      long long iu = nu[k], iq = nq[k];
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const long long tu = __shfl_up(iu, o, 64), tq = __shfl_up(iq, o, 64);
+        if (lane >= o) { iu += tu; iq += tq; }
+      }
+      __syncthreads();  // the previous row's wave totals have been consumed
+      if (lane == 63) { wave_tot[0][wave] = iu; wave_tot[1][wave] = iq; }
+      __syncthreads();
+      long long before_u = 0, before_q = 0, all_u = 0, all_q = 0;
+#pragma unroll
+      for (int v = 0; v < 16; ++v) {
+        const long long tu = wave_tot[0][v], tq = wave_tot[1][v];
+        if (v < wave) { before_u += tu; before_q += tq; }
+        all_u += tu;
+        all_q += tq;
+      }
+      const int64_t r = base + k * 1024 + tid;
+      if (r < n) {
+        const long long ou = carry_u + before_u + iu - nu[k], oq = carry_q + before_q + iq - nq[k];
+        a.cdd_off[2 * r + 0] = (ou + nu[k] <= a.cap_u) ? ou : -1;
+        a.cdd_off[2 * r + 1] = (oq + nq[k] <= a.cap_q) ? oq : -1;
+      }
+      carry_u += all_u;
+      carry_q += all_q;
+    }
   }
-  part[0][tid] = su;
-  part[1][tid] = sq;
-  __syncthreads();
-  for (int o = 1; o < 1024; o <<= 1) {  // Hillis-Steele inclusive scan of the 1024 partial sums
-    const long long u = tid >= o ? part[0][tid - o] : 0;
-    const long long q = tid >= o ? part[1][tid - o] : 0;
-    __syncthreads();
-    part[0][tid] += u;
-    part[1][tid] += q;
-    __syncthreads();
-  }
-  long long ou = part[0][tid] - su, oq = part[1][tid] - sq;
-  for (int64_t r = r0; r < r1; ++r) {
-    const long long nu = a.records[r].u_count, nq = a.records[r].n_cdd_q;
-    a.cdd_off[2 * r + 0] = (ou + nu <= a.cap_u) ? ou : -1;
-    a.cdd_off[2 * r + 1] = (oq + nq <= a.cap_q) ? oq : -1;
-    ou += nu;
-    oq += nq;
-  }
-  if (tid == 1023) {
-    a.cdd_total[0] = part[0][1023];
-    a.cdd_total[1] = part[1][1023];
+  if (tid == 0) {
+    a.cdd_total[0] = carry_u;
+    a.cdd_total[1] = carry_q;
   }
 }
 

@@ -11,6 +11,7 @@ from pathlib import Path
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 workload_key = sys.argv[2] if len(sys.argv) > 2 else "10000000x1000+1000+2"
 warmup = int(sys.argv[3]) if len(sys.argv) > 3 else 2
+dominant = sys.argv[4] if len(sys.argv) > 4 else "site_counts"
 src = Path("gpurun_out") / f"prof_{tag}"
 dst = Path("profiles")
 dst.mkdir(exist_ok=True)
@@ -62,9 +63,9 @@ with open(dst / f"{tag}_pmc_summary.csv", "w") as f:
         f.write(f"{k},{n},{fs:.3f},{ws:.3f},{rd:.0f},{wr:.0f},{rd + wr:.0f}\n")
 tfile = dst / "traffic.json"
 rec = json.loads(tfile.read_text()) if tfile.exists() else {}
-if "site_counts" in pmc:
-    fs = pmc["site_counts"]["FETCH_SIZE"][1]
-    ws = pmc["site_counts"].get("WRITE_SIZE", (0, 0.0))[1]
+if dominant in pmc:
+    fs = pmc[dominant]["FETCH_SIZE"][1]
+    ws = pmc[dominant].get("WRITE_SIZE", (0, 0.0))[1]
     rec[workload_key] = {
         "source": f"profiles/{tag}_pmc_summary.csv",
         "site_counts_fetch_size_kib_raw": fs,
