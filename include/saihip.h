@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define SAI_ABI_VERSION 1
+#define SAI_ABI_VERSION 2
 #define SAI_TILE_SITES 64
 #define SAI_MAX_SRC 6   /* source populations per call */
 #define SAI_MAX_SETS 16 /* parameter sets per call */
@@ -53,6 +53,7 @@ enum sai_status {
 
 /* comparison operators of the source-frequency conditions (stat_utils.py:133-139) */
 enum sai_op { SAI_OP_EQ = 0, SAI_OP_LT = 1, SAI_OP_GT = 2, SAI_OP_LE = 3, SAI_OP_GE = 4 };
+enum sai_freq_mode { SAI_FREQ_DENSE = 0, SAI_FREQ_CANDIDATES = 1 }; /* see sai_site_pass */
 
 typedef struct sai_ctx sai_ctx;
 
@@ -121,10 +122,14 @@ int sai_site_counts(sai_ctx* ctx, int64_t n_sites, int32_t n_pops, const sai_pop
  * genotypes that also evaluates sai_site_flags' per-site decision for each set at the end of every
  * tile, while the counts are still on chip.  `counts` may be NULL (then the 8 bytes per site and
  * population are neither written nor re-read); pops[p].ploidy is used.  Results are identical to
- * sai_site_counts followed by sai_site_flags. */
+ * sai_site_counts followed by sai_site_flags.
+ * freq_mode = SAI_FREQ_DENSE writes tgt_freq[site] for every site; SAI_FREQ_CANDIDATES writes it
+ * only where some set's flags bit 0 is set -- the only entries sai_window_stats reads -- and
+ * leaves the rest of the buffer untouched (dense 8-byte stores interleaved with the genotype
+ * stream cost about 10 % of the pass on MI355X). */
 int sai_site_pass(sai_ctx* ctx, int64_t n_sites, int32_t n_pops, const sai_pop* pops,
-                  uint32_t* counts, int32_t n_sets, const sai_params* sets_host, double* tgt_freq,
-                  uint8_t* flags, void* stream);
+                  uint32_t* counts, int32_t n_sets, const sai_params* sets_host, int32_t freq_mode,
+                  double* tgt_freq, uint8_t* flags, void* stream);
 
 /* Kernel 2: calc_freq's f64 division (stat_utils.py:51-52) and compute_matching_loci
  * (stat_utils.py:114-166) for every site and parameter set, plus U's final test
@@ -221,7 +226,7 @@ int sai_pack2_from_tiles(sai_ctx* ctx, const int8_t* tiles, int64_t n_sites, int
  * obtain only the counts.  Results are identical to the int8 entry points. */
 int sai_site_pass_packed2(sai_ctx* ctx, int64_t n_sites, int32_t n_pops, const sai_pop* pops,
                           uint32_t* counts, int32_t n_sets, const sai_params* sets_host,
-                          double* tgt_freq, uint8_t* flags, void* stream);
+                          int32_t freq_mode, double* tgt_freq, uint8_t* flags, void* stream);
 
 /* ---- synthetic data ("synth-v1") ---------------------------------- */
 
@@ -271,8 +276,9 @@ int sai_vcf_block_free(sai_vcf_block* block);
 
 /* ---- measurement aid -------------------------------------------------------------------- */
 
-/* Plain streaming read of `n_bytes` (multiple of 16) with 16-byte loads, XOR-reduced into
- * *xor_out (device).  No reference counterpart: bench.py times it to obtain the on-box read
+/* Plain streaming read of `n_bytes` (multiple of 16) with 16-byte non-temporal loads, one wave per
+ * contiguous 125 KiB run; the XOR of all 32-bit words is XOR-ed INTO *xor_out (device; the caller
+ * zeroes it, so that a timed region holds this one kernel only).  No reference counterpart: bench.py times it to obtain the on-box read
  * ceiling that the site_counts rate is compared with, next to the 8 TB/s datasheet peak. */
 int sai_probe_stream_read(sai_ctx* ctx, const void* buf, int64_t n_bytes, uint32_t* xor_out,
                           void* stream);

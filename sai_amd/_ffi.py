@@ -18,7 +18,8 @@ SAI_TILE_SITES = 64
 SAI_MAX_SRC = 6
 SAI_MAX_SETS = 16
 SAI_FUSED_SETS = 4
-SAI_ABI_VERSION = 1
+FREQ_MODES = {"dense": 0, "candidates": 1}  # enum sai_freq_mode
+SAI_ABI_VERSION = 2
 
 OPS = {"=": 0, "<": 1, ">": 2, "<=": 3, ">=": 4}
 
@@ -74,7 +75,7 @@ SIGNATURES = {
     "sai_site_counts": (C.c_int, [_p, _i64, _i32, C.POINTER(SaiPop), _p, _p]),
     "sai_site_pass": (
         C.c_int,
-        [_p, _i64, _i32, C.POINTER(SaiPop), _p, _i32, C.POINTER(SaiParams), _p, _p, _p],
+        [_p, _i64, _i32, C.POINTER(SaiPop), _p, _i32, C.POINTER(SaiParams), _i32, _p, _p, _p],
     ),
     "sai_site_flags": (
         C.c_int,
@@ -93,7 +94,7 @@ SIGNATURES = {
     "sai_pack2_from_tiles": (C.c_int, [_p, _p, _i64, _i32, _p, _p, _p]),
     "sai_site_pass_packed2": (
         C.c_int,
-        [_p, _i64, _i32, C.POINTER(SaiPop), _p, _i32, C.POINTER(SaiParams), _p, _p, _p],
+        [_p, _i64, _i32, C.POINTER(SaiPop), _p, _i32, C.POINTER(SaiParams), _i32, _p, _p, _p],
     ),
     "sai_synth_fill": (C.c_int, [_p, _u64, _i32, _i64, _i64, _i32, _i32, _i32, _i32, _p, _p]),
     "sai_synth_fill_host": (C.c_int, [_u64, _i32, _i64, _i64, _i32, _i32, _i32, _i32, _p]),

@@ -138,7 +138,7 @@ __device__ __forceinline__ bool cmp_op(int op, double f, double y) {
 template <typename GetCounts>
 __device__ __forceinline__ void eval_site(int n_pops, const int32_t* ploidy, GetCounts get, int n_sets,
                                           const sai_params* sets, int64_t site, int64_t n_sites, double* tgt_freq,
-                                          uint8_t* flags, double* adj_freq) {
+                                          uint8_t* flags, double* adj_freq, bool sparse_freq = false) {
   double f[kMaxPops];
   bool valid = true;
 #pragma unroll
@@ -154,7 +154,7 @@ __device__ __forceinline__ void eval_site(int n_pops, const int32_t* ploidy, Get
       f[p] = 0.0;
     }
   }
-  tgt_freq[site] = f[1];
+  bool any_cond = false;
   const int n_src = n_pops - 2;
   for (int s = 0; s < n_sets; ++s) {
     const sai_params& ps = sets[s];
@@ -173,13 +173,20 @@ __device__ __forceinline__ void eval_site(int n_pops, const int32_t* ploidy, Get
     const double tf = inverted ? 1.0 - f[1] : f[1];
     const bool cond = valid && hit && (rf < ps.w);
     const bool ucand = cond && (tf > ps.x);
-    flags[static_cast<int64_t>(s) * n_sites + site] =
-        static_cast<uint8_t>((cond ? 1 : 0) | (ucand ? 2 : 0) | (inverted ? 4 : 0));
+    any_cond = any_cond || cond;
+    // non-temporal stores: measured on MI355X, plain stores in the middle of the genotype stream cost
+    // twice as much of the pass as streaming ones
+    __builtin_nontemporal_store(static_cast<uint8_t>((cond ? 1 : 0) | (ucand ? 2 : 0) | (inverted ? 4 : 0)),
+                                flags + static_cast<int64_t>(s) * n_sites + site);
     if (adj_freq) {
       adj_freq[(static_cast<int64_t>(s) * 2 + 0) * n_sites + site] = rf;
       adj_freq[(static_cast<int64_t>(s) * 2 + 1) * n_sites + site] = tf;
     }
   }
+  // The windows stage reads tgt_freq only where a set's bit 0 is up (about 1 site in 1000), and
+  // dense f64 stores in the middle of the genotype stream cost ~10 % of the pass (HBM read/write
+  // turnarounds): SAI_FREQ_CANDIDATES leaves every other entry untouched.
+  if (!sparse_freq || any_cond) __builtin_nontemporal_store(f[1], tgt_freq + site);
 }
 
 struct FlagArgs {
@@ -206,6 +213,7 @@ constexpr int kFusedSets = 4;  // parameter sets the fused tail of site_counts c
 
 struct FusedArgs {
   int32_t n_sets;  // 0 = plain site_counts
+  int32_t sparse_freq;
   int32_t ploidy[kMaxPops];
   double* tgt_freq;
   uint8_t* flags;
@@ -225,6 +233,11 @@ struct FusedArgs {
 // ------------------------------------------------------------------------------------------
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void store_counts_nt(uint2* dst, uint2 v) {
+  __builtin_nontemporal_store(u32x2{v.x, v.y}, reinterpret_cast<u32x2*>(dst));
+}
 
 struct PopArg {
   const int8_t* tiles;
@@ -275,6 +288,7 @@ constexpr int kChunkIters = 248;  // iterations (rows per lane) the 16-/8-bit fi
 // Accumulate iterations [it, full_end) of full 16-row groups plus, when it is the last one, the
 // partial group, into the packed fields lo/hi (16-bit dosage sums) and ms (8-bit missing counts).
 constexpr int kUnroll = 4;  // wave loads (1 KiB each) in flight per group
+static_assert(kChunkIters % kUnroll == 0 && kChunkIters + kUnroll <= 255, "8-bit missing fields overflow");
 
 // Accumulate iterations [it, full_end) of full 16-row groups plus, when it is the last one, the
 // partial group, into the packed fields lo/hi (16-bit dosage sums) and ms (8-bit missing counts).
@@ -292,15 +306,24 @@ __device__ __forceinline__ void accumulate_rows(const u32x4* base, int& it, int 
 #pragma unroll
     for (int u = 0; u < kUnroll; ++u) acc_vec(v[u], lo, hi, ms);
   }
-  for (; it < full_end; ++it) {
-    const u32x4 v = __builtin_nontemporal_load(base + it * 64);
-    acc_vec(v, lo, hi, ms);
-  }
-  if (it == n_full && it < n_iter) {  // partial last group of rows
-    u32x4 v = {0u, 0u, 0u, 0u};
-    if (it * 16 + r < n_ind) v = __builtin_nontemporal_load(base + it * 64);
-    acc_vec(v, lo, hi, ms);
-    ++it;
+  // Tail: the < kUnroll remaining full groups and the partial group go out as ONE batch of
+  // unconditional loads (addresses clamped into the tile, invalid lanes zeroed afterwards), so the
+  // wave pays one memory latency for the tail instead of one per group.
+  const int last = (full_end == n_full) ? n_iter : full_end;
+  if (it < last) {
+    u32x4 v[kUnroll];
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u) {
+      const int row = min(it + u, last - 1) * 16 + r;
+      v[u] = __builtin_nontemporal_load(base + (min(row, n_ind - 1) - r) * 4);
+    }
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u) {
+      const bool valid = (it + u < last) && ((it + u) * 16 + r < n_ind);
+      if (!valid) v[u] = u32x4{0u, 0u, 0u, 0u};
+      acc_vec(v[u], lo, hi, ms);
+    }
+    it = last;
   }
 }
 
@@ -364,7 +387,7 @@ __global__ __launch_bounds__(64) void site_counts_kernel(CountsArgs a, FusedArgs
       reduce_scatter_step<2, 4>(miss32, lane);
       const int64_t site = tile * kTile + (lane & 3) * 16 + r;
       const uint2 cnt = make_uint2(sum32[0], static_cast<uint32_t>(n_ind) - miss32[0]);
-      if (a.counts && site < a.n_sites) a.counts[static_cast<int64_t>(p) * a.n_sites + site] = cnt;
+      if (a.counts && site < a.n_sites) store_counts_nt(a.counts + static_cast<int64_t>(p) * a.n_sites + site, cnt);
       if (FUSED) stash[p][lane] = cnt;
     }
     if (FUSED) {
@@ -372,7 +395,7 @@ __global__ __launch_bounds__(64) void site_counts_kernel(CountsArgs a, FusedArgs
       if (site < a.n_sites)
         eval_site(
             a.n_pops, fa.ploidy, [&](int p) { return stash[p][lane]; }, fa.n_sets, fa.sets, site,
-            a.n_sites, fa.tgt_freq, fa.flags, nullptr);
+            a.n_sites, fa.tgt_freq, fa.flags, nullptr, fa.sparse_freq != 0);
     }
   }
 }
@@ -397,6 +420,7 @@ __host__ __device__ __forceinline__ int packed2_row_chunks(int n_ind) {  // 16-b
   return p;
 }
 
+constexpr int kPackedUnroll = 8;  // wave loads in flight per batch
 constexpr int kPackedMaxInd = 16384;  // sum and missing count of one site share a 32-bit word
 
 // tiled int8 -> packed2.  One workgroup per (tile, 64 individuals); n_bad counts bytes above 2.
@@ -476,13 +500,13 @@ __global__ __launch_bounds__(64) void site_counts_packed2_kernel(PackedArgs a, F
       const u32x4* base = a.pop[p].data + (tile * kTile << lg);  // the tile's rows are contiguous
       if (lg <= 6) {
         const int n_loads = 1 << lg;  // each wave load covers 64 >> lg whole rows
-        for (int i0 = 0; i0 < n_loads; i0 += 4) {
-          u32x4 v[4];
+        for (int i0 = 0; i0 < n_loads; i0 += kPackedUnroll) {
+          u32x4 v[kPackedUnroll];
 #pragma unroll
-          for (int u = 0; u < 4; ++u)
+          for (int u = 0; u < kPackedUnroll; ++u)
             v[u] = (i0 + u < n_loads) ? __builtin_nontemporal_load(base + (i0 + u) * 64 + lane) : u32x4{0u, 0u, 0u, 0u};
 #pragma unroll
-          for (int u = 0; u < 4; ++u) {
+          for (int u = 0; u < kPackedUnroll; ++u) {
             if (i0 + u < n_loads) {
               uint32_t ones = 0, twos = 0, miss = 0;
               count_codes(v[u], ones, twos, miss);
@@ -509,11 +533,11 @@ __global__ __launch_bounds__(64) void site_counts_packed2_kernel(PackedArgs a, F
     const int64_t site = tile * kTile + lane;
     if (site < a.n_sites) {
       if (a.counts)
-        for (int p = 0; p < a.n_pops; ++p) a.counts[static_cast<int64_t>(p) * a.n_sites + site] = stash[p][lane];
+        for (int p = 0; p < a.n_pops; ++p) store_counts_nt(a.counts + static_cast<int64_t>(p) * a.n_sites + site, stash[p][lane]);
       if (FUSED)
         eval_site(
             a.n_pops, fa.ploidy, [&](int p) { return stash[p][lane]; }, fa.n_sets, fa.sets, site, a.n_sites, fa.tgt_freq,
-            fa.flags, nullptr);
+            fa.flags, nullptr, fa.sparse_freq != 0);
     }
     wave_lds_fence_counts();  // the next tile overwrites the stash
   }
@@ -1293,27 +1317,36 @@ __global__ __launch_bounds__(256) void synth_gaps_kernel(uint64_t seed, int32_t 
 
 
 // ------------------------------------------------------------------------------------------
-// stream_read probe: the plainest possible streaming read (16 B per lane, XOR-reduced, one
-// result word per wave) -- the on-box read ceiling the site_counts rate is compared with.
+// stream_read probe: the plainest streaming read in the access pattern site_counts uses -- one
+// wave per workgroup walks contiguous 125 KiB runs, 8 non-temporal 1 KiB wave loads in flight,
+// XOR-reduced to one word.  It is the on-box read ceiling the site_counts rate is compared with
+// (a thread-strided grid loop reads ~8 % slower on MI355X than per-wave contiguous runs).
 // ------------------------------------------------------------------------------------------
 
-__global__ __launch_bounds__(256) void stream_read_kernel(const u32x4* __restrict__ src, int64_t n_vec,
-                                                           uint32_t* __restrict__ out) {
-  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
-  int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+constexpr int64_t kProbeRunVecs = 8000;  // 125 KiB, the size of one C3 tile (ref + tgt rows)
+
+__global__ __launch_bounds__(64) void stream_read_kernel(const u32x4* __restrict__ src, int64_t n_vec,
+                                                          uint32_t* __restrict__ out) {
+  const int lane = threadIdx.x;
+  const int64_t n_runs = n_vec / kProbeRunVecs;
   u32x4 acc = {0u, 0u, 0u, 0u};
-  for (; i + 3 * stride < n_vec; i += 4 * stride) {
-    const u32x4 a = __builtin_nontemporal_load(src + i);
-    const u32x4 b = __builtin_nontemporal_load(src + i + stride);
-    const u32x4 c = __builtin_nontemporal_load(src + i + 2 * stride);
-    const u32x4 d = __builtin_nontemporal_load(src + i + 3 * stride);
-    acc ^= a ^ b ^ c ^ d;
+  for (int64_t run = blockIdx.x; run < n_runs; run += gridDim.x) {
+    const u32x4* base = src + run * kProbeRunVecs + lane;
+    for (int it = 0; it < kProbeRunVecs / 64; it += 5) {  // 125 wave loads in 25 groups of 5
+      u32x4 v[5];
+#pragma unroll
+      for (int u = 0; u < 5; ++u) v[u] = __builtin_nontemporal_load(base + (it + u) * 64);
+#pragma unroll
+      for (int u = 0; u < 5; ++u) acc ^= v[u];
+    }
   }
-  for (; i < n_vec; i += stride) acc ^= __builtin_nontemporal_load(src + i);
+  for (int64_t i = n_runs * kProbeRunVecs + static_cast<int64_t>(blockIdx.x) * 64 + lane; i < n_vec;
+       i += static_cast<int64_t>(gridDim.x) * 64)
+    acc ^= __builtin_nontemporal_load(src + i);
   uint32_t v = acc.x ^ acc.y ^ acc.z ^ acc.w;
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v ^= __shfl_xor(v, o, 64);
-  if ((threadIdx.x & 63) == 0) atomicXor(out, v);
+  if (lane == 0 && v != 0u) atomicXor(out, v);
 }
 
 }  // namespace
@@ -1401,8 +1434,8 @@ static int check_sets(int32_t n_sets, const sai_params* sets, int32_t n_src);
 
 // shared by sai_site_counts (n_sets == 0) and sai_site_pass
 static int launch_site_counts(sai_ctx* ctx, int64_t n_sites, int32_t n_pops, const sai_pop* pops, uint32_t* counts,
-                              int32_t n_sets, const sai_params* sets_host, double* tgt_freq, uint8_t* flags,
-                              void* stream) {
+                              int32_t n_sets, const sai_params* sets_host, int32_t freq_mode, double* tgt_freq,
+                              uint8_t* flags, void* stream) {
   if (n_sites < 0 || n_sites >= 0x7FFFFFFFll) return fail(SAI_ERR_ARG, "n_sites out of range");
   if (n_pops < 1 || n_pops > kMaxPops) return fail(SAI_ERR_ARG, "n_pops must be 1..%d", kMaxPops);
   if (!pops) return fail(SAI_ERR_ARG, "pops is NULL");
@@ -1428,6 +1461,7 @@ static int launch_site_counts(sai_ctx* ctx, int64_t n_sites, int32_t n_pops, con
   }
   a.counts = reinterpret_cast<uint2*>(counts);
   fa.n_sets = n_sets;
+  fa.sparse_freq = freq_mode == SAI_FREQ_CANDIDATES;
   fa.tgt_freq = tgt_freq;
   fa.flags = flags;
   for (int s = 0; s < n_sets; ++s) fa.sets[s] = sets_host[s];
@@ -1448,12 +1482,14 @@ int sai_site_counts(sai_ctx* ctx, int64_t n_sites, int32_t n_pops, const sai_pop
                     void* stream) {
   if (int rc = enter(ctx)) return rc;
   if (!counts && n_sites > 0) return fail(SAI_ERR_ARG, "counts is NULL");
-  return launch_site_counts(ctx, n_sites, n_pops, pops, counts, 0, nullptr, nullptr, nullptr, stream);
+  return launch_site_counts(ctx, n_sites, n_pops, pops, counts, 0, nullptr, SAI_FREQ_DENSE, nullptr, nullptr, stream);
 }
 
 int sai_site_pass(sai_ctx* ctx, int64_t n_sites, int32_t n_pops, const sai_pop* pops, uint32_t* counts,
-                  int32_t n_sets, const sai_params* sets_host, double* tgt_freq, uint8_t* flags, void* stream) {
+                  int32_t n_sets, const sai_params* sets_host, int32_t freq_mode, double* tgt_freq, uint8_t* flags,
+                  void* stream) {
   if (int rc = enter(ctx)) return rc;
+  if (freq_mode != SAI_FREQ_DENSE && freq_mode != SAI_FREQ_CANDIDATES) return fail(SAI_ERR_ARG, "bad freq_mode %d", freq_mode);
   if (n_pops < 2) return fail(SAI_ERR_ARG, "n_pops must be >= 2 (ref, tgt, sources)");
   if (n_sets > kFusedSets)
     return fail(SAI_ERR_UNSUPPORTED, "sai_site_pass carries at most %d parameter sets; use sai_site_counts + sai_site_flags",
@@ -1463,7 +1499,7 @@ int sai_site_pass(sai_ctx* ctx, int64_t n_sites, int32_t n_pops, const sai_pop* 
     for (int p = 0; p < n_pops && p < kMaxPops; ++p)
       if (pops[p].ploidy <= 0) return fail(SAI_ERR_ARG, "ploidy[%d] must be positive", p);
   if (n_sites > 0 && (!tgt_freq || !flags)) return fail(SAI_ERR_ARG, "NULL buffer");
-  return launch_site_counts(ctx, n_sites, n_pops, pops, counts, n_sets, sets_host, tgt_freq, flags, stream);
+  return launch_site_counts(ctx, n_sites, n_pops, pops, counts, n_sets, sets_host, freq_mode, tgt_freq, flags, stream);
 }
 
 static int check_sets(int32_t n_sets, const sai_params* sets, int32_t n_src) {
@@ -1623,10 +1659,9 @@ int sai_probe_stream_read(sai_ctx* ctx, const void* buf, int64_t n_bytes, uint32
   if (n_bytes < 0 || (n_bytes & 15)) return fail(SAI_ERR_ARG, "n_bytes must be a non-negative multiple of 16");
   if (!xor_out || (n_bytes > 0 && !buf)) return fail(SAI_ERR_ARG, "NULL buffer");
   if (reinterpret_cast<uintptr_t>(buf) & 15u) return fail(SAI_ERR_ARG, "buf must be 16-byte aligned");
-  SAI_HIP(hipMemsetAsync(xor_out, 0, sizeof(uint32_t), static_cast<hipStream_t>(stream)));
   if (n_bytes == 0) return SAI_OK;
-  const unsigned grid = static_cast<unsigned>(ctx->n_cu) * 8;
-  hipLaunchKernelGGL(stream_read_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream),
+  const unsigned grid = static_cast<unsigned>(ctx->n_cu) * 32;
+  hipLaunchKernelGGL(stream_read_kernel, dim3(grid), dim3(64), 0, static_cast<hipStream_t>(stream),
                      static_cast<const u32x4*>(buf), n_bytes / 16, xor_out);
   return check_launch("stream_read");
 }
@@ -1760,8 +1795,10 @@ int sai_pack2_from_tiles(sai_ctx* ctx, const int8_t* tiles, int64_t n_sites, int
 }
 
 int sai_site_pass_packed2(sai_ctx* ctx, int64_t n_sites, int32_t n_pops, const sai_pop* pops, uint32_t* counts,
-                          int32_t n_sets, const sai_params* sets_host, double* tgt_freq, uint8_t* flags, void* stream) {
+                          int32_t n_sets, const sai_params* sets_host, int32_t freq_mode, double* tgt_freq,
+                          uint8_t* flags, void* stream) {
   if (int rc = enter(ctx)) return rc;
+  if (freq_mode != SAI_FREQ_DENSE && freq_mode != SAI_FREQ_CANDIDATES) return fail(SAI_ERR_ARG, "bad freq_mode %d", freq_mode);
   if (n_sites < 0 || n_sites >= 0x7FFFFFFFll) return fail(SAI_ERR_ARG, "n_sites out of range");
   if (n_pops < 1 || n_pops > kMaxPops) return fail(SAI_ERR_ARG, "n_pops must be 1..%d", kMaxPops);
   if (!pops) return fail(SAI_ERR_ARG, "pops is NULL");
@@ -1795,6 +1832,7 @@ int sai_site_pass_packed2(sai_ctx* ctx, int64_t n_sites, int32_t n_pops, const s
   }
   a.counts = reinterpret_cast<uint2*>(counts);
   fa.n_sets = n_sets;
+  fa.sparse_freq = freq_mode == SAI_FREQ_CANDIDATES;
   fa.tgt_freq = tgt_freq;
   fa.flags = flags;
   for (int s = 0; s < n_sets; ++s) fa.sets[s] = sets_host[s];

@@ -172,11 +172,21 @@ class Engine:
         _ffi.check(self.lib.sai_site_counts(self.ctx, n_sites, len(pops), arr, self._ptr(out), self._stream()))
         return out
 
+    def _pass_out(self, n_sites: int, n_sets: int, freq_mode: str):
+        torch = _torch()
+        if freq_mode == "candidates":  # entries the pass does not write read as NaN, never as garbage
+            freq = torch.full((n_sites,), float("nan"), dtype=torch.float64, device=self.device)
+        else:
+            freq = self._empty((n_sites,), torch.float64)
+        return freq, self._empty((n_sets, n_sites), torch.uint8)
+
     def site_pass(self, pops: Sequence[TiledPop], ploidies: Sequence[int], sets: Sequence[_ffi.SaiParams], out=None,
-                  counts=None):
+                  counts=None, freq_mode: str = "dense"):
         """Fused site_counts + site_flags (at most SAI_FUSED_SETS parameter sets): one launch,
         the per-population counts stay on chip unless a ``counts`` tensor is passed.  Returns
-        (tgt_freq, flags) exactly as ``site_flags(site_counts(pops), ...)`` would."""
+        (tgt_freq, flags) exactly as ``site_flags(site_counts(pops), ...)`` would; with
+        ``freq_mode="candidates"`` tgt_freq is written only where some set's flags bit 0 is up
+        (all that ``window_stats`` reads) and every other entry of ``out[0]`` is left as it was."""
         torch = _torch()
         n_sites = pops[0].n_sites
         if any(p.n_sites != n_sites for p in pops):
@@ -189,11 +199,12 @@ class Engine:
             arr[i].n_ind = p.n_ind
             arr[i].ploidy = int(ploidies[i])
         if out is None:
-            out = (self._empty((n_sites,), torch.float64), self._empty((len(sets), n_sites), torch.uint8))
+            out = self._pass_out(n_sites, len(sets), freq_mode)
         _ffi.check(
             self.lib.sai_site_pass(
                 self.ctx, n_sites, len(pops), arr, self._ptr(counts) if counts is not None else None, len(sets),
-                self._params_array(sets), self._ptr(out[0]), self._ptr(out[1]), self._stream(),
+                self._params_array(sets), _ffi.FREQ_MODES[freq_mode], self._ptr(out[0]), self._ptr(out[1]),
+                self._stream(),
             )
         )  # fmt: skip
         return out
@@ -217,7 +228,7 @@ class Engine:
         return PackedPop(data, pop.n_sites, pop.n_ind)
 
     def site_pass_packed2(self, pops: Sequence[PackedPop], ploidies: Sequence[int], sets: Sequence[_ffi.SaiParams],
-                          out=None, counts=None):
+                          out=None, counts=None, freq_mode: str = "dense"):
         """``site_pass`` on packed2 blocks; with ``sets == []`` only the counts are produced."""
         torch = _torch()
         n_sites = pops[0].n_sites
@@ -229,12 +240,12 @@ class Engine:
             arr[i].n_ind = p.n_ind
             arr[i].ploidy = int(ploidies[i])
         if out is None and sets:
-            out = (self._empty((n_sites,), torch.float64), self._empty((len(sets), n_sites), torch.uint8))
+            out = self._pass_out(n_sites, len(sets), freq_mode)
         _ffi.check(
             self.lib.sai_site_pass_packed2(
                 self.ctx, n_sites, len(pops), arr, self._ptr(counts) if counts is not None else None, len(sets),
-                self._params_array(sets) if sets else None, self._ptr(out[0]) if out else None,
-                self._ptr(out[1]) if out else None, self._stream(),
+                self._params_array(sets) if sets else None, _ffi.FREQ_MODES[freq_mode],
+                self._ptr(out[0]) if out else None, self._ptr(out[1]) if out else None, self._stream(),
             )
         )  # fmt: skip
         return out
@@ -392,13 +403,14 @@ class Engine:
     # -- measurement aid ------------------------------------------------------------------
 
     def probe_stream_read(self, buf, repeats: int = 5) -> float:
-        """GB/s of a plain 16-B-per-lane streaming read over ``buf`` (best of ``repeats``)."""
+        """GB/s of the library's plain streaming-read kernel over ``buf`` (best of ``repeats``)."""
         torch = _torch()
         out = self._empty((1,), torch.int32)
         n = (buf.numel() * buf.element_size()) & ~15
         best = 0.0
         for _ in range(repeats + 1):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            out.zero_()
             e0.record()
             _ffi.check(self.lib.sai_probe_stream_read(self.ctx, self._ptr(buf), n, self._ptr(out), self._stream()))
             e1.record()

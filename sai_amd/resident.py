@@ -76,7 +76,8 @@ class ResidentScorer:
         # at most SAI_FUSED_SETS sets: one fused launch, the per-population counts never leave the chip
         self.fused = n_s <= _ffi.SAI_FUSED_SETS
         self.counts = None if self.fused else torch.empty((len(block.pops), n, 2), dtype=torch.int32, device=dev)
-        self.tgt_freq = torch.empty((n,), dtype=torch.float64, device=dev)
+        # the fused pass writes tgt_freq only at candidate sites (all the windows stage reads)
+        self.tgt_freq = torch.full((n,), float("nan"), dtype=torch.float64, device=dev)
         self.flags = torch.empty((n_s, n), dtype=torch.uint8, device=dev)
         self.lo = torch.empty((n_w,), dtype=torch.int32, device=dev)
         self.hi = torch.empty((n_w,), dtype=torch.int32, device=dev)
@@ -95,11 +96,12 @@ class ResidentScorer:
             e0.record()
         if self.packed is not None:
             if self.fused:
-                eng.site_pass_packed2(self.packed, b.ploidies, self.sets, out=(self.tgt_freq, self.flags))
+                eng.site_pass_packed2(self.packed, b.ploidies, self.sets, out=(self.tgt_freq, self.flags),
+                                      freq_mode="candidates")
             else:
                 eng.site_pass_packed2(self.packed, b.ploidies, [], counts=self.counts)
         elif self.fused:
-            eng.site_pass(b.pops, b.ploidies, self.sets, out=(self.tgt_freq, self.flags))
+            eng.site_pass(b.pops, b.ploidies, self.sets, out=(self.tgt_freq, self.flags), freq_mode="candidates")
         else:
             eng.site_counts(b.pops, out=self.counts)
         if time_counts:

@@ -246,6 +246,7 @@ def test_fused_site_pass_equals_two_kernels(eng):
 
     rng = np.random.default_rng(17)
     n_sites = 1500
+    n_cand_seen = 0
     for n_src in (1, 3):
         mats = [rng.integers(-2, 3, size=(n_sites, n)).astype(np.int8) for n in [33, 4100, *([2] * n_src)]]
         pl = [2, 2] + [int(rng.integers(1, 4)) for _ in range(n_src)]
@@ -265,6 +266,18 @@ def test_fused_site_pass_equals_two_kernels(eng):
             for a, b in ((tf, tf2), (tf, tf3)):
                 assert a.cpu().numpy().tobytes() == b.cpu().numpy().tobytes()
             assert torch.equal(fl, fl2) and torch.equal(fl, fl3) and torch.equal(counts, c3)
+            # SAI_FREQ_CANDIDATES: same flags; tgt_freq written exactly where a set has bit 0 up
+            sentinel = -7.25
+            out = (torch.full_like(tf, sentinel), torch.zeros_like(fl))
+            eng.site_pass(pops, pl, sets, out=out, freq_mode="candidates")
+            cand = ((fl & 1) != 0).any(dim=0)
+            assert torch.equal(out[1], fl) and int(cand.sum()) < n_sites
+            n_cand_seen += int(cand.sum())
+            assert out[0][cand].cpu().numpy().tobytes() == tf[cand].cpu().numpy().tobytes()
+            assert bool((out[0][~cand] == sentinel).all())
+            tf4, fl4 = eng.site_pass(pops, pl, sets, freq_mode="candidates")  # fresh buffer: NaN elsewhere
+            assert torch.equal(fl4, fl) and bool(torch.isnan(tf4[~cand]).all())
+    assert n_cand_seen > 0
     with pytest.raises(ValueError, match="at most"):
         eng.site_pass(pops, pl, sets * 2)
 
@@ -364,7 +377,29 @@ def test_packed2_layout_equals_int8_path(eng, sizes):
     c3 = torch.zeros_like(counts)
     eng.site_pass_packed2(packed, pl, [], counts=c3)
     assert torch.equal(counts, c3)
+    tf4, fl4 = eng.site_pass_packed2(packed, pl, sets, freq_mode="candidates")
+    cand = ((fl & 1) != 0).any(dim=0)
+    assert torch.equal(fl4, fl) and tf4[cand].cpu().numpy().tobytes() == tf[cand].cpu().numpy().tobytes()
+    assert bool(torch.isnan(tf4[~cand]).all())
     bad = mats[0].copy()
     bad[3, 0] = 3
     with pytest.raises(ValueError, match="dosage above 2"):
         eng.pack2(eng.tile(bad))
+
+
+def test_stream_read_probe_xor(eng):
+    """The bandwidth probe really reads every word: its XOR equals numpy's, for sizes below,
+    at and above the 125 KiB run length (whole runs + grid-strided remainder)."""
+    import torch
+
+    from sai_amd import _ffi
+
+    rng = np.random.default_rng(5)
+    for n_vec in (0, 1, 63, 8000, 8000 * 3 + 77, 8000 * 700 + 5):
+        host = rng.integers(0, 2**32, size=n_vec * 4, dtype=np.uint32)
+        buf = torch.from_numpy(host.view(np.int32)).to(eng.device)
+        out = torch.zeros((1,), dtype=torch.int32, device=eng.device)
+        _ffi.check(eng.lib.sai_probe_stream_read(eng.ctx, eng._ptr(buf) if n_vec else None, n_vec * 16, eng._ptr(out), eng._stream()))
+        expect = int(np.bitwise_xor.reduce(host)) if n_vec else 0
+        assert int(out.cpu().numpy().view(np.uint32)[0]) == expect
+    assert eng.probe_stream_read(buf) > 0

@@ -30,6 +30,10 @@ counts = eng.site_counts(pops)
 mn, av = timeit(lambda: eng.site_counts(pops, out=counts))
 print(f"site_counts min {mn:.3f} ms avg {av:.3f} ms  -> {nbytes / mn / 1e6:.1f} GB/s (min) {nbytes / av / 1e6:.1f} GB/s (avg)")
 sets = [_ffi.make_params(0.01, 0.5, 0.95, [("=", 1.0)], True)]
+fused = eng.site_pass(pops, [2, 2, 2], sets)
+for mode in ("dense", "candidates"):
+    mn, av = timeit(lambda: eng.site_pass(pops, [2, 2, 2], sets, out=fused, freq_mode=mode), 8)
+    print(f"site_pass/{mode} min {mn:.3f} ms avg {av:.3f} ms  -> {nbytes / mn / 1e6:.1f} GB/s (min)")
 out = eng.site_flags(counts, [2, 2, 2], sets)
 mn, av = timeit(lambda: eng.site_flags(counts, [2, 2, 2], sets, out=out[:2]))
 print(f"site_flags  min {mn:.3f} ms avg {av:.3f}")
