@@ -246,6 +246,7 @@ def main() -> None:
     # on-box ceiling: plain 16-B-per-lane streaming read of the ref block (outside the timed region)
     stream_read = eng.probe_stream_read(block.pops[0].tiles)
 
+    path_bytes = alg_bytes + 4 * n_sites + 24 * len(windows)
     if rank == 0:
         traffic = None
         tfile = ROOT / "profiles" / "traffic.json"
@@ -289,6 +290,9 @@ def main() -> None:
                 "avg_launch_ms": round(avg_ms, 4),
                 "stream_read_probe_gbps": round(stream_read, 1),
                 "frac_of_stream_read_probe": round(achieved / stream_read, 4),
+                # genotypes + 4 B per position + 24 B per record, over the whole step
+                "whole_path_bytes_per_step": path_bytes,
+                "whole_path_gbps_this_rank": round(path_bytes / (dt / args.steps) / 1e9, 1),
             },
             "cpu_baseline": cpu,
         }

@@ -210,11 +210,14 @@ int sai_window_dd(sai_ctx* ctx, int64_t n_sites, int32_t n_src_ind, const uint32
 /* ---- packed2: optional 2-bit layout ----------------------------- */
 
 /* For dosages in {0, 1, 2} plus missing (unphased diploid or haploid biallelic calls) a block can
- * be held 4x denser: site-major, 2 bits per individual (0, 1, 2 = dosage, 3 = missing), every
- * site's row padded to 16 * 2^k bytes, whole 64-site tiles allocated:
- *   field(site, ind) = bits [2 * (ind % 16), +2) of uint32 word [site * row_words + ind / 16].
- * At most 16 384 individuals per population.  The byte count of a launch is 4x smaller, so
- * throughput figures on this layout are always reported separately from the int8 ones. */
+ * be held 4x denser: 2 bits per individual (0, 1, 2 = dosage, 3 = missing), in 1 KiB blocks of
+ * 64 consecutive sites (a tile) x 64 consecutive individuals (a group), site-major inside the
+ * block (16 bytes per site), blocks ordered by tile, then group; n_groups = ceil(n_ind / 64):
+ *   field(site, ind) = bits [2 * (ind % 16), +2) of uint32 word
+ *                      ((site / 64 * n_groups + ind / 64) * 64 + site % 64) * 4 + (ind % 64) / 16.
+ * Padding individuals hold code 0, padding sites of the last tile code 3.  The byte count of a
+ * launch is 4x smaller, so throughput figures on this layout are always reported separately from
+ * the int8 ones. */
 int64_t sai_packed2_bytes(int64_t n_sites, int32_t n_ind); /* -1 on bad arguments */
 
 /* Convert a tiled int8 block; *n_unrepresentable (device) receives the number of words holding a

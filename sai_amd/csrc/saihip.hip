@@ -56,7 +56,10 @@ constexpr int kMaxPops = 2 + SAI_MAX_SRC;
 struct sai_ctx {
   int device;
   int n_cu;
+  uint32_t* probe_partials;  // n_cu * kProbeWavesPerCu words, the only scratch the library owns
 };
+
+constexpr int kProbeWavesPerCu = 32;
 
 namespace {
 
@@ -308,9 +311,16 @@ __device__ __forceinline__ void accumulate_rows(const u32x4* base, int& it, int 
   }
   // Tail: the < kUnroll remaining full groups and the partial group go out as ONE batch of
   // unconditional loads (addresses clamped into the tile, invalid lanes zeroed afterwards), so the
-  // wave pays one memory latency for the tail instead of one per group.
+  // wave pays one memory latency for the tail instead of one per group; a tail of one group (small
+  // source populations) is a single load.
   const int last = (full_end == n_full) ? n_iter : full_end;
-  if (it < last) {
+  if (it + 1 == last) {
+    const int row = it * 16 + r;
+    u32x4 v = __builtin_nontemporal_load(base + (min(row, n_ind - 1) - r) * 4);
+    if (row >= n_ind) v = u32x4{0u, 0u, 0u, 0u};
+    acc_vec(v, lo, hi, ms);
+    it = last;
+  } else if (it < last) {
     u32x4 v[kUnroll];
 #pragma unroll
     for (int u = 0; u < kUnroll; ++u) {
@@ -402,32 +412,30 @@ __global__ __launch_bounds__(64) void site_counts_kernel(CountsArgs a, FusedArgs
 
 // ------------------------------------------------------------------------------------------
 // packed2: an optional 4x denser layout for dosages in {0, 1, 2} (+ missing), i.e. unphased
-// diploid (or haploid) biallelic calls -- SURVEY.md section 8f #4.  Site-major, 2 bits per
-// individual (0, 1, 2 = dosage, 3 = missing), each site's row padded to 16 * 2^k bytes:
-//     field(site, ind) = bits [2*(ind%16), +2) of word  packed32[site * row_words + ind / 16]
-// One wave still owns a 64-site tile; a wave instruction reads 1 KiB = 64 / 2^k whole rows, the
-// three codes are counted with v_bcnt_u32_b32 (popcount with accumulate), partial sums of the
-// 2^k lanes of a site are combined by xor-shuffles, and the per-site counts meet in the same LDS
-// stash / eval_site tail as the int8 kernel.  Results are identical to the int8 path; the
-// algorithmic bytes are 4x fewer, so this is reported as a separate roofline, never mixed with
-// the int8 numbers.
+// diploid (or haploid) biallelic calls -- SURVEY.md section 8f #4.  2 bits per individual
+// (0, 1, 2 = dosage, 3 = missing), blocked so that one lane owns one site:
+//     tile t = 64 consecutive sites, group g = 64 consecutive individuals (16 bytes per site);
+//     block (t, g) = 64 sites x 16 B = 1 KiB at byte offset (t * n_groups + g) * 1024, site-major;
+//     field(site, ind) = bits [2*(ind%16), +2) of uint32 word
+//                        ((site/64 * n_groups + ind/64) * 64 + site%64) * 4 + (ind%64)/16.
+// A wave instruction reads one block: lane l gets the 64 individuals of site l of the tile, counts
+// the three codes with v_bcnt_u32_b32 (popcount with accumulate) and keeps the totals in its own
+// registers across the groups -- no cross-lane step at all, and the per-site tail (eval_site) runs
+// on values the lane already holds.  Results are identical to the int8 path; the algorithmic
+// bytes are 4x fewer, so this is reported as a separate roofline, never mixed with the int8
+// numbers.  Padding individuals carry code 0 (n_called = n_ind - missing), padding sites code 3.
 // ------------------------------------------------------------------------------------------
 
-__host__ __device__ __forceinline__ int packed2_row_chunks(int n_ind) {  // 16-byte chunks per site row
-  const int c = (n_ind + 63) / 64;
-  int p = 1;
-  while (p < c) p <<= 1;
-  return p;
-}
+__host__ __device__ __forceinline__ int packed2_groups(int n_ind) { return (n_ind + 63) / 64; }
 
 constexpr int kPackedUnroll = 8;  // wave loads in flight per batch
-constexpr int kPackedMaxInd = 16384;  // sum and missing count of one site share a 32-bit word
+constexpr int kPackedMaxInd = 1 << 24;  // as for the int8 layout: per-site totals are 32-bit
 
-// tiled int8 -> packed2.  One workgroup per (tile, 64 individuals); n_bad counts bytes above 2.
+// tiled int8 -> packed2.  One workgroup per (tile, group); n_bad counts words holding a byte above 2.
 __global__ __launch_bounds__(256) void pack2_from_tiles_kernel(const int8_t* __restrict__ tiles, int64_t n_sites,
-                                                                int32_t n_ind, int32_t row_chunks,
+                                                                int32_t n_ind, int32_t n_groups,
                                                                 uint32_t* __restrict__ packed, int32_t* n_bad) {
-  __shared__ int8_t blk[kTile][kTile + 4];  // [individual][site]
+  __shared__ int8_t blk[kTile][kTile + 4];  // [individual of the group][site]
   const int64_t tile = blockIdx.x;
   const int ind0 = blockIdx.y * kTile;
   const int tid = threadIdx.x;
@@ -442,25 +450,26 @@ __global__ __launch_bounds__(256) void pack2_from_tiles_kernel(const int8_t* __r
       for (int k = 0; k < 4; ++k) blk[i][part * 16 + j * 4 + k] = static_cast<int8_t>((w[j] >> (8 * k)) & 0xFF);
   }
   __syncthreads();
-  const int s = tid >> 2, j = tid & 3;  // site in tile, 16-individual word of this 64-individual chunk
-  const int64_t site = tile * kTile + s;
-  if (site >= n_sites) return;
-  uint32_t w = 0;
+  const int s = tid >> 2, j = tid & 3;  // site in tile, 16-individual word of the group
+  uint32_t w = 0xFFFFFFFFu;             // padding sites of the last tile: all missing
   bool bad = false;
+  if (tile * kTile + s < n_sites) {
+    w = 0;
 #pragma unroll
-  for (int k = 0; k < 16; ++k) {
-    const int g = blk[j * 16 + k][s];
-    bad = bad || g > 2;
-    w |= static_cast<uint32_t>(g < 0 ? 3 : (g & 3)) << (2 * k);
+    for (int k = 0; k < 16; ++k) {
+      const int g = blk[j * 16 + k][s];
+      bad = bad || g > 2;
+      w |= static_cast<uint32_t>(g < 0 ? 3 : (g & 3)) << (2 * k);
+    }
   }
-  packed[(site * row_chunks + blockIdx.y) * 4 + j] = w;
+  packed[((tile * n_groups + blockIdx.y) * kTile + s) * 4 + j] = w;  // the workgroup writes its 1 KiB block in order
   if (bad) atomicAdd(n_bad, 1);
 }
 
 struct PackedPop {
   const u32x4* data;
   int32_t n_ind;
-  int32_t lg;  // log2 of the 16-byte chunks per site row
+  int32_t n_groups;
 };
 
 struct PackedArgs {
@@ -482,64 +491,45 @@ __device__ __forceinline__ void count_codes(const u32x4& v, uint32_t& ones, uint
   }
 }
 
-__device__ __forceinline__ void wave_lds_fence_counts() {
-  // single-wave workgroup: LDS operations execute in order; only the compiler needs the fence
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
 template <bool FUSED>
 __global__ __launch_bounds__(64) void site_counts_packed2_kernel(PackedArgs a, FusedArgs fa) {
+  // indexed per-lane storage only: entry [p][lane] is written and read by the same lane
   __shared__ uint2 stash[kMaxPops][64];
   const int lane = threadIdx.x;
   for (int64_t tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
+    const int64_t site = tile * kTile + lane;
     for (int p = 0; p < a.n_pops; ++p) {
-      const int lg = a.pop[p].lg;
-      const uint32_t n_ind = static_cast<uint32_t>(a.pop[p].n_ind);
-      const u32x4* base = a.pop[p].data + (tile * kTile << lg);  // the tile's rows are contiguous
-      if (lg <= 6) {
-        const int n_loads = 1 << lg;  // each wave load covers 64 >> lg whole rows
-        for (int i0 = 0; i0 < n_loads; i0 += kPackedUnroll) {
-          u32x4 v[kPackedUnroll];
+      const int n_groups = a.pop[p].n_groups;
+      const u32x4* base = a.pop[p].data + tile * n_groups * kTile + lane;
+      uint32_t ones = 0, twos = 0, miss = 0;
+      int g = 0;
+      for (; g + kPackedUnroll <= n_groups; g += kPackedUnroll) {
+        u32x4 v[kPackedUnroll];
 #pragma unroll
-          for (int u = 0; u < kPackedUnroll; ++u)
-            v[u] = (i0 + u < n_loads) ? __builtin_nontemporal_load(base + (i0 + u) * 64 + lane) : u32x4{0u, 0u, 0u, 0u};
+        for (int u = 0; u < kPackedUnroll; ++u) v[u] = __builtin_nontemporal_load(base + (g + u) * kTile);
 #pragma unroll
-          for (int u = 0; u < kPackedUnroll; ++u) {
-            if (i0 + u < n_loads) {
-              uint32_t ones = 0, twos = 0, miss = 0;
-              count_codes(v[u], ones, twos, miss);
-              uint32_t val = (ones + 2 * twos) | (miss << 16);
-              for (int o = (1 << lg) >> 1; o > 0; o >>= 1) val += __shfl_xor(val, o, 64);
-              if ((lane & ((1 << lg) - 1)) == 0)
-                stash[p][((i0 + u) << (6 - lg)) + (lane >> lg)] = make_uint2(val & 0xFFFFu, n_ind - (val >> 16));
-            }
-          }
-        }
-      } else {  // more than 4096 individuals: several wave loads per site
-        const int per_site = 1 << (lg - 6);
-        for (int s = 0; s < kTile; ++s) {
-          uint32_t ones = 0, twos = 0, miss = 0;
-          for (int j = 0; j < per_site; ++j) count_codes(__builtin_nontemporal_load(base + (s * per_site + j) * 64 + lane), ones, twos, miss);
-          uint32_t val = (ones + 2 * twos) | (miss << 16);
+        for (int u = 0; u < kPackedUnroll; ++u) count_codes(v[u], ones, twos, miss);
+      }
+      if (g + 1 == n_groups) {  // one group left (small source populations): a single load
+        count_codes(__builtin_nontemporal_load(base + g * kTile), ones, twos, miss);
+      } else if (g < n_groups) {  // 2 .. kPackedUnroll-1 groups as one batch: clamped addresses, zeroed extras
+        u32x4 v[kPackedUnroll - 1];
 #pragma unroll
-          for (int o = 32; o > 0; o >>= 1) val += __shfl_xor(val, o, 64);
-          if (lane == 0) stash[p][s] = make_uint2(val & 0xFFFFu, n_ind - (val >> 16));
+        for (int u = 0; u < kPackedUnroll - 1; ++u) v[u] = __builtin_nontemporal_load(base + min(g + u, n_groups - 1) * kTile);
+#pragma unroll
+        for (int u = 0; u < kPackedUnroll - 1; ++u) {
+          if (g + u >= n_groups) v[u] = u32x4{0u, 0u, 0u, 0u};
+          count_codes(v[u], ones, twos, miss);
         }
       }
+      const uint2 cnt = make_uint2(ones + 2u * twos, static_cast<uint32_t>(a.pop[p].n_ind) - miss);
+      if (a.counts && site < a.n_sites) store_counts_nt(a.counts + static_cast<int64_t>(p) * a.n_sites + site, cnt);
+      if (FUSED) stash[p][lane] = cnt;
     }
-    wave_lds_fence_counts();
-    const int64_t site = tile * kTile + lane;
-    if (site < a.n_sites) {
-      if (a.counts)
-        for (int p = 0; p < a.n_pops; ++p) store_counts_nt(a.counts + static_cast<int64_t>(p) * a.n_sites + site, stash[p][lane]);
-      if (FUSED)
-        eval_site(
-            a.n_pops, fa.ploidy, [&](int p) { return stash[p][lane]; }, fa.n_sets, fa.sets, site, a.n_sites, fa.tgt_freq,
-            fa.flags, nullptr, fa.sparse_freq != 0);
-    }
-    wave_lds_fence_counts();  // the next tile overwrites the stash
+    if (FUSED && site < a.n_sites)
+      eval_site(
+          a.n_pops, fa.ploidy, [&](int p) { return stash[p][lane]; }, fa.n_sets, fa.sets, site, a.n_sites, fa.tgt_freq,
+          fa.flags, nullptr, fa.sparse_freq != 0);
   }
 }
 
@@ -1346,7 +1336,20 @@ __global__ __launch_bounds__(64) void stream_read_kernel(const u32x4* __restrict
   uint32_t v = acc.x ^ acc.y ^ acc.z ^ acc.w;
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v ^= __shfl_xor(v, o, 64);
-  if (lane == 0 && v != 0u) atomicXor(out, v);
+  if (lane == 0) out[blockIdx.x] = v;  // one word per wave; thousands of atomics on one address would
+                                       // add ~5 % to the time this kernel exists to measure
+}
+
+__global__ __launch_bounds__(256) void stream_read_fold_kernel(const uint32_t* __restrict__ partials, int n,
+                                                                uint32_t* __restrict__ xor_out) {
+  __shared__ uint32_t sh[4];
+  uint32_t v = 0;
+  for (int i = threadIdx.x; i < n; i += 256) v ^= partials[i];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v ^= __shfl_xor(v, o, 64);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) *xor_out ^= sh[0] ^ sh[1] ^ sh[2] ^ sh[3];
 }
 
 }  // namespace
@@ -1399,11 +1402,17 @@ int sai_ctx_create(int device, sai_ctx** ctx_out) {
   if (!c) return fail(SAI_ERR_HIP, "out of host memory");
   c->device = device;
   c->n_cu = prop.multiProcessorCount;
+  c->probe_partials = nullptr;
+  if (hipMalloc(&c->probe_partials, sizeof(uint32_t) * c->n_cu * kProbeWavesPerCu) != hipSuccess) {
+    delete c;
+    return fail(SAI_ERR_HIP, "hipMalloc of the context scratch failed");
+  }
   *ctx_out = c;
   return SAI_OK;
 }
 
 int sai_ctx_destroy(sai_ctx* ctx) {
+  if (ctx && ctx->probe_partials) (void)hipFree(ctx->probe_partials);
   delete ctx;
   return SAI_OK;
 }
@@ -1660,9 +1669,11 @@ int sai_probe_stream_read(sai_ctx* ctx, const void* buf, int64_t n_bytes, uint32
   if (!xor_out || (n_bytes > 0 && !buf)) return fail(SAI_ERR_ARG, "NULL buffer");
   if (reinterpret_cast<uintptr_t>(buf) & 15u) return fail(SAI_ERR_ARG, "buf must be 16-byte aligned");
   if (n_bytes == 0) return SAI_OK;
-  const unsigned grid = static_cast<unsigned>(ctx->n_cu) * 32;
+  const unsigned grid = static_cast<unsigned>(ctx->n_cu) * kProbeWavesPerCu;
   hipLaunchKernelGGL(stream_read_kernel, dim3(grid), dim3(64), 0, static_cast<hipStream_t>(stream),
-                     static_cast<const u32x4*>(buf), n_bytes / 16, xor_out);
+                     static_cast<const u32x4*>(buf), n_bytes / 16, ctx->probe_partials);
+  hipLaunchKernelGGL(stream_read_fold_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     ctx->probe_partials, static_cast<int>(grid), xor_out);
   return check_launch("stream_read");
 }
 
@@ -1773,7 +1784,7 @@ int sai_window_dd(sai_ctx* ctx, int64_t n_sites, int32_t n_src_ind, const uint32
 int64_t sai_packed2_bytes(int64_t n_sites, int32_t n_ind) {
   if (n_sites < 0 || n_ind < 0 || n_ind > kPackedMaxInd) return -1;
   const int64_t n_tiles = (n_sites + kTile - 1) / kTile;
-  return n_tiles * kTile * packed2_row_chunks(n_ind) * 16;  // whole tiles, so the kernel never reads past the end
+  return n_tiles * packed2_groups(n_ind) * 1024;  // whole 1 KiB blocks: 64 sites x 64 individuals
 }
 
 int sai_pack2_from_tiles(sai_ctx* ctx, const int8_t* tiles, int64_t n_sites, int32_t n_ind, uint8_t* packed,
@@ -1786,10 +1797,9 @@ int sai_pack2_from_tiles(sai_ctx* ctx, const int8_t* tiles, int64_t n_sites, int
   SAI_HIP(hipMemsetAsync(n_unrepresentable, 0, sizeof(int32_t), st));
   if (n_sites == 0) return SAI_OK;
   if (!tiles || !packed) return fail(SAI_ERR_ARG, "NULL buffer");
-  SAI_HIP(hipMemsetAsync(packed, 0, static_cast<size_t>(sai_packed2_bytes(n_sites, n_ind)), st));
   const int64_t n_tiles = (n_sites + kTile - 1) / kTile;
   const dim3 grid(static_cast<unsigned>(n_tiles), static_cast<unsigned>((n_ind + kTile - 1) / kTile));
-  hipLaunchKernelGGL(pack2_from_tiles_kernel, grid, dim3(256), 0, st, tiles, n_sites, n_ind, packed2_row_chunks(n_ind),
+  hipLaunchKernelGGL(pack2_from_tiles_kernel, grid, dim3(256), 0, st, tiles, n_sites, n_ind, packed2_groups(n_ind),
                      reinterpret_cast<uint32_t*>(packed), n_unrepresentable);
   return check_launch("pack2_from_tiles");
 }
@@ -1825,9 +1835,7 @@ int sai_site_pass_packed2(sai_ctx* ctx, int64_t n_sites, int32_t n_pops, const s
     if (n_sets > 0 && pops[p].ploidy <= 0) return fail(SAI_ERR_ARG, "ploidy[%d] must be positive", p);
     a.pop[p].data = reinterpret_cast<const u32x4*>(pops[p].tiles);
     a.pop[p].n_ind = pops[p].n_ind;
-    int lg = 0;
-    while ((1 << lg) < packed2_row_chunks(pops[p].n_ind)) ++lg;
-    a.pop[p].lg = lg;
+    a.pop[p].n_groups = packed2_groups(pops[p].n_ind);
     fa.ploidy[p] = pops[p].ploidy;
   }
   a.counts = reinterpret_cast<uint2*>(counts);

@@ -215,7 +215,7 @@ class Engine:
         torch = _torch()
         nbytes = self.lib.sai_packed2_bytes(pop.n_sites, pop.n_ind)
         if nbytes < 0:
-            raise ValueError("packed2 supports at most 16384 individuals per population")
+            raise ValueError("packed2: population too large")
         data = self._empty((nbytes,), torch.uint8)
         bad = self._empty((1,), torch.int32)
         _ffi.check(
@@ -402,8 +402,10 @@ class Engine:
 
     # -- measurement aid ------------------------------------------------------------------
 
-    def probe_stream_read(self, buf, repeats: int = 5) -> float:
-        """GB/s of the library's plain streaming-read kernel over ``buf`` (best of ``repeats``)."""
+    def probe_stream_read(self, buf, repeats: int = 5, launches: int = 4) -> float:
+        """GB/s of the library's plain streaming-read kernel over ``buf``: best of ``repeats``
+        timed regions of ``launches`` back-to-back launches each (so the queue stays full and
+        the host's launch gap is not billed to the kernel)."""
         torch = _torch()
         out = self._empty((1,), torch.int32)
         n = (buf.numel() * buf.element_size()) & ~15
@@ -412,10 +414,11 @@ class Engine:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             out.zero_()
             e0.record()
-            _ffi.check(self.lib.sai_probe_stream_read(self.ctx, self._ptr(buf), n, self._ptr(out), self._stream()))
+            for _ in range(launches):
+                _ffi.check(self.lib.sai_probe_stream_read(self.ctx, self._ptr(buf), n, self._ptr(out), self._stream()))
             e1.record()
             e1.synchronize()
-            best = max(best, n / (e0.elapsed_time(e1) * 1e-3) / 1e9)
+            best = max(best, launches * n / (e0.elapsed_time(e1) * 1e-3) / 1e9)
         return best
 
     # -- synthetic data --------------------------------------------------------------------

@@ -36,7 +36,7 @@ class ResidentBlock:
     @property
     def packed2_bytes(self) -> int:
         """Algorithmic bytes of one packed2 launch: two bits per genotype, each site's row rounded
-        up to whole bytes (the layout's power-of-two row padding is not counted)."""
+        up to whole bytes (the layout's padding of every site to 64-individual groups is not counted)."""
         return self.n_sites * sum((p.n_ind + 3) // 4 for p in self.pops)
 
 

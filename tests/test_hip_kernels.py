@@ -359,13 +359,20 @@ def test_packed2_layout_equals_int8_path(eng, sizes):
     tiled = [eng.tile(m) for m in mats]
     packed = [eng.pack2(t) for t in tiled]
     for m, pk in zip(mats, packed):  # the documented bit layout
-        chunks = 1
-        while chunks < (m.shape[1] + 63) // 64:
-            chunks *= 2
-        words = pk.data.cpu().numpy().view(np.uint32).reshape(-1, chunks * 4)[:n_sites]
+        n_groups = (m.shape[1] + 63) // 64
+        n_tiles = (n_sites + 63) // 64
+        words = pk.data.cpu().numpy().view(np.uint32).reshape(n_tiles, n_groups, 64, 4)
+        assert pk.data.numel() == n_tiles * n_groups * 1024
         codes = np.where(m < 0, 3, m).astype(np.uint32)
+        sites = np.arange(n_sites)
         for ind in (0, m.shape[1] // 2, m.shape[1] - 1):
-            assert np.array_equal((words[:, ind // 16] >> (2 * (ind % 16))) & 3, codes[:, ind])
+            got = (words[sites // 64, ind // 64, sites % 64, (ind % 64) // 16] >> (2 * (ind % 16))) & 3
+            assert np.array_equal(got, codes[:, ind])
+        if m.shape[1] % 64:  # padding individuals: code 0
+            ind = m.shape[1]
+            assert not ((words[sites // 64, ind // 64, sites % 64, (ind % 64) // 16] >> (2 * (ind % 16))) & 3).any()
+        if n_sites % 64:  # padding sites of the last tile: code 3 everywhere
+            assert (words[-1, :, n_sites % 64:, :] == 0xFFFFFFFF).all()
     n_src = len(sizes) - 2
     sets = [_ffi.make_params(0.4, 0.3, 0.9, [(">=", 0.5)] * n_src, False), _ffi.make_params(1.0, 0.0, 0.5, [("<=", 1.0)] * n_src, True)]
     counts = eng.site_counts(tiled)
