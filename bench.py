@@ -149,6 +149,10 @@ def main() -> None:
     ap.add_argument("--layout", choices=["int8", "packed2"], default="int8",
                     help="int8 = the SoA int8 block the metric is defined on (default); packed2 = the optional "
                     "2-bit layout (4x fewer genotype bytes; reported with its own algorithmic bytes)")
+    ap.add_argument("--overlap", choices=["auto", "on", "off"], default="auto",
+                    help="pipeline every step's windows stage under the next step's site pass on a second stream; "
+                    "auto = on for int8 (windows stage = 4 %% of a step), off for packed2 (site pass too short "
+                    "for the small kernels to find free CUs under it: measured slower)")
     ap.add_argument("--cpu-sites", type=float, default=4e5, help="site prefix timed on the CPU (0 = skip)")
     ap.add_argument("--cpu-workers", type=int, default=0, help="0 = usable cores (affinity mask capped by the cgroup quota)")
     args = ap.parse_args()
@@ -199,7 +203,9 @@ def main() -> None:
     p0, p1 = int(block.pos[0]), int(block.pos[-1])
     windows = default_windows(p0, p1, WIN_LEN, WIN_STEP)
     prm = _ffi.make_params(U_Q_PARAMS["w"], U_Q_PARAMS["x"], U_Q_PARAMS["quantile"], U_Q_PARAMS["y_list"], U_Q_PARAMS["anc"])
-    scorer = ResidentScorer(eng, block, windows, [prm], cap_u=1 << 22, cap_q=1 << 22, layout=args.layout)
+    overlap = args.overlap == "on" or (args.overlap == "auto" and args.layout == "int8")
+    scorer = ResidentScorer(eng, block, windows, [prm], cap_u=1 << 22, cap_q=1 << 22, layout=args.layout,
+                            overlap=overlap)
     alg_bytes = block.genotype_bytes if args.layout == "int8" else block.packed2_bytes
 
     cdev = eng.device if backend == "nccl" else torch.device("cpu")  # where the small collectives live
@@ -213,7 +219,8 @@ def main() -> None:
     def step(timed: bool) -> None:
         scorer.step(time_counts=timed)
         if world > 1:
-            gather_padded(scorer.bufs[0], sizes)
+            with scorer.window_stream():  # ordered after this step's records, not after the next site pass
+                gather_padded(scorer.bufs[0], sizes)
 
     def fence() -> None:
         torch.cuda.synchronize()
@@ -271,6 +278,7 @@ def main() -> None:
                 "workload": f"synthetic chr: {n_sites:.0e} sites, {args.ref} ref/{args.tgt} tgt/{args.src} src diploids, "
                 "50kb/25kb windows, U+Q95 (BASELINE.json configs[2]); one chromosome per GPU",
                 "layout": args.layout,
+                "steps_pipelined": overlap,
                 "n_sites_per_gpu": n_sites,
                 "windows_per_gpu": len(windows),
                 "windows_total": total_windows,

@@ -54,9 +54,14 @@ def synth_block(eng: Engine, seed: int, chrom: int, n_sites: int, n_ref: int, n_
 
 class ResidentScorer:
     def __init__(self, eng: Engine, block: ResidentBlock, windows: Sequence[tuple], sets: Sequence[_ffi.SaiParams],
-                 cap_u: int = 1 << 20, cap_q: int = 1 << 20, layout: str = "int8"):  # fmt: skip
+                 cap_u: int = 1 << 20, cap_q: int = 1 << 20, layout: str = "int8", overlap: bool = False):  # fmt: skip
         """``layout="packed2"`` re-encodes the block once into the 2-bit layout (dosages 0..2 only)
-        and streams that instead: 4x fewer genotype bytes per step, identical results."""
+        and streams that instead: 4x fewer genotype bytes per step, identical results.
+
+        ``overlap=True`` software-pipelines consecutive steps: the windows stage of step k
+        (bounds, statistics, candidate lists, copy to the host) runs on a second HIP stream while
+        the site pass of step k+1 already streams genotypes on the caller's stream; the per-site
+        arrays are double-buffered and events order every reuse.  Same kernels, same results."""
         import torch
 
         if layout not in ("int8", "packed2"):
@@ -76,9 +81,15 @@ class ResidentScorer:
         # at most SAI_FUSED_SETS sets: one fused launch, the per-population counts never leave the chip
         self.fused = n_s <= _ffi.SAI_FUSED_SETS
         self.counts = None if self.fused else torch.empty((len(block.pops), n, 2), dtype=torch.int32, device=dev)
+        self.overlap = bool(overlap)
+        n_buf = 2 if self.overlap else 1
         # the fused pass writes tgt_freq only at candidate sites (all the windows stage reads)
-        self.tgt_freq = torch.full((n,), float("nan"), dtype=torch.float64, device=dev)
-        self.flags = torch.empty((n_s, n), dtype=torch.uint8, device=dev)
+        self._tgt_freq = [torch.full((n,), float("nan"), dtype=torch.float64, device=dev) for _ in range(n_buf)]
+        self._flags = [torch.empty((n_s, n), dtype=torch.uint8, device=dev) for _ in range(n_buf)]
+        self.side = torch.cuda.Stream(device=dev, priority=-1) if self.overlap else None  # small kernels first
+        self._site_done = [torch.cuda.Event() for _ in range(n_buf)]
+        self._win_done = [None] * n_buf  # event after the windows stage that last read buffer b
+        self._k = 0
         self.lo = torch.empty((n_w,), dtype=torch.int32, device=dev)
         self.hi = torch.empty((n_w,), dtype=torch.int32, device=dev)
         self.bufs = eng.alloc_window_bufs(n_s, n_w, cap_u, cap_q)
@@ -87,35 +98,71 @@ class ResidentScorer:
         self.host_totals = torch.empty((2,), dtype=torch.int64).pin_memory()
         self.count_events: list = []  # (start, end) torch events around site_counts, when requested
 
+    @property
+    def tgt_freq(self):
+        """Per-site buffers of the most recent step."""
+        return self._tgt_freq[(self._k - 1) % len(self._tgt_freq)]
+
+    @property
+    def flags(self):
+        return self._flags[(self._k - 1) % len(self._flags)]
+
+    def window_stream(self):
+        """Context manager selecting the stream on which the last step's window records are
+        produced (for follow-up work such as the multi-GPU gather of ``bufs[0]``)."""
+        import contextlib
+
+        import torch
+
+        return torch.cuda.stream(self.side) if self.overlap else contextlib.nullcontext()
+
     def step(self, time_counts: bool = False) -> None:
         import torch
 
-        eng, b = self.eng, self.block
+        eng, blk = self.eng, self.block
+        b = self._k % len(self._flags)
+        tgt_freq, flags = self._tgt_freq[b], self._flags[b]
+        main = torch.cuda.current_stream(eng.device)
+        if self.overlap and self._win_done[b] is not None:
+            main.wait_event(self._win_done[b])  # the windows stage of step k-2 has finished with buffer b
         if time_counts:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
         if self.packed is not None:
             if self.fused:
-                eng.site_pass_packed2(self.packed, b.ploidies, self.sets, out=(self.tgt_freq, self.flags),
-                                      freq_mode="candidates")
+                eng.site_pass_packed2(self.packed, blk.ploidies, self.sets, out=(tgt_freq, flags), freq_mode="candidates")
             else:
-                eng.site_pass_packed2(self.packed, b.ploidies, [], counts=self.counts)
+                eng.site_pass_packed2(self.packed, blk.ploidies, [], counts=self.counts)
         elif self.fused:
-            eng.site_pass(b.pops, b.ploidies, self.sets, out=(self.tgt_freq, self.flags), freq_mode="candidates")
+            eng.site_pass(blk.pops, blk.ploidies, self.sets, out=(tgt_freq, flags), freq_mode="candidates")
         else:
-            eng.site_counts(b.pops, out=self.counts)
+            eng.site_counts(blk.pops, out=self.counts)
         if time_counts:
             e1.record()
             self.count_events.append((e0, e1))
         if not self.fused:
-            eng.site_flags(self.counts, b.ploidies, self.sets, out=(self.tgt_freq, self.flags))
+            eng.site_flags(self.counts, blk.ploidies, self.sets, out=(tgt_freq, flags))
+        self._k += 1
+        if not self.overlap:
+            self._window_stage(tgt_freq, flags)
+            return
+        self._site_done[b].record(main)
+        with torch.cuda.stream(self.side):
+            self.side.wait_event(self._site_done[b])
+            self._window_stage(tgt_freq, flags)
+            done = torch.cuda.Event()
+            done.record(self.side)
+            self._win_done[b] = done
+
+    def _window_stage(self, tgt_freq, flags) -> None:
+        eng, blk = self.eng, self.block
         _ffi.check(
             eng.lib.sai_window_bounds(
-                eng.ctx, eng._ptr(b.pos), b.n_sites, self.n_windows, eng._ptr(self.win_start), eng._ptr(self.win_end),
+                eng.ctx, eng._ptr(blk.pos), blk.n_sites, self.n_windows, eng._ptr(self.win_start), eng._ptr(self.win_end),
                 eng._ptr(self.lo), eng._ptr(self.hi), eng._stream(),
             )
         )  # fmt: skip
-        eng.window_stats_async(self.tgt_freq, self.flags, self.sets, self.lo, self.hi, b.pos, self.bufs)
+        eng.window_stats_async(tgt_freq, flags, self.sets, self.lo, self.hi, blk.pos, self.bufs)
         self.host_records.copy_(self.bufs[0], non_blocking=True)
         self.host_offsets.copy_(self.bufs[1], non_blocking=True)
         self.host_totals.copy_(self.bufs[4], non_blocking=True)
@@ -125,6 +172,8 @@ class ResidentScorer:
         import torch
 
         torch.cuda.current_stream(self.eng.device).synchronize()
+        if self.side is not None:
+            self.side.synchronize()
         need_u, need_q = (int(v) for v in self.host_totals.tolist())
         if need_u > self.bufs[2].numel() or need_q > self.bufs[3].numel():
             raise RuntimeError(
@@ -132,7 +181,9 @@ class ResidentScorer:
             )
         rec = np.frombuffer(self.host_records.numpy().tobytes(), dtype=RECORD_DTYPE).reshape(self.n_sets, self.n_windows)
         off = self.host_offsets.numpy().reshape(self.n_sets, self.n_windows, 2).copy()
-        return WindowResults(rec, off, self.bufs[2][:need_u].cpu().numpy(), self.bufs[3][:need_q].cpu().numpy())
+        with self.window_stream():
+            cdd_u, cdd_q = self.bufs[2][:need_u].cpu().numpy(), self.bufs[3][:need_q].cpu().numpy()
+        return WindowResults(rec, off, cdd_u, cdd_q)
 
 
 def default_windows(pos_first: int, pos_last: int, win_len: int, win_step: int) -> list[tuple]:

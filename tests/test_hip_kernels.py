@@ -410,3 +410,68 @@ def test_stream_read_probe_xor(eng):
         expect = int(np.bitwise_xor.reduce(host)) if n_vec else 0
         assert int(out.cpu().numpy().view(np.uint32)[0]) == expect
     assert eng.probe_stream_read(buf) > 0
+
+
+@pytest.mark.parametrize("layout,n_sets", [("int8", 2), ("packed2", 1), ("int8", 6)])
+def test_overlapped_steps_equal_plain_steps(eng, layout, n_sets):
+    """ResidentScorer(overlap=True) pipelines the windows stage of step k under the site pass of
+    step k+1 on a second stream with double-buffered per-site arrays: after 1, 2 and 5 steps its
+    records, offsets and candidate lists are byte-identical to the plain scorer's."""
+    import torch
+
+    from sai_amd import _ffi
+    from sai_amd.resident import ResidentScorer, default_windows, synth_block
+
+    block = synth_block(eng, 77, 3, 300_000, 130, 70, [2], missing_per_million=2000)
+    pos = block.pos.cpu().numpy()
+    windows = default_windows(int(pos[0]), int(pos[-1]), 50_000, 10_000)
+    sets = [_ffi.make_params(0.05 + 0.01 * s, 0.3, 0.9, [("=", 1.0)], bool(s % 2)) for s in range(n_sets)]
+    plain = ResidentScorer(eng, block, windows, sets, layout=layout)
+    piped = ResidentScorer(eng, block, windows, sets, layout=layout, overlap=True)
+    plain.step()
+    want = plain.results()
+    assert int(want.records["u_count"].sum()) > 0
+    done = 0
+    for n_steps in (1, 1, 3):
+        for _ in range(n_steps):
+            piped.step()
+        done += n_steps
+        got = piped.results()
+        assert got.records.tobytes() == want.records.tobytes(), done
+        assert np.array_equal(got.offsets, want.offsets)
+        assert np.array_equal(got.cdd_u, want.cdd_u) and np.array_equal(got.cdd_q, want.cdd_q)
+        assert torch.equal(piped.flags, plain.flags)
+
+
+def test_gather_on_window_stream_with_rccl(eng):
+    """bench.py's N>1 step on one GPU: a one-rank RCCL group, the records gathered from inside
+    ``scorer.window_stream()`` while the next site pass is already queued on the main stream."""
+    import torch
+    import torch.distributed as dist
+
+    from sai_amd import _ffi
+    from sai_amd.distributed import gather_padded
+    from sai_amd.resident import ResidentScorer, default_windows, synth_block
+
+    if dist.is_initialized():
+        pytest.skip("a process group already exists in this process")
+    block = synth_block(eng, 78, 2, 200_000, 64, 64, [1])
+    pos = block.pos.cpu().numpy()
+    windows = default_windows(int(pos[0]), int(pos[-1]), 50_000, 25_000)
+    sets = [_ffi.make_params(0.05, 0.3, 0.9, [("=", 1.0)], True)]
+    scorer = ResidentScorer(eng, block, windows, sets, overlap=True)
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29631", rank=0, world_size=1,
+                            device_id=eng.device)  # fmt: skip
+    try:
+        sizes = [scorer.bufs[0].numel()]
+        got = None
+        for _ in range(3):
+            scorer.step()
+            with scorer.window_stream():
+                got = gather_padded(scorer.bufs[0], sizes)
+        res = scorer.results()
+        torch.cuda.synchronize()
+        assert got is not None and len(got) == 1
+        assert got[0].cpu().numpy().tobytes() == res.records.tobytes()
+    finally:
+        dist.destroy_process_group()
