@@ -61,7 +61,7 @@ class ResidentScorer:
         ``overlap=True`` software-pipelines consecutive steps: the windows stage of step k
         (bounds, statistics, candidate lists, copy to the host) runs on a second HIP stream while
         the site pass of step k+1 already streams genotypes on the caller's stream; the per-site
-        arrays are double-buffered and events order every reuse.  Same kernels, same results."""
+        arrays are triple-buffered and events order every reuse.  Same kernels, same results."""
         import torch
 
         if layout not in ("int8", "packed2"):
@@ -82,7 +82,9 @@ class ResidentScorer:
         self.fused = n_s <= _ffi.SAI_FUSED_SETS
         self.counts = None if self.fused else torch.empty((len(block.pops), n, 2), dtype=torch.int32, device=dev)
         self.overlap = bool(overlap)
-        n_buf = 2 if self.overlap else 1
+        # three sets: under a saturated HBM stream the small kernels of step k only finish when site
+        # pass k+1 does, so with two sets site pass k+2 would wait for them at every step
+        n_buf = 3 if self.overlap else 1
         # the fused pass writes tgt_freq only at candidate sites (all the windows stage reads)
         self._tgt_freq = [torch.full((n,), float("nan"), dtype=torch.float64, device=dev) for _ in range(n_buf)]
         self._flags = [torch.empty((n_s, n), dtype=torch.uint8, device=dev) for _ in range(n_buf)]
@@ -124,7 +126,7 @@ class ResidentScorer:
         tgt_freq, flags = self._tgt_freq[b], self._flags[b]
         main = torch.cuda.current_stream(eng.device)
         if self.overlap and self._win_done[b] is not None:
-            main.wait_event(self._win_done[b])  # the windows stage of step k-2 has finished with buffer b
+            main.wait_event(self._win_done[b])  # the windows stage that last read buffer b (3 steps ago) is done
         if time_counts:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()

@@ -415,7 +415,7 @@ def test_stream_read_probe_xor(eng):
 @pytest.mark.parametrize("layout,n_sets", [("int8", 2), ("packed2", 1), ("int8", 6)])
 def test_overlapped_steps_equal_plain_steps(eng, layout, n_sets):
     """ResidentScorer(overlap=True) pipelines the windows stage of step k under the site pass of
-    step k+1 on a second stream with double-buffered per-site arrays: after 1, 2 and 5 steps its
+    step k+1 on a second stream with triple-buffered per-site arrays: after 1, 2 and 5 steps its
     records, offsets and candidate lists are byte-identical to the plain scorer's."""
     import torch
 
