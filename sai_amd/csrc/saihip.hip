@@ -1108,30 +1108,50 @@ __global__ __launch_bounds__(64) void site_absdiff_kernel(AbsArgs a) {
     for (int k = 0; k < NS; ++k)
 #pragma unroll
       for (int j = 0; j < 16; ++j) sum32[k][j] = 0;
-    const int n_iter = (a.n_ind + 15) >> 4;
+    const int n_full = a.n_ind >> 4;         // iterations in which all 16 rows exist
+    const int n_iter = (a.n_ind + 15) >> 4;  // plus at most one partial iteration
     int it = 0;
     while (it < n_iter) {
-      const int chunk_end = min(n_iter, it + kChunkIters);  // 255 * 248 < 2^16: the fields cannot overflow
+      const int full_end = min(n_full, it + kChunkIters);  // 255 * (248 + 4) < 2^16: the fields cannot overflow
       uint32_t acc_lo[NS][4], acc_hi[NS][4];
 #pragma unroll
       for (int k = 0; k < NS; ++k)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc_lo[k][j] = acc_hi[k][j] = 0;
-      for (; it < chunk_end; ++it) {
-        if (it * 16 + r < a.n_ind) {  // only the last group of rows can be partial
-          const u32x4 v = __builtin_nontemporal_load(base + it * 64);
-          const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+      auto consume = [&](const u32x4& v) {
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const uint32_t u = w[j] ^ 0x80808080u;
-            const uint32_t lo = u & 0x00FF00FFu, hi = (u >> 8) & 0x00FF00FFu;
+        for (int j = 0; j < 4; ++j) {
+          const uint32_t u = w[j] ^ 0x80808080u;
+          const uint32_t lo = u & 0x00FF00FFu, hi = (u >> 8) & 0x00FF00FFu;
 #pragma unroll
-            for (int k = 0; k < NS; ++k) {
-              acc_lo[k][j] += absdiff_u16x2(lo, sv_lo[k][j]);
-              acc_hi[k][j] += absdiff_u16x2(hi, sv_hi[k][j]);
-            }
+          for (int k = 0; k < NS; ++k) {
+            acc_lo[k][j] += absdiff_u16x2(lo, sv_lo[k][j]);
+            acc_hi[k][j] += absdiff_u16x2(hi, sv_hi[k][j]);
           }
         }
+      };
+      for (; it + kUnroll <= full_end; it += kUnroll) {
+        u32x4 v[kUnroll];
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) v[u] = __builtin_nontemporal_load(base + (it + u) * 64);
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) consume(v[u]);
+      }
+      // tail of the population (as in accumulate_rows): one batch of clamped loads, rows that do
+      // not exist are skipped after the loads have been issued
+      const int last = (full_end == n_full) ? n_iter : full_end;
+      if (it < last) {
+        u32x4 v[kUnroll];
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) {
+          const int row = min(it + u, last - 1) * 16 + r;
+          v[u] = __builtin_nontemporal_load(base + (min(row, a.n_ind - 1) - r) * 4);
+        }
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u)
+          if ((it + u < last) && ((it + u) * 16 + r < a.n_ind)) consume(v[u]);
+        it = last;
       }
 #pragma unroll
       for (int k = 0; k < NS; ++k)
@@ -1150,7 +1170,7 @@ __global__ __launch_bounds__(64) void site_absdiff_kernel(AbsArgs a) {
       reduce_scatter_step<8, 16>(sum32[k], lane);
       reduce_scatter_step<4, 8>(sum32[k], lane);
       reduce_scatter_step<2, 4>(sum32[k], lane);
-      if (site < a.n_sites) a.out[static_cast<int64_t>(a.a0 + k) * a.n_sites + site] = sum32[k][0];
+      if (site < a.n_sites) __builtin_nontemporal_store(sum32[k][0], a.out + static_cast<int64_t>(a.a0 + k) * a.n_sites + site);
     }
   }
 }
@@ -1748,7 +1768,7 @@ int sai_site_absdiff(sai_ctx* ctx, int64_t n_sites, const sai_pop* pop, const sa
   a.src_tiles = src->tiles;
   a.n_src_ind = src->n_ind;
   a.out = out;
-  const int64_t max_grid = static_cast<int64_t>(ctx->n_cu) * 64;
+  const int64_t max_grid = static_cast<int64_t>(ctx->n_cu) * kStreamWavesPerCu;
   const dim3 grid(static_cast<unsigned>(a.n_tiles < max_grid ? a.n_tiles : max_grid));
   hipStream_t st = static_cast<hipStream_t>(stream);
   for (int a0 = 0; a0 < src->n_ind; a0 += 2) {  // two source individuals per pass over the population
