@@ -1,7 +1,7 @@
 """numpy statement of the "synth-v1" generator -- TEST INFRASTRUCTURE ONLY.
 
 The generator is this repo's own, not the reference's; this file is the
-independent definition the HIP/host implementation in sai_amd/csrc/saihip.hip is tested
+independent definition the HIP/host implementation in sai_amd/csrc/synth.hip is tested
 against.  All arithmetic is uint64 wrap-around / IEEE f64.
 
   mix64            splitmix64 finaliser

@@ -1,0 +1,71 @@
+// Shared by every translation unit of libsaihip: error reporting, the context, launch helpers.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <limits>
+#include <new>
+
+#include "saihip.h"
+
+// core.hip; also called by vcf_ingest.cpp.  Stores the thread's message, returns `code`.
+extern "C" int sai_set_error(int code, const char* fmt, ...);
+#define fail sai_set_error
+
+#define SAI_HIP(call)                                                                     \
+  do {                                                                                    \
+    hipError_t e_ = (call);                                                               \
+    if (e_ != hipSuccess)                                                                 \
+      return fail(SAI_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_),     \
+                  __FILE__, __LINE__);                                                    \
+  } while (0)
+
+constexpr int kTile = SAI_TILE_SITES;
+constexpr int kMaxPops = 2 + SAI_MAX_SRC;
+constexpr int kProbeWavesPerCu = 32;
+// Grid of the streaming passes: 16 single-wave workgroups per CU = 4 waves per SIMD, enough to
+// saturate HBM (measured flat from 8 to 611 per CU) while leaving registers and LDS on every SIMD
+// for the small kernels the pipelined scorer runs on a second stream under them.
+constexpr int kStreamWavesPerCu = 16;
+
+struct sai_ctx {
+  int device;
+  int n_cu;
+  uint32_t* probe_partials;  // n_cu * kProbeWavesPerCu words, the only scratch the library owns
+};
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+inline int enter(sai_ctx* ctx) {
+  if (!ctx) return fail(SAI_ERR_ARG, "ctx is NULL");
+  SAI_HIP(hipSetDevice(ctx->device));
+  return SAI_OK;
+}
+
+inline int check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(SAI_ERR_HIP, "launch of %s failed: %s", what, hipGetErrorString(e));
+  return SAI_OK;
+}
+
+// site_pass.hip: argument checks of a parameter-set array (n_src < 0: any number of sources)
+int check_sets(int32_t n_sets, const sai_params* sets, int32_t n_src);
+
+inline unsigned stream_grid(const sai_ctx* ctx, int64_t n_tiles) {
+  const int64_t max_grid = static_cast<int64_t>(ctx->n_cu) * kStreamWavesPerCu;  // grid-stride beyond this
+  return static_cast<unsigned>(n_tiles < max_grid ? n_tiles : max_grid);
+}
+
+// XCD-aware block order: consecutive workgroup ids go round-robin over the 8 XCDs; give each XCD a
+// contiguous run of (overlapping) windows so their shared sites stay in one L2.
+__device__ __forceinline__ int xcd_contiguous(int b, int n_blocks) {
+  const int per = n_blocks >> 3;
+  return (per > 0 && b < per * 8) ? (b & 7) * per + (b >> 3) : b;
+}

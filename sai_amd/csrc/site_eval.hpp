@@ -1,0 +1,87 @@
+// The per-site decision of compute_matching_loci, shared by site_flags, the fused site pass and
+// the packed2 site pass.
+#pragma once
+
+#include "common.hpp"
+
+// ------------------------------------------------------------------------------------------
+// Per-site decision: calc_freq's f64 division and compute_matching_loci for every parameter set,
+// exactly as numpy evaluates it.  One device function, used by the stand-alone site_flags kernel
+// (counts read back from HBM) and by the fused tail of site_counts (counts still in LDS).
+// ------------------------------------------------------------------------------------------
+
+__device__ __forceinline__ bool cmp_op(int op, double f, double y) {
+  switch (op) {
+    case SAI_OP_EQ: return f == y;
+    case SAI_OP_LT: return f < y;
+    case SAI_OP_GT: return f > y;
+    case SAI_OP_LE: return f <= y;
+    default: return f >= y;
+  }
+}
+
+// get(p) -> uint2 {alt_sum, n_called} of population p at this site.
+template <typename GetCounts>
+__device__ __forceinline__ void eval_site(int n_pops, const int32_t* ploidy, GetCounts get, int n_sets,
+                                          const sai_params* sets, int64_t site, int64_t n_sites, double* tgt_freq,
+                                          uint8_t* flags, double* adj_freq, bool sparse_freq = false) {
+  double f[kMaxPops];
+  bool valid = true;
+#pragma unroll
+  for (int p = 0; p < kMaxPops; ++p) {
+    if (p < n_pops) {
+      const uint2 c = get(p);
+      const int64_t den = static_cast<int64_t>(c.y) * ploidy[p];
+      const double v = den > 0 ? static_cast<double>(c.x) / static_cast<double>(den)
+                               : std::numeric_limits<double>::quiet_NaN();
+      f[p] = v;
+      valid = valid && (v >= 0.0) && (v <= 1.0);  // false for NaN; the quotient is never inf
+    } else {
+      f[p] = 0.0;
+    }
+  }
+  bool any_cond = false;
+  const int n_src = n_pops - 2;
+  for (int s = 0; s < n_sets; ++s) {
+    const sai_params& ps = sets[s];
+    bool hit_y = true, hit_m = true;
+#pragma unroll
+    for (int k = 0; k < SAI_MAX_SRC; ++k) {
+      if (k < n_src) {
+        hit_y = hit_y && cmp_op(ps.op[k], f[2 + k], ps.y[k]);
+        hit_m = hit_m && cmp_op(ps.op[k], f[2 + k], ps.one_minus_y[k]);
+      }
+    }
+    const bool anc = ps.anc_allele_available != 0;
+    const bool inverted = !anc && hit_m && valid;
+    const bool hit = anc ? hit_y : (hit_y || hit_m);
+    const double rf = inverted ? 1.0 - f[0] : f[0];
+    const double tf = inverted ? 1.0 - f[1] : f[1];
+    const bool cond = valid && hit && (rf < ps.w);
+    const bool ucand = cond && (tf > ps.x);
+    any_cond = any_cond || cond;
+    // non-temporal stores: measured on MI355X, plain stores in the middle of the genotype stream cost
+    // twice as much of the pass as streaming ones
+    __builtin_nontemporal_store(static_cast<uint8_t>((cond ? 1 : 0) | (ucand ? 2 : 0) | (inverted ? 4 : 0)),
+                                flags + static_cast<int64_t>(s) * n_sites + site);
+    if (adj_freq) {
+      adj_freq[(static_cast<int64_t>(s) * 2 + 0) * n_sites + site] = rf;
+      adj_freq[(static_cast<int64_t>(s) * 2 + 1) * n_sites + site] = tf;
+    }
+  }
+  // The windows stage reads tgt_freq only where a set's bit 0 is up (about 1 site in 1000), and
+  // dense f64 stores in the middle of the genotype stream cost ~10 % of the pass (HBM read/write
+  // turnarounds): SAI_FREQ_CANDIDATES leaves every other entry untouched.
+  if (!sparse_freq || any_cond) __builtin_nontemporal_store(f[1], tgt_freq + site);
+}
+
+constexpr int kFusedSets = 4;  // parameter sets the fused tail of site_counts can carry in its arguments
+
+struct FusedArgs {
+  int32_t n_sets;  // 0 = plain site_counts
+  int32_t sparse_freq;
+  int32_t ploidy[kMaxPops];
+  double* tgt_freq;
+  uint8_t* flags;
+  sai_params sets[kFusedSets];
+};

@@ -1,0 +1,231 @@
+// site_counts / site_flags / the fused site pass: the hot kernel of the U / Q path.
+
+#include "site_eval.hpp"
+#include "stream_loops.hpp"
+
+namespace {
+
+struct FlagArgs {
+  int64_t n_sites;
+  int32_t n_pops;
+  int32_t n_sets;
+  int32_t ploidy[kMaxPops];
+  const uint2* counts;
+  double* tgt_freq;
+  uint8_t* flags;
+  double* adj_freq;
+  sai_params sets[SAI_MAX_SETS];
+};
+
+__global__ __launch_bounds__(256) void site_flags_kernel(FlagArgs a) {
+  const int64_t site = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (site >= a.n_sites) return;
+  eval_site(
+      a.n_pops, a.ploidy, [&](int p) { return a.counts[static_cast<int64_t>(p) * a.n_sites + site]; }, a.n_sets, a.sets,
+      site, a.n_sites, a.tgt_freq, a.flags, a.adj_freq);
+}
+
+// ------------------------------------------------------------------------------------------
+// site_counts: the HBM-bound kernel.
+//
+// One wavefront owns one 64-site tile and streams every population's rows of that tile.  A wave
+// instruction loads 16 rows x 64 B = 1 KiB contiguous: lane l holds individual (16*q + l/4),
+// sites (l%4)*16 .. +15 as four 32-bit words.  Bytes are accumulated SWAR-style into 16-bit
+// (dosage) and 8-bit (missing) fields, widened to 32 bit every <= 248 rows per lane, and the 16
+// row-groups are combined with a 4-step butterfly reduce-scatter so that lane l ends with the
+// totals of site (l%4)*16 + l/4.  No LDS, no barriers; occupancy and 4-8 KiB of loads in flight
+// per wave hide HBM latency.
+// ------------------------------------------------------------------------------------------
+
+struct PopArg {
+  const int8_t* tiles;
+  int32_t n_ind;
+  int32_t pad;
+};
+
+struct CountsArgs {
+  int64_t n_sites;
+  int64_t n_tiles;
+  int32_t n_pops;
+  PopArg pop[kMaxPops];
+  uint2* counts;
+};
+
+// MULTI: some population has more than 16 * kChunkIters individuals, so the packed fields are
+// widened several times per population (keeps 32 more registers live across the load loop).
+// FUSED: evaluate the parameter sets at the end of each tile (site_flags folded in).
+template <bool MULTI, bool FUSED>
+__global__ __launch_bounds__(64) void site_counts_kernel(CountsArgs a, FusedArgs fa) {
+  // FUSED: each lane parks its site's {alt_sum, n_called} per population here and evaluates the
+  // parameter sets itself once all populations of the tile are done (only the lane that wrote a
+  // slot reads it back, so no synchronisation is involved)
+  __shared__ uint2 stash[FUSED ? kMaxPops : 1][FUSED ? 64 : 1];
+  const int lane = threadIdx.x;
+  const int r = lane >> 2;
+  for (int64_t tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
+    for (int p = 0; p < a.n_pops; ++p) {
+      const int n_ind = a.pop[p].n_ind;
+      const u32x4* base =
+          reinterpret_cast<const u32x4*>(a.pop[p].tiles + tile * static_cast<int64_t>(n_ind) * kTile) + lane;
+      const int n_full = n_ind >> 4;         // iterations in which all 16 rows exist
+      const int n_iter = (n_ind + 15) >> 4;  // plus at most one partial iteration
+      uint32_t sum32[16], miss32[16];
+      int it = 0;
+      if (MULTI) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) sum32[j] = miss32[j] = 0;
+        while (it < n_iter) {
+          uint32_t lo[4] = {0, 0, 0, 0}, hi[4] = {0, 0, 0, 0}, ms[4] = {0, 0, 0, 0};
+          accumulate_rows(base, it, min(n_full, it + kChunkIters), n_full, n_iter, n_ind, r, lo, hi, ms);
+          widen_fields(lo, hi, ms, sum32, miss32);
+        }
+      } else {  // n_iter <= kChunkIters + 1: one pass, widen once
+        uint32_t lo[4] = {0, 0, 0, 0}, hi[4] = {0, 0, 0, 0}, ms[4] = {0, 0, 0, 0};
+        accumulate_rows(base, it, n_full, n_full, n_iter, n_ind, r, lo, hi, ms);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) sum32[j] = miss32[j] = 0;
+        widen_fields(lo, hi, ms, sum32, miss32);
+      }
+      reduce_scatter_step<16, 32>(sum32, lane);
+      reduce_scatter_step<8, 16>(sum32, lane);
+      reduce_scatter_step<4, 8>(sum32, lane);
+      reduce_scatter_step<2, 4>(sum32, lane);
+      reduce_scatter_step<16, 32>(miss32, lane);
+      reduce_scatter_step<8, 16>(miss32, lane);
+      reduce_scatter_step<4, 8>(miss32, lane);
+      reduce_scatter_step<2, 4>(miss32, lane);
+      const int64_t site = tile * kTile + (lane & 3) * 16 + r;
+      const uint2 cnt = make_uint2(sum32[0], static_cast<uint32_t>(n_ind) - miss32[0]);
+      if (a.counts && site < a.n_sites) store_counts_nt(a.counts + static_cast<int64_t>(p) * a.n_sites + site, cnt);
+      if (FUSED) stash[p][lane] = cnt;
+    }
+    if (FUSED) {
+      const int64_t site = tile * kTile + (lane & 3) * 16 + r;
+      if (site < a.n_sites)
+        eval_site(
+            a.n_pops, fa.ploidy, [&](int p) { return stash[p][lane]; }, fa.n_sets, fa.sets, site,
+            a.n_sites, fa.tgt_freq, fa.flags, nullptr, fa.sparse_freq != 0);
+    }
+  }
+}
+
+}  // namespace
+
+int check_sets(int32_t n_sets, const sai_params* sets, int32_t n_src) {
+  if (n_sets < 1 || n_sets > SAI_MAX_SETS) return fail(SAI_ERR_ARG, "n_sets must be 1..%d", SAI_MAX_SETS);
+  if (!sets) return fail(SAI_ERR_ARG, "sets_host is NULL");
+  for (int s = 0; s < n_sets; ++s) {
+    if (n_src >= 0 && sets[s].n_src != n_src)
+      return fail(SAI_ERR_ARG, "set %d: n_src %d != source populations %d", s, sets[s].n_src, n_src);
+    for (int k = 0; k < sets[s].n_src && k < SAI_MAX_SRC; ++k)
+      if (sets[s].op[k] < SAI_OP_EQ || sets[s].op[k] > SAI_OP_GE)
+        return fail(SAI_ERR_ARG, "set %d: bad operator %d", s, sets[s].op[k]);
+  }
+  return SAI_OK;
+}
+
+// shared by sai_site_counts (n_sets == 0) and sai_site_pass
+static int launch_site_counts(sai_ctx* ctx, int64_t n_sites, int32_t n_pops, const sai_pop* pops, uint32_t* counts,
+                              int32_t n_sets, const sai_params* sets_host, int32_t freq_mode, double* tgt_freq,
+                              uint8_t* flags, void* stream) {
+  if (n_sites < 0 || n_sites >= 0x7FFFFFFFll) return fail(SAI_ERR_ARG, "n_sites out of range");
+  if (n_pops < 1 || n_pops > kMaxPops) return fail(SAI_ERR_ARG, "n_pops must be 1..%d", kMaxPops);
+  if (!pops) return fail(SAI_ERR_ARG, "pops is NULL");
+  if (n_sites == 0) return SAI_OK;
+  CountsArgs a;
+  FusedArgs fa;
+  std::memset(&fa, 0, sizeof(fa));
+  a.n_sites = n_sites;
+  a.n_tiles = (n_sites + kTile - 1) / kTile;
+  a.n_pops = n_pops;
+  bool multi = false;
+  for (int p = 0; p < n_pops; ++p) {
+    if (pops[p].n_ind < 0) return fail(SAI_ERR_ARG, "population %d: negative n_ind", p);
+    if (pops[p].n_ind > 0 && !pops[p].tiles) return fail(SAI_ERR_ARG, "population %d: NULL tiles", p);
+    if (pops[p].n_ind > (1 << 24)) return fail(SAI_ERR_UNSUPPORTED, "population %d: n_ind > 2^24", p);
+    if (reinterpret_cast<uintptr_t>(pops[p].tiles) & 15u)
+      return fail(SAI_ERR_ARG, "population %d: tiles must be 16-byte aligned", p);
+    a.pop[p].tiles = pops[p].tiles;
+    a.pop[p].n_ind = pops[p].n_ind;
+    a.pop[p].pad = 0;
+    multi = multi || pops[p].n_ind > 16 * kChunkIters;
+    fa.ploidy[p] = pops[p].ploidy;
+  }
+  a.counts = reinterpret_cast<uint2*>(counts);
+  fa.n_sets = n_sets;
+  fa.sparse_freq = freq_mode == SAI_FREQ_CANDIDATES;
+  fa.tgt_freq = tgt_freq;
+  fa.flags = flags;
+  for (int s = 0; s < n_sets; ++s) fa.sets[s] = sets_host[s];
+  const dim3 grid(stream_grid(ctx, a.n_tiles));
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (n_sets > 0) {
+    if (multi) hipLaunchKernelGGL((site_counts_kernel<true, true>), grid, dim3(64), 0, st, a, fa);
+    else hipLaunchKernelGGL((site_counts_kernel<false, true>), grid, dim3(64), 0, st, a, fa);
+  } else {
+    if (multi) hipLaunchKernelGGL((site_counts_kernel<true, false>), grid, dim3(64), 0, st, a, fa);
+    else hipLaunchKernelGGL((site_counts_kernel<false, false>), grid, dim3(64), 0, st, a, fa);
+  }
+  return check_launch("site_counts");
+}
+
+// ------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------
+
+extern "C" {
+
+int sai_site_counts(sai_ctx* ctx, int64_t n_sites, int32_t n_pops, const sai_pop* pops, uint32_t* counts,
+                    void* stream) {
+  if (int rc = enter(ctx)) return rc;
+  if (!counts && n_sites > 0) return fail(SAI_ERR_ARG, "counts is NULL");
+  return launch_site_counts(ctx, n_sites, n_pops, pops, counts, 0, nullptr, SAI_FREQ_DENSE, nullptr, nullptr, stream);
+}
+
+int sai_site_pass(sai_ctx* ctx, int64_t n_sites, int32_t n_pops, const sai_pop* pops, uint32_t* counts,
+                  int32_t n_sets, const sai_params* sets_host, int32_t freq_mode, double* tgt_freq, uint8_t* flags,
+                  void* stream) {
+  if (int rc = enter(ctx)) return rc;
+  if (freq_mode != SAI_FREQ_DENSE && freq_mode != SAI_FREQ_CANDIDATES) return fail(SAI_ERR_ARG, "bad freq_mode %d", freq_mode);
+  if (n_pops < 2) return fail(SAI_ERR_ARG, "n_pops must be >= 2 (ref, tgt, sources)");
+  if (n_sets > kFusedSets)
+    return fail(SAI_ERR_UNSUPPORTED, "sai_site_pass carries at most %d parameter sets; use sai_site_counts + sai_site_flags",
+                kFusedSets);
+  if (int rc = check_sets(n_sets, sets_host, n_pops - 2)) return rc;
+  if (pops)
+    for (int p = 0; p < n_pops && p < kMaxPops; ++p)
+      if (pops[p].ploidy <= 0) return fail(SAI_ERR_ARG, "ploidy[%d] must be positive", p);
+  if (n_sites > 0 && (!tgt_freq || !flags)) return fail(SAI_ERR_ARG, "NULL buffer");
+  return launch_site_counts(ctx, n_sites, n_pops, pops, counts, n_sets, sets_host, freq_mode, tgt_freq, flags, stream);
+}
+
+int sai_site_flags(sai_ctx* ctx, int64_t n_sites, int32_t n_pops, const int32_t* ploidy_host,
+                   const uint32_t* counts, int32_t n_sets, const sai_params* sets_host, double* tgt_freq,
+                   uint8_t* flags, double* adj_freq, void* stream) {
+  if (int rc = enter(ctx)) return rc;
+  if (n_sites < 0 || n_sites >= 0x7FFFFFFFll) return fail(SAI_ERR_ARG, "n_sites out of range");
+  if (n_pops < 2 || n_pops > kMaxPops) return fail(SAI_ERR_ARG, "n_pops must be 2..%d (ref, tgt, sources)", kMaxPops);
+  if (!ploidy_host) return fail(SAI_ERR_ARG, "ploidy_host is NULL");
+  if (int rc = check_sets(n_sets, sets_host, n_pops - 2)) return rc;
+  if (n_sites == 0) return SAI_OK;
+  if (!counts || !tgt_freq || !flags) return fail(SAI_ERR_ARG, "NULL buffer");
+  FlagArgs a;
+  std::memset(&a, 0, sizeof(a));
+  a.n_sites = n_sites;
+  a.n_pops = n_pops;
+  a.n_sets = n_sets;
+  for (int p = 0; p < n_pops; ++p) {
+    if (ploidy_host[p] <= 0) return fail(SAI_ERR_ARG, "ploidy[%d] must be positive", p);
+    a.ploidy[p] = ploidy_host[p];
+  }
+  a.counts = reinterpret_cast<const uint2*>(counts);
+  a.tgt_freq = tgt_freq;
+  a.flags = flags;
+  a.adj_freq = adj_freq;
+  for (int s = 0; s < n_sets; ++s) a.sets[s] = sets_host[s];
+  const unsigned grid = static_cast<unsigned>((n_sites + 255) / 256);
+  hipLaunchKernelGGL(site_flags_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+  return check_launch("site_flags");
+}
+
+}  // extern "C"

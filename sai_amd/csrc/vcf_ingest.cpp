@@ -25,7 +25,7 @@
 
 #include "saihip.h"
 
-extern "C" int sai_set_error(int code, const char* fmt, ...);  // defined in saihip.hip
+extern "C" int sai_set_error(int code, const char* fmt, ...);  // defined in core.hip
 
 namespace {
 

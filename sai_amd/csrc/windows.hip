@@ -1,0 +1,439 @@
+// Window stage: site-index ranges of the windows, U / Q records and candidate lists.
+
+#include "common.hpp"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------
+// window_bounds
+// ------------------------------------------------------------------------------------------
+
+__global__ __launch_bounds__(256) void window_bounds_kernel(const int32_t* __restrict__ pos,
+                                                             int64_t n_sites, int32_t n_windows,
+                                                             const int64_t* __restrict__ ws,
+                                                             const int64_t* __restrict__ we,
+                                                             int32_t* __restrict__ lo,
+                                                             int32_t* __restrict__ hi) {
+  const int w = blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= n_windows) return;
+  const int64_t s = ws[w], e = we[w];
+  int64_t a = 0, b = n_sites;  // first index with pos >= s
+  while (a < b) {
+    const int64_t m = (a + b) >> 1;
+    if (static_cast<int64_t>(pos[m]) < s) a = m + 1; else b = m;
+  }
+  const int64_t first = a;
+  b = n_sites;                 // first index with pos > e
+  while (a < b) {
+    const int64_t m = (a + b) >> 1;
+    if (static_cast<int64_t>(pos[m]) <= e) a = m + 1; else b = m;
+  }
+  lo[w] = static_cast<int32_t>(first);
+  hi[w] = static_cast<int32_t>(a < first ? first : a);
+}
+
+// ------------------------------------------------------------------------------------------
+// window statistics.  Four launches, no atomics on shared words (a returning atomic on one
+// address saturates at ~90 per microsecond, which at one reservation per window was 85 % of the
+// old single-kernel version):
+//   window_stats_wave   one WAVEFRONT per (window, set): U count, condition count, Q, Q-list size
+//   window_stats_heavy  workgroup fallback for windows with > kWaveCap qualifying sites
+//   window_scan         exclusive prefix sums of the list sizes -> CSR offsets + totals
+//   window_lists        one wavefront per (window, set): candidate lists in ascending site order
+// ------------------------------------------------------------------------------------------
+
+struct WinArgs {
+  int64_t n_sites;
+  const double* tgt_freq;
+  const uint8_t* flags;
+  int32_t n_sets;
+  int32_t n_windows;
+  const int32_t* lo;
+  const int32_t* hi;
+  const int32_t* pos;
+  sai_window_record* records;
+  int64_t* cdd_off;
+  int32_t* cdd_u;
+  int64_t cap_u;
+  int32_t* cdd_q;
+  int64_t cap_q;
+  int64_t* cdd_total;
+  double quantile[SAI_MAX_SETS];
+};
+
+constexpr int kWinThreads = 256;
+constexpr int kWaveCap = 256;       // qualifying sites a wave keeps in LDS; more -> heavy kernel
+constexpr int kSelCap = 4096;       // values the heavy kernel keeps in LDS (32 KiB); beyond: re-read
+constexpr int32_t kHeavyMark = -1;  // records[].n_cdd_q value that hands a window to the fallback
+
+__device__ __forceinline__ double eff_freq(const double* tgt_freq, uint8_t f, int64_t i) {
+  const double v = tgt_freq[i];
+  return (f & 4) ? 1.0 - v : v;
+}
+
+// numpy 'linear' quantile from the two neighbouring order statistics (numpy _quantile/_lerp):
+// virtual index v = (n-1)*q; a + (b-a)*g, or b - (b-a)*(1-g) when g >= 0.5.
+__device__ __forceinline__ double numpy_lerp(double x0, double x1, double v, double fl_v) {
+  const double g = v - fl_v;
+  const double d = x1 - x0;
+  return (g >= 0.5) ? x1 - d * (1.0 - g) : x0 + d * g;
+}
+
+__device__ __forceinline__ void wave_lds_fence() {
+  // LDS operations of one wave execute in order; this only stops the compiler from moving
+  // accesses across the point where lanes start reading what other lanes of the wave wrote.
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__global__ __launch_bounds__(256) void window_stats_wave_kernel(WinArgs a) {
+  __shared__ double sh_vals[4][kWaveCap];
+  const int lane = threadIdx.x & 63;
+  const int wv = threadIdx.x >> 6;
+  const int w = xcd_contiguous(blockIdx.x, gridDim.x) * 4 + wv;
+  if (w >= a.n_windows) return;  // whole wave
+  const int set = blockIdx.y;
+  const int lo = a.lo[w], hi = a.hi[w];
+  const uint8_t* fl = a.flags + static_cast<int64_t>(set) * a.n_sites;
+  const int64_t ridx = static_cast<int64_t>(set) * a.n_windows + w;
+  double* vals = sh_vals[wv];
+  const unsigned long long lt_mask = (1ull << lane) - 1ull;
+
+  // pass 1: counts + compaction of the qualifying effective frequencies into LDS
+  uint32_t n_c = 0, n_u = 0;
+  for (int i0 = lo; i0 < hi; i0 += 64) {
+    const int i = i0 + lane;
+    const uint8_t f = i < hi ? fl[i] : static_cast<uint8_t>(0);
+    const bool c = (f & 1u) != 0;
+    const unsigned long long bc = __ballot(c);
+    if (c) {
+      const uint32_t slot = n_c + __popcll(bc & lt_mask);
+      if (slot < kWaveCap) vals[slot] = eff_freq(a.tgt_freq, f, i);
+    }
+    n_c += __popcll(bc);
+    n_u += __popcll(__ballot((f & 2u) != 0));
+  }
+  double q = std::numeric_limits<double>::quiet_NaN();
+  uint32_t n_q = 0;
+  if (n_c > kWaveCap) {
+    n_q = static_cast<uint32_t>(kHeavyMark);  // uniform: the workgroup kernel finishes this window
+  } else if (n_c > 0) {
+    wave_lds_fence();
+    const double v = static_cast<double>(n_c - 1) * a.quantile[set];
+    const bool take_max = v >= static_cast<double>(n_c - 1);  // at/after the last index: maximum
+    const double fl_v = floor(v);
+    const uint32_t k0 = take_max ? n_c - 1 : static_cast<uint32_t>(fl_v);
+    const uint32_t k1 = take_max ? n_c - 1 : k0 + 1;
+    double x0 = 0.0, x1 = 0.0;
+    // rank counting: rank(e) = #{j: v_j < v_e or (v_j == v_e and j < e)} is a permutation
+    for (uint32_t e0 = 0; e0 < n_c; e0 += 64) {
+      const uint32_t e = e0 + lane;
+      const bool act = e < n_c;
+      const double ve = act ? vals[e] : 0.0;
+      uint32_t rank = 0;
+      for (uint32_t j = 0; j < n_c; ++j) {
+        const double vj = vals[j];  // same address in every lane: LDS broadcast
+        rank += (vj < ve) || (vj == ve && j < e);
+      }
+      const unsigned long long h0 = __ballot(act && rank == k0);
+      const unsigned long long h1 = __ballot(act && rank == k1);
+      if (h0) x0 = __shfl(ve, __ffsll(static_cast<long long>(h0)) - 1, 64);
+      if (h1) x1 = __shfl(ve, __ffsll(static_cast<long long>(h1)) - 1, 64);
+    }
+    q = take_max ? x0 : numpy_lerp(x0, x1, v, fl_v);
+    for (uint32_t e0 = 0; e0 < n_c; e0 += 64) {
+      const uint32_t e = e0 + lane;
+      n_q += __popcll(__ballot(e < n_c && vals[e] >= q));
+    }
+  }
+  if (lane == 0) {
+    sai_window_record rec;
+    rec.n_sites = hi - lo;
+    rec.u_count = static_cast<int32_t>(n_u);
+    rec.n_cond = static_cast<int32_t>(n_c);
+    rec.n_cdd_q = static_cast<int32_t>(n_q);
+    rec.q = q;
+    a.records[ridx] = rec;
+  }
+}
+
+// ---- heavy fallback ------------------------------------------------------------------------
+
+struct WinShared {
+  double vals[kSelCap];
+  uint32_t hist[256];
+  uint32_t wave_tot[4];
+  uint32_t red[4];
+  uint32_t n_stored;
+  uint32_t digit;
+  uint32_t k_rem;
+};
+
+__device__ __forceinline__ uint32_t block_sum(uint32_t v, uint32_t* red, int tid) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  __syncthreads();
+  if ((tid & 63) == 0) red[tid >> 6] = v;
+  __syncthreads();
+  return red[0] + red[1] + red[2] + red[3];
+}
+
+// k-th smallest (0-based) of the selected values: MSB-first radix select on the f64 bit pattern
+// (all selected values are finite and >= 0, so the unsigned order of the bits is the numeric order).
+template <bool IN_LDS>
+__device__ double select_kth(WinShared& sh, const double* tgt_freq, const uint8_t* fl, int lo, int hi,
+                             uint32_t n_sel, uint32_t k, int tid) {
+  unsigned long long prefix = 0;
+  for (int shift = 56; shift >= 0; shift -= 8) {
+    sh.hist[tid] = 0;
+    __syncthreads();
+    const unsigned long long himask = shift == 56 ? 0ull : (~0ull << (shift + 8));
+    if (IN_LDS) {
+      for (uint32_t i = tid; i < n_sel; i += kWinThreads) {
+        const unsigned long long key = __double_as_longlong(sh.vals[i]);
+        if ((key & himask) == prefix) atomicAdd(&sh.hist[(key >> shift) & 255u], 1u);
+      }
+    } else {
+      for (int i = lo + tid; i < hi; i += kWinThreads) {
+        const uint8_t f = fl[i];
+        if (f & 1) {
+          const unsigned long long key = __double_as_longlong(eff_freq(tgt_freq, f, i));
+          if ((key & himask) == prefix) atomicAdd(&sh.hist[(key >> shift) & 255u], 1u);
+        }
+      }
+    }
+    __syncthreads();
+    // inclusive scan of the 256 bins: shuffles inside each wave, wave totals through LDS
+    const uint32_t h = sh.hist[tid];
+    uint32_t inc = h;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t t = __shfl_up(inc, o, 64);
+      if ((tid & 63) >= o) inc += t;
+    }
+    if ((tid & 63) == 63) sh.wave_tot[tid >> 6] = inc;
+    __syncthreads();
+    uint32_t before = 0;
+    for (int wv = 0; wv < (tid >> 6); ++wv) before += sh.wave_tot[wv];
+    inc += before;
+    const uint32_t exc = inc - h;
+    if (h != 0 && k >= exc && k < inc) {  // exactly one bin satisfies this
+      sh.digit = tid;
+      sh.k_rem = k - exc;
+    }
+    __syncthreads();
+    prefix |= static_cast<unsigned long long>(sh.digit) << shift;
+    k = sh.k_rem;
+    __syncthreads();
+  }
+  return __longlong_as_double(static_cast<long long>(prefix));
+}
+
+// The grid covers every window; those not marked by the wave kernel exit at once.
+__global__ __launch_bounds__(kWinThreads) void window_stats_heavy_kernel(WinArgs a) {
+  __shared__ WinShared sh;
+  const int tid = threadIdx.x;
+  const int w = blockIdx.x;
+  const int set = blockIdx.y;
+  const int64_t ridx = static_cast<int64_t>(set) * a.n_windows + w;
+  if (a.records[ridx].n_cdd_q != kHeavyMark) return;  // uniform over the workgroup
+  const int lo = a.lo[w], hi = a.hi[w];
+  const uint8_t* fl = a.flags + static_cast<int64_t>(set) * a.n_sites;
+  const uint32_t n_c = static_cast<uint32_t>(a.records[ridx].n_cond);
+  const bool in_lds = n_c <= kSelCap;
+  if (tid == 0) sh.n_stored = 0;
+  __syncthreads();
+  if (in_lds) {
+    for (int i = lo + tid; i < hi; i += kWinThreads) {
+      const uint8_t f = fl[i];
+      if (f & 1u) sh.vals[atomicAdd(&sh.n_stored, 1u)] = eff_freq(a.tgt_freq, f, i);
+    }
+  }
+  __syncthreads();
+  const double v = static_cast<double>(n_c - 1) * a.quantile[set];
+  double q;
+  if (v >= static_cast<double>(n_c - 1)) {
+    q = in_lds ? select_kth<true>(sh, a.tgt_freq, fl, lo, hi, n_c, n_c - 1, tid)
+               : select_kth<false>(sh, a.tgt_freq, fl, lo, hi, n_c, n_c - 1, tid);
+  } else {
+    const double fl_v = floor(v);
+    const uint32_t k = static_cast<uint32_t>(fl_v);
+    const double x0 = in_lds ? select_kth<true>(sh, a.tgt_freq, fl, lo, hi, n_c, k, tid)
+                             : select_kth<false>(sh, a.tgt_freq, fl, lo, hi, n_c, k, tid);
+    const double x1 = in_lds ? select_kth<true>(sh, a.tgt_freq, fl, lo, hi, n_c, k + 1, tid)
+                             : select_kth<false>(sh, a.tgt_freq, fl, lo, hi, n_c, k + 1, tid);
+    q = numpy_lerp(x0, x1, v, fl_v);
+  }
+  uint32_t c_q = 0;
+  for (int i = lo + tid; i < hi; i += kWinThreads) {
+    const uint8_t f = fl[i];
+    if ((f & 1u) && eff_freq(a.tgt_freq, f, i) >= q) ++c_q;
+  }
+  const uint32_t n_q = block_sum(c_q, sh.red, tid);
+  if (tid == 0) {
+    a.records[ridx].n_cdd_q = static_cast<int32_t>(n_q);
+    a.records[ridx].q = q;
+  }
+}
+
+// ---- CSR offsets ---------------------------------------------------------------------------
+
+// One 1024-thread workgroup: exclusive prefix sums of u_count and n_cdd_q over the records in
+// (set, window) order.  cdd_off[2r] / cdd_off[2r+1] = start of record r's U / Q list (or -1 when
+// the list would not fit its buffer); cdd_total[0..1] = entries needed in all.  Records are taken
+// 4 x 1024 at a time (coalesced, all loads of a batch in flight together); each row of 1024 is
+// scanned with wave shuffles + one LDS hop, the running totals carry over in registers.
+__global__ __launch_bounds__(1024) void window_scan_kernel(WinArgs a) {
+  __shared__ long long wave_tot[2][16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t n = static_cast<int64_t>(a.n_sets) * a.n_windows;
+  long long carry_u = 0, carry_q = 0;
+  constexpr int kBatch = 4;
+  for (int64_t base = 0; base < n; base += 1024 * kBatch) {
+    long long nu[kBatch], nq[kBatch];
+#pragma unroll
+    for (int k = 0; k < kBatch; ++k) {
+      const int64_t r = base + k * 1024 + tid;
+      nu[k] = r < n ? a.records[r].u_count : 0;
+      nq[k] = r < n ? a.records[r].n_cdd_q : 0;
+    }
+#pragma unroll
+    for (int k = 0; k < kBatch; ++k) {
+      if (base + k * 1024 >= n) break;  // uniform
+      long long iu = nu[k], iq = nq[k];
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const long long tu = __shfl_up(iu, o, 64), tq = __shfl_up(iq, o, 64);
+        if (lane >= o) { iu += tu; iq += tq; }
+      }
+      __syncthreads();  // the previous row's wave totals have been consumed
+      if (lane == 63) { wave_tot[0][wave] = iu; wave_tot[1][wave] = iq; }
+      __syncthreads();
+      long long before_u = 0, before_q = 0, all_u = 0, all_q = 0;
+#pragma unroll
+      for (int v = 0; v < 16; ++v) {
+        const long long tu = wave_tot[0][v], tq = wave_tot[1][v];
+        if (v < wave) { before_u += tu; before_q += tq; }
+        all_u += tu;
+        all_q += tq;
+      }
+      const int64_t r = base + k * 1024 + tid;
+      if (r < n) {
+        const long long ou = carry_u + before_u + iu - nu[k], oq = carry_q + before_q + iq - nq[k];
+        a.cdd_off[2 * r + 0] = (ou + nu[k] <= a.cap_u) ? ou : -1;
+        a.cdd_off[2 * r + 1] = (oq + nq[k] <= a.cap_q) ? oq : -1;
+      }
+      carry_u += all_u;
+      carry_q += all_q;
+    }
+  }
+  if (tid == 0) {
+    a.cdd_total[0] = carry_u;
+    a.cdd_total[1] = carry_q;
+  }
+}
+
+// ---- candidate lists -----------------------------------------------------------------------
+
+__global__ __launch_bounds__(256) void window_lists_kernel(WinArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int w = xcd_contiguous(blockIdx.x, gridDim.x) * 4 + (threadIdx.x >> 6);
+  if (w >= a.n_windows) return;
+  const int set = blockIdx.y;
+  const int64_t ridx = static_cast<int64_t>(set) * a.n_windows + w;
+  const sai_window_record rec = a.records[ridx];
+  const long long off_u = a.cdd_off[2 * ridx + 0], off_q = a.cdd_off[2 * ridx + 1];
+  const bool write_u = rec.u_count > 0 && off_u >= 0 && a.cdd_u != nullptr;
+  const bool write_q = rec.n_cdd_q > 0 && off_q >= 0 && a.cdd_q != nullptr;
+  if (!write_u && !write_q) return;
+  const int lo = a.lo[w], hi = a.hi[w];
+  const uint8_t* fl = a.flags + static_cast<int64_t>(set) * a.n_sites;
+  const unsigned long long lt_mask = (1ull << lane) - 1ull;
+  const double q = rec.q;
+  uint32_t done_u = 0, done_q = 0;
+  for (int i0 = lo; i0 < hi; i0 += 64) {
+    const int i = i0 + lane;
+    const uint8_t f = i < hi ? fl[i] : static_cast<uint8_t>(0);
+    const bool pu = (f & 2u) != 0;
+    const bool pq = write_q && (f & 1u) && eff_freq(a.tgt_freq, f, i) >= q;
+    const unsigned long long mu = __ballot(pu);
+    const unsigned long long mq = __ballot(pq);
+    if (mu | mq) {
+      const int32_t out = (pu || pq) ? (a.pos ? a.pos[i] : i) : 0;
+      if (write_u && pu) a.cdd_u[off_u + done_u + __popcll(mu & lt_mask)] = out;
+      if (pq) a.cdd_q[off_q + done_q + __popcll(mq & lt_mask)] = out;
+      done_u += __popcll(mu);
+      done_q += __popcll(mq);
+    }
+  }
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------
+
+extern "C" {
+
+int sai_window_bounds(sai_ctx* ctx, const int32_t* pos, int64_t n_sites, int32_t n_windows,
+                      const int64_t* win_start, const int64_t* win_end, int32_t* lo, int32_t* hi, void* stream) {
+  if (int rc = enter(ctx)) return rc;
+  if (n_sites < 0 || n_sites >= 0x7FFFFFFFll || n_windows < 0) return fail(SAI_ERR_ARG, "size out of range");
+  if (n_windows == 0) return SAI_OK;
+  if ((n_sites > 0 && !pos) || !win_start || !win_end || !lo || !hi) return fail(SAI_ERR_ARG, "NULL buffer");
+  const unsigned grid = static_cast<unsigned>((n_windows + 255) / 256);
+  hipLaunchKernelGGL(window_bounds_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), pos, n_sites,
+                     n_windows, win_start, win_end, lo, hi);
+  return check_launch("window_bounds");
+}
+
+int sai_window_stats(sai_ctx* ctx, int64_t n_sites, const double* tgt_freq, const uint8_t* flags, int32_t n_sets,
+                     const sai_params* sets_host, int32_t n_windows, const int32_t* lo, const int32_t* hi,
+                     const int32_t* pos, sai_window_record* records, int64_t* cdd_off, int32_t* cdd_u, int64_t cap_u,
+                     int32_t* cdd_q, int64_t cap_q, int64_t* cdd_total, void* stream) {
+  if (int rc = enter(ctx)) return rc;
+  if (n_sites < 0 || n_sites >= 0x7FFFFFFFll || n_windows < 0) return fail(SAI_ERR_ARG, "size out of range");
+  if (int rc = check_sets(n_sets, sets_host, -1)) return rc;
+  if (!cdd_total) return fail(SAI_ERR_ARG, "cdd_total is NULL");
+  if (cap_u < 0 || cap_q < 0 || (cap_u > 0 && !cdd_u) || (cap_q > 0 && !cdd_q))
+    return fail(SAI_ERR_ARG, "candidate buffers do not match their capacities");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (n_windows == 0) {
+    SAI_HIP(hipMemsetAsync(cdd_total, 0, 2 * sizeof(int64_t), st));
+    return SAI_OK;
+  }
+  if ((n_sites > 0 && (!tgt_freq || !flags)) || !lo || !hi || !records || !cdd_off)
+    return fail(SAI_ERR_ARG, "NULL buffer");
+  WinArgs a;
+  std::memset(&a, 0, sizeof(a));
+  a.n_sites = n_sites;
+  a.tgt_freq = tgt_freq;
+  a.flags = flags;
+  a.n_sets = n_sets;
+  a.n_windows = n_windows;
+  a.lo = lo;
+  a.hi = hi;
+  a.pos = pos;
+  a.records = records;
+  a.cdd_off = cdd_off;
+  a.cdd_u = cdd_u;
+  a.cap_u = cap_u;
+  a.cdd_q = cdd_q;
+  a.cap_q = cap_q;
+  a.cdd_total = cdd_total;
+  for (int s = 0; s < n_sets; ++s) a.quantile[s] = sets_host[s].quantile;
+  const dim3 wave_grid(static_cast<unsigned>((n_windows + 3) / 4), static_cast<unsigned>(n_sets));
+  const dim3 block_grid(static_cast<unsigned>(n_windows), static_cast<unsigned>(n_sets));
+  hipLaunchKernelGGL(window_stats_wave_kernel, wave_grid, dim3(256), 0, st, a);
+  if (int rc = check_launch("window_stats_wave")) return rc;
+  hipLaunchKernelGGL(window_stats_heavy_kernel, block_grid, dim3(kWinThreads), 0, st, a);
+  if (int rc = check_launch("window_stats_heavy")) return rc;
+  hipLaunchKernelGGL(window_scan_kernel, dim3(1), dim3(1024), 0, st, a);
+  if (int rc = check_launch("window_scan")) return rc;
+  hipLaunchKernelGGL(window_lists_kernel, wave_grid, dim3(256), 0, st, a);
+  return check_launch("window_lists");
+}
+
+}  // extern "C"
