@@ -204,6 +204,37 @@ __global__ __launch_bounds__(64) void k_dot4(const int8_t* __restrict__ ref, con
   }
 }
 
+// F: cache-policy bits of the load instruction (gfx950: sc0 / sc1 / nt), 5 wave loads in flight
+template <int POL>
+__global__ __launch_bounds__(64) void k_policy(const u32x4* __restrict__ src, int64_t n, uint32_t* out) {
+  const int lane = threadIdx.x;
+  u32x4 acc = {0, 0, 0, 0};
+  const int64_t n_runs = n / 8000;
+  for (int64_t c = blockIdx.x; c < n_runs; c += gridDim.x) {
+    const u32x4* base = src + c * 8000 + lane;
+    for (int it = 0; it < 125; it += 5) {
+      u32x4 v[5];
+#pragma unroll
+      for (int u = 0; u < 5; ++u) {
+        const u32x4* p = base + (it + u) * 64;
+        if (POL == 0) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v[u]) : "v"(p) : "memory");
+        if (POL == 1) asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(v[u]) : "v"(p) : "memory");
+        if (POL == 2) asm volatile("global_load_dwordx4 %0, %1, off sc0" : "=v"(v[u]) : "v"(p) : "memory");
+        if (POL == 3) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v[u]) : "v"(p) : "memory");
+        if (POL == 4) asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(v[u]) : "v"(p) : "memory");
+        if (POL == 5) asm volatile("global_load_dwordx4 %0, %1, off sc0 nt" : "=v"(v[u]) : "v"(p) : "memory");
+        if (POL == 6) asm volatile("global_load_dwordx4 %0, %1, off sc1 nt" : "=v"(v[u]) : "v"(p) : "memory");
+        if (POL == 7) asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1 nt" : "=v"(v[u]) : "v"(p) : "memory");
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int u = 0; u < 5; ++u) acc ^= v[u];
+    }
+  }
+  uint32_t r = acc.x ^ acc.y ^ acc.z ^ acc.w;
+  if (r == 0x12345678u) out[0] = r;
+}
+
 int main() {
   const int64_t n_tiles = 156250;
   const int64_t pop_bytes = n_tiles * 64000ll;
@@ -217,24 +248,12 @@ int main() {
   auto rep = [&](const char* name, double ms) { printf("%-52s %8.3f ms  %8.1f GB/s\n", name, ms, bytes / ms / 1e6); fflush(stdout); };
   // two streams 10 GB apart vs [ref|tgt] interleaved per tile; with / without the per-site writes
 #define E(U, G, W, NAME, TGT, STRIDE, NIND, NT) rep("dot4 U=" #U " grid=cu*" #G " write=" #W " " NAME, time_ms([&] { hipLaunchKernelGGL((k_dot4<U, W>), dim3(cu * G), dim3(64), 0, 0, big, big + (TGT), (int64_t)(NT), NIND, (int64_t)(STRIDE), freq, flags); }))
-  E(8, 32, 0, "2 streams", pop_bytes, 64000, 1000, n_tiles);
-  E(8, 32, 1, "2 streams", pop_bytes, 64000, 1000, n_tiles);
-  E(8, 32, 2, "2 streams", pop_bytes, 64000, 1000, n_tiles);
-  E(8, 32, 3, "2 streams", pop_bytes, 64000, 1000, n_tiles);
-  E(8, 32, 4, "2 streams", pop_bytes, 64000, 1000, n_tiles);
-  E(8, 32, 5, "2 streams", pop_bytes, 64000, 1000, n_tiles);
-  E(8, 32, 6, "2 streams", pop_bytes, 64000, 1000, n_tiles);
-  E(8, 32, 9, "2 streams", pop_bytes, 64000, 1000, n_tiles);
-  E(8, 32, 5, "2 streams", pop_bytes, 64000, 1000, n_tiles);
-  E(8, 32, 9, "2 streams", pop_bytes, 64000, 1000, n_tiles);
-  E(8, 32, 2, "2 streams", pop_bytes, 64000, 1000, n_tiles);
-  E(8, 32, 0, "2 streams", pop_bytes, 64000, 1000, n_tiles);
-  E(16, 32, 0, "2 streams", pop_bytes, 64000, 1000, n_tiles);
-  E(16, 32, 6, "2 streams", pop_bytes, 64000, 1000, n_tiles);
   const int64_t n = 2 * pop_bytes / 16;
   rep("wavechunk 128000B U=4 grid=cu*32", time_ms([&] { hipLaunchKernelGGL((k_wavechunk<4, true>), dim3(cu * 32), dim3(64), 0, 0, (const u32x4*)big, n, (int64_t)8000, out); }));
   rep("wavechunk 256000B U=4 grid=cu*32", time_ms([&] { hipLaunchKernelGGL((k_wavechunk<4, true>), dim3(cu * 32), dim3(64), 0, 0, (const u32x4*)big, n, (int64_t)16000, out); }));
   rep("wavechunk 64000B U=5 grid=cu*32", time_ms([&] { hipLaunchKernelGGL((k_wavechunk<5, true>), dim3(cu * 32), dim3(64), 0, 0, (const u32x4*)big, n, (int64_t)4000, out); }));
+#define P(POL, NAME) rep("policy " NAME " U=5 128000B grid=cu*32", time_ms([&] { hipLaunchKernelGGL((k_policy<POL>), dim3(cu * 32), dim3(64), 0, 0, (const u32x4*)big, n, out); }))
+  P(0, "default"); P(1, "nt"); P(2, "sc0"); P(3, "sc1"); P(4, "sc0 sc1"); P(5, "sc0 nt"); P(6, "sc1 nt"); P(7, "sc0 sc1 nt"); P(1, "nt"); P(0, "default");
   rep("swar 256000B U=4 grid=cu*32", time_ms([&] { hipLaunchKernelGGL((k_swar<4, 1>), dim3(cu * 32), dim3(64), 0, 0, (const u32x4*)big, n, (int64_t)16000, out); }));
   return 0;
 }
