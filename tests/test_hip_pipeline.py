@@ -314,3 +314,105 @@ def test_score_sharded_two_ranks_equals_single_process(in_repo_root, tmp_path):
     for k in ("U", "Q"):
         a, b = (tmp_path / f"sharded.{k}.log").read_text().splitlines(), (tmp_path / f"single.{k}.log").read_text().splitlines()
         assert a[0] == b[0] and sorted(a) == sorted(b)
+
+
+def _fuzz_scenario(seed):
+    """A seeded random chromosome + config: several ref / tgt populations, 1-2 sources, optional
+    outgroup, ploidy 1-4, missing calls, random window grid, optional chunk bounds."""
+    rng = np.random.default_rng(seed)
+    n_sites = int(rng.integers(200, 2500))
+    pos = np.cumsum(rng.integers(1, 60, n_sites)).astype(np.int32)
+    n_ref, n_tgt, n_src = int(rng.integers(1, 3)), int(rng.integers(1, 3)), int(rng.integers(1, 3))
+    with_out = bool(rng.random() < 0.5)
+    anc = True if with_out else bool(rng.random() < 0.5)
+    p = rng.random(n_sites) ** float(rng.choice([1, 2, 4]))
+
+    def pop(n_ind, ploidy, fixed=False):
+        g = rng.binomial(ploidy, np.broadcast_to(p[:, None], (n_sites, n_ind))).astype(np.int64)
+        if fixed:
+            g[rng.random(n_sites) < 0.25] = ploidy
+        miss = rng.random(g.shape) < float(rng.choice([0.0, 0.02, 0.2]))
+        g[miss] = -ploidy
+        return g
+
+    pl = {"ref": {}, "tgt": {}, "src": {}}
+    gts = {"ref": {}, "tgt": {}, "src": {}, "outgroup": {}}
+    for grp, n, prefix in (("ref", n_ref, "R"), ("tgt", n_tgt, "T"), ("src", n_src, "S")):
+        for i in range(n):
+            ploidy = int(rng.integers(1, 5))
+            pl[grp][f"{prefix}{i}"] = ploidy
+            gts[grp][f"{prefix}{i}"] = pop(int(rng.integers(1, 40 if grp != "src" else 4)), ploidy, fixed=grp == "src")
+    if with_out:
+        pl["outgroup"] = {"O": int(rng.integers(1, 3))}
+        gts["outgroup"]["O"] = pop(int(rng.integers(1, 6)), pl["outgroup"]["O"])
+    ops = ["=", "<", ">", "<=", ">="]
+
+    def uq():
+        return {
+            "ref": {k: float(rng.choice([0.05, 0.3, 1.0])) for k in pl["ref"]},
+            "tgt": {k: float(rng.choice([0.0, 0.2, 0.5, 0.95])) for k in pl["tgt"]},
+            "src": {k: f"{rng.choice(ops)}{rng.choice([0, 0.5, 1])}" for k in pl["src"]},
+        }
+
+    stats = {"U": uq(), "Q": uq()}
+    if anc and rng.random() < 0.7:
+        for name in ("fd", "df", "Danc", "Dplus", "DD"):
+            if rng.random() < 0.7:
+                stats[name] = True
+    win = int(rng.integers(500, 6000))
+    step = int(rng.integers(100, win + 1))
+    start = end = None
+    if rng.random() < 0.4:  # a chunk the way ChunkGenerator cuts it: window-aligned bounds
+        start = int(pos[n_sites // 4] // step * step + 1)
+        end = start + int(rng.integers(1, 6)) * step + win - step - 1
+    return dict(pos=pos, gts=gts, pl=pl, stats=stats, win=win, step=step, start=start, end=end, anc=anc, with_out=with_out)
+
+
+@pytest.mark.parametrize("seed", range(100, 116))
+def test_pipeline_fuzz_against_oracle(seed, tmp_path):
+    """FeaturePreprocessor.run_windows + process_items on random chromosomes / configs: every item
+    and every byte of the TSV and log files equal the oracle's (which is pinned to the reference)."""
+    from oracle import sai_oracle as O
+    from sai_amd.configs import PloidyConfig, StatConfig
+    from sai_amd.generators import WindowGenerator
+    from sai_amd.preprocessors import FeaturePreprocessor
+    from sai_amd.sai import write_headers
+    from sai_amd.utils import ChromosomeData
+    from test_oracle_golden import _validated
+
+    sc = _fuzz_scenario(seed)
+    pos = sc["pos"]
+    sel = np.ones(len(pos), bool) if sc["start"] is None else (pos >= sc["start"]) & (pos <= sc["end"])
+    if not sel.any():
+        pytest.skip("empty chunk")
+    mk = lambda g: ChromosomeData(pos[sel], None, None, g[sel].astype(np.int8))  # noqa: E731
+    data = {grp: {k: mk(v) for k, v in sc["gts"][grp].items()} for grp in sc["gts"]}
+    pc = PloidyConfig(sc["pl"])
+    wg = WindowGenerator.from_arrays("7", data["ref"], data["tgt"], data["src"], sc["win"], sc["step"], pc,
+                                     start=sc["start"], end=sc["end"], out_data=data["outgroup"] or None)  # fmt: skip
+    stat_config = StatConfig(json.loads(json.dumps(sc["stats"])))
+    out = tmp_path / "o.tsv"
+    fp = FeaturePreprocessor(str(out), stat_config, anc_allele_available=sc["anc"])
+    items = fp.run_windows(wg)
+
+    ostats = {n: (_validated({n: p})[n] if n in ("U", "Q") else p) for n, p in sc["stats"].items()}
+    odata = {grp: {k: O.Chrom(pos, v) for k, v in sc["gts"][grp].items()} for grp in sc["gts"]}
+    want = O.run_chunk("7", odata["ref"], odata["tgt"], odata["src"], sc["win"], sc["step"], ostats, sc["pl"], sc["anc"],
+                       start=sc["start"], end=sc["end"], out_data=odata["outgroup"] or None)  # fmt: skip
+    assert len(items) == len(want) > 0
+    names = list(sc["stats"].keys())
+    for a, b in zip(items, want):
+        for k in ("chr_name", "start", "end", "ref_pop", "tgt_pop", "out_pop", "nsnps"):
+            assert a[k] == b[k], (k, a[k], b[k])
+        assert list(a["src_pop_list"]) == list(b["src_pop_list"])
+        for k in names:
+            if k in ("U", "Q"):
+                assert (a[k] == b[k] and isinstance(a[k], int)) if isinstance(b[k], int) else same_f64(a[k], b[k]), (k, a[k], b[k])
+                assert np.asarray(a["cdd_pos"][k]).astype(np.int64).tolist() == np.asarray(b["cdd_pos"][k]).astype(np.int64).tolist()
+            else:
+                assert len(a[k]) == len(b[k]) and all(same_f64(x, y) for x, y in zip(a[k], b[k])), (k, a[k], b[k])
+    write_headers(str(out), stat_config, pc)
+    fp.process_items(items)
+    assert out.read_text() == O.header_line(names, list(sc["pl"]["src"])) + "".join(O.score_lines(want, names))
+    for k in ("U", "Q"):
+        assert (tmp_path / f"o.{k}.log").read_text() == O.log_header_line(k) + "".join(O.log_lines(want, k))
