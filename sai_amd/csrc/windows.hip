@@ -87,6 +87,38 @@ __device__ __forceinline__ void wave_lds_fence() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// Walk flags[lo, hi) of one parameter set with one wave, 4 bytes per lane and kFlagBatch wave loads
+// in flight: word k of the walk (lane k % 64 of chunk k / 64) holds sites s0 + 4k .. 4k+3, where s0 <=
+// lo makes the address 4-byte aligned; bytes outside [lo, hi) arrive as 0.  An aligned word that
+// contains one valid byte cannot cross a page, so the up to 3 bytes read past either end of the
+// caller's buffer never fault.  on_chunk(word, first_site) is called by the whole wave, chunks in
+// site order.  (One byte per lane per iteration, as in the first version, costs one L2 round trip
+// per 64 sites: 31 dependent trips for a C3 window; this form needs two.)
+constexpr int kFlagBatch = 4;
+
+template <typename F>
+__device__ __forceinline__ void walk_flags(const uint8_t* fl, int lo, int hi, int lane, F&& on_chunk) {
+  if (hi <= lo) return;
+  const int s0 = lo - static_cast<int>(reinterpret_cast<uintptr_t>(fl + lo) & 3u);
+  const uint32_t* words = reinterpret_cast<const uint32_t*>(fl + s0);
+  const int n_words = (hi - s0 + 3) >> 2;
+  for (int c0 = 0; c0 < n_words; c0 += 64 * kFlagBatch) {
+    uint32_t w[kFlagBatch];
+#pragma unroll
+    for (int u = 0; u < kFlagBatch; ++u) w[u] = words[min(c0 + u * 64 + lane, n_words - 1)];
+#pragma unroll
+    for (int u = 0; u < kFlagBatch; ++u) {
+      if (c0 + u * 64 >= n_words) break;  // uniform
+      const int k = c0 + u * 64 + lane;
+      const int site = s0 + 4 * k;
+      uint32_t keep = k < n_words ? 0xFFFFFFFFu : 0u;
+      if (site < lo) keep &= 0xFFFFFFFFu << (8 * (lo - site));          // 1..3 leading bytes before lo
+      if (site + 4 > hi && site < hi) keep &= 0xFFFFFFFFu >> (8 * (site + 4 - hi));  // 1..3 trailing bytes
+      on_chunk(w[u] & keep, site);
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void window_stats_wave_kernel(WinArgs a) {
   __shared__ double sh_vals[4][kWaveCap];
   const int lane = threadIdx.x & 63;
@@ -100,20 +132,32 @@ __global__ __launch_bounds__(256) void window_stats_wave_kernel(WinArgs a) {
   double* vals = sh_vals[wv];
   const unsigned long long lt_mask = (1ull << lane) - 1ull;
 
-  // pass 1: counts + compaction of the qualifying effective frequencies into LDS
-  uint32_t n_c = 0, n_u = 0;
-  for (int i0 = lo; i0 < hi; i0 += 64) {
-    const int i = i0 + lane;
-    const uint8_t f = i < hi ? fl[i] : static_cast<uint8_t>(0);
-    const bool c = (f & 1u) != 0;
-    const unsigned long long bc = __ballot(c);
-    if (c) {
-      const uint32_t slot = n_c + __popcll(bc & lt_mask);
-      if (slot < kWaveCap) vals[slot] = eff_freq(a.tgt_freq, f, i);
+  // pass 1: counts + order-preserving compaction of the qualifying effective frequencies into LDS
+  uint32_t n_c = 0, n_u_lane = 0;
+  walk_flags(fl, lo, hi, lane, [&](uint32_t v, int site) {
+    n_u_lane += __popc(v & 0x02020202u);
+    const uint32_t cm = v & 0x01010101u;
+    if (__ballot(cm != 0u) == 0ull) return;  // no condition site among these 256: the usual case
+    uint32_t below = 0, total = 0;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const unsigned long long bc = __ballot(((cm >> (8 * b)) & 1u) != 0u);
+      below += __popcll(bc & lt_mask);
+      total += __popcll(bc);
     }
-    n_c += __popcll(bc);
-    n_u += __popcll(__ballot((f & 2u) != 0));
-  }
+    uint32_t slot = n_c + below;  // lanes hold consecutive sites: lower lanes first, then byte order
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      if ((cm >> (8 * b)) & 1u) {
+        if (slot < kWaveCap) vals[slot] = eff_freq(a.tgt_freq, static_cast<uint8_t>(v >> (8 * b)), site + b);
+        ++slot;
+      }
+    }
+    n_c += total;
+  });
+  uint32_t n_u = n_u_lane;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) n_u += __shfl_xor(n_u, o, 64);
   double q = std::numeric_limits<double>::quiet_NaN();
   uint32_t n_q = 0;
   if (n_c > kWaveCap) {
@@ -279,54 +323,72 @@ __global__ __launch_bounds__(kWinThreads) void window_stats_heavy_kernel(WinArgs
 
 // ---- CSR offsets ---------------------------------------------------------------------------
 
-// One 1024-thread workgroup: exclusive prefix sums of u_count and n_cdd_q over the records in
+// One 512-thread workgroup: exclusive prefix sums of u_count and n_cdd_q over the records in
 // (set, window) order.  cdd_off[2r] / cdd_off[2r+1] = start of record r's U / Q list (or -1 when
-// the list would not fit its buffer); cdd_total[0..1] = entries needed in all.  Records are taken
-// 4 x 1024 at a time (coalesced, all loads of a batch in flight together); each row of 1024 is
-// scanned with wave shuffles + one LDS hop, the running totals carry over in registers.
-__global__ __launch_bounds__(1024) void window_scan_kernel(WinArgs a) {
-  __shared__ long long wave_tot[2][16];
+// the list would not fit its buffer); cdd_total[0..1] = entries needed in all.  Every thread owns
+// 20 consecutive records (all 40 loads in flight at once), adds them up, the 512 partial sums
+// are scanned once (wave shuffles + one LDS hop) and each thread writes its 20 offset pairs;
+// more than 10 240 records take further rounds with the totals carried in registers.  (512 threads,
+// not 1024: the compiler hoists the round-invariant index arithmetic out of the loop, and under
+// the 128-register cap of a 1024-thread workgroup that spilled to scratch -- 30 us per launch.)
+constexpr int kScanThreads = 512;
+
+__global__ __launch_bounds__(kScanThreads) void window_scan_kernel(WinArgs a) {
+  __shared__ long long wave_tot[2][kScanThreads / 64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int64_t n = static_cast<int64_t>(a.n_sets) * a.n_windows;
   long long carry_u = 0, carry_q = 0;
-  constexpr int kBatch = 4;
-  for (int64_t base = 0; base < n; base += 1024 * kBatch) {
-    long long nu[kBatch], nq[kBatch];
+  constexpr int kPer = 20;
+  for (int64_t base = 0; base < n; base += kScanThreads * kPer) {
+    // 32-bit offsets from the round's (uniform) base pointer; loads are unconditional from a clamped
+    // index -- a load under a per-element condition is branched around and waited for one at a time
+    const int rel_max = static_cast<int>(min(n - base, static_cast<int64_t>(kScanThreads * kPer))) - 1;
+    const int i0 = tid * kPer;
+    const sai_window_record* rp = a.records + base;
+    int32_t nu[kPer], nq[kPer];
 #pragma unroll
-    for (int k = 0; k < kBatch; ++k) {
-      const int64_t r = base + k * 1024 + tid;
-      nu[k] = r < n ? a.records[r].u_count : 0;
-      nq[k] = r < n ? a.records[r].n_cdd_q : 0;
+    for (int k = 0; k < kPer; ++k) {
+      const int i = min(i0 + k, rel_max);
+      nu[k] = rp[i].u_count;
+      nq[k] = rp[i].n_cdd_q;
     }
 #pragma unroll
-    for (int k = 0; k < kBatch; ++k) {
-      if (base + k * 1024 >= n) break;  // uniform
-      long long iu = nu[k], iq = nq[k];
+    for (int k = 0; k < kPer; ++k)
+      if (i0 + k > rel_max) nu[k] = nq[k] = 0;
+    long long su = 0, sq = 0;
 #pragma unroll
-      for (int o = 1; o < 64; o <<= 1) {
-        const long long tu = __shfl_up(iu, o, 64), tq = __shfl_up(iq, o, 64);
-        if (lane >= o) { iu += tu; iq += tq; }
-      }
-      __syncthreads();  // the previous row's wave totals have been consumed
-      if (lane == 63) { wave_tot[0][wave] = iu; wave_tot[1][wave] = iq; }
-      __syncthreads();
-      long long before_u = 0, before_q = 0, all_u = 0, all_q = 0;
-#pragma unroll
-      for (int v = 0; v < 16; ++v) {
-        const long long tu = wave_tot[0][v], tq = wave_tot[1][v];
-        if (v < wave) { before_u += tu; before_q += tq; }
-        all_u += tu;
-        all_q += tq;
-      }
-      const int64_t r = base + k * 1024 + tid;
-      if (r < n) {
-        const long long ou = carry_u + before_u + iu - nu[k], oq = carry_q + before_q + iq - nq[k];
-        a.cdd_off[2 * r + 0] = (ou + nu[k] <= a.cap_u) ? ou : -1;
-        a.cdd_off[2 * r + 1] = (oq + nq[k] <= a.cap_q) ? oq : -1;
-      }
-      carry_u += all_u;
-      carry_q += all_q;
+    for (int k = 0; k < kPer; ++k) {
+      su += nu[k];
+      sq += nq[k];
     }
+    long long iu = su, iq = sq;  // inclusive scan over the wave
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const long long tu = __shfl_up(iu, o, 64), tq = __shfl_up(iq, o, 64);
+      if (lane >= o) { iu += tu; iq += tq; }
+    }
+    if (lane == 63) { wave_tot[0][wave] = iu; wave_tot[1][wave] = iq; }
+    __syncthreads();
+    long long before_u = 0, before_q = 0, all_u = 0, all_q = 0;
+#pragma unroll
+    for (int v = 0; v < kScanThreads / 64; ++v) {
+      const long long tu = wave_tot[0][v], tq = wave_tot[1][v];
+      if (v < wave) { before_u += tu; before_q += tq; }
+      all_u += tu;
+      all_q += tq;
+    }
+    long long ou = carry_u + before_u + iu - su, oq = carry_q + before_q + iq - sq;
+    longlong2* op = reinterpret_cast<longlong2*>(a.cdd_off) + base;
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) {
+      if (i0 + k <= rel_max)
+        op[i0 + k] = make_longlong2((ou + nu[k] <= a.cap_u) ? ou : -1, (oq + nq[k] <= a.cap_q) ? oq : -1);
+      ou += nu[k];
+      oq += nq[k];
+    }
+    carry_u += all_u;
+    carry_q += all_q;
+    __syncthreads();  // wave_tot is rewritten in the next round
   }
   if (tid == 0) {
     a.cdd_total[0] = carry_u;
@@ -352,21 +414,40 @@ __global__ __launch_bounds__(256) void window_lists_kernel(WinArgs a) {
   const unsigned long long lt_mask = (1ull << lane) - 1ull;
   const double q = rec.q;
   uint32_t done_u = 0, done_q = 0;
-  for (int i0 = lo; i0 < hi; i0 += 64) {
-    const int i = i0 + lane;
-    const uint8_t f = i < hi ? fl[i] : static_cast<uint8_t>(0);
-    const bool pu = (f & 2u) != 0;
-    const bool pq = write_q && (f & 1u) && eff_freq(a.tgt_freq, f, i) >= q;
-    const unsigned long long mu = __ballot(pu);
-    const unsigned long long mq = __ballot(pq);
-    if (mu | mq) {
-      const int32_t out = (pu || pq) ? (a.pos ? a.pos[i] : i) : 0;
-      if (write_u && pu) a.cdd_u[off_u + done_u + __popcll(mu & lt_mask)] = out;
-      if (pq) a.cdd_q[off_q + done_q + __popcll(mq & lt_mask)] = out;
-      done_u += __popcll(mu);
-      done_q += __popcll(mq);
+  walk_flags(fl, lo, hi, lane, [&](uint32_t v, int site) {
+    const uint32_t um = (v >> 1) & 0x01010101u;
+    uint32_t qm = 0;
+    if (write_q) {
+#pragma unroll
+      for (int b = 0; b < 4; ++b)
+        if (((v >> (8 * b)) & 1u) && eff_freq(a.tgt_freq, static_cast<uint8_t>(v >> (8 * b)), site + b) >= q) qm |= 1u << (8 * b);
     }
-  }
+    if (__ballot((um | qm) != 0u) == 0ull) return;
+    uint32_t below_u = 0, below_q = 0, total_u = 0, total_q = 0;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const unsigned long long mu = __ballot(((um >> (8 * b)) & 1u) != 0u);
+      const unsigned long long mq = __ballot(((qm >> (8 * b)) & 1u) != 0u);
+      below_u += __popcll(mu & lt_mask);
+      below_q += __popcll(mq & lt_mask);
+      total_u += __popcll(mu);
+      total_q += __popcll(mq);
+    }
+    uint32_t slot_u = done_u + below_u, slot_q = done_q + below_q;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const bool pu = (um >> (8 * b)) & 1u, pq = (qm >> (8 * b)) & 1u;
+      if (pu || pq) {
+        const int32_t out = a.pos ? a.pos[site + b] : site + b;
+        if (pu && write_u) a.cdd_u[off_u + slot_u] = out;
+        if (pq) a.cdd_q[off_q + slot_q] = out;
+        slot_u += pu;
+        slot_q += pq;
+      }
+    }
+    done_u += total_u;
+    done_q += total_q;
+  });
 }
 
 }  // namespace
@@ -430,7 +511,7 @@ int sai_window_stats(sai_ctx* ctx, int64_t n_sites, const double* tgt_freq, cons
   if (int rc = check_launch("window_stats_wave")) return rc;
   hipLaunchKernelGGL(window_stats_heavy_kernel, block_grid, dim3(kWinThreads), 0, st, a);
   if (int rc = check_launch("window_stats_heavy")) return rc;
-  hipLaunchKernelGGL(window_scan_kernel, dim3(1), dim3(1024), 0, st, a);
+  hipLaunchKernelGGL(window_scan_kernel, dim3(1), dim3(kScanThreads), 0, st, a);
   if (int rc = check_launch("window_scan")) return rc;
   hipLaunchKernelGGL(window_lists_kernel, wave_grid, dim3(256), 0, st, a);
   return check_launch("window_lists");

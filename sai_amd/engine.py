@@ -343,11 +343,11 @@ class Engine:
 
     def window_stats_async(self, tgt_freq, flags, sets, lo, hi, pos, bufs):
         """Enqueue the window kernel into caller-held buffers (no sync).  ``bufs`` =
-        (records u8 [S*W*24], offsets i64 [S*W*2], cdd_u i32, cdd_q i32, totals i64 [2])."""
+        (records u8 [S*W*24], offsets i64 [S*W*2], cdd_u i32, cdd_q i32, totals i64 [2], ...)."""
         n_sets, n_sites = int(flags.shape[0]), int(flags.shape[1])
         if n_sets > _ffi.SAI_MAX_SETS:
             raise ValueError("window_stats_async handles at most SAI_MAX_SETS sets per call")
-        records, offsets, cdd_u, cdd_q, totals = bufs
+        records, offsets, cdd_u, cdd_q, totals = bufs[:5]
         _ffi.check(
             self.lib.sai_window_stats(
                 self.ctx, n_sites, self._ptr(tgt_freq), self._ptr(flags), n_sets, self._params_array(sets),
@@ -358,13 +358,19 @@ class Engine:
         )  # fmt: skip
 
     def alloc_window_bufs(self, n_sets, n_windows, cap_u, cap_q):
+        """(records, offsets, cdd_u, cdd_q, totals, head): records, offsets and totals are views of
+        the one contiguous byte buffer ``head``, so a single copy brings them to the host."""
         torch = _torch()
+        n_rec = n_sets * n_windows
+        rec_bytes, off_bytes = n_rec * RECORD_DTYPE.itemsize, n_rec * 16  # 24 B records keep 8-byte alignment
+        head = self._empty((rec_bytes + off_bytes + 16,), torch.uint8)
         return (
-            self._empty((n_sets * n_windows * RECORD_DTYPE.itemsize,), torch.uint8),
-            self._empty((n_sets * n_windows * 2,), torch.int64),
+            head[:rec_bytes],
+            head[rec_bytes : rec_bytes + off_bytes].view(torch.int64),
             self._empty((max(int(cap_u), 1),), torch.int32),
             self._empty((max(int(cap_q), 1),), torch.int32),
-            self._empty((2,), torch.int64),
+            head[rec_bytes + off_bytes :].view(torch.int64),
+            head,
         )
 
     def window_stats(self, tgt_freq, flags, sets, lo, hi, pos=None, cap_hint=1 << 16) -> WindowResults:

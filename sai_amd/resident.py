@@ -95,9 +95,12 @@ class ResidentScorer:
         self.lo = torch.empty((n_w,), dtype=torch.int32, device=dev)
         self.hi = torch.empty((n_w,), dtype=torch.int32, device=dev)
         self.bufs = eng.alloc_window_bufs(n_s, n_w, cap_u, cap_q)
-        self.host_records = torch.empty((n_s * n_w * RECORD_DTYPE.itemsize,), dtype=torch.uint8).pin_memory()
-        self.host_offsets = torch.empty((n_s * n_w * 2,), dtype=torch.int64).pin_memory()
-        self.host_totals = torch.empty((2,), dtype=torch.int64).pin_memory()
+        # pinned mirror of the records | offsets | totals buffer: one copy per step
+        self.host_head = torch.empty((self.bufs[5].numel(),), dtype=torch.uint8).pin_memory()
+        rec_bytes = n_s * n_w * RECORD_DTYPE.itemsize
+        self.host_records = self.host_head[:rec_bytes]
+        self.host_offsets = self.host_head[rec_bytes:-16].view(torch.int64)
+        self.host_totals = self.host_head[-16:].view(torch.int64)
         self.count_events: list = []  # (start, end) torch events around site_counts, when requested
 
     @property
@@ -165,9 +168,7 @@ class ResidentScorer:
             )
         )  # fmt: skip
         eng.window_stats_async(tgt_freq, flags, self.sets, self.lo, self.hi, blk.pos, self.bufs)
-        self.host_records.copy_(self.bufs[0], non_blocking=True)
-        self.host_offsets.copy_(self.bufs[1], non_blocking=True)
-        self.host_totals.copy_(self.bufs[4], non_blocking=True)
+        self.host_head.copy_(self.bufs[5], non_blocking=True)
 
     def results(self) -> WindowResults:
         """Synchronise and return the last step's records and candidate lists."""
