@@ -153,6 +153,9 @@ def main() -> None:
                     help="pipeline every step's windows stage under the next step's site pass on a second stream; "
                     "auto = on for int8 (windows stage = 4 %% of a step), off for packed2 (site pass too short "
                     "for the small kernels to find free CUs under it: measured slower)")
+    ap.add_argument("--gather", choices=["end", "step"], default="end",
+                    help="N>1: 'end' keeps every step's records on the GPU and brings them to rank 0 with ONE RCCL "
+                    "gather before the closing fence (inside the timed region); 'step' gathers after every step")
     ap.add_argument("--cpu-sites", type=float, default=4e5, help="site prefix timed on the CPU (0 = skip)")
     ap.add_argument("--cpu-workers", type=int, default=0, help="0 = usable cores (affinity mask capped by the cgroup quota)")
     args = ap.parse_args()
@@ -216,11 +219,23 @@ def main() -> None:
         dist.all_gather(all_sizes, t)
         sizes = [int(s.item()) for s in all_sizes]
 
-    def step(timed: bool) -> None:
+    # N>1: the records of every step stay on the GPU (one row per step) and go to rank 0 in one gather
+    ring = None
+    if world > 1 and args.gather == "end":
+        ring = torch.empty((max(args.steps, args.warmup, 1), sizes[rank]), dtype=torch.uint8, device=eng.device)
+
+    def step(timed: bool, k: int) -> None:
         scorer.step(time_counts=timed)
         if world > 1:
             with scorer.window_stream():  # ordered after this step's records, not after the next site pass
-                gather_padded(scorer.bufs[0], sizes)
+                if ring is None:
+                    gather_padded(scorer.bufs[0], sizes)
+                else:
+                    ring[k].copy_(scorer.bufs[0], non_blocking=True)
+
+    def gather_ring(n_rows: int):
+        with scorer.window_stream():
+            return gather_padded(ring[:n_rows].reshape(-1), [n_rows * s for s in sizes])
 
     def fence() -> None:
         torch.cuda.synchronize()
@@ -228,12 +243,18 @@ def main() -> None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step(False)
+    for k in range(args.warmup):
+        step(False, k)
+    if ring is not None:
+        gather_ring(max(args.warmup, 1))  # also sets up RCCL's point-to-point channels outside the timed region
     fence()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step(True)
+    for k in range(args.steps):
+        step(True, k)
+    if ring is not None:
+        gathered = gather_ring(args.steps)
+        if rank == 0:
+            assert len(gathered) == world and all(g.numel() == args.steps * s for g, s in zip(gathered, sizes))
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -282,7 +303,7 @@ def main() -> None:
                 "n_sites_per_gpu": n_sites,
                 "windows_per_gpu": len(windows),
                 "windows_total": total_windows,
-                "sharding": "windows sharded by chromosome, RCCL gather of records to rank 0" if world > 1 else "none",
+                "sharding": f"windows sharded by chromosome, RCCL gather of records to rank 0 ({args.gather})" if world > 1 else "none",
                 "u_sum_rank0": int(res.records["u_count"].sum()),
                 "q_finite_rank0": int(np.isfinite(res.records["q"]).sum()),
             },
