@@ -1,0 +1,37 @@
+"""``mp_pool`` of the reference (sai/multiprocessing/mp_pool.py:25-73) over GPUs instead of host
+processes: one process drives one GPU, so the tasks of ``data_generator.get()`` are not handed to a
+``multiprocessing.Pool`` but run in this process, or -- under ``torchrun`` -- in contiguous blocks
+on the ranks of the job, whose results come back to rank 0 in task order."""
+
+from __future__ import annotations
+
+from typing import Any
+
+from ..distributed import my_chunk_indices
+from ..generators import DataGenerator
+from ..preprocessors import DataPreprocessor
+
+
+def mp_worker(params: tuple[DataPreprocessor, dict]) -> Any:
+    """``data_processor.run(**param_dict)`` (mp_pool.py:27-42)."""
+    data_processor, param_dict = params
+    return data_processor.run(**param_dict)
+
+
+def mp_pool(data_processor: DataPreprocessor, data_generator: DataGenerator, nprocess: int = 1) -> None:
+    """Same contract as the reference: one task per ``data_generator.get()`` entry, results in
+    task order, ``data_processor.process_items(results)`` once at the end (on rank 0 of a
+    multi-rank job).  ``nprocess`` is accepted for signature compatibility; the degree of
+    parallelism is the number of ranks (= GPUs) the job was launched with."""
+    import torch.distributed as dist
+
+    tasks = [(data_processor, params) for params in data_generator.get()]
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        data_processor.process_items([mp_worker(t) for t in tasks])
+        return
+    rank, world = dist.get_rank(), dist.get_world_size()
+    mine = [mp_worker(tasks[i]) for i in my_chunk_indices(len(tasks), rank, world)]
+    gathered = [None] * world if rank == 0 else None
+    dist.gather_object(mine, gathered, dst=0)
+    if rank == 0:
+        data_processor.process_items([res for per_rank in gathered for res in per_rank])

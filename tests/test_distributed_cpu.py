@@ -55,6 +55,17 @@ def _worker(rank: int, world: int, port: int, out_dir: str) -> None:
     else:
         assert items is None and pre.written is None and mine == [4, 5, 6]
 
+    # the reference's executor name and contract (results per task, unflattened, in task order)
+    from sai_amd.multiprocessing import mp_pool
+
+    pre2 = Pre()
+    mp_pool(pre2, Gen(), nprocess=4)
+    if rank == 0:
+        assert [[it["start"] for it in res] for res in pre2.written] == [[i * 100 + 1] * 2 for i in range(7)]
+        assert [res[0]["rank"] for res in pre2.written] == [0, 0, 0, 0, 1, 1, 1]
+    else:
+        assert pre2.written is None
+
     # records of different lengths per rank -> rank 0, in rank order
     local = torch.arange(10 + 5 * rank, dtype=torch.uint8) + 100 * rank
     got = gather_window_records(local)
@@ -110,3 +121,27 @@ def test_single_process_run_sharded_is_the_serial_loop():
 
     t = torch.arange(4)
     assert gather_window_records(t)[0] is t
+
+
+def test_mp_pool_single_process():
+    """Without a process group mp_pool runs the tasks in order in this process
+    (reference contract: tests/multiprocessing/test_mp_pool.py:25-46)."""
+    from sai_amd.generators import DataGenerator
+    from sai_amd.multiprocessing import mp_pool
+    from sai_amd.preprocessors import DataPreprocessor
+
+    class Gen(DataGenerator):
+        def get(self):
+            for i in range(5):
+                yield {"a": i, "b": 2 * i}
+
+    class Pre(DataPreprocessor):
+        def run(self, a, b):
+            return a + b
+
+        def process_items(self, items):
+            self.items = items
+
+    pre = Pre()
+    mp_pool(pre, Gen(), nprocess=2)
+    assert pre.items == [0, 3, 6, 9, 12]
