@@ -475,3 +475,20 @@ def test_gather_on_window_stream_with_rccl(eng):
         assert got[0].cpu().numpy().tobytes() == res.records.tobytes()
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_sites", [1, 2, 63, 64, 65, 66, 4225, 4226, 300_001])
+def test_window_bounds_equals_searchsorted(eng, n_sites):
+    """The 64-ary wave search: lo = first site with pos >= start, hi = first site with pos > end,
+    for windows inside, across and outside the position range, duplicate positions included."""
+    import torch
+
+    rng = np.random.default_rng(n_sites)
+    pos = np.cumsum(rng.integers(0 if n_sites > 2 else 1, 40, n_sites)).astype(np.int32) + 5  # ties allowed
+    top = int(pos[-1])
+    starts = np.concatenate([rng.integers(-10, top + 20, 400), [0, 5, int(pos[0]), top, top + 1, int(pos[n_sites // 2])]]).astype(np.int64)
+    ends = starts + np.concatenate([rng.integers(-3, 900, 400), [0, 0, 0, 0, 5, 0]]).astype(np.int64)
+    lo, hi = eng.window_bounds(torch.as_tensor(pos).to(eng.device), starts, ends)
+    want_lo = np.searchsorted(pos, starts, side="left")
+    want_hi = np.maximum(np.searchsorted(pos, ends, side="right"), want_lo)
+    assert np.array_equal(lo.cpu().numpy(), want_lo) and np.array_equal(hi.cpu().numpy(), want_hi)
