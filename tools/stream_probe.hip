@@ -1,6 +1,7 @@
 // Stand-alone microbenchmark: which streaming-read form gets closest to the HBM ceiling on this box?
 // hipcc -O3 --offload-arch=gfx950 tools/stream_probe.hip -o /tmp/stream_probe && /tmp/stream_probe
 #include <hip/hip_runtime.h>
+#include <cstring>
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -235,9 +236,15 @@ __global__ __launch_bounds__(64) void k_policy(const u32x4* __restrict__ src, in
   if (r == 0x12345678u) out[0] = r;
 }
 
-int main() {
-  const int64_t n_tiles = 156250;
-  const int64_t pop_bytes = n_tiles * 64000ll;
+int main(int argc, char** argv) {
+  // usage: stream_probe [section ...]   sections: stride chunk glds swar writes policy (default: all)
+  auto want = [&](const char* name) {
+    if (argc < 2) return true;
+    for (int i = 1; i < argc; ++i) if (!strcmp(argv[i], name)) return true;
+    return false;
+  };
+  const int64_t n_tiles = 156250;                // the C3 block: 10^7 sites
+  const int64_t pop_bytes = n_tiles * 64000ll;   // 1000 individuals x 64 sites per tile
   int8_t* big; double* freq; uint8_t* flags; uint32_t* out;
   CK(hipMalloc(&big, 2 * pop_bytes + 4096)); CK(hipMalloc(&freq, n_tiles * 64 * 8)); CK(hipMalloc(&flags, n_tiles * 64)); CK(hipMalloc(&out, 4));
   hipLaunchKernelGGL(k_fill_random, dim3(4096), dim3(256), 0, 0, (uint32_t*)big, 2 * pop_bytes / 4);
@@ -245,15 +252,33 @@ int main() {
   hipDeviceProp_t pr; CK(hipGetDeviceProperties(&pr, 0));
   const int cu = pr.multiProcessorCount;
   const double bytes = 2.0 * pop_bytes;
-  auto rep = [&](const char* name, double ms) { printf("%-52s %8.3f ms  %8.1f GB/s\n", name, ms, bytes / ms / 1e6); fflush(stdout); };
-  // two streams 10 GB apart vs [ref|tgt] interleaved per tile; with / without the per-site writes
-#define E(U, G, W, NAME, TGT, STRIDE, NIND, NT) rep("dot4 U=" #U " grid=cu*" #G " write=" #W " " NAME, time_ms([&] { hipLaunchKernelGGL((k_dot4<U, W>), dim3(cu * G), dim3(64), 0, 0, big, big + (TGT), (int64_t)(NT), NIND, (int64_t)(STRIDE), freq, flags); }))
   const int64_t n = 2 * pop_bytes / 16;
-  rep("wavechunk 128000B U=4 grid=cu*32", time_ms([&] { hipLaunchKernelGGL((k_wavechunk<4, true>), dim3(cu * 32), dim3(64), 0, 0, (const u32x4*)big, n, (int64_t)8000, out); }));
-  rep("wavechunk 256000B U=4 grid=cu*32", time_ms([&] { hipLaunchKernelGGL((k_wavechunk<4, true>), dim3(cu * 32), dim3(64), 0, 0, (const u32x4*)big, n, (int64_t)16000, out); }));
-  rep("wavechunk 64000B U=5 grid=cu*32", time_ms([&] { hipLaunchKernelGGL((k_wavechunk<5, true>), dim3(cu * 32), dim3(64), 0, 0, (const u32x4*)big, n, (int64_t)4000, out); }));
-#define P(POL, NAME) rep("policy " NAME " U=5 128000B grid=cu*32", time_ms([&] { hipLaunchKernelGGL((k_policy<POL>), dim3(cu * 32), dim3(64), 0, 0, (const u32x4*)big, n, out); }))
-  P(0, "default"); P(1, "nt"); P(2, "sc0"); P(3, "sc1"); P(4, "sc0 sc1"); P(5, "sc0 nt"); P(6, "sc1 nt"); P(7, "sc0 sc1 nt"); P(1, "nt"); P(0, "default");
-  rep("swar 256000B U=4 grid=cu*32", time_ms([&] { hipLaunchKernelGGL((k_swar<4, 1>), dim3(cu * 32), dim3(64), 0, 0, (const u32x4*)big, n, (int64_t)16000, out); }));
+  const u32x4* src = (const u32x4*)big;
+  auto rep = [&](const char* name, double ms) { printf("%-56s %8.3f ms  %8.1f GB/s\n", name, ms, bytes / ms / 1e6); fflush(stdout); };
+  if (want("stride")) {  // thread-strided grid loops
+#define A(U, NT, G) rep("gridstride U=" #U " nt=" #NT " grid=cu*" #G, time_ms([&] { hipLaunchKernelGGL((k_gridstride<U, NT>), dim3(cu * G), dim3(256), 0, 0, src, n, out); }))
+    A(4, true, 8); A(4, false, 8); A(8, true, 8); A(8, true, 16);
+  }
+  if (want("chunk")) {  // one wave per contiguous run (chunk sizes divide 20.0 GB exactly with these unrolls)
+#define B(U, NT, G, CH) rep("wavechunk " #CH "x16B U=" #U " nt=" #NT " grid=cu*" #G, time_ms([&] { hipLaunchKernelGGL((k_wavechunk<U, NT>), dim3(cu * G), dim3(64), 0, 0, src, n, (int64_t)(CH), out); }))
+    B(4, true, 32, 8000); B(4, true, 32, 16000); B(5, true, 32, 8000); B(8, true, 16, 16000); B(8, true, 32, 16000); B(8, false, 32, 16000);
+  }
+  if (want("glds")) {  // LDS-DMA ring instead of registers
+#define Cc(S, AUX, G) rep("glds ring slots=" #S " aux=" #AUX " grid=cu*" #G, time_ms([&] { hipLaunchKernelGGL((k_glds<S, AUX>), dim3(cu * G), dim3(64), 0, 0, src, n, (int64_t)16000, out); }))
+    Cc(8, 0, 16); Cc(8, 2, 16); Cc(16, 2, 16); Cc(4, 2, 32);
+  }
+  if (want("swar")) {  // + the byte arithmetic of site_counts
+#define D(U, W, G, CH) rep("swar U=" #U " minwaves=" #W " grid=cu*" #G " run=" #CH "x16B", time_ms([&] { hipLaunchKernelGGL((k_swar<U, W>), dim3(cu * G), dim3(64), 0, 0, src, n, (int64_t)(CH), out); }))
+    D(4, 1, 16, 16000); D(4, 1, 32, 16000); D(4, 1, 64, 16000); D(8, 1, 32, 16000); D(4, 8, 32, 16000);
+  }
+  if (want("writes")) {  // lane = site layout, per-site outputs: 0 none, 1 freq+flags, 2 flags, 3 freq, 4 both nt,
+                         // 5 flags + freq where flagged, 6 ballot-packed flags, 7 flags of 4 tiles batched, 9 nt flags + sparse freq
+#define E(U, G, W) rep("dot4 U=" #U " grid=cu*" #G " write=" #W, time_ms([&] { hipLaunchKernelGGL((k_dot4<U, W>), dim3(cu * G), dim3(64), 0, 0, big, big + pop_bytes, n_tiles, 1000, (int64_t)64000, freq, flags); }))
+    E(8, 32, 0); E(8, 32, 1); E(8, 32, 2); E(8, 32, 3); E(8, 32, 4); E(8, 32, 5); E(8, 32, 6); E(8, 32, 7); E(8, 32, 9); E(16, 32, 0); E(4, 32, 0);
+  }
+  if (want("policy")) {  // cache-policy bits of the load
+#define P(POL, NAME) rep("policy " NAME " U=5 run=8000x16B grid=cu*32", time_ms([&] { hipLaunchKernelGGL((k_policy<POL>), dim3(cu * 32), dim3(64), 0, 0, src, n, out); }))
+    P(0, "default"); P(1, "nt"); P(2, "sc0"); P(3, "sc1"); P(4, "sc0 sc1"); P(5, "sc0 nt"); P(6, "sc1 nt"); P(7, "sc0 sc1 nt");
+  }
   return 0;
 }
