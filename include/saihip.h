@@ -145,8 +145,8 @@ int sai_site_flags(sai_ctx* ctx, int64_t n_sites, int32_t n_pops, const int32_t*
 
 /* Kernel 3: window -> site-index range.  Replaces the per-window position masks of
  * WindowGenerator._window_generator (window_generator.py:173-183) for a resident block with
- * strictly increasing positions: lo[w] = first site with pos >= win_start[w], hi[w] = one past
- * the last site with pos <= win_end[w] (inclusive windows, utils.py:607-610). */
+ * non-decreasing positions: lo[w] = first site with pos >= win_start[w], hi[w] = one past the
+ * last site with pos <= win_end[w] (inclusive windows, utils.py:607-610). */
 int sai_window_bounds(sai_ctx* ctx, const int32_t* pos, int64_t n_sites, int32_t n_windows,
                       const int64_t* win_start, const int64_t* win_end, int32_t* lo, int32_t* hi,
                       void* stream);
@@ -163,7 +163,10 @@ int sai_window_bounds(sai_ctx* ctx, const int32_t* pos, int64_t n_sites, int32_t
  *   list entries are pos[site] when `pos` is non-NULL, else block-relative site indices;
  *   cdd_total[0..1] = entries needed for all U / Q lists: when a total exceeds its capacity,
  *     re-run with larger buffers.
- * `quantile` is taken from sets_host[set].quantile. */
+ * `quantile` is taken from sets_host[set].quantile.  `flags` is read as aligned 32-bit words, so up
+ * to 3 bytes on either side of the n_sets * n_sites bytes are loaded (never used): inside the
+ * same aligned word as a valid byte, hence always inside the same page.  tgt_freq is read only
+ * at sites whose flags bit 0 is set (see SAI_FREQ_CANDIDATES). */
 int sai_window_stats(sai_ctx* ctx, int64_t n_sites, const double* tgt_freq, const uint8_t* flags,
                      int32_t n_sets, const sai_params* sets_host, int32_t n_windows,
                      const int32_t* lo, const int32_t* hi, const int32_t* pos,
