@@ -1,0 +1,63 @@
+"""End-to-end `score` on a synthetic VCF (host parse -> GPU -> TSV): where does the time go?"""
+import cProfile, io, os, pstats, sys, tempfile, time
+import numpy as np
+sys.path.insert(0, ".")
+
+n_sites = int(float(sys.argv[1])) if len(sys.argv) > 1 else 50000
+n_ref, n_tgt, n_src = 1000, 1000, 2
+rng = np.random.default_rng(1)
+d = tempfile.mkdtemp(dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+names = [f"i{k}" for k in range(n_ref + n_tgt + n_src)]
+calls = np.array(["0|0", "0|1", "1|0", "1|1", ".|."])
+vcf = os.path.join(d, "synth.vcf")
+t0 = time.perf_counter()
+with open(vcf, "w") as f:
+    f.write("##fileformat=VCFv4.2\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t" + "\t".join(names) + "\n")
+    pos = 0
+    for s in range(n_sites):
+        pos += int(rng.integers(1, 50))
+        intro = rng.random() < 0.01
+        p = rng.random() ** 4
+        pr = 0.0 if intro else p
+        row = np.concatenate([rng.binomial(1, pr, 2 * n_ref), rng.binomial(1, 0.6 if intro else p, 2 * n_tgt),
+                              rng.binomial(1, 1.0 if intro else p, 2 * n_src)]).reshape(-1, 2)
+        f.write(f"1\t{pos}\t.\tA\tT\t100\tPASS\t.\tGT\t" + "\t".join(f"{a}|{b}" for a, b in row) + "\n")
+for grp, sl in (("ref", names[:n_ref]), ("tgt", names[n_ref:n_ref + n_tgt]), ("src", names[n_ref + n_tgt:])):
+    with open(os.path.join(d, f"{grp}.list"), "w") as f:
+        f.write("".join(f"{grp.upper()}\t{n}\n" for n in sl))
+cfg = os.path.join(d, "cfg.yaml")
+with open(cfg, "w") as f:
+    f.write(f"""statistics:
+  U:
+    ref: {{REF: 0.01}}
+    tgt: {{TGT: 0.5}}
+    src: {{SRC: "=1"}}
+  Q:
+    ref: {{REF: 0.01}}
+    tgt: {{TGT: 0.95}}
+    src: {{SRC: "=1"}}
+ploidies:
+  ref: {{REF: 2}}
+  tgt: {{TGT: 2}}
+  src: {{SRC: 2}}
+populations:
+  ref: {d}/ref.list
+  tgt: {d}/tgt.list
+  src: {d}/src.list
+""")
+print(f"VCF {os.path.getsize(vcf) / 1e6:.0f} MB written in {time.perf_counter() - t0:.1f} s", flush=True)
+from sai_amd.sai import score
+import torch; torch.cuda.init()
+out = os.path.join(d, "out.tsv")
+score(vcf_file=vcf, chr_name="1", win_len=50000, win_step=25000, anc_allele_file=None, output_file=out, config=cfg, num_workers=1)  # warm
+pr = cProfile.Profile()
+t0 = time.perf_counter()
+pr.enable()
+score(vcf_file=vcf, chr_name="1", win_len=50000, win_step=25000, anc_allele_file=None, output_file=out, config=cfg, num_workers=1)
+pr.disable()
+dt = time.perf_counter() - t0
+rows = sum(1 for _ in open(out)) - 1
+print(f"score: {dt:.3f} s for {n_sites} sites, {rows} windows -> {os.path.getsize(vcf) / dt / 1e6:.0f} MB/s of VCF")
+s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats("cumulative").print_stats(18); print(s.getvalue()[-3500:])
+print(open(out).read()[:400])
+import shutil; shutil.rmtree(d)
