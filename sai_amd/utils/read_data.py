@@ -42,7 +42,7 @@ def read_data(
     if out_ind_file is not None and "outgroup" in ploidy_config.root:
         groups.append(("outgroup", out_ind_file))
     samples_by_group: dict[str, Optional[dict[str, list[str]]]] = {}
-    wanted: list[str] = []
+    wanted: set[str] = set()
     for group, ind_file in groups:
         if ind_file is None:
             samples_by_group[group] = None
@@ -58,7 +58,7 @@ def read_data(
         samples_by_group[group] = samples
         for population, names in samples.items():
             if population in ploidy_config.root[group]:
-                wanted.extend(n for n in names if n not in wanted)
+                wanted.update(names)
 
     results: dict = {"outgroup": (None, None)}
     if not wanted:
@@ -70,14 +70,19 @@ def read_data(
     where = chr_name if start is None and end is None else f"{chr_name}:{start}-{end}"
     # one pass per distinct ploidy (normally one or two), each over the samples that need it
     by_ploidy: dict[int, list[str]] = {}
+    seen: dict[int, set[str]] = {}
     for group, _ in groups:
         samples = samples_by_group[group]
         if samples is None:
             continue
         for population, names in samples.items():
             if population in ploidy_config.root[group]:
-                bucket = by_ploidy.setdefault(ploidy_config.root[group][population], [])
-                bucket.extend(n for n in names if n not in bucket)
+                ploidy = ploidy_config.root[group][population]
+                bucket, have = by_ploidy.setdefault(ploidy, []), seen.setdefault(ploidy, set())
+                for n in names:  # first occurrence keeps its place (a sample may sit in several populations)
+                    if n not in have:
+                        have.add(n)
+                        bucket.append(n)
     loaded = {}
     for ploidy, names in by_ploidy.items():
         try:
@@ -108,7 +113,11 @@ def read_data(
             pos, dos, column, n_matched = loaded[ploidy_config.root[group][population]]
             if n_matched == 0:  # no record in the region: the reference's "vcf_data is None" case
                 continue
-            gt = np.ascontiguousarray(dos[:, [column[n] for n in names]])
+            cols = [column[n] for n in names]
+            if cols and cols == list(range(cols[0], cols[0] + len(cols))):  # the usual case: one block of columns
+                gt = np.ascontiguousarray(dos[:, cols[0] : cols[0] + len(cols)])
+            else:
+                gt = np.ascontiguousarray(dos[:, cols])
             data[population] = ChromosomeData(POS=pos.copy(), REF=None, ALT=None, GT=gt)
         results[group] = (data if data else None, samples)
     return results
