@@ -29,6 +29,8 @@ extern "C" int sai_set_error(int code, const char* fmt, ...);  // defined in cor
 
 namespace {
 
+constexpr int kScanThreads = 8;  // inflate threads of sai_vcf_scan (it has no thread argument)
+
 struct GzReader {
   gzFile f = nullptr;
   explicit GzReader(const char* path) { f = gzopen(path, "rb"); if (f) gzbuffer(f, 1 << 20); }
@@ -236,10 +238,160 @@ int load_anc(const char* path, const std::string& chrom, int64_t start, int64_t 
   return SAI_OK;
 }
 
-// Streams the file in blocks of whole lines and hands each block to `consume(begin, end)`.
-// Returns 0, or a negative status after sai_set_error.
+// ---- BGZF (bgzip) input ---------------------------------------------------------------------
+// A bgzip file is a sequence of independent gzip members of at most 64 KiB, each carrying its
+// own compressed size in a 'BC' extra subfield and its uncompressed size in the trailer: the
+// members of a batch are inflated in parallel straight into their places in the output buffer.
+
+struct BgzfMember {
+  size_t data_off;   // first byte of the raw deflate stream inside the compressed buffer
+  uint32_t data_len;
+  uint32_t isize;    // uncompressed bytes
+  uint32_t crc;
+  size_t out_off;
+};
+
+inline uint32_t le32(const unsigned char* p) {
+  return static_cast<uint32_t>(p[0]) | static_cast<uint32_t>(p[1]) << 8 | static_cast<uint32_t>(p[2]) << 16 |
+         static_cast<uint32_t>(p[3]) << 24;
+}
+
+// Size of the gzip member starting at p (n bytes available) when it is a BGZF member; 0 when more
+// bytes are needed, -1 when it is not BGZF.
+inline long bgzf_member_size(const unsigned char* p, size_t n, size_t* header_len) {
+  if (n < 12) return 0;
+  if (p[0] != 0x1f || p[1] != 0x8b || p[2] != 8 || !(p[3] & 4)) return -1;
+  const size_t xlen = static_cast<size_t>(p[10]) | static_cast<size_t>(p[11]) << 8;
+  if (n < 12 + xlen) return 0;
+  for (size_t o = 12; o + 4 <= 12 + xlen;) {
+    const size_t slen = static_cast<size_t>(p[o + 2]) | static_cast<size_t>(p[o + 3]) << 8;
+    if (p[o] == 'B' && p[o + 1] == 'C' && slen == 2 && o + 6 <= 12 + xlen) {
+      *header_len = 12 + xlen;
+      return static_cast<long>(static_cast<size_t>(p[o + 4]) | static_cast<size_t>(p[o + 5]) << 8) + 1;
+    }
+    o += 4 + slen;
+  }
+  return -1;
+}
+
+bool inflate_member(const unsigned char* src, const BgzfMember& m, char* dst) {
+  if (m.isize == 0) return true;
+  z_stream zs;
+  memset(&zs, 0, sizeof(zs));
+  if (inflateInit2(&zs, -15) != Z_OK) return false;
+  zs.next_in = const_cast<unsigned char*>(src + m.data_off);
+  zs.avail_in = m.data_len;
+  zs.next_out = reinterpret_cast<unsigned char*>(dst + m.out_off);
+  zs.avail_out = m.isize;
+  const int rc = inflate(&zs, Z_FINISH);
+  const bool ok = rc == Z_STREAM_END && zs.total_out == m.isize;
+  inflateEnd(&zs);
+  return ok && crc32(crc32(0L, Z_NULL, 0), reinterpret_cast<const unsigned char*>(dst + m.out_off), m.isize) == m.crc;
+}
+
+// uncompressed bytes handed to the consumer at a time (SAI_VCF_BATCH_BYTES overrides it: the tests
+// use a few KiB so that every carry-over path between batches runs)
+inline size_t batch_out_bytes() {
+  if (const char* e = getenv("SAI_VCF_BATCH_BYTES")) {
+    const long long v = atoll(e);
+    if (v > 0) return static_cast<size_t>(v);
+  }
+  return size_t(48) << 20;
+}
+
 template <typename F>
-int for_each_block(const char* path, F&& consume) {
+int for_each_block_bgzf(FILE* f, const char* path, int n_threads, F&& consume) {
+  std::vector<unsigned char> cbuf(size_t(16) << 20);
+  std::vector<char> ubuf;
+  std::vector<BgzfMember> members;
+  size_t chave = 0, carry = 0;
+  bool ceof = false;
+  const size_t batch_out = batch_out_bytes();
+  for (;;) {
+    if (!ceof && chave < cbuf.size()) {
+      const size_t got = fread(cbuf.data() + chave, 1, cbuf.size() - chave, f);
+      if (got == 0) {
+        if (ferror(f)) return sai_set_error(SAI_ERR_ARG, "read error in %s", path);
+        ceof = true;
+      }
+      chave += got;
+    }
+    members.clear();
+    size_t off = 0, out_total = 0;
+    while (off < chave && out_total < batch_out) {
+      size_t hlen = 0;
+      const long bsize = bgzf_member_size(cbuf.data() + off, chave - off, &hlen);
+      if (bsize < 0) return sai_set_error(SAI_ERR_ARG, "%s: corrupt BGZF block", path);
+      if (bsize == 0 || off + static_cast<size_t>(bsize) > chave) break;  // incomplete member
+      if (static_cast<size_t>(bsize) < hlen + 8) return sai_set_error(SAI_ERR_ARG, "%s: corrupt BGZF block", path);
+      const unsigned char* tail = cbuf.data() + off + bsize - 8;
+      members.push_back({off + hlen, static_cast<uint32_t>(static_cast<size_t>(bsize) - hlen - 8), le32(tail + 4),
+                         le32(tail), out_total});
+      out_total += le32(tail + 4);
+      off += static_cast<size_t>(bsize);
+    }
+    if (members.empty()) {
+      if (ceof) {
+        if (chave) return sai_set_error(SAI_ERR_ARG, "%s: truncated BGZF file", path);
+        if (carry) {  // last line without a newline
+          const int rc = consume(ubuf.data(), ubuf.data() + carry);
+          if (rc < 0) return rc;
+        }
+        return SAI_OK;
+      }
+      if (chave == cbuf.size()) cbuf.resize(cbuf.size() * 2);
+      continue;
+    }
+    if (ubuf.size() < carry + out_total) ubuf.resize(carry + out_total);
+    {
+      const int nt = std::max(1, std::min<int>(n_threads, static_cast<int>(members.size())));
+      std::vector<char> bad(static_cast<size_t>(nt), 0);
+      auto work = [&](int t) {
+        const size_t lo = members.size() * static_cast<size_t>(t) / static_cast<size_t>(nt);
+        const size_t hi = members.size() * static_cast<size_t>(t + 1) / static_cast<size_t>(nt);
+        for (size_t i = lo; i < hi; ++i)
+          if (!inflate_member(cbuf.data(), members[i], ubuf.data() + carry)) bad[static_cast<size_t>(t)] = 1;
+      };
+      std::vector<std::thread> th;
+      for (int t = 1; t < nt; ++t) th.emplace_back(work, t);
+      work(0);
+      for (auto& x : th) x.join();
+      for (char b : bad)
+        if (b) return sai_set_error(SAI_ERR_ARG, "%s: BGZF block fails to inflate or its CRC", path);
+    }
+    memmove(cbuf.data(), cbuf.data() + off, chave - off);
+    chave -= off;
+    const size_t have = carry + out_total;
+    size_t usable = 0;
+    for (size_t i = have; i > 0; --i)
+      if (ubuf[i - 1] == '\n') { usable = i; break; }
+    if (usable) {
+      const int rc = consume(ubuf.data(), ubuf.data() + usable);
+      if (rc < 0) return rc;
+      if (rc > 0) return SAI_OK;  // consumer has seen enough
+    }
+    carry = have - usable;
+    if (carry && usable) memmove(ubuf.data(), ubuf.data() + usable, carry);
+  }
+}
+
+// Streams the file in blocks of whole lines and hands each block to `consume(begin, end)`; bgzip
+// files are inflated by `n_threads` threads, plain gzip and uncompressed text go through zlib's
+// gzread.  Returns 0, or a negative status after sai_set_error.
+template <typename F>
+int for_each_block(const char* path, int n_threads, F&& consume) {
+  if (FILE* f = fopen(path, "rb")) {
+    unsigned char head[64];
+    const size_t n = fread(head, 1, sizeof(head), f);
+    size_t hlen = 0;
+    if (bgzf_member_size(head, n, &hlen) > 0) {
+      rewind(f);
+      const int rc = for_each_block_bgzf(f, path, n_threads, consume);
+      fclose(f);
+      return rc;
+    }
+    fclose(f);
+  }
   GzReader r(path);
   if (!r.f) return sai_set_error(SAI_ERR_ARG, "cannot open VCF %s", path);
   std::vector<char> buf(size_t(8) << 20);
@@ -317,7 +469,7 @@ int sai_vcf_scan(const char* path, const char* chrom, int64_t* first_pos, int64_
   const std::string c(chrom);
   int64_t first = -1, last = -1;
   bool header_seen = false;
-  const int rc = for_each_block(path, [&](const char* p, const char* end) -> int {
+  const int rc = for_each_block(path, kScanThreads, [&](const char* p, const char* end) -> int {
     while (p < end) {
       const char* eol = static_cast<const char*>(memchr(p, '\n', static_cast<size_t>(end - p)));
       if (!eol) eol = end;
@@ -367,7 +519,7 @@ int sai_vcf_load(const char* path, const char* chrom, int64_t start, int64_t end
   // per-thread scratch lives across blocks: clear() keeps the capacity, so the allocator (and the
   // page-fault cost of fresh memory) is paid once, not per block
   std::vector<ThreadOut> outs(static_cast<size_t>(n_threads));
-  const int rc = for_each_block(path, [&](const char* p, const char* endp) -> int {
+  const int rc = for_each_block(path, n_threads, [&](const char* p, const char* endp) -> int {
     while (!header_seen && p < endp) {  // header lines (serial)
       const char* eol = static_cast<const char*>(memchr(p, '\n', static_cast<size_t>(endp - p)));
       if (!eol) eol = endp;

@@ -32,7 +32,9 @@ def write_vcf(path, rng, n_sites, n_samples, chroms=("7", "21", "22"), gz=False,
                 calls.append(":".join(sub))
             lines.append("\t".join([chrom, str(pos), ".", ref, alt, "100", "PASS", "AA=" + ref, fmt] + calls))
     text = ("\r\n" if crlf else "\n").join(lines) + ("\r\n" if crlf else "\n")
-    if gz:
+    if gz == "bgzf":
+        write_bgzf(path, text.encode(), rng)
+    elif gz:
         with gzip.open(path, "wt", newline="") as f:
             f.write(text)
     else:
@@ -41,18 +43,40 @@ def write_vcf(path, rng, n_sites, n_samples, chroms=("7", "21", "22"), gz=False,
     return names
 
 
+def write_bgzf(path, data: bytes, rng, max_block=6000):
+    """bgzip container (SAM spec 4.1): independent gzip members with a 'BC' extra subfield holding
+    the member size - 1, ragged small blocks so that lines straddle members, empty EOF member."""
+    import struct
+    import zlib
+
+    def member(chunk: bytes) -> bytes:
+        comp = zlib.compressobj(6, zlib.DEFLATED, -15)
+        raw = comp.compress(chunk) + comp.flush()
+        bsize = 12 + 6 + len(raw) + 8
+        head = b"\x1f\x8b\x08\x04" + b"\x00" * 4 + b"\x00\xff" + struct.pack("<H", 6) + b"BC" + struct.pack("<HH", 2, bsize - 1)
+        return head + raw + struct.pack("<II", zlib.crc32(chunk) & 0xFFFFFFFF, len(chunk))
+
+    with open(path, "wb") as f:
+        off = 0
+        while off < len(data):
+            n = int(rng.integers(1, max_block))
+            f.write(member(data[off : off + n]))
+            off += n
+        f.write(member(b""))
+
+
 def python_reader(path, chrom, names, ploidy, start=None, end=None, anc=None):
     from sai_amd.utils.read_data import _load_python
 
     return _load_python(str(path), chrom, list(names), ploidy, start, end, anc)
 
 
-@pytest.mark.parametrize("gz,crlf", [(False, False), (True, False), (False, True)])
+@pytest.mark.parametrize("gz,crlf", [(False, False), (True, False), (False, True), ("bgzf", False), ("bgzf", True)])
 def test_native_equals_python_reader(tmp_path, gz, crlf):
     from sai_amd.utils.native_vcf import load_dosage, scan_first_last
     from sai_amd.utils.vcf import first_last_pos
 
-    rng = np.random.default_rng(11 + gz + 2 * crlf)
+    rng = np.random.default_rng(11 + bool(gz) + 2 * crlf + 4 * (gz == "bgzf"))
     path = tmp_path / ("t.vcf.gz" if gz else "t.vcf")
     names = write_vcf(path, rng, 400, 13, gz=gz, crlf=crlf)
     bed = tmp_path / "anc.bed"
@@ -140,3 +164,31 @@ def test_native_errors(tmp_path, in_repo_root):
         empty = read_data("tests/data/test.data.vcf", "21", pc, "tests/data/test.ref.ind.list", "tests/data/test.tgt.ind.list",
                           None, anc_allele_file="tests/data/test.anc.allele.bed", start=100, end=2000, engine=engine)  # fmt: skip
         assert empty["ref"][0] is None and empty["tgt"][0] is None
+
+
+def test_bgzf_batches_and_damage(tmp_path, monkeypatch):
+    """Tiny batches (every member boundary is also a batch boundary with a carried partial line)
+    give the same matrix as one batch; a flipped byte or a cut file is an error, not garbage."""
+    from sai_amd.utils.native_vcf import load_dosage, scan_first_last
+
+    rng = np.random.default_rng(77)
+    path = tmp_path / "b.vcf.gz"
+    names = write_vcf(path, rng, 300, 9, gz="bgzf")
+    want = load_dosage(str(path), "21", names, [2] * len(names), None, None, None, 3)
+    first_last = scan_first_last(str(path), "22")
+    for batch in ("1", "700", "5000"):
+        monkeypatch.setenv("SAI_VCF_BATCH_BYTES", batch)
+        got = load_dosage(str(path), "21", names, [2] * len(names), None, None, None, 3)
+        assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]) and got[2:] == want[2:]
+        assert scan_first_last(str(path), "22") == first_last
+    monkeypatch.delenv("SAI_VCF_BATCH_BYTES")
+    raw = bytearray(path.read_bytes())
+    cut = tmp_path / "cut.vcf.gz"
+    cut.write_bytes(bytes(raw[: len(raw) // 2]))
+    with pytest.raises((ValueError, OSError), match="BGZF"):
+        load_dosage(str(cut), "21", names, [2] * len(names))
+    raw[len(raw) // 2] ^= 0x5A
+    bad = tmp_path / "bad.vcf.gz"
+    bad.write_bytes(bytes(raw))
+    with pytest.raises((ValueError, OSError), match="BGZF"):
+        load_dosage(str(bad), "21", names, [2] * len(names))
