@@ -37,6 +37,11 @@ struct GzReader {
   ~GzReader() { if (f) gzclose(f); }
 };
 
+inline uint32_t le32(const unsigned char* p) {
+  return static_cast<uint32_t>(p[0]) | static_cast<uint32_t>(p[1]) << 8 | static_cast<uint32_t>(p[2]) << 16 |
+         static_cast<uint32_t>(p[3]) << 24;
+}
+
 inline const char* find_tab(const char* p, const char* end) {
   const void* t = memchr(p, '\t', static_cast<size_t>(end - p));
   return t ? static_cast<const char*>(t) : end;
@@ -59,6 +64,9 @@ struct ThreadOut {
   std::vector<int8_t> dosage;
   int64_t matched = 0;  // records of the chromosome inside the region, before polarisation
   int64_t first = -1, last = -1;
+  bool saw_chrom = false;        // a record line of the requested chromosome
+  bool beyond_stop = false;      // ... with POS past the region
+  bool last_line_other = false;  // the last record line of the piece is another chromosome
   std::string error;
 };
 
@@ -93,13 +101,19 @@ void parse_lines(const char* begin, const char* end, const std::string& chrom, i
     if (le > line && le[-1] == '\r') --le;
     if (le == line || *line == '#') continue;
     const char* t1 = find_tab(line, le);
-    if (static_cast<size_t>(t1 - line) != chrom.size() || memcmp(line, chrom.data(), chrom.size()) != 0) continue;
+    if (static_cast<size_t>(t1 - line) != chrom.size() || memcmp(line, chrom.data(), chrom.size()) != 0) {
+      out.last_line_other = true;
+      continue;
+    }
     if (t1 >= le) continue;
+    out.last_line_other = false;
+    out.saw_chrom = true;
     const char* f = t1 + 1;
     int64_t pos = 0;
     while (f < le && *f >= '0' && *f <= '9') pos = pos * 10 + (*f++ - '0');
     if (out.first < 0) out.first = pos;
     out.last = pos;
+    if (stop >= 0 && pos > stop) out.beyond_stop = true;
     if ((start >= 0 && pos < start) || (stop >= 0 && pos > stop)) continue;
     ++out.matched;
     if (!want_rows) continue;
@@ -238,6 +252,87 @@ int load_anc(const char* path, const std::string& chrom, int64_t start, int64_t 
   return SAI_OK;
 }
 
+// ---- tabix index (.tbi) ----------------------------------------------------------------------
+// When `<vcf>.tbi` lies next to a bgzip VCF, a region load seeks to the first 16 kb window of the
+// region through the index's linear part and stops at the first record past the region (an
+// indexed file is sorted), and the chromosome scan reads two records instead of the file.  The
+// reference gets the same effect from scikit-allel / pysam using the same index
+// (utils.py:123-138, chunk_generator.py:64-73).  Virtual offset = compressed offset of a member
+// << 16 | offset inside its uncompressed data.
+
+struct TbiRef {
+  bool present = false;           // the chromosome is in the index
+  std::vector<uint64_t> ioff;     // linear index: first record overlapping each 16 kb window
+  uint64_t first_voff = ~0ull;    // smallest / largest start of a chunk of the chromosome's bins
+  uint64_t last_chunk_voff = 0;
+};
+
+bool read_all_gz(const std::string& path, std::vector<unsigned char>& out) {
+  gzFile f = gzopen(path.c_str(), "rb");
+  if (!f) return false;
+  out.clear();
+  unsigned char buf[1 << 16];
+  int got;
+  while ((got = gzread(f, buf, sizeof(buf))) > 0) out.insert(out.end(), buf, buf + got);
+  gzclose(f);
+  return got == 0;
+}
+
+// false: no usable index (absent, unreadable, malformed) -- the caller falls back to a full pass
+bool load_tbi(const char* vcf_path, const std::string& chrom, TbiRef& ref) {
+  std::vector<unsigned char> d;
+  if (!read_all_gz(std::string(vcf_path) + ".tbi", d)) return false;
+  size_t o = 0;
+  auto need = [&](size_t n) { return o + n <= d.size(); };
+  auto i32 = [&]() { const int32_t v = static_cast<int32_t>(le32(d.data() + o)); o += 4; return v; };
+  auto u64 = [&]() { const uint64_t v = static_cast<uint64_t>(le32(d.data() + o)) | static_cast<uint64_t>(le32(d.data() + o + 4)) << 32; o += 8; return v; };
+  if (!need(36) || memcmp(d.data(), "TBI\1", 4) != 0) return false;
+  o = 4;
+  const int32_t n_ref = i32();
+  o += 6 * 4;  // format, col_seq, col_beg, col_end, meta, skip
+  const int32_t l_nm = i32();
+  if (n_ref < 0 || l_nm < 0 || !need(static_cast<size_t>(l_nm))) return false;
+  std::vector<std::string> names;
+  for (size_t b = o, e = o + static_cast<size_t>(l_nm); b < e;) {
+    const void* z = memchr(d.data() + b, 0, e - b);
+    if (!z) return false;
+    names.emplace_back(reinterpret_cast<const char*>(d.data() + b));
+    b = static_cast<size_t>(static_cast<const unsigned char*>(z) - d.data()) + 1;
+  }
+  o += static_cast<size_t>(l_nm);
+  if (static_cast<int32_t>(names.size()) != n_ref) return false;
+  for (int32_t r = 0; r < n_ref; ++r) {
+    const bool mine = names[static_cast<size_t>(r)] == chrom;
+    if (!need(4)) return false;
+    const int32_t n_bin = i32();
+    for (int32_t b = 0; b < n_bin; ++b) {
+      if (!need(8)) return false;
+      const uint32_t bin = static_cast<uint32_t>(i32());
+      const int32_t n_chunk = i32();
+      if (n_chunk < 0 || !need(static_cast<size_t>(n_chunk) * 16)) return false;
+      for (int32_t c = 0; c < n_chunk; ++c) {
+        const uint64_t beg = u64();
+        u64();  // end
+        if (mine && bin != 37450u) {  // 37450 is the metadata pseudo-bin
+          ref.first_voff = std::min(ref.first_voff, beg);
+          ref.last_chunk_voff = std::max(ref.last_chunk_voff, beg);
+        }
+      }
+    }
+    if (!need(4)) return false;
+    const int32_t n_intv = i32();
+    if (n_intv < 0 || !need(static_cast<size_t>(n_intv) * 8)) return false;
+    if (mine) {
+      ref.present = true;
+      ref.ioff.resize(static_cast<size_t>(n_intv));
+      for (auto& v : ref.ioff) v = u64();
+    } else {
+      o += static_cast<size_t>(n_intv) * 8;
+    }
+  }
+  return true;
+}
+
 // ---- BGZF (bgzip) input ---------------------------------------------------------------------
 // A bgzip file is a sequence of independent gzip members of at most 64 KiB, each carrying its
 // own compressed size in a 'BC' extra subfield and its uncompressed size in the trailer: the
@@ -250,11 +345,6 @@ struct BgzfMember {
   uint32_t crc;
   size_t out_off;
 };
-
-inline uint32_t le32(const unsigned char* p) {
-  return static_cast<uint32_t>(p[0]) | static_cast<uint32_t>(p[1]) << 8 | static_cast<uint32_t>(p[2]) << 16 |
-         static_cast<uint32_t>(p[3]) << 24;
-}
 
 // Size of the gzip member starting at p (n bytes available) when it is a BGZF member; 0 when more
 // bytes are needed, -1 when it is not BGZF.
@@ -300,13 +390,18 @@ inline size_t batch_out_bytes() {
 }
 
 template <typename F>
-int for_each_block_bgzf(FILE* f, const char* path, int n_threads, F&& consume) {
+int for_each_block_bgzf(FILE* f, const char* path, int n_threads, uint64_t voff_start, size_t batch_out, F&& consume) {
   std::vector<unsigned char> cbuf(size_t(16) << 20);
   std::vector<char> ubuf;
   std::vector<BgzfMember> members;
   size_t chave = 0, carry = 0;
+  size_t skip = static_cast<size_t>(voff_start & 0xFFFFu);  // bytes of the first member that precede the record
   bool ceof = false;
-  const size_t batch_out = batch_out_bytes();
+  // batches grow from `batch_out` (default 1 MiB) to the maximum: a small indexed region or the
+  // header is not charged for 48 MiB of inflating
+  const size_t batch_max = batch_out_bytes();
+  size_t batch_now = std::min(batch_max, batch_out ? batch_out : size_t(1) << 20);
+  if (fseeko(f, static_cast<off_t>(voff_start >> 16), SEEK_SET) != 0) return sai_set_error(SAI_ERR_ARG, "seek failed in %s", path);
   for (;;) {
     if (!ceof && chave < cbuf.size()) {
       const size_t got = fread(cbuf.data() + chave, 1, cbuf.size() - chave, f);
@@ -318,7 +413,7 @@ int for_each_block_bgzf(FILE* f, const char* path, int n_threads, F&& consume) {
     }
     members.clear();
     size_t off = 0, out_total = 0;
-    while (off < chave && out_total < batch_out) {
+    while (off < chave && out_total < batch_now) {
       size_t hlen = 0;
       const long bsize = bgzf_member_size(cbuf.data() + off, chave - off, &hlen);
       if (bsize < 0) return sai_set_error(SAI_ERR_ARG, "%s: corrupt BGZF block", path);
@@ -359,9 +454,16 @@ int for_each_block_bgzf(FILE* f, const char* path, int n_threads, F&& consume) {
       for (char b : bad)
         if (b) return sai_set_error(SAI_ERR_ARG, "%s: BGZF block fails to inflate or its CRC", path);
     }
+    batch_now = std::min(batch_max, batch_now * 2);
     memmove(cbuf.data(), cbuf.data() + off, chave - off);
     chave -= off;
-    const size_t have = carry + out_total;
+    size_t have = carry + out_total;
+    if (skip) {  // only ever on the first batch (carry == 0): drop what precedes the indexed record
+      if (skip > have) return sai_set_error(SAI_ERR_ARG, "%s: index offset beyond its block", path);
+      memmove(ubuf.data(), ubuf.data() + skip, have - skip);
+      have -= skip;
+      skip = 0;
+    }
     size_t usable = 0;
     for (size_t i = have; i > 0; --i)
       if (ubuf[i - 1] == '\n') { usable = i; break; }
@@ -375,6 +477,26 @@ int for_each_block_bgzf(FILE* f, const char* path, int n_threads, F&& consume) {
   }
 }
 
+bool file_is_bgzf(const char* path) {
+  FILE* f = fopen(path, "rb");
+  if (!f) return false;
+  unsigned char head[64];
+  const size_t n = fread(head, 1, sizeof(head), f);
+  fclose(f);
+  size_t hlen = 0;
+  return bgzf_member_size(head, n, &hlen) > 0;
+}
+
+// bgzip file from virtual offset `voff` on, in batches of about `batch_out` uncompressed bytes
+template <typename F>
+int for_each_block_from(const char* path, int n_threads, uint64_t voff, size_t batch_out, F&& consume) {
+  FILE* f = fopen(path, "rb");
+  if (!f) return sai_set_error(SAI_ERR_ARG, "cannot open VCF %s", path);
+  const int rc = for_each_block_bgzf(f, path, n_threads, voff, batch_out, consume);
+  fclose(f);
+  return rc;
+}
+
 // Streams the file in blocks of whole lines and hands each block to `consume(begin, end)`; bgzip
 // files are inflated by `n_threads` threads, plain gzip and uncompressed text go through zlib's
 // gzread.  Returns 0, or a negative status after sai_set_error.
@@ -385,8 +507,7 @@ int for_each_block(const char* path, int n_threads, F&& consume) {
     const size_t n = fread(head, 1, sizeof(head), f);
     size_t hlen = 0;
     if (bgzf_member_size(head, n, &hlen) > 0) {
-      rewind(f);
-      const int rc = for_each_block_bgzf(f, path, n_threads, consume);
+      const int rc = for_each_block_bgzf(f, path, n_threads, 0, 0, consume);
       fclose(f);
       return rc;
     }
@@ -469,7 +590,7 @@ int sai_vcf_scan(const char* path, const char* chrom, int64_t* first_pos, int64_
   const std::string c(chrom);
   int64_t first = -1, last = -1;
   bool header_seen = false;
-  const int rc = for_each_block(path, kScanThreads, [&](const char* p, const char* end) -> int {
+  auto scan = [&](const char* p, const char* end) -> int {
     while (p < end) {
       const char* eol = static_cast<const char*>(memchr(p, '\n', static_cast<size_t>(end - p)));
       if (!eol) eol = end;
@@ -489,7 +610,34 @@ int sai_vcf_scan(const char* path, const char* chrom, int64_t* first_pos, int64_
       p = eol + 1;
     }
     return 0;
-  });
+  };
+  TbiRef idx;
+  if (file_is_bgzf(path) && load_tbi(path, c, idx)) {
+    // indexed: the first record sits at the smallest chunk start, the last one inside the chunk that
+    // starts last -- two short reads instead of the whole file
+    if (idx.present && idx.first_voff != ~0ull) {
+      int64_t lo = -1;
+      int rc = for_each_block_from(path, 1, idx.first_voff, size_t(1) << 16, [&](const char* p, const char* end) -> int {
+        const int r = scan(p, end);
+        return (r != 0 || first >= 0) ? 1 : 0;
+      });
+      if (rc) return rc;
+      lo = first;
+      first = -1;
+      rc = for_each_block_from(path, kScanThreads, idx.last_chunk_voff, size_t(4) << 20, scan);
+      if (rc) return rc;
+      if (lo >= 0 && last >= 0) {
+        *first_pos = lo;
+        *last_pos = last;
+        return SAI_OK;
+      }
+      first = last = -1;  // index and file disagree: fall through to the full pass
+    } else {
+      *first_pos = *last_pos = -1;  // chromosome not in the index
+      return SAI_OK;
+    }
+  }
+  const int rc = for_each_block(path, kScanThreads, scan);
   if (rc) return rc;
   if (!header_seen && first < 0) return sai_set_error(SAI_ERR_ARG, "%s: not a VCF (no #CHROM header)", path);
   *first_pos = first;
@@ -519,7 +667,8 @@ int sai_vcf_load(const char* path, const char* chrom, int64_t start, int64_t end
   // per-thread scratch lives across blocks: clear() keeps the capacity, so the allocator (and the
   // page-fault cost of fresh memory) is paid once, not per block
   std::vector<ThreadOut> outs(static_cast<size_t>(n_threads));
-  const int rc = for_each_block(path, n_threads, [&](const char* p, const char* endp) -> int {
+  bool done = false, seen_chrom = false;  // early stop of an indexed (hence sorted) region read
+  auto on_header = [&](const char*& p, const char* endp) -> int {
     while (!header_seen && p < endp) {  // header lines (serial)
       const char* eol = static_cast<const char*>(memchr(p, '\n', static_cast<size_t>(endp - p)));
       if (!eol) eol = endp;
@@ -530,6 +679,9 @@ int sai_vcf_load(const char* path, const char* chrom, int64_t start, int64_t end
       }
       p = eol + 1;
     }
+    return 0;
+  };
+  auto on_records = [&](const char* p, const char* endp) -> int {
     if (p >= endp) return 0;
     // split [p, endp) into n_threads pieces at line boundaries
     std::vector<const char*> cut(static_cast<size_t>(n_threads) + 1, endp);
@@ -545,6 +697,7 @@ int sai_vcf_load(const char* path, const char* chrom, int64_t start, int64_t end
       o.pos.clear();
       o.dosage.clear();
       o.matched = 0;
+      o.saw_chrom = o.beyond_stop = o.last_line_other = false;
     }
     std::vector<std::thread> th;
     for (int t = 1; t < n_threads; ++t) {
@@ -554,14 +707,38 @@ int sai_vcf_load(const char* path, const char* chrom, int64_t start, int64_t end
     }
     if (cut[0] < cut[1]) parse_lines(cut[0], cut[1], c, start, end, sel, anc, true, outs[0]);  // this thread works too
     for (auto& x : th) x.join();
-    for (auto& o : outs) {
+    for (auto& o : outs) {  // pieces in file order
       if (!o.error.empty()) return sai_set_error(SAI_ERR_ARG, "%s: %s", path, o.error.c_str());
       blk->n_matched += o.matched;
       blk->pos.insert(blk->pos.end(), o.pos.begin(), o.pos.end());
       blk->dosage.insert(blk->dosage.end(), o.dosage.begin(), o.dosage.end());
+      seen_chrom = seen_chrom || o.saw_chrom;
+      if (o.beyond_stop || (seen_chrom && o.last_line_other)) done = true;
     }
     return 0;
-  });
+  };
+  int rc;
+  TbiRef idx;
+  if (start >= 0 && file_is_bgzf(path) && load_tbi(path, c, idx)) {
+    // indexed region: the header from the top of the file, then the records from the region's first
+    // 16 kb window until the first record past it
+    rc = for_each_block_from(path, 1, 0, size_t(1) << 16, [&](const char* p, const char* endp) -> int {
+      if (int hrc = on_header(p, endp)) return hrc;
+      return (header_seen || p < endp) ? 1 : 0;
+    });
+    const uint64_t window = static_cast<uint64_t>(start > 0 ? start - 1 : 0) >> 14;
+    if (rc == SAI_OK && header_seen && idx.present && window < idx.ioff.size()) {
+      rc = for_each_block_from(path, n_threads, idx.ioff[window], 0, [&](const char* p, const char* endp) -> int {
+        if (int rrc = on_records(p, endp)) return rrc;
+        return done ? 1 : 0;
+      });
+    }
+  } else {
+    rc = for_each_block(path, n_threads, [&](const char* p, const char* endp) -> int {
+      if (int hrc = on_header(p, endp)) return hrc;
+      return on_records(p, endp);
+    });
+  }
   if (rc) { delete blk; return rc; }
   if (!header_seen) { delete blk; return sai_set_error(SAI_ERR_ARG, "%s: not a VCF (no #CHROM header)", path); }
   *block_out = blk;

@@ -192,3 +192,133 @@ def test_bgzf_batches_and_damage(tmp_path, monkeypatch):
     bad.write_bytes(bytes(raw))
     with pytest.raises((ValueError, OSError), match="BGZF"):
         load_dosage(str(bad), "21", names, [2] * len(names))
+
+
+def write_tbi(gz_path):
+    """A tabix index (TBI, SAM/tabix spec) for a bgzip VCF written by ``write_bgzf``: bins with one
+    chunk each, the linear index with the htslib back-fill, plain-gzip compressed."""
+    import struct
+    import zlib
+
+    raw = open(gz_path, "rb").read()
+    members, off, upos = [], 0, 0  # (compressed offset, uncompressed offset, text)
+    text = b""
+    while off < len(raw):
+        bsize = struct.unpack_from("<H", raw, off + 16)[0] + 1
+        chunk = zlib.decompress(raw[off + 18 : off + bsize - 8], -15)
+        members.append((off, upos, len(chunk)))
+        text += chunk
+        upos += len(chunk)
+        off += bsize
+
+    def voff(t):
+        for coff, u0, n in members:
+            if u0 <= t < u0 + n:
+                return (coff << 16) | (t - u0)
+        return (len(raw) << 16)  # end of file
+
+    def reg2bin(beg, end):
+        end -= 1
+        for shift, base in ((14, 4681), (17, 585), (20, 73), (23, 9), (26, 1)):
+            if beg >> shift == end >> shift:
+                return base + (beg >> shift)
+        return 0
+
+    refs, order = {}, []
+    t = 0
+    for line in text.split(b"\n"):
+        start_t, t = t, t + len(line) + 1
+        if not line or line.startswith(b"#"):
+            continue
+        f = line.split(b"\t", 5)
+        name, beg = f[0].decode(), int(f[1]) - 1
+        end = beg + len(f[3])
+        if name not in refs:
+            refs[name] = {"bins": {}, "lin": {}}
+            order.append(name)
+        r = refs[name]
+        v0, v1 = voff(start_t), voff(t)
+        b = r["bins"].setdefault(reg2bin(beg, end), [v0, v1])
+        b[1] = v1
+        for w in range(beg >> 14, ((end - 1) >> 14) + 1):
+            r["lin"][w] = min(r["lin"].get(w, v0), v0)
+    names = b"".join(n.encode() + b"\0" for n in order)
+    out = b"TBI\1" + struct.pack("<8i", len(order), 2, 1, 2, 0, ord("#"), 0, len(names)) + names
+    for n in order:
+        r = refs[n]
+        out += struct.pack("<i", len(r["bins"]))
+        for b, (v0, v1) in sorted(r["bins"].items()):
+            out += struct.pack("<Ii", b, 1) + struct.pack("<QQ", v0, v1)
+        n_intv = max(r["lin"]) + 1
+        lin, prev = [], min(r["lin"].values())
+        for w in range(n_intv):
+            prev = r["lin"].get(w, prev)
+            lin.append(prev)
+        out += struct.pack("<i", n_intv) + struct.pack(f"<{n_intv}Q", *lin)
+    with gzip.open(str(gz_path) + ".tbi", "wb") as f:
+        f.write(out)
+    return members
+
+
+def test_tabix_index_seek_equals_full_pass(tmp_path, monkeypatch):
+    """With <vcf>.tbi next to a bgzip VCF a region load seeks through the linear index and stops
+    after the region, the chromosome scan reads two records: same results as without the index --
+    and a damaged block outside the region is never touched (proof that it seeks)."""
+    import os
+
+    from sai_amd.utils.native_vcf import load_dosage, scan_first_last
+
+    rng = np.random.default_rng(5)
+    path = tmp_path / "i.vcf.gz"
+    names = write_vcf(path, rng, 1500, 7, gz="bgzf")  # ~1500 * 45 bp: several 16 kb windows per chromosome
+    regions = [(1, 10**9), (1, 1), (5000, 40000), (16384, 16385), (16385, 32768), (70000, 70010), (10**6, 10**7), (33000, None)]
+    plain = {}
+    for chrom in ("7", "21", "22", "nope"):
+        plain[chrom, "scan"] = scan_first_last(str(path), chrom)
+        for reg in regions:
+            plain[chrom, reg] = load_dosage(str(path), chrom, names, [2] * len(names), reg[0], reg[1], None, 3)
+    members = write_tbi(path)
+    for chrom in ("7", "21", "22", "nope"):
+        assert scan_first_last(str(path), chrom) == plain[chrom, "scan"]
+        for reg in regions:
+            got = load_dosage(str(path), chrom, names, [2] * len(names), reg[0], reg[1], None, 3)
+            want = plain[chrom, reg]
+            assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]) and got[2] == want[2], (chrom, reg)
+    # damage a block in the middle of the file (inside chromosome 21): regions of 7 and 22 still load
+    raw = bytearray(path.read_bytes())
+    victim = members[len(members) // 2][0]
+    raw[victim + 30] ^= 0xFF
+    path.write_bytes(bytes(raw))
+    monkeypatch.setenv("SAI_VCF_BATCH_BYTES", "20000")  # the whole test file is smaller than a default batch
+    for chrom, reg in (("7", (5000, 40000)), ("22", (5000, 40000))):
+        got = load_dosage(str(path), chrom, names, [2] * len(names), reg[0], reg[1], None, 3)
+        assert np.array_equal(got[1], plain[chrom, reg][1])
+    os.remove(str(path) + ".tbi")
+    with pytest.raises((ValueError, OSError), match="BGZF"):
+        load_dosage(str(path), "22", names, [2] * len(names), 5000, 40000, None, 3)
+
+
+@pytest.mark.parametrize("fixture,chroms", [("tests/data/test.with.outgroup.vcf.gz", ["1", "2"]),
+                                            ("tests/data/test.mixed.ploidy.data.vcf.gz", ["20", "21", "22", "X"])])  # fmt: skip
+def test_htslib_written_index_equals_unindexed_copy(in_repo_root, tmp_path, fixture, chroms):
+    """The reference's fixtures ship with their real (htslib-written, bgzip-compressed) .tbi files:
+    scans and region loads through them equal those on a copy of the VCF that has no index."""
+    import shutil
+
+    from sai_amd.utils.native_vcf import load_dosage, scan_first_last
+
+    assert (in_repo_root / (fixture + ".tbi")).exists()
+    plain = tmp_path / "copy.vcf.gz"
+    shutil.copy(fixture, plain)
+    with gzip.open(fixture, "rt") as f:
+        header = next(line for line in f if line.startswith("#CHROM")).rstrip("\n").split("\t")[9:]
+    pick = header[:40]
+    for chrom in chroms:
+        span = scan_first_last(fixture, chrom)
+        assert span == scan_first_last(str(plain), chrom)
+        first, last = span if span[0] is not None else (100, 200)
+        for reg in ((None, None), (first, last), (first + 1000, max(first + 1000, last - 1000)), (last, last + 10),
+                    (last + 1, None), (1, first), (16384, 16385), (16385, 40000)):  # fmt: skip
+            a = load_dosage(fixture, chrom, pick, [2] * len(pick), reg[0], reg[1], None, 4)
+            b = load_dosage(str(plain), chrom, pick, [2] * len(pick), reg[0], reg[1], None, 4)
+            assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2] == b[2], (chrom, reg)
