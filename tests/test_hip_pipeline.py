@@ -368,7 +368,11 @@ def _fuzz_scenario(seed):
     return dict(pos=pos, gts=gts, pl=pl, stats=stats, win=win, step=step, start=start, end=end, anc=anc, with_out=with_out)
 
 
-@pytest.mark.parametrize("seed", range(100, 116))
+import os
+
+
+# SAI_FUZZ_SEEDS=1500 was run once on the GPU box (all equal); 300 is a scenario with empty windows
+@pytest.mark.parametrize("seed", sorted({*range(100, 100 + int(os.environ.get("SAI_FUZZ_SEEDS", "16"))), 300}))
 def test_pipeline_fuzz_against_oracle(seed, tmp_path):
     """FeaturePreprocessor.run_windows + process_items on random chromosomes / configs: every item
     and every byte of the TSV and log files equal the oracle's (which is pinned to the reference)."""
@@ -409,8 +413,10 @@ def test_pipeline_fuzz_against_oracle(seed, tmp_path):
             if k in ("U", "Q"):
                 assert (a[k] == b[k] and isinstance(a[k], int)) if isinstance(b[k], int) else same_f64(a[k], b[k]), (k, a[k], b[k])
                 assert np.asarray(a["cdd_pos"][k]).astype(np.int64).tolist() == np.asarray(b["cdd_pos"][k]).astype(np.int64).tolist()
-            else:
+            elif isinstance(b[k], list):
                 assert len(a[k]) == len(b[k]) and all(same_f64(x, y) for x, y in zip(a[k], b[k])), (k, a[k], b[k])
+            else:  # an empty window: one NaN, not a list (feature_preprocessor.py:131-144)
+                assert not isinstance(a[k], list) and same_f64(a[k], b[k]), (k, a[k], b[k])
     write_headers(str(out), stat_config, pc)
     fp.process_items(items)
     assert out.read_text() == O.header_line(names, list(sc["pl"]["src"])) + "".join(O.score_lines(want, names))
