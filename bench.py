@@ -138,6 +138,11 @@ def cpu_baseline(n_sites: int, n_ref: int, n_tgt: int, n_src: int, workers: int)
 
 
 def main() -> None:
+    # stdout carries exactly one line, the JSON record: everything libraries print while the job runs
+    # (RCCL's version banner at communicator creation, gloo's rank messages, ...) goes to stderr
+    sys.stdout.flush()
+    result_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -182,9 +187,16 @@ def main() -> None:
 
     import __graft_entry__ as entry
 
+    # rehearsal knob: run the N>1 branches (process group, gather, reductions) with one rank, so that the
+    # RCCL calls themselves execute on a one-GPU box
+    dist_on = world > 1 or bool(os.environ.get("SAI_BENCH_FORCE_DIST"))
+    if dist_on and world == 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+
     torch.cuda.set_device(local_rank)
     backend = os.environ.get("SAI_BENCH_BACKEND", "nccl")  # "gloo" only for rehearsals on a 1-GPU box
-    if world > 1:
+    if dist_on:
         if backend == "nccl":
             dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         else:
@@ -192,7 +204,7 @@ def main() -> None:
     # one process per node builds (a no-op when the in-tree library is current); the others wait
     if local_rank == 0:
         entry.build()
-    if world > 1:
+    if dist_on:
         dist.barrier()
     from sai_amd import _ffi
     from sai_amd.distributed import gather_padded
@@ -213,7 +225,7 @@ def main() -> None:
 
     cdev = eng.device if backend == "nccl" else torch.device("cpu")  # where the small collectives live
     sizes = [scorer.bufs[0].numel()]
-    if world > 1:
+    if dist_on:
         t = torch.tensor(sizes, dtype=torch.int64, device=cdev)
         all_sizes = [torch.zeros_like(t) for _ in range(world)]
         dist.all_gather(all_sizes, t)
@@ -221,12 +233,12 @@ def main() -> None:
 
     # N>1: the records of every step stay on the GPU (one row per step) and go to rank 0 in one gather
     ring = None
-    if world > 1 and args.gather == "end":
+    if dist_on and args.gather == "end":
         ring = torch.empty((max(args.steps, args.warmup, 1), sizes[rank]), dtype=torch.uint8, device=eng.device)
 
     def step(timed: bool, k: int) -> None:
         scorer.step(time_counts=timed)
-        if world > 1:
+        if dist_on:
             with scorer.window_stream():  # ordered after this step's records, not after the next site pass
                 if ring is None:
                     gather_padded(scorer.bufs[0], sizes)
@@ -239,7 +251,7 @@ def main() -> None:
 
     def fence() -> None:
         torch.cuda.synchronize()
-        if world > 1:
+        if dist_on:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -257,7 +269,7 @@ def main() -> None:
             assert len(gathered) == world and all(g.numel() == args.steps * s for g, s in zip(gathered, sizes))
     fence()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if dist_on:
         tmax = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
@@ -303,7 +315,7 @@ def main() -> None:
                 "n_sites_per_gpu": n_sites,
                 "windows_per_gpu": len(windows),
                 "windows_total": total_windows,
-                "sharding": f"windows sharded by chromosome, RCCL gather of records to rank 0 ({args.gather})" if world > 1 else "none",
+                "sharding": f"windows sharded by chromosome, RCCL gather of records to rank 0 ({args.gather})" if dist_on else "none",
                 "u_sum_rank0": int(res.records["u_count"].sum()),
                 "q_finite_rank0": int(np.isfinite(res.records["q"]).sum()),
             },
@@ -325,8 +337,8 @@ def main() -> None:
             },
             "cpu_baseline": cpu,
         }
-        print(json.dumps(line), flush=True)
-    if world > 1:
+        print(json.dumps(line), file=result_out, flush=True)
+    if dist_on:
         dist.barrier()
         dist.destroy_process_group()
 
