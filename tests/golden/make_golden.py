@@ -707,3 +707,72 @@ def make_dd():
 
 if __name__ == "__main__" and os.path.isdir(REF):
     make_dd()
+
+
+# ---------------------------------------------------------------------------
+# 9. random chromosomes / configs through the reference's own WindowGenerator +
+#    FeaturePreprocessor + process_items (several ref / tgt populations, two
+#    sources, outgroups, ploidy 1-4, chunk bounds, all seven statistics); only
+#    the seeds and the output text are stored, seeded.fuzz_scenario rebuilds
+#    the inputs
+# ---------------------------------------------------------------------------
+
+FUZZ_SEEDS = sorted({*range(100, 132), 300})
+
+
+def make_pipeline_fuzz():
+    sys.path.insert(0, str(OUT))
+    from itertools import combinations
+
+    from seeded import fuzz_scenario
+    from sai.configs import PloidyConfig, StatConfig
+    from sai.generators import WindowGenerator
+    from sai.preprocessors import FeaturePreprocessor
+    from sai.utils import split_genome
+    from sai.utils.genomic_dataclasses import ChromosomeData
+
+    out = []
+    for seed in FUZZ_SEEDS:
+        sc = fuzz_scenario(seed)
+        pos, start, end = sc["pos"], sc["start"], sc["end"]
+        sel = np.ones(len(pos), bool) if start is None else (pos >= start) & (pos <= end)
+        if not sel.any():
+            continue
+        wg = object.__new__(WindowGenerator)
+        wg.win_len, wg.win_step, wg.chr_name, wg.ploidy_config = sc["win"], sc["step"], "7", PloidyConfig(sc["pl"])
+        for g in ("ref", "tgt", "src"):
+            setattr(wg, f"{g}_data", {k: ChromosomeData(POS=pos[sel].copy(), REF=None, ALT=None, GT=v[sel].copy())
+                                      for k, v in sc["gts"][g].items()})
+            setattr(wg, f"{g}_samples", {k: [] for k in sc["gts"][g]})
+        if sc["gts"]["outgroup"]:
+            wg.out_data = {k: ChromosomeData(POS=pos[sel].copy(), REF=None, ALT=None, GT=v[sel].copy())
+                           for k, v in sc["gts"]["outgroup"].items()}
+            wg.out_samples = {k: [] for k in sc["gts"]["outgroup"]}
+        else:
+            wg.out_data = wg.out_samples = None
+        wg.num_src = len(sc["gts"]["src"])
+        wg.src_combinations = list(combinations(wg.src_samples.keys(), wg.num_src))
+        wg.tgt_windows = {
+            t: split_genome(pos=(wg.tgt_data[t].POS if start is None and end is None
+                                 else [start, end - sc["win"] + sc["step"]]),
+                            window_size=sc["win"], step_size=sc["step"], start=start)
+            for t in wg.tgt_samples
+        }
+        stat_config = StatConfig(json.loads(json.dumps(sc["stats"])))
+        with tempfile.TemporaryDirectory() as td:
+            tsv = os.path.join(td, "o.tsv")
+            fp = FeaturePreprocessor(output_file=tsv, stat_config=stat_config, anc_allele_available=sc["anc"])
+            items = []
+            for item in wg.get():
+                items.extend(fp.run(**item))
+            fp.process_items(items)
+            text = {"tsv": open(tsv).read()}
+            for k in ("U", "Q"):
+                text[k] = open(os.path.join(td, f"o.{k}.log")).read()
+        out.append(dict(seed=seed, n_items=len(items), text=text))
+        print("fuzz", seed, len(items), "items", list(sc["stats"]))
+    (OUT / "pipeline_fuzz.json").write_text(json.dumps(out, separators=(",", ":")) + "\n")
+
+
+if __name__ == "__main__" and os.path.isdir(REF):
+    make_pipeline_fuzz()

@@ -22,3 +22,55 @@ def fourpop_inputs(seed, n_sites, n_ref, n_tgt, src_sizes, n_out, ploidies, miss
     srcs = [block(n, pl, 0.5) for n, pl in zip(src_sizes, ploidies[2])]
     out = block(n_out, ploidies[3], -0.6) if n_out else None
     return ref, tgt, srcs, out
+
+
+def fuzz_scenario(seed):
+    """A seeded random chromosome + config: several ref / tgt populations, 1-2 sources, optional
+    outgroup, ploidy 1-4, missing calls, random window grid, optional chunk bounds."""
+    rng = np.random.default_rng(seed)
+    n_sites = int(rng.integers(200, 2500))
+    pos = np.cumsum(rng.integers(1, 60, n_sites)).astype(np.int32)
+    n_ref, n_tgt, n_src = int(rng.integers(1, 3)), int(rng.integers(1, 3)), int(rng.integers(1, 3))
+    with_out = bool(rng.random() < 0.5)
+    anc = True if with_out else bool(rng.random() < 0.5)
+    p = rng.random(n_sites) ** float(rng.choice([1, 2, 4]))
+
+    def pop(n_ind, ploidy, fixed=False):
+        g = rng.binomial(ploidy, np.broadcast_to(p[:, None], (n_sites, n_ind))).astype(np.int64)
+        if fixed:
+            g[rng.random(n_sites) < 0.25] = ploidy
+        miss = rng.random(g.shape) < float(rng.choice([0.0, 0.02, 0.2]))
+        g[miss] = -ploidy
+        return g
+
+    pl = {"ref": {}, "tgt": {}, "src": {}}
+    gts = {"ref": {}, "tgt": {}, "src": {}, "outgroup": {}}
+    for grp, n, prefix in (("ref", n_ref, "R"), ("tgt", n_tgt, "T"), ("src", n_src, "S")):
+        for i in range(n):
+            ploidy = int(rng.integers(1, 5))
+            pl[grp][f"{prefix}{i}"] = ploidy
+            gts[grp][f"{prefix}{i}"] = pop(int(rng.integers(1, 40 if grp != "src" else 4)), ploidy, fixed=grp == "src")
+    if with_out:
+        pl["outgroup"] = {"O": int(rng.integers(1, 3))}
+        gts["outgroup"]["O"] = pop(int(rng.integers(1, 6)), pl["outgroup"]["O"])
+    ops = ["=", "<", ">", "<=", ">="]
+
+    def uq():
+        return {
+            "ref": {k: float(rng.choice([0.05, 0.3, 1.0])) for k in pl["ref"]},
+            "tgt": {k: float(rng.choice([0.0, 0.2, 0.5, 0.95])) for k in pl["tgt"]},
+            "src": {k: f"{rng.choice(ops)}{rng.choice([0, 0.5, 1])}" for k in pl["src"]},
+        }
+
+    stats = {"U": uq(), "Q": uq()}
+    if anc and rng.random() < 0.7:
+        for name in ("fd", "df", "Danc", "Dplus", "DD"):
+            if rng.random() < 0.7:
+                stats[name] = True
+    win = int(rng.integers(500, 6000))
+    step = int(rng.integers(100, win + 1))
+    start = end = None
+    if rng.random() < 0.4:  # a chunk the way ChunkGenerator cuts it: window-aligned bounds
+        start = int(pos[n_sites // 4] // step * step + 1)
+        end = start + int(rng.integers(1, 6)) * step + win - step - 1
+    return dict(pos=pos, gts=gts, pl=pl, stats=stats, win=win, step=step, start=start, end=end, anc=anc, with_out=with_out)

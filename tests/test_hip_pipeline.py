@@ -7,7 +7,12 @@ import json
 import numpy as np
 import pytest
 
-from conftest import load_golden, same_f64, unhex
+import sys
+
+from conftest import GOLDEN, load_golden, same_f64, unhex
+
+sys.path.insert(0, str(GOLDEN))
+from seeded import fuzz_scenario  # noqa: E402
 from test_host_logic import PIPE, _from_scenario
 
 pytestmark = pytest.mark.gpu
@@ -316,63 +321,15 @@ def test_score_sharded_two_ranks_equals_single_process(in_repo_root, tmp_path):
         assert a[0] == b[0] and sorted(a) == sorted(b)
 
 
-def _fuzz_scenario(seed):
-    """A seeded random chromosome + config: several ref / tgt populations, 1-2 sources, optional
-    outgroup, ploidy 1-4, missing calls, random window grid, optional chunk bounds."""
-    rng = np.random.default_rng(seed)
-    n_sites = int(rng.integers(200, 2500))
-    pos = np.cumsum(rng.integers(1, 60, n_sites)).astype(np.int32)
-    n_ref, n_tgt, n_src = int(rng.integers(1, 3)), int(rng.integers(1, 3)), int(rng.integers(1, 3))
-    with_out = bool(rng.random() < 0.5)
-    anc = True if with_out else bool(rng.random() < 0.5)
-    p = rng.random(n_sites) ** float(rng.choice([1, 2, 4]))
-
-    def pop(n_ind, ploidy, fixed=False):
-        g = rng.binomial(ploidy, np.broadcast_to(p[:, None], (n_sites, n_ind))).astype(np.int64)
-        if fixed:
-            g[rng.random(n_sites) < 0.25] = ploidy
-        miss = rng.random(g.shape) < float(rng.choice([0.0, 0.02, 0.2]))
-        g[miss] = -ploidy
-        return g
-
-    pl = {"ref": {}, "tgt": {}, "src": {}}
-    gts = {"ref": {}, "tgt": {}, "src": {}, "outgroup": {}}
-    for grp, n, prefix in (("ref", n_ref, "R"), ("tgt", n_tgt, "T"), ("src", n_src, "S")):
-        for i in range(n):
-            ploidy = int(rng.integers(1, 5))
-            pl[grp][f"{prefix}{i}"] = ploidy
-            gts[grp][f"{prefix}{i}"] = pop(int(rng.integers(1, 40 if grp != "src" else 4)), ploidy, fixed=grp == "src")
-    if with_out:
-        pl["outgroup"] = {"O": int(rng.integers(1, 3))}
-        gts["outgroup"]["O"] = pop(int(rng.integers(1, 6)), pl["outgroup"]["O"])
-    ops = ["=", "<", ">", "<=", ">="]
-
-    def uq():
-        return {
-            "ref": {k: float(rng.choice([0.05, 0.3, 1.0])) for k in pl["ref"]},
-            "tgt": {k: float(rng.choice([0.0, 0.2, 0.5, 0.95])) for k in pl["tgt"]},
-            "src": {k: f"{rng.choice(ops)}{rng.choice([0, 0.5, 1])}" for k in pl["src"]},
-        }
-
-    stats = {"U": uq(), "Q": uq()}
-    if anc and rng.random() < 0.7:
-        for name in ("fd", "df", "Danc", "Dplus", "DD"):
-            if rng.random() < 0.7:
-                stats[name] = True
-    win = int(rng.integers(500, 6000))
-    step = int(rng.integers(100, win + 1))
-    start = end = None
-    if rng.random() < 0.4:  # a chunk the way ChunkGenerator cuts it: window-aligned bounds
-        start = int(pos[n_sites // 4] // step * step + 1)
-        end = start + int(rng.integers(1, 6)) * step + win - step - 1
-    return dict(pos=pos, gts=gts, pl=pl, stats=stats, win=win, step=step, start=start, end=end, anc=anc, with_out=with_out)
-
-
 import os
 
 
-# SAI_FUZZ_SEEDS=1500 was run once on the GPU box (all equal); 300 is a scenario with empty windows
-@pytest.mark.parametrize("seed", sorted({*range(100, 100 + int(os.environ.get("SAI_FUZZ_SEEDS", "16"))), 300}))
+FUZZ_GOLDEN = {r["seed"]: r for r in load_golden("pipeline_fuzz.json")}
+
+
+# the first 32 seeds and 300 (empty windows) are pinned by text captured from the reference; SAI_FUZZ_SEEDS=1500
+# was run once on the GPU box against the oracle (all equal)
+@pytest.mark.parametrize("seed", sorted({*range(100, 100 + int(os.environ.get("SAI_FUZZ_SEEDS", "32"))), 300}))
 def test_pipeline_fuzz_against_oracle(seed, tmp_path):
     """FeaturePreprocessor.run_windows + process_items on random chromosomes / configs: every item
     and every byte of the TSV and log files equal the oracle's (which is pinned to the reference)."""
@@ -384,7 +341,7 @@ def test_pipeline_fuzz_against_oracle(seed, tmp_path):
     from sai_amd.utils import ChromosomeData
     from test_oracle_golden import _validated
 
-    sc = _fuzz_scenario(seed)
+    sc = fuzz_scenario(seed)
     pos = sc["pos"]
     sel = np.ones(len(pos), bool) if sc["start"] is None else (pos >= sc["start"]) & (pos <= sc["end"])
     if not sel.any():
@@ -422,3 +379,8 @@ def test_pipeline_fuzz_against_oracle(seed, tmp_path):
     assert out.read_text() == O.header_line(names, list(sc["pl"]["src"])) + "".join(O.score_lines(want, names))
     for k in ("U", "Q"):
         assert (tmp_path / f"o.{k}.log").read_text() == O.log_header_line(k) + "".join(O.log_lines(want, k))
+    if seed in FUZZ_GOLDEN:  # this scenario was also run through the reference itself (make_golden.py section 9)
+        ref_text = FUZZ_GOLDEN[seed]["text"]
+        assert out.read_text() == O.header_line(names, list(sc["pl"]["src"])) + ref_text["tsv"]
+        for k in ("U", "Q"):
+            assert (tmp_path / f"o.{k}.log").read_text() == O.log_header_line(k) + ref_text[k]

@@ -299,3 +299,28 @@ def test_dd_bit_exact(case):
     ref, tgt, srcs = dd_case_inputs(case)
     got = O.dd_stat(ref, tgt, srcs)
     assert len(got) == len(case["out"]) and all(same_f64(g, unhex(e)) for g, e in zip(got, case["out"]))
+
+
+# ---- random chromosomes / configs captured from the reference (make_golden.py section 9) ------
+
+from seeded import fuzz_scenario  # noqa: E402
+
+PIPE_FUZZ = load_golden("pipeline_fuzz.json")
+
+
+@pytest.mark.parametrize("rec", PIPE_FUZZ, ids=[str(r["seed"]) for r in PIPE_FUZZ])
+def test_pipeline_fuzz_text_equals_reference(rec):
+    """The oracle's chunk driver + text formatting on 33 random chromosomes / configs (several ref /
+    tgt populations, two sources, outgroups, ploidy 1-4, chunk bounds, all seven statistics):
+    every byte of the TSV and the two log files as the reference wrote them."""
+    sc = fuzz_scenario(rec["seed"])
+    pos = sc["pos"]
+    ostats = {n: (_validated({n: p})[n] if n in ("U", "Q") else p) for n, p in sc["stats"].items()}
+    odata = {grp: {k: O.Chrom(pos, v) for k, v in sc["gts"][grp].items()} for grp in sc["gts"]}
+    items = O.run_chunk("7", odata["ref"], odata["tgt"], odata["src"], sc["win"], sc["step"], ostats, sc["pl"], sc["anc"],
+                        start=sc["start"], end=sc["end"], out_data=odata["outgroup"] or None)  # fmt: skip
+    assert len(items) == rec["n_items"]
+    names = list(sc["stats"].keys())
+    assert "".join(O.score_lines(items, names)) == rec["text"]["tsv"]
+    for k in ("U", "Q"):
+        assert "".join(O.log_lines(items, k)) == rec["text"][k]
