@@ -33,8 +33,9 @@ __global__ __launch_bounds__(256) void site_flags_kernel(FlagArgs a) {
 // sites (l%4)*16 .. +15 as four 32-bit words.  Bytes are accumulated SWAR-style into 16-bit
 // (dosage) and 8-bit (missing) fields, widened to 32 bit every <= 248 rows per lane, and the 16
 // row-groups are combined with a 4-step butterfly reduce-scatter so that lane l ends with the
-// totals of site (l%4)*16 + l/4.  No LDS, no barriers; occupancy and 4-8 KiB of loads in flight
-// per wave hide HBM latency.
+// totals of site (l%4)*16 + l/4.  No barriers, no LDS staging of the genotypes (the fused form
+// parks each lane's per-population counts in LDS as an indexed register file); 4 KiB of loads in
+// flight per wave and 4 waves per SIMD hide HBM latency.
 // ------------------------------------------------------------------------------------------
 
 struct PopArg {

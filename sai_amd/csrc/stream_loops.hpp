@@ -39,18 +39,15 @@ __device__ __forceinline__ void reduce_scatter_step(uint32_t (&a)[16], int lane)
 }
 
 constexpr int kChunkIters = 248;  // iterations (rows per lane) the 16-/8-bit fields can absorb
-
-// Accumulate iterations [it, full_end) of full 16-row groups plus, when it is the last one, the
-// partial group, into the packed fields lo/hi (16-bit dosage sums) and ms (8-bit missing counts).
-constexpr int kUnroll = 4;  // wave loads (1 KiB each) in flight per group
+constexpr int kUnroll = 4;        // wave loads (1 KiB each) in flight per group
 static_assert(kChunkIters % kUnroll == 0 && kChunkIters + kUnroll <= 255, "8-bit missing fields overflow");
 
 // Accumulate iterations [it, full_end) of full 16-row groups plus, when it is the last one, the
 // partial group, into the packed fields lo/hi (16-bit dosage sums) and ms (8-bit missing counts).
 // Loads are non-temporal: every genotype byte is read exactly once.  (Measured alternatives --
 // 8 loads per group, ping-pong prefetch of the next group, default cache policy, 4 waves per
-// workgroup, 64-register builds with 8 waves per SIMD -- all landed within 2 % of this form: the
-// kernel sits at the rate a plain streaming read reaches on the same box.)
+// workgroup, 64-register builds with 8 waves per SIMD -- all landed within 2 % of this form, and a
+// default-policy load 8 % below it: the kernel sits at the rate a plain streaming read reaches.)
 __device__ __forceinline__ void accumulate_rows(const u32x4* base, int& it, int full_end, int n_full, int n_iter,
                                                 int n_ind, int r, uint32_t (&lo)[4], uint32_t (&hi)[4],
                                                 uint32_t (&ms)[4]) {
