@@ -224,26 +224,42 @@ def main() -> None:
     alg_bytes = block.genotype_bytes if args.layout == "int8" else block.packed2_bytes
 
     cdev = eng.device if backend == "nccl" else torch.device("cpu")  # where the small collectives live
-    sizes = [scorer.bufs[0].numel()]
+    # N>1: what travels to rank 0 per step is one row = the window records + both candidate lists
+    # (SURVEY.md 8e); their sizes are fixed for a resident block and come from one untimed step
+    rec_bytes = scorer.bufs[0].numel()
+    n_cdd_u = n_cdd_q = 0
+    if dist_on:
+        scorer.step()
+        first = scorer.results()
+        n_cdd_u, n_cdd_q = int(first.cdd_u.size), int(first.cdd_q.size)
+    row_bytes = rec_bytes + 4 * (n_cdd_u + n_cdd_q)
+    sizes = [row_bytes]
     if dist_on:
         t = torch.tensor(sizes, dtype=torch.int64, device=cdev)
         all_sizes = [torch.zeros_like(t) for _ in range(world)]
         dist.all_gather(all_sizes, t)
         sizes = [int(s.item()) for s in all_sizes]
 
-    # N>1: the records of every step stay on the GPU (one row per step) and go to rank 0 in one gather
+    def fill_row(row) -> None:  # on the stream that produced the records
+        row[:rec_bytes].copy_(scorer.bufs[0], non_blocking=True)
+        row[rec_bytes : rec_bytes + 4 * n_cdd_u].copy_(scorer.bufs[2][:n_cdd_u].view(torch.uint8), non_blocking=True)
+        row[rec_bytes + 4 * n_cdd_u :].copy_(scorer.bufs[3][:n_cdd_q].view(torch.uint8), non_blocking=True)
+
+    # 'end': the rows of every step stay on the GPU and go to rank 0 in one gather before the closing fence
     ring = None
-    if dist_on and args.gather == "end":
-        ring = torch.empty((max(args.steps, args.warmup, 1), sizes[rank]), dtype=torch.uint8, device=eng.device)
+    if dist_on:
+        n_rows = max(args.steps, args.warmup, 1) if args.gather == "end" else 1
+        ring = torch.empty((n_rows, row_bytes), dtype=torch.uint8, device=eng.device)
 
     def step(timed: bool, k: int) -> None:
         scorer.step(time_counts=timed)
         if dist_on:
             with scorer.window_stream():  # ordered after this step's records, not after the next site pass
-                if ring is None:
-                    gather_padded(scorer.bufs[0], sizes)
+                if args.gather == "end":
+                    fill_row(ring[k])
                 else:
-                    ring[k].copy_(scorer.bufs[0], non_blocking=True)
+                    fill_row(ring[0])
+                    gather_padded(ring[0], sizes)
 
     def gather_ring(n_rows: int):
         with scorer.window_stream():
@@ -257,13 +273,13 @@ def main() -> None:
 
     for k in range(args.warmup):
         step(False, k)
-    if ring is not None:
+    if dist_on and args.gather == "end":
         gather_ring(max(args.warmup, 1))  # also sets up RCCL's point-to-point channels outside the timed region
     fence()
     t0 = time.perf_counter()
     for k in range(args.steps):
         step(True, k)
-    if ring is not None:
+    if dist_on and args.gather == "end":
         gathered = gather_ring(args.steps)
         if rank == 0:
             assert len(gathered) == world and all(g.numel() == args.steps * s for g, s in zip(gathered, sizes))
@@ -315,7 +331,7 @@ def main() -> None:
                 "n_sites_per_gpu": n_sites,
                 "windows_per_gpu": len(windows),
                 "windows_total": total_windows,
-                "sharding": f"windows sharded by chromosome, RCCL gather of records to rank 0 ({args.gather})" if dist_on else "none",
+                "sharding": f"windows sharded by chromosome, RCCL gather of records + candidate lists to rank 0 ({args.gather})" if dist_on else "none",
                 "u_sum_rank0": int(res.records["u_count"].sum()),
                 "q_finite_rank0": int(np.isfinite(res.records["q"]).sum()),
             },
