@@ -462,7 +462,12 @@ def test_gather_on_window_stream_with_rccl(eng):
     windows = default_windows(int(pos[0]), int(pos[-1]), 50_000, 25_000)
     sets = [_ffi.make_params(0.05, 0.3, 0.9, [("=", 1.0)], True)]
     scorer = ResidentScorer(eng, block, windows, sets, overlap=True)
-    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29631", rank=0, world_size=1,
+    import socket
+
+    with socket.socket() as sock:  # a free port: the fixed one of an earlier version could be taken
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
                             device_id=eng.device)  # fmt: skip
     try:
         sizes = [scorer.bufs[0].numel()]
