@@ -280,6 +280,14 @@ int sai_vcf_block_info(const sai_vcf_block* block, int64_t* n_records, int64_t* 
 int sai_vcf_block_copy(const sai_vcf_block* block, int32_t* pos_host, int8_t* dosage_host);
 int sai_vcf_block_free(sai_vcf_block* block);
 
+/* In-memory counterpart of the ingest: narrow a reference-style [rows][cols] integer matrix (the
+ * reference holds genotypes as int64 after utils.py:410) to the int8 the device layout uses, in one
+ * multithreaded pass.  itemsize in {1, 2, 4, 8}; row_stride_bytes between consecutive rows, the
+ * elements of a row contiguous.  Values below -128 can only be missing calls for calc_freq and are
+ * stored as -128; a value above 127 is SAI_ERR_UNSUPPORTED. */
+int sai_narrow_to_int8(const void* src, int32_t itemsize, int32_t is_signed, int64_t n_rows, int64_t n_cols,
+                       int64_t row_stride_bytes, int8_t* dst, int32_t n_threads);
+
 /* ---- measurement aid -------------------------------------------------------------------- */
 
 /* Plain streaming read of `n_bytes` (multiple of 16) with 16-byte non-temporal loads, one wave per

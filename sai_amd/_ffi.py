@@ -18,6 +18,7 @@ SAI_TILE_SITES = 64
 SAI_MAX_SRC = 6
 SAI_MAX_SETS = 16
 SAI_FUSED_SETS = 4
+SAI_ERR_UNSUPPORTED = -4  # enum sai_status
 FREQ_MODES = {"dense": 0, "candidates": 1}  # enum sai_freq_mode
 SAI_ABI_VERSION = 2
 
@@ -100,6 +101,7 @@ SIGNATURES = {
     "sai_synth_fill_host": (C.c_int, [_u64, _i32, _i64, _i64, _i32, _i32, _i32, _i32, _p]),
     "sai_synth_gaps_host": (C.c_int, [_u64, _i32, _i64, _i64, _p]),
     "sai_synth_gaps": (C.c_int, [_p, _u64, _i32, _i64, _i64, _p, _p]),
+    "sai_narrow_to_int8": (C.c_int, [_p, _i32, _i32, _i64, _i64, _i64, _p, _i32]),
     "sai_probe_stream_read": (C.c_int, [_p, _p, _i64, _p, _p]),
     "sai_vcf_scan": (C.c_int, [C.c_char_p, C.c_char_p, C.POINTER(_i64), C.POINTER(_i64)]),
     "sai_vcf_load": (

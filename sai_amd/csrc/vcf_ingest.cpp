@@ -20,6 +20,7 @@
 #include <new>
 #include <string>
 #include <thread>
+#include <type_traits>
 #include <unordered_map>
 #include <vector>
 
@@ -575,6 +576,28 @@ int parse_header(const char* p, const char* eol, const char* path, int32_t n_sam
 
 }  // namespace
 
+namespace {
+
+template <typename T>
+bool narrow_rows(const char* src, int64_t row_stride, int64_t r0, int64_t r1, int64_t n_cols, int8_t* dst) {
+  bool too_big = false;
+  for (int64_t r = r0; r < r1; ++r) {
+    const T* row = reinterpret_cast<const T*>(src + r * row_stride);
+    int8_t* out = dst + r * n_cols;
+    T hi = 0;  // running maximum: one compare per element instead of a branch
+    for (int64_t c = 0; c < n_cols; ++c) {
+      const T v = row[c];
+      hi = v > hi ? v : hi;
+      if constexpr (std::is_signed<T>::value) out[c] = static_cast<int8_t>(v < static_cast<T>(-128) ? static_cast<T>(-128) : v);
+      else out[c] = static_cast<int8_t>(v);
+    }
+    too_big = too_big || hi > static_cast<T>(127);
+  }
+  return !too_big;
+}
+
+}  // namespace
+
 struct sai_vcf_block {
   int32_t n_samples = 0;
   int64_t n_matched = 0;      // records of the chromosome inside the region
@@ -742,6 +765,40 @@ int sai_vcf_load(const char* path, const char* chrom, int64_t start, int64_t end
   if (rc) { delete blk; return rc; }
   if (!header_seen) { delete blk; return sai_set_error(SAI_ERR_ARG, "%s: not a VCF (no #CHROM header)", path); }
   *block_out = blk;
+  return SAI_OK;
+}
+
+int sai_narrow_to_int8(const void* src, int32_t itemsize, int32_t is_signed, int64_t n_rows, int64_t n_cols,
+                       int64_t row_stride_bytes, int8_t* dst, int32_t n_threads) {
+  if (n_rows < 0 || n_cols < 0) return sai_set_error(SAI_ERR_ARG, "negative shape");
+  if (n_rows == 0 || n_cols == 0) return SAI_OK;
+  if (!src || !dst) return sai_set_error(SAI_ERR_ARG, "NULL buffer");
+  if (itemsize != 1 && itemsize != 2 && itemsize != 4 && itemsize != 8) return sai_set_error(SAI_ERR_ARG, "itemsize must be 1, 2, 4 or 8");
+  const int64_t total = n_rows * n_cols;
+  int nt = std::max(1, std::min<int>(n_threads, static_cast<int>(std::min<int64_t>(n_rows, 1 + total / (1 << 20)))));
+  std::vector<char> ok(static_cast<size_t>(nt), 1);
+  const char* base = static_cast<const char*>(src);
+  auto work = [&](int t) {
+    const int64_t r0 = n_rows * t / nt, r1 = n_rows * (t + 1) / nt;
+    bool good = true;
+    switch (itemsize * 2 + (is_signed ? 1 : 0)) {
+      case 3: good = narrow_rows<int8_t>(base, row_stride_bytes, r0, r1, n_cols, dst); break;
+      case 2: good = narrow_rows<uint8_t>(base, row_stride_bytes, r0, r1, n_cols, dst); break;
+      case 5: good = narrow_rows<int16_t>(base, row_stride_bytes, r0, r1, n_cols, dst); break;
+      case 4: good = narrow_rows<uint16_t>(base, row_stride_bytes, r0, r1, n_cols, dst); break;
+      case 9: good = narrow_rows<int32_t>(base, row_stride_bytes, r0, r1, n_cols, dst); break;
+      case 8: good = narrow_rows<uint32_t>(base, row_stride_bytes, r0, r1, n_cols, dst); break;
+      case 17: good = narrow_rows<int64_t>(base, row_stride_bytes, r0, r1, n_cols, dst); break;
+      default: good = narrow_rows<uint64_t>(base, row_stride_bytes, r0, r1, n_cols, dst); break;
+    }
+    ok[static_cast<size_t>(t)] = good ? 1 : 0;
+  };
+  std::vector<std::thread> th;
+  for (int t = 1; t < nt; ++t) th.emplace_back(work, t);
+  work(0);
+  for (auto& x : th) x.join();
+  for (char g : ok)
+    if (!g) return sai_set_error(SAI_ERR_UNSUPPORTED, "dosage above 127 is not representable in the int8 device layout");
   return SAI_OK;
 }
 

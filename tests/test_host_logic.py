@@ -355,6 +355,22 @@ def test_to_int8_dosage():
         to_int8_dosage(np.array([[0.5]]))
     with pytest.raises(ValueError, match="2-D"):
         to_int8_dosage(np.array([1, 2]))
+    # the native pass against numpy on every integer dtype, contiguous and row-strided, and the
+    # numpy fallback for column-strided views
+    rng = np.random.default_rng(3)
+    for dt in (np.int64, np.int32, np.int16, np.uint8, np.uint16, np.uint32, np.uint64):
+        lo = max(np.iinfo(dt).min, -400)
+        m = rng.integers(lo, 128, size=(257, 131)).astype(dt)
+        want = np.maximum(m.astype(np.int64), -128).astype(np.int8)
+        assert np.array_equal(to_int8_dosage(m), want)
+        assert np.array_equal(to_int8_dosage(m[::2, 3:77]), want[::2, 3:77])      # rows strided, elements contiguous
+        assert np.array_equal(to_int8_dosage(m[:, ::2]), want[:, ::2])           # elements strided: numpy path
+        assert np.array_equal(to_int8_dosage(np.asfortranarray(m)), want)
+        bad = m.copy()
+        bad[200, 100] = 128
+        with pytest.raises(ValueError, match="above 127"):
+            to_int8_dosage(bad)
+    assert to_int8_dosage(np.zeros((0, 5), dtype=np.int64)).shape == (0, 5)
 
 
 # ---- outlier --------------------------------------------------------------
