@@ -156,8 +156,9 @@ def main() -> None:
                     "2-bit layout (4x fewer genotype bytes; reported with its own algorithmic bytes)")
     ap.add_argument("--overlap", choices=["auto", "on", "off"], default="auto",
                     help="pipeline every step's windows stage under the next step's site pass on a second stream; "
-                    "auto = on for int8 (windows stage = 4 %% of a step), off for packed2 (site pass too short "
-                    "for the small kernels to find free CUs under it: measured slower)")
+                    "auto = on for int8 runs of at least 16 steps (each burst of steps pays one ~1.5 ms start-up "
+                    "bubble before the pipeline is 3 %% faster per step), off for packed2 (site pass too short to "
+                    "hide the stage under: measured slower)")
     ap.add_argument("--gather", choices=["end", "step"], default="end",
                     help="N>1: 'end' keeps every step's records on the GPU and brings them to rank 0 with ONE RCCL "
                     "gather before the closing fence (inside the timed region); 'step' gathers after every step")
@@ -218,7 +219,7 @@ def main() -> None:
     p0, p1 = int(block.pos[0]), int(block.pos[-1])
     windows = default_windows(p0, p1, WIN_LEN, WIN_STEP)
     prm = _ffi.make_params(U_Q_PARAMS["w"], U_Q_PARAMS["x"], U_Q_PARAMS["quantile"], U_Q_PARAMS["y_list"], U_Q_PARAMS["anc"])
-    overlap = args.overlap == "on" or (args.overlap == "auto" and args.layout == "int8")
+    overlap = args.overlap == "on" or (args.overlap == "auto" and args.layout == "int8" and args.steps >= 16)
     scorer = ResidentScorer(eng, block, windows, [prm], cap_u=1 << 22, cap_q=1 << 22, layout=args.layout,
                             overlap=overlap)
     alg_bytes = block.genotype_bytes if args.layout == "int8" else block.packed2_bytes

@@ -354,76 +354,91 @@ __global__ __launch_bounds__(kWinThreads) void window_stats_heavy_kernel(WinArgs
 
 // ---- CSR offsets ---------------------------------------------------------------------------
 
-// One 512-thread workgroup: exclusive prefix sums of u_count and n_cdd_q over the records in
+// One 256-thread workgroup: exclusive prefix sums of u_count and n_cdd_q over the records in
 // (set, window) order.  cdd_off[2r] / cdd_off[2r+1] = start of record r's U / Q list (or -1 when
-// the list would not fit its buffer); cdd_total[0..1] = entries needed in all.  Every thread owns
-// 20 consecutive records (all 40 loads in flight at once), adds them up, the 512 partial sums
-// are scanned once (wave shuffles + one LDS hop) and each thread writes its 20 offset pairs;
-// more than 10 240 records take further rounds with the totals carried in registers.  (512 threads,
-// not 1024: the compiler hoists the round-invariant index arithmetic out of the loop, and under
-// the 128-register cap of a 1024-thread workgroup that spilled to scratch -- 30 us per launch.)
-constexpr int kScanThreads = 512;
+// the list would not fit its buffer); cdd_total[0..1] = entries needed in all.  Each of the 4 waves
+// owns a contiguous run of 64-record rows and reads them lane-consecutive: 12 cache lines per wave
+// load of the 24-byte records and 8 per store, where a thread-owns-a-chunk mapping touched 64.
+// The workgroup is one wave per SIMD with < 128 registers on purpose: the pipelined scorer runs this
+// kernel under the next step's site pass, whose 4 waves per SIMD leave exactly that much free -- a
+// 512-thread version could not be placed on any CU until the site pass retired (2.4 ms instead
+// of 20 us, which made the whole windows stage as long as the site pass it was hiding under).
+// Pass 1 adds each wave's run up, one LDS hop gives every wave its base, pass 2 re-reads the rows
+// (L2 hits), scans each with wave shuffles and stores the offset pairs.
+constexpr int kScanThreads = 256;
+constexpr int kScanRows = 8;  // rows of 64 records loaded together
 
 __global__ __launch_bounds__(kScanThreads) void window_scan_kernel(WinArgs a) {
   __shared__ long long wave_tot[2][kScanThreads / 64];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t n = static_cast<int64_t>(a.n_sets) * a.n_windows;
-  long long carry_u = 0, carry_q = 0;
-  constexpr int kPer = 20;
-  for (int64_t base = 0; base < n; base += kScanThreads * kPer) {
-    // 32-bit offsets from the round's (uniform) base pointer; loads are unconditional from a clamped
-    // index -- a load under a per-element condition is branched around and waited for one at a time
-    const int rel_max = static_cast<int>(min(n - base, static_cast<int64_t>(kScanThreads * kPer))) - 1;
-    const int i0 = tid * kPer;
-    const sai_window_record* rp = a.records + base;
-    int32_t nu[kPer], nq[kPer];
+  const int64_t rows = (n + 63) / 64;
+  const int64_t rows_per_wave = (rows + kScanThreads / 64 - 1) / (kScanThreads / 64);
+  const int64_t row0 = wave * rows_per_wave, row1 = min(rows, row0 + rows_per_wave);
+  // loads are unconditional from a clamped index (a load under a per-element condition is branched
+  // around and waited for one at a time); records past the end count as empty
+  auto load_rows = [&](int64_t first_row, int32_t (&nu)[kScanRows], int32_t (&nq)[kScanRows]) {
 #pragma unroll
-    for (int k = 0; k < kPer; ++k) {
-      const int i = min(i0 + k, rel_max);
-      nu[k] = rp[i].u_count;
-      nq[k] = rp[i].n_cdd_q;
+    for (int k = 0; k < kScanRows; ++k) {
+      const int64_t r = (first_row + k) * 64 + lane;
+      const sai_window_record& rec = a.records[min(r, n - 1)];
+      nu[k] = rec.u_count;
+      nq[k] = rec.n_cdd_q;
     }
 #pragma unroll
-    for (int k = 0; k < kPer; ++k)
-      if (i0 + k > rel_max) nu[k] = nq[k] = 0;
-    long long su = 0, sq = 0;
+    for (int k = 0; k < kScanRows; ++k) {
+      const int64_t r = (first_row + k) * 64 + lane;
+      if (first_row + k >= row1 || r >= n) nu[k] = nq[k] = 0;
+    }
+  };
+  long long su = 0, sq = 0;  // pass 1: this lane's share of the wave's run
+  for (int64_t row = row0; row < row1; row += kScanRows) {
+    int32_t nu[kScanRows], nq[kScanRows];
+    load_rows(row, nu, nq);
 #pragma unroll
-    for (int k = 0; k < kPer; ++k) {
+    for (int k = 0; k < kScanRows; ++k) {
       su += nu[k];
       sq += nq[k];
     }
-    long long iu = su, iq = sq;  // inclusive scan over the wave
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const long long tu = __shfl_up(iu, o, 64), tq = __shfl_up(iq, o, 64);
-      if (lane >= o) { iu += tu; iq += tq; }
-    }
-    if (lane == 63) { wave_tot[0][wave] = iu; wave_tot[1][wave] = iq; }
-    __syncthreads();
-    long long before_u = 0, before_q = 0, all_u = 0, all_q = 0;
-#pragma unroll
-    for (int v = 0; v < kScanThreads / 64; ++v) {
-      const long long tu = wave_tot[0][v], tq = wave_tot[1][v];
-      if (v < wave) { before_u += tu; before_q += tq; }
-      all_u += tu;
-      all_q += tq;
-    }
-    long long ou = carry_u + before_u + iu - su, oq = carry_q + before_q + iq - sq;
-    longlong2* op = reinterpret_cast<longlong2*>(a.cdd_off) + base;
-#pragma unroll
-    for (int k = 0; k < kPer; ++k) {
-      if (i0 + k <= rel_max)
-        op[i0 + k] = make_longlong2((ou + nu[k] <= a.cap_u) ? ou : -1, (oq + nq[k] <= a.cap_q) ? oq : -1);
-      ou += nu[k];
-      oq += nq[k];
-    }
-    carry_u += all_u;
-    carry_q += all_q;
-    __syncthreads();  // wave_tot is rewritten in the next round
   }
-  if (tid == 0) {
-    a.cdd_total[0] = carry_u;
-    a.cdd_total[1] = carry_q;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    su += __shfl_xor(su, o, 64);
+    sq += __shfl_xor(sq, o, 64);
+  }
+  if (lane == 0) { wave_tot[0][wave] = su; wave_tot[1][wave] = sq; }
+  __syncthreads();
+  long long carry_u = 0, carry_q = 0, all_u = 0, all_q = 0;
+#pragma unroll
+  for (int v = 0; v < kScanThreads / 64; ++v) {
+    const long long tu = wave_tot[0][v], tq = wave_tot[1][v];
+    if (v < wave) { carry_u += tu; carry_q += tq; }
+    all_u += tu;
+    all_q += tq;
+  }
+  longlong2* out = reinterpret_cast<longlong2*>(a.cdd_off);
+  for (int64_t row = row0; row < row1; row += kScanRows) {  // pass 2
+    int32_t nu[kScanRows], nq[kScanRows];
+    load_rows(row, nu, nq);
+#pragma unroll
+    for (int k = 0; k < kScanRows; ++k) {
+      if (row + k >= row1) break;  // uniform
+      long long iu = nu[k], iq = nq[k];  // inclusive scan over the row
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const long long tu = __shfl_up(iu, o, 64), tq = __shfl_up(iq, o, 64);
+        if (lane >= o) { iu += tu; iq += tq; }
+      }
+      const long long ou = carry_u + iu - nu[k], oq = carry_q + iq - nq[k];
+      const int64_t r = (row + k) * 64 + lane;
+      if (r < n) out[r] = make_longlong2((ou + nu[k] <= a.cap_u) ? ou : -1, (oq + nq[k] <= a.cap_q) ? oq : -1);
+      carry_u += __shfl(iu, 63, 64);
+      carry_q += __shfl(iq, 63, 64);
+    }
+  }
+  if (threadIdx.x == 0) {
+    a.cdd_total[0] = all_u;
+    a.cdd_total[1] = all_q;
   }
 }
 

@@ -61,7 +61,7 @@ class ResidentScorer:
         ``overlap=True`` software-pipelines consecutive steps: the windows stage of step k
         (bounds, statistics, candidate lists, copy to the host) runs on a second HIP stream while
         the site pass of step k+1 already streams genotypes on the caller's stream; the per-site
-        arrays are triple-buffered and events order every reuse.  Same kernels, same results."""
+        arrays are double-buffered and events order every reuse.  Same kernels, same results."""
         import torch
 
         if layout not in ("int8", "packed2"):
@@ -82,15 +82,16 @@ class ResidentScorer:
         self.fused = n_s <= _ffi.SAI_FUSED_SETS
         self.counts = None if self.fused else torch.empty((len(block.pops), n, 2), dtype=torch.int32, device=dev)
         self.overlap = bool(overlap)
-        # three sets: under a saturated HBM stream the small kernels of step k only finish when site
-        # pass k+1 does, so with two sets site pass k+2 would wait for them at every step
-        n_buf = 3 if self.overlap else 1
+        # two sets: the windows stage of step k runs under site pass k+1 and is over long before the
+        # host may enqueue site pass k+2 into the same buffers
+        n_buf = 2 if self.overlap else 1
         # the fused pass writes tgt_freq only at candidate sites (all the windows stage reads)
         self._tgt_freq = [torch.full((n,), float("nan"), dtype=torch.float64, device=dev) for _ in range(n_buf)]
         self._flags = [torch.empty((n_s, n), dtype=torch.uint8, device=dev) for _ in range(n_buf)]
         self.side = torch.cuda.Stream(device=dev, priority=-1) if self.overlap else None  # small kernels first
         self._site_done = [torch.cuda.Event() for _ in range(n_buf)]
-        self._win_done = [None] * n_buf  # event after the windows stage that last read buffer b
+        self._win_done = [torch.cuda.Event() for _ in range(n_buf)]  # after the windows stage that last read buffer b
+        self._win_used = [False] * n_buf
         self._k = 0
         self.lo = torch.empty((n_w,), dtype=torch.int32, device=dev)
         self.hi = torch.empty((n_w,), dtype=torch.int32, device=dev)
@@ -128,8 +129,13 @@ class ResidentScorer:
         b = self._k % len(self._flags)
         tgt_freq, flags = self._tgt_freq[b], self._flags[b]
         main = torch.cuda.current_stream(eng.device)
-        if self.overlap and self._win_done[b] is not None:
-            main.wait_event(self._win_done[b])  # the windows stage that last read buffer b (3 steps ago) is done
+        if self.overlap and self._win_used[b]:
+            # the windows stage that last read buffer b (2 steps ago) is done.  A host-side wait, not a
+            # stream wait: it also keeps the host at most two steps ahead of the GPU -- with the
+            # queues filled dozens of steps deep right after a synchronisation, every other site pass
+            # of the burst sat 1-2 ms behind its cross-stream dependency (measured; gone in this form)
+            while not self._win_done[b].query():  # polling: synchronize() was seen to oversleep by ~7 ms
+                pass
         if time_counts:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -155,9 +161,9 @@ class ResidentScorer:
         with torch.cuda.stream(self.side):
             self.side.wait_event(self._site_done[b])
             self._window_stage(tgt_freq, flags)
-            done = torch.cuda.Event()
-            done.record(self.side)
-            self._win_done[b] = done
+            self._win_done[b].record(self.side)
+            self._win_used[b] = True
+        self.side.query()  # submits the stage now: the runtime batches a stream's commands until something asks
 
     def _window_stage(self, tgt_freq, flags) -> None:
         eng, blk = self.eng, self.block
