@@ -145,7 +145,7 @@ def main() -> None:
     os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--sites", type=float, default=1e7)
     ap.add_argument("--ref", type=int, default=1000)
