@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define SAI_ABI_VERSION 2
+#define SAI_ABI_VERSION 3
 #define SAI_TILE_SITES 64
 #define SAI_MAX_SRC 6   /* source populations per call */
 #define SAI_MAX_SETS 16 /* parameter sets per call */
