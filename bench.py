@@ -155,10 +155,8 @@ def main() -> None:
                     help="int8 = the SoA int8 block the metric is defined on (default); packed2 = the optional "
                     "2-bit layout (4x fewer genotype bytes; reported with its own algorithmic bytes)")
     ap.add_argument("--overlap", choices=["auto", "on", "off"], default="auto",
-                    help="pipeline every step's windows stage under the next step's site pass on a second stream; "
-                    "auto = on for int8 runs of at least 16 steps (each burst of steps pays one ~1.5 ms start-up "
-                    "bubble before the pipeline is 3 %% faster per step), off for packed2 (site pass too short to "
-                    "hide the stage under: measured slower)")
+                    help="pipeline every step's windows stage under the next step's site pass on a second stream "
+                    "(auto = on)")
     ap.add_argument("--gather", choices=["end", "step"], default="end",
                     help="N>1: 'end' keeps every step's records on the GPU and brings them to rank 0 with ONE RCCL "
                     "gather before the closing fence (inside the timed region); 'step' gathers after every step")
@@ -219,7 +217,7 @@ def main() -> None:
     p0, p1 = int(block.pos[0]), int(block.pos[-1])
     windows = default_windows(p0, p1, WIN_LEN, WIN_STEP)
     prm = _ffi.make_params(U_Q_PARAMS["w"], U_Q_PARAMS["x"], U_Q_PARAMS["quantile"], U_Q_PARAMS["y_list"], U_Q_PARAMS["anc"])
-    overlap = args.overlap == "on" or (args.overlap == "auto" and args.layout == "int8" and args.steps >= 16)
+    overlap = args.overlap != "off"
     scorer = ResidentScorer(eng, block, windows, [prm], cap_u=1 << 22, cap_q=1 << 22, layout=args.layout,
                             overlap=overlap)
     alg_bytes = block.genotype_bytes if args.layout == "int8" else block.packed2_bytes
@@ -252,15 +250,25 @@ def main() -> None:
         n_rows = max(args.steps, args.warmup, 1) if args.gather == "end" else 1
         ring = torch.empty((n_rows, row_bytes), dtype=torch.uint8, device=eng.device)
 
+    # the scorer calls this on the window stream right after each step's windows stage (in the pipelined
+    # form one step late): steps and stages come in the same order, so the rows queue up first-in first-out
+    row_queue: list[int] = []
+
+    def on_stage(_index: int) -> None:
+        k = row_queue.pop(0)
+        if args.gather == "end":
+            fill_row(ring[k])
+        else:
+            fill_row(ring[0])
+            gather_padded(ring[0], sizes)
+
+    if dist_on:
+        scorer.after_stage = on_stage
+
     def step(timed: bool, k: int) -> None:
-        scorer.step(time_counts=timed)
         if dist_on:
-            with scorer.window_stream():  # ordered after this step's records, not after the next site pass
-                if args.gather == "end":
-                    fill_row(ring[k])
-                else:
-                    fill_row(ring[0])
-                    gather_padded(ring[0], sizes)
+            row_queue.append(k)
+        scorer.step(time_counts=timed)
 
     def gather_ring(n_rows: int):
         with scorer.window_stream():
@@ -274,12 +282,14 @@ def main() -> None:
 
     for k in range(args.warmup):
         step(False, k)
+    scorer.flush()
     if dist_on and args.gather == "end":
         gather_ring(max(args.warmup, 1))  # also sets up RCCL's point-to-point channels outside the timed region
     fence()
     t0 = time.perf_counter()
     for k in range(args.steps):
         step(True, k)
+    scorer.flush()  # the pipelined form holds the last step's windows stage back until asked
     if dist_on and args.gather == "end":
         gathered = gather_ring(args.steps)
         if rank == 0:

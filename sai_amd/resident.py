@@ -92,6 +92,8 @@ class ResidentScorer:
         self._site_done = [torch.cuda.Event() for _ in range(n_buf)]
         self._win_done = [torch.cuda.Event() for _ in range(n_buf)]  # after the windows stage that last read buffer b
         self._win_used = [False] * n_buf
+        self._pending = None  # (buffer set, step index) whose windows stage has not been enqueued yet
+        self.after_stage = None  # optional callable(step_index), run on the window stream right after a stage
         self._k = 0
         self.lo = torch.empty((n_w,), dtype=torch.int32, device=dev)
         self.hi = torch.empty((n_w,), dtype=torch.int32, device=dev)
@@ -114,13 +116,45 @@ class ResidentScorer:
         return self._flags[(self._k - 1) % len(self._flags)]
 
     def window_stream(self):
-        """Context manager selecting the stream on which the last step's window records are
-        produced (for follow-up work such as the multi-GPU gather of ``bufs[0]``)."""
+        """Context manager selecting the stream on which window records are produced (for follow-up
+        work such as the multi-GPU gather of ``bufs[0]``).  In the pipelined form call ``flush()``
+        first, or use ``after_stage``: the newest step's stage is enqueued one step late."""
         import contextlib
 
         import torch
 
         return torch.cuda.stream(self.side) if self.overlap else contextlib.nullcontext()
+
+    @staticmethod
+    def _wait(event) -> None:
+        while not event.query():  # polling: Event.synchronize() was seen to oversleep by ~7 ms
+            pass
+
+    def _launch_pending(self) -> None:
+        """Pipelined form: enqueue the windows stage of the pending step on the second stream, as soon
+        as the host sees its site pass finished.  Host-driven on purpose -- a stream-side wait makes
+        the second queue sit behind a cross-queue barrier, and right after a synchronisation such a
+        queue was not scheduled until the main queue drained (a 1.5-10 ms bubble per burst of steps),
+        while dozens of queued steps made every other site pass trail its dependency by 1-2 ms."""
+        import torch
+
+        if self._pending is None:
+            return
+        b, index = self._pending
+        self._pending = None
+        self._wait(self._site_done[b])
+        with torch.cuda.stream(self.side):
+            self._window_stage(self._tgt_freq[b], self._flags[b])
+            if self.after_stage is not None:
+                self.after_stage(index)
+            self._win_done[b].record(self.side)
+            self._win_used[b] = True
+        self.side.query()  # submit now: the runtime batches a stream's commands until something asks
+
+    def flush(self) -> None:
+        """Enqueue whatever the pipelined form still holds back (no-op otherwise)."""
+        if self.overlap:
+            self._launch_pending()
 
     def step(self, time_counts: bool = False) -> None:
         import torch
@@ -130,12 +164,7 @@ class ResidentScorer:
         tgt_freq, flags = self._tgt_freq[b], self._flags[b]
         main = torch.cuda.current_stream(eng.device)
         if self.overlap and self._win_used[b]:
-            # the windows stage that last read buffer b (2 steps ago) is done.  A host-side wait, not a
-            # stream wait: it also keeps the host at most two steps ahead of the GPU -- with the
-            # queues filled dozens of steps deep right after a synchronisation, every other site pass
-            # of the burst sat 1-2 ms behind its cross-stream dependency (measured; gone in this form)
-            while not self._win_done[b].query():  # polling: synchronize() was seen to oversleep by ~7 ms
-                pass
+            self._wait(self._win_done[b])  # the windows stage that last read buffer set b (2 steps ago) is done
         if time_counts:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -153,17 +182,17 @@ class ResidentScorer:
             self.count_events.append((e0, e1))
         if not self.fused:
             eng.site_flags(self.counts, blk.ploidies, self.sets, out=(tgt_freq, flags))
+        index = self._k
         self._k += 1
         if not self.overlap:
             self._window_stage(tgt_freq, flags)
+            if self.after_stage is not None:
+                self.after_stage(index)
             return
         self._site_done[b].record(main)
-        with torch.cuda.stream(self.side):
-            self.side.wait_event(self._site_done[b])
-            self._window_stage(tgt_freq, flags)
-            self._win_done[b].record(self.side)
-            self._win_used[b] = True
-        self.side.query()  # submits the stage now: the runtime batches a stream's commands until something asks
+        main.query()                 # submit the site pass before the host starts waiting
+        self._launch_pending()       # the previous step's stage runs under this site pass
+        self._pending = (b, index)
 
     def _window_stage(self, tgt_freq, flags) -> None:
         eng, blk = self.eng, self.block
@@ -180,6 +209,7 @@ class ResidentScorer:
         """Synchronise and return the last step's records and candidate lists."""
         import torch
 
+        self.flush()
         torch.cuda.current_stream(self.eng.device).synchronize()
         if self.side is not None:
             self.side.synchronize()

@@ -472,11 +472,13 @@ def test_gather_on_window_stream_with_rccl(eng):
     try:
         sizes = [scorer.bufs[0].numel()]
         got = None
+        got = []
+        scorer.after_stage = lambda index: got.append(gather_padded(scorer.bufs[0], sizes))  # on the window stream
         for _ in range(3):
             scorer.step()
-            with scorer.window_stream():
-                got = gather_padded(scorer.bufs[0], sizes)
         res = scorer.results()
+        assert len(got) == 3
+        got = got[-1]
         torch.cuda.synchronize()
         assert got is not None and len(got) == 1
         assert got[0].cpu().numpy().tobytes() == res.records.tobytes()
