@@ -430,6 +430,9 @@ def test_overlapped_steps_equal_plain_steps(eng, layout, n_sets):
     sets = [_ffi.make_params(0.05 + 0.01 * s, 0.3, 0.9, [("=", 1.0)], bool(s % 2)) for s in range(n_sets)]
     plain = ResidentScorer(eng, block, windows, sets, layout=layout)
     piped = ResidentScorer(eng, block, windows, sets, layout=layout, overlap=True)
+    calls = {"plain": [], "piped": []}
+    plain.after_stage = calls["plain"].append  # the hook runs once per step, in step order, in both forms
+    piped.after_stage = calls["piped"].append
     plain.step()
     want = plain.results()
     assert int(want.records["u_count"].sum()) > 0
@@ -443,6 +446,7 @@ def test_overlapped_steps_equal_plain_steps(eng, layout, n_sets):
         assert np.array_equal(got.offsets, want.offsets)
         assert np.array_equal(got.cdd_u, want.cdd_u) and np.array_equal(got.cdd_q, want.cdd_q)
         assert torch.equal(piped.flags, plain.flags)
+        assert calls["piped"] == list(range(done)) and calls["plain"] == [0]
 
 
 def test_gather_on_window_stream_with_rccl(eng):
