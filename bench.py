@@ -1,31 +1,49 @@
 #!/usr/bin/env python3
 """Benchmark of the sliding-window U/Q hot path on MI355X.
 
-    python bench.py --gpus 1 --steps 20 --warmup 3
+    python bench.py                      # N = 1: BASELINE.json configs[2] (C3), the metric's configuration
+    python bench.py --workload c2|c4|c5  # the other configs (C4 on one GPU holds 220 GB)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-        --master-port P bench.py --gpus N --steps K --warmup W
+        --master-port P bench.py --gpus N --steps K --warmup W     # N > 1: configs[3] (C4)
 
-Workload (BASELINE.json configs[2], the configuration the metric is quoted on): one synthetic
-chromosome per GPU -- 1e7 sites, 1,000 ref / 1,000 tgt / 2 src diploids, 50 kb windows every
-25 kb, U (w=0.01, x=0.5, y "=1") and Q95 -- generated in place in HBM by the counter-based
-synth-v1 generator (rank r holds chromosome r+1: weak scaling, windows are independent).  One
-step = one pass of the whole path over the resident block: site_counts -> site_flags ->
-window_bounds -> window_stats -> copy of the per-window records to pinned host memory, plus, for
-N > 1, the RCCL gather of all records to rank 0.  Rank 0 prints one JSON line.
+Workloads (BASELINE.json `configs`; all synthetic "synth-v1" data generated
+in place in HBM by the counter-based generator, so a shard holds exactly the bytes a one-GPU run
+holds at those sites):
+
+  c2  1e6 sites, 200 ref / 200 tgt / 2 src diploids, 50 kb windows every 10 kb, U
+  c3  1e7 sites, 1,000 / 1,000 / 2, 50 kb every 25 kb, U + Q95            (default for --gpus 1)
+  c4  22 chromosomes x 5e6 sites, same populations and windows as c3       (default for --gpus N>1)
+  c5  1e7 sites, two source populations of 1 diploid, Q95 sweep over 18 (op, y1, y2) sets
+
+N > 1 is STRONG scaling: the job is fixed, its global window list (the chromosomes' lists end to
+end) is cut into N contiguous ranges by the reference's chunk rule (chunk_generator.py:111-142, the
+first `n % N` ranks get one window more), each rank generates only the sites of its range plus the
+`win_len - win_step` halo, and there is no data-path collective: ONE gather per pass brings the
+24-byte window records and the CSR candidate lists to rank 0 (RCCL over xGMI), issued on the stream
+the windows stage ran on (`--gather step`, the default; `--gather end` keeps the K passes' rows in
+HBM and gathers them once before the closing fence).
+
+One step = one pass of the whole path over the resident block: site pass (site_counts + the fused
+per-site decision) -> window_bounds -> window statistics -> copy of the records to pinned host
+memory (+ the gather).  Rank 0 prints one JSON line.
 
 `roofline` prices the dominant kernel (site_counts) with HIP events on the launch stream:
-algorithmic bytes = n_sites x (n_ref + n_tgt + n_src) genotype bytes per launch.
-`cpu_baseline` times the numpy oracle (the reference's per-window structure) on the host
-cores over a bounded site prefix of the same chromosome, before the GPU is initialised.
+algorithmic bytes = resident sites x (n_ref + n_tgt + n_src) genotype bytes per launch of rank 0.
+`cpu_baseline` times the numpy oracle (the reference's per-window structure) on the host cores over
+a bounded site prefix of the same chromosome, before the GPU is initialised.  `score_path` is the
+rate of the product entry point on the same resident block: FeaturePreprocessor.run_windows (the
+same fused pass and windows stage) + item dictionaries + process_items' TSV / log text.
 """
 
 from __future__ import annotations
 
 import argparse
 import ctypes as C
+import datetime
 import json
 import os
 import sys
+import tempfile
 import time
 from pathlib import Path
 
@@ -34,11 +52,48 @@ sys.path.insert(0, str(ROOT))
 
 import numpy as np  # noqa: E402
 
-SEED = 20260633  # 20260630 + config number 3
-WIN_LEN, WIN_STEP = 50000, 25000
-U_Q_PARAMS = dict(w=0.01, x=0.5, quantile=0.95, y_list=[("=", 1.0)], anc=True)
+SEED0 = 20260630  # + config number
 METRIC = "windows/sec (whole node) + achieved HBM GB/s, 50kb windows over 1e7 sites"
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+UQ = dict(w=0.01, x=0.5, quantile=0.95, y_list=[("=", 1.0)], anc=True)
+
+
+def make_workload(name: str, sites=None, chroms=None, scaling: str = "strong", world: int = 1):
+    """The SynthWorkload of a BASELINE config; ``sites`` / ``chroms`` scale it down for tests and
+    rehearsals (the JSON line then says so)."""
+    from sai_amd.sharding import SynthWorkload
+
+    if name == "c2":
+        wl = SynthWorkload("c2", SEED0 + 2, [1], int(1e6), 200, 200, [2], 50000, 10000, [dict(UQ)],
+                           description="synthetic chr: 1e6 sites, 200 ref/200 tgt/2 src diploids, 50kb/10kb windows, U stat "
+                           "(BASELINE.json configs[1])")  # fmt: skip
+    elif name == "c3":
+        wl = SynthWorkload("c3", SEED0 + 3, [1], int(1e7), 1000, 1000, [2], 50000, 25000, [dict(UQ)],
+                           description="synthetic chr: 1e7 sites, 1000 ref/1000 tgt/2 src diploids, 50kb/25kb windows, U+Q95 "
+                           "(BASELINE.json configs[2])")  # fmt: skip
+    elif name == "c4":
+        wl = SynthWorkload("c4", SEED0 + 4, list(range(1, 23)), int(5e6), 1000, 1000, [2], 50000, 25000, [dict(UQ)],
+                           description="whole-genome synthetic: 22 chroms x 5e6 sites, 1000 ref/1000 tgt/2 src diploids, "
+                           "50kb/25kb windows, U+Q95, windows sharded over the GPUs (BASELINE.json configs[3])")  # fmt: skip
+    elif name == "c5":
+        specs = [dict(w=0.01, x=0.5, quantile=0.95, y_list=[(op, y1), (op, y2)], anc=True)
+                 for op in ("=", ">=") for y1 in (0.0, 0.5, 1.0) for y2 in (0.0, 0.5, 1.0)]  # fmt: skip
+        wl = SynthWorkload("c5", SEED0 + 5, [1], int(1e7), 1000, 1000, [1, 1], 50000, 25000, specs,
+                           description="two source populations (src1+src2, 1 diploid each), Q95 sweep over an 18-set "
+                           "(op, y1, y2) grid from one genotype pass, 1e7 sites, 1000 ref/1000 tgt, 50kb/25kb windows "
+                           "(BASELINE.json configs[4])")  # fmt: skip
+    else:
+        raise ValueError(f"unknown workload {name}")
+    if scaling == "weak" and world > 1:  # the round-1 form: one chromosome of this size per GPU
+        wl.chroms = list(range(1, len(wl.chroms) * world + 1))
+        wl.description += f"; WEAK scaling: {len(wl.chroms)} such chromosomes"
+    if sites:
+        wl.n_sites = int(sites)
+        wl.description += f"; REDUCED to {wl.n_sites} sites per chromosome"
+    if chroms:
+        wl.chroms = list(range(1, int(chroms) + 1))
+        wl.description += f"; REDUCED to {len(wl.chroms)} chromosomes"
+    return wl
 
 
 # ------------------------------------------------------------------------------------------
@@ -67,19 +122,29 @@ def usable_cores() -> int:
     return n
 
 
+def cpu_model() -> str:
+    try:
+        for line in Path("/proc/cpuinfo").read_text().splitlines():
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def _cpu_chunk(bounds):
     from oracle import sai_oracle as O
 
     d = _CPU
     return len(
-        O.run_chunk("1", {"ref": d["ref"]}, {"tgt": d["tgt"]}, {"src": d["src"]}, WIN_LEN, WIN_STEP, d["stats"],
+        O.run_chunk("1", {"ref": d["ref"]}, {"tgt": d["tgt"]}, d["src"], d["win_len"], d["win_step"], d["stats"],
                     d["ploidies"], True, start=bounds[0], end=bounds[1])  # fmt: skip
     )
 
 
-def cpu_baseline(n_sites: int, n_ref: int, n_tgt: int, n_src: int, workers: int) -> dict:
-    """windows/s of the numpy oracle on a site prefix of chromosome 1 (same seed and generator as
-    the GPU run).  Runs before any HIP call so that forking the pool is safe."""
+def cpu_baseline(wl, n_sites: int, workers: int) -> dict:
+    """windows/s of the numpy oracle on a site prefix of the job's first chromosome (same seed and
+    generator as the GPU run).  Runs before any HIP call so that forking the pool is safe."""
     import multiprocessing as mp
     from concurrent.futures import ThreadPoolExecutor
 
@@ -87,6 +152,7 @@ def cpu_baseline(n_sites: int, n_ref: int, n_tgt: int, n_src: int, workers: int)
     from sai_amd import _ffi
 
     lib = _ffi.load()
+    chrom = int(wl.chroms[0])
 
     def host_block(stream, n_ind):
         out = np.empty((n_sites, n_ind), dtype=np.int8)
@@ -94,26 +160,33 @@ def cpu_baseline(n_sites: int, n_ref: int, n_tgt: int, n_src: int, workers: int)
 
         def fill(s0):
             n = min(step, n_sites - s0)
-            _ffi.check(lib.sai_synth_fill_host(SEED, 1, s0, n, stream, n_ind, 2, 0, out[s0:].ctypes.data_as(C.c_void_p)))
+            _ffi.check(lib.sai_synth_fill_host(wl.seed, chrom, s0, n, stream, n_ind, wl.ploidy, 0,
+                                               out[s0:].ctypes.data_as(C.c_void_p)))  # fmt: skip
 
         with ThreadPoolExecutor(workers) as ex:
             list(ex.map(fill, range(0, n_sites, step)))
         return out.astype(np.int64)  # the reference's resident layout (utils.py:410)
 
     gaps = np.empty(n_sites, dtype=np.int32)
-    _ffi.check(lib.sai_synth_gaps_host(SEED, 1, 0, n_sites, gaps.ctypes.data_as(C.c_void_p)))
+    _ffi.check(lib.sai_synth_gaps_host(wl.seed, chrom, 0, n_sites, gaps.ctypes.data_as(C.c_void_p)))
     pos = np.cumsum(gaps).astype(np.int32)
+    src_names = ["src"] if len(wl.src_sizes) == 1 else [f"src{i + 1}" for i in range(len(wl.src_sizes))]
+    # the product's configuration of this workload: U and Q as the reference configures them (two
+    # statistics, each recomputing its frequencies); a sweep contributes its first parameter set
+    s0 = wl.specs[0]
+    y = {n: yy for n, yy in zip(src_names, s0["y_list"])}
     _CPU.update(
-        ref=O.Chrom(pos, host_block(0, n_ref)),
-        tgt=O.Chrom(pos, host_block(1, n_tgt)),
-        src=O.Chrom(pos, host_block(2, n_src)),
+        ref=O.Chrom(pos, host_block(0, wl.n_ref)),
+        tgt=O.Chrom(pos, host_block(1, wl.n_tgt)),
+        src={n: O.Chrom(pos, host_block(2 + i, k)) for i, (n, k) in enumerate(zip(src_names, wl.src_sizes))},
+        win_len=wl.win_len, win_step=wl.win_step,
         stats={
-            "U": {"ref": {"ref": 0.01}, "tgt": {"tgt": 0.5}, "src": {"src": ("=", 1.0)}},
-            "Q": {"ref": {"ref": 0.01}, "tgt": {"tgt": 0.95}, "src": {"src": ("=", 1.0)}},
+            "U": {"ref": {"ref": s0["w"]}, "tgt": {"tgt": s0["x"]}, "src": dict(y)},
+            "Q": {"ref": {"ref": s0["w"]}, "tgt": {"tgt": s0["quantile"]}, "src": dict(y)},
         },
-        ploidies={"ref": {"ref": 2}, "tgt": {"tgt": 2}, "src": {"src": 2}},
-    )
-    windows = O.split_windows([int(pos[0]), int(pos[-1])], WIN_LEN, WIN_STEP)
+        ploidies={"ref": {"ref": wl.ploidy}, "tgt": {"tgt": wl.ploidy}, "src": {n: wl.ploidy for n in src_names}},
+    )  # fmt: skip
+    windows = O.split_windows([int(pos[0]), int(pos[-1])], wl.win_len, wl.win_step)
     windows = [w for w in windows if w[1] <= int(pos[-1])]  # only windows fully inside the prefix
     chunks = O.split_window_ranges(windows, workers * 8)  # 8 chunks per worker (sai.py:91)
     t0 = time.perf_counter()
@@ -127,14 +200,134 @@ def cpu_baseline(n_sites: int, n_ref: int, n_tgt: int, n_src: int, workers: int)
         "unit": "windows/s",
         "cores": workers,
         "kind": "port",
-        "sample": f"first {n_sites} sites of chromosome 1 ({len(windows)} windows, {n_ref}/{n_tgt}/{n_src} diploids, "
-        f"int64 matrices, U+Q95), multiprocessing.Pool({workers}) over {len(chunks)} chunks, {dt:.1f} s",
+        "cpu_model": cpu_model(),
+        "wall_s": round(dt, 2),
+        "cpu_s": round(dt * workers, 1),
+        "sample": f"first {n_sites} sites of chromosome {chrom} of {wl.name} ({len(windows)} windows, "
+        f"{wl.n_ref}/{wl.n_tgt}/{'+'.join(map(str, wl.src_sizes))} diploids, int64 matrices, U+Q95), "
+        f"multiprocessing.Pool({workers}) over {len(chunks)} chunks, {dt:.1f} s wall",
     }
+
+
+# ------------------------------------------------------------------------------------------
+# the timed passes (shared by the GPU run and the CPU rehearsal of tests/test_bench_sharded_cpu.py)
+# ------------------------------------------------------------------------------------------
+
+
+def run_passes(scorer, gather, row_of, steps: int, warmup: int, gather_mode: str, fence, new_ring=None) -> dict:
+    """W untimed + K timed passes of ``scorer`` with the per-pass gather of its row.
+
+    ``scorer`` = a ResidentScorer (or None on a rank without windows); ``gather`` = a RowGather;
+    ``row_of(k)`` = the uint8 tensor pass k's row is packed into; ``fence()`` = barrier +
+    synchronize on both sides of the timed region.  Returns the wall time and what rank 0 received
+    last (a list of per-rank rows)."""
+    layout = gather.layouts[gather.rank]
+    dist_on = gather.on
+    got = {"rows": None}
+    queue: list[int] = []
+
+    def on_stage(_index: int) -> None:  # on the stream the windows stage ran on, right after it
+        k = queue.pop(0)
+        if not dist_on:
+            return
+        scorer.pack_row(row_of(k), layout)
+        if gather_mode == "step":
+            got["rows"] = gather.gather(row_of(k))
+
+    def one_pass(k: int, timed: bool) -> None:
+        if scorer is None:  # a rank without windows still takes part in every collective
+            if dist_on and gather_mode == "step":
+                got["rows"] = gather.gather(row_of(k))
+            return
+        queue.append(k)
+        scorer.step(time_counts=timed)
+
+    def finish(n_rows: int) -> None:
+        if scorer is not None:
+            scorer.flush()  # the pipelined form holds the last pass's windows stage back until asked
+        if dist_on and gather_mode == "end":
+            got["rows"] = new_ring(n_rows)
+
+    if scorer is not None:
+        scorer.after_stage = on_stage
+    for k in range(warmup):
+        one_pass(k, False)
+    finish(max(warmup, 1) if warmup else 0)  # also sets up RCCL's channels outside the timed region
+    fence()
+    t0 = time.perf_counter()
+    for k in range(steps):
+        one_pass(k, True)
+    finish(steps)
+    fence()
+    return {"dt": time.perf_counter() - t0, "rows": got["rows"]}
 
 
 # ------------------------------------------------------------------------------------------
 # GPU run
 # ------------------------------------------------------------------------------------------
+
+
+def score_path_rate(eng, wl, block, lay, repeats: int = 3) -> dict:
+    """The product entry point on the resident block: FeaturePreprocessor.run_windows (fused site
+    pass + windows stage through ResidentScorer, the kernels timed above) + the reference's item
+    dictionaries + process_items' TSV / .U.log / .Q.log text, written to a scratch directory."""
+    import torch
+
+    from sai_amd.configs import PloidyConfig, StatConfig
+    from sai_amd.generators import WindowGenerator
+    from sai_amd.preprocessors import FeaturePreprocessor
+    from sai_amd.sai import write_headers
+
+    src_names = ["src"] if len(wl.src_sizes) == 1 else [f"src{i + 1}" for i in range(len(wl.src_sizes))]
+    s0 = wl.specs[0]
+    ystr = {n: f"{op}{y:g}" for n, (op, y) in zip(src_names, s0["y_list"])}
+    stats = StatConfig({"U": {"ref": {"ref": s0["w"]}, "tgt": {"tgt": s0["x"]}, "src": dict(ystr)},
+                        "Q": {"ref": {"ref": s0["w"]}, "tgt": {"tgt": s0["quantile"]}, "src": dict(ystr)}})  # fmt: skip
+    ploidies = PloidyConfig({"ref": {"ref": wl.ploidy}, "tgt": {"tgt": wl.ploidy}, "src": {n: wl.ploidy for n in src_names}})
+    n = lay.n_sites[0]
+    pos_host = block.pos[:n].cpu().numpy()
+    wg = WindowGenerator.from_resident(
+        str(wl.chroms[0]), pos_host, block.pos[:n], {"ref": _trim(block.pops[0], n)}, {"tgt": _trim(block.pops[1], n)},
+        {nm: _trim(p, n) for nm, p in zip(src_names, block.pops[2:])}, wl.win_len, wl.win_step, ploidies,
+    )  # fmt: skip
+    times = []
+    with tempfile.TemporaryDirectory() as tmp:
+        out = os.path.join(tmp, "scores.tsv")
+        fp = FeaturePreprocessor(out, stats, anc_allele_available=s0["anc"])
+        n_items = 0
+        for _ in range(repeats + 1):
+            write_headers(out, stats, ploidies)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            batch = fp.score_windows(wg)
+            t1 = time.perf_counter()
+            items = fp.items_from_batch(batch)
+            t2 = time.perf_counter()
+            fp.process_items(items)
+            t3 = time.perf_counter()
+            times.append((t3 - t0, t1 - t0, t2 - t1, t3 - t2))
+            n_items = len(items)
+        text_bytes = sum(os.path.getsize(os.path.join(tmp, f)) for f in os.listdir(tmp))
+    total, gpu, build, write = min(times[1:])
+    return {
+        "value": round(n_items / total, 1),
+        "unit": "windows/s",
+        "windows": n_items,
+        "ms_total": round(total * 1e3, 2),
+        "ms_gpu_score_windows": round(gpu * 1e3, 2),
+        "ms_item_dicts": round(build * 1e3, 2),
+        "ms_process_items_text": round(write * 1e3, 2),
+        "host_us_per_window": round((build + write) / max(n_items, 1) * 1e6, 2),
+        "output_bytes": text_bytes,
+        "what": "FeaturePreprocessor.score_windows + items_from_batch + process_items on the resident block "
+        "(U and Q as two statistics, one fused pass); best of %d" % repeats,
+    }
+
+
+def _trim(pop, n_sites):
+    from sai_amd.engine import TiledPop
+
+    return TiledPop(pop.tiles, n_sites, pop.n_ind)
 
 
 def main() -> None:
@@ -147,45 +340,57 @@ def main() -> None:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--sites", type=float, default=1e7)
-    ap.add_argument("--ref", type=int, default=1000)
-    ap.add_argument("--tgt", type=int, default=1000)
-    ap.add_argument("--src", type=int, default=2)
+    ap.add_argument("--workload", choices=["auto", "c2", "c3", "c4", "c5"], default="auto",
+                    help="auto = c3 on one GPU (the configuration the metric is quoted on), c4 on several")
+    ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
+                    help="N>1: strong = the fixed job sharded over the GPUs (default); weak = N chromosomes of the "
+                    "workload's size, still sharded by contiguous window ranges")
+    ap.add_argument("--sites", type=float, default=0, help="sites per chromosome (0 = the workload's own size)")
+    ap.add_argument("--chroms", type=int, default=0, help="number of chromosomes (0 = the workload's own)")
     ap.add_argument("--layout", choices=["int8", "packed2"], default="int8",
                     help="int8 = the SoA int8 block the metric is defined on (default); packed2 = the optional "
                     "2-bit layout (4x fewer genotype bytes; reported with its own algorithmic bytes)")
     ap.add_argument("--overlap", choices=["auto", "on", "off"], default="auto",
                     help="pipeline every step's windows stage under the next step's site pass on a second stream "
                     "(auto = on)")
-    ap.add_argument("--gather", choices=["end", "step"], default="end",
-                    help="N>1: 'end' keeps every step's records on the GPU and brings them to rank 0 with ONE RCCL "
-                    "gather before the closing fence (inside the timed region); 'step' gathers after every step")
-    ap.add_argument("--cpu-sites", type=float, default=4e5, help="site prefix timed on the CPU (0 = skip)")
+    ap.add_argument("--gather", choices=["step", "end"], default="step",
+                    help="N>1: 'step' gathers records + candidate lists to rank 0 after every pass, as a real run "
+                    "does (default); 'end' keeps the K passes' rows in HBM and gathers them once before the closing fence")
+    ap.add_argument("--cpu-sites", type=float, default=1e6, help="site prefix timed on the CPU (0 = skip)")
     ap.add_argument("--cpu-workers", type=int, default=0, help="0 = usable cores (affinity mask capped by the cgroup quota)")
+    ap.add_argument("--score-path", choices=["auto", "on", "off"], default="auto",
+                    help="also time the product entry point (run_windows + items + text) on the resident block "
+                    "(auto = on for one GPU and a one-chromosome workload)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
-    if "SAI_BENCH_DEVICE" in os.environ:  # rehearsal knob: every rank on one device of a 1-GPU box
-        local_rank = int(os.environ["SAI_BENCH_DEVICE"])
     world = int(os.environ.get("WORLD_SIZE", 1))
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             sys.exit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
         args.gpus = world
-    n_sites = int(args.sites)
+
+    # build first, before anything touches the GPU or joins a process group: hipcc children are
+    # forked from a process that has not initialised HIP; concurrent ranks serialise on a file lock
+    import __graft_entry__ as entry
+
+    entry.build()
+
+    name = args.workload if args.workload != "auto" else ("c3" if world == 1 else "c4")
+    wl = make_workload(name, args.sites, args.chroms, args.scaling, world)
 
     cpu = None
     if rank == 0 and world == 1 and args.cpu_sites > 0:
         # a one-GPU box grants a 16-CPU share of the host whatever nproc says
         workers = args.cpu_workers or min(usable_cores(), 16)
-        cpu = cpu_baseline(int(args.cpu_sites), args.ref, args.tgt, args.src, workers)
+        cpu = cpu_baseline(wl, min(int(args.cpu_sites), wl.n_sites), workers)
 
     import torch
     import torch.distributed as dist
 
-    import __graft_entry__ as entry
-
+    if "SAI_BENCH_DEVICE" in os.environ:  # rehearsal knob: every rank on one device of a 1-GPU box
+        local_rank = int(os.environ["SAI_BENCH_DEVICE"])
     # rehearsal knob: run the N>1 branches (process group, gather, reductions) with one rank, so that the
     # RCCL calls themselves execute on a one-GPU box
     dist_on = world > 1 or bool(os.environ.get("SAI_BENCH_FORCE_DIST"))
@@ -196,83 +401,51 @@ def main() -> None:
     torch.cuda.set_device(local_rank)
     backend = os.environ.get("SAI_BENCH_BACKEND", "nccl")  # "gloo" only for rehearsals on a 1-GPU box
     if dist_on:
+        kw = dict(backend=backend, rank=rank, world_size=world, timeout=datetime.timedelta(minutes=10))
         if backend == "nccl":
-            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(backend=backend, rank=rank, world_size=world)
-    # one process per node builds (a no-op when the in-tree library is current); the others wait
-    if local_rank == 0:
-        entry.build()
-    if dist_on:
-        dist.barrier()
-    from sai_amd import _ffi
-    from sai_amd.distributed import gather_padded
+            kw["device_id"] = torch.device("cuda", local_rank)
+        dist.init_process_group(**kw)
+    from sai_amd.distributed import RowGather
     from sai_amd.engine import Engine
-    from sai_amd.resident import ResidentScorer, default_windows, synth_block
+    from sai_amd.resident import ResidentScorer
+    from sai_amd.sharding import build_synth_shard, merge_rank_results, plan_shards
 
     eng = Engine.get(local_rank)
-
-    chrom = rank + 1
-    block = synth_block(eng, SEED, chrom, n_sites, args.ref, args.tgt, [args.src])
-    p0, p1 = int(block.pos[0]), int(block.pos[-1])
-    windows = default_windows(p0, p1, WIN_LEN, WIN_STEP)
-    prm = _ffi.make_params(U_Q_PARAMS["w"], U_Q_PARAMS["x"], U_Q_PARAMS["quantile"], U_Q_PARAMS["y_list"], U_Q_PARAMS["anc"])
+    t_setup = time.perf_counter()
+    block, lay, win_counts = build_synth_shard(eng, wl, rank, world)
+    total_windows = int(sum(win_counts))
     overlap = args.overlap != "off"
-    scorer = ResidentScorer(eng, block, windows, [prm], cap_u=1 << 22, cap_q=1 << 22, layout=args.layout,
-                            overlap=overlap)
-    alg_bytes = block.genotype_bytes if args.layout == "int8" else block.packed2_bytes
+    scorer = None
+    if block is not None:
+        scorer = ResidentScorer(eng, block, [(s, e) for _, s, e in lay.windows], wl.params(), cap_u=1 << 22, cap_q=1 << 22,
+                                layout=args.layout, overlap=overlap, window_segment=lay.window_segment)  # fmt: skip
+        scorer.step()  # untimed: the list sizes of a resident block are fixed, the row layout comes from them
+        row_layout = scorer.row_layout()
+    else:
+        row_layout = None
+    torch.cuda.synchronize()
+    t_setup = time.perf_counter() - t_setup
 
     cdev = eng.device if backend == "nccl" else torch.device("cpu")  # where the small collectives live
-    # N>1: what travels to rank 0 per step is one row = the window records + both candidate lists
-    # (SURVEY.md 8e); their sizes are fixed for a resident block and come from one untimed step
-    rec_bytes = scorer.bufs[0].numel()
-    n_cdd_u = n_cdd_q = 0
-    if dist_on:
-        scorer.step()
-        first = scorer.results()
-        n_cdd_u, n_cdd_q = int(first.cdd_u.size), int(first.cdd_q.size)
-    row_bytes = rec_bytes + 4 * (n_cdd_u + n_cdd_q)
-    sizes = [row_bytes]
-    if dist_on:
-        t = torch.tensor(sizes, dtype=torch.int64, device=cdev)
-        all_sizes = [torch.zeros_like(t) for _ in range(world)]
-        dist.all_gather(all_sizes, t)
-        sizes = [int(s.item()) for s in all_sizes]
+    gather = RowGather(row_layout, cdev)
+    row_bytes = max(gather.sizes[gather.rank], 1)
+    n_rows = max(args.steps, args.warmup, 1) if (dist_on and args.gather == "end") else 1
+    ring = torch.empty((n_rows, row_bytes), dtype=torch.uint8, device=eng.device)
 
-    def fill_row(row) -> None:  # on the stream that produced the records
-        row[:rec_bytes].copy_(scorer.bufs[0], non_blocking=True)
-        row[rec_bytes : rec_bytes + 4 * n_cdd_u].copy_(scorer.bufs[2][:n_cdd_u].view(torch.uint8), non_blocking=True)
-        row[rec_bytes + 4 * n_cdd_u :].copy_(scorer.bufs[3][:n_cdd_q].view(torch.uint8), non_blocking=True)
+    def row_of(k: int):
+        return ring[k % n_rows]
 
-    # 'end': the rows of every step stay on the GPU and go to rank 0 in one gather before the closing fence
-    ring = None
-    if dist_on:
-        n_rows = max(args.steps, args.warmup, 1) if args.gather == "end" else 1
-        ring = torch.empty((n_rows, row_bytes), dtype=torch.uint8, device=eng.device)
+    def gather_ring(n: int):
+        if n == 0:
+            return None
+        ctx = scorer.window_stream() if scorer is not None else torch.cuda.stream(torch.cuda.current_stream())
+        with ctx:
+            from sai_amd.distributed import gather_padded
 
-    # the scorer calls this on the window stream right after each step's windows stage (in the pipelined
-    # form one step late): steps and stages come in the same order, so the rows queue up first-in first-out
-    row_queue: list[int] = []
-
-    def on_stage(_index: int) -> None:
-        k = row_queue.pop(0)
-        if args.gather == "end":
-            fill_row(ring[k])
-        else:
-            fill_row(ring[0])
-            gather_padded(ring[0], sizes)
-
-    if dist_on:
-        scorer.after_stage = on_stage
-
-    def step(timed: bool, k: int) -> None:
-        if dist_on:
-            row_queue.append(k)
-        scorer.step(time_counts=timed)
-
-    def gather_ring(n_rows: int):
-        with scorer.window_stream():
-            return gather_padded(ring[:n_rows].reshape(-1), [n_rows * s for s in sizes])
+            rows = gather_padded(ring[:n, : gather.sizes[gather.rank]].reshape(-1), [n * s for s in gather.sizes])
+        if rows is None:
+            return None
+        return [r.reshape(n, -1)[n - 1] if r.numel() else r for r in rows]  # the last pass's rows
 
     def fence() -> None:
         torch.cuda.synchronize()
@@ -280,47 +453,48 @@ def main() -> None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for k in range(args.warmup):
-        step(False, k)
-    scorer.flush()
-    if dist_on and args.gather == "end":
-        gather_ring(max(args.warmup, 1))  # also sets up RCCL's point-to-point channels outside the timed region
-    fence()
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        step(True, k)
-    scorer.flush()  # the pipelined form holds the last step's windows stage back until asked
-    if dist_on and args.gather == "end":
-        gathered = gather_ring(args.steps)
-        if rank == 0:
-            assert len(gathered) == world and all(g.numel() == args.steps * s for g, s in zip(gathered, sizes))
-    fence()
-    dt = time.perf_counter() - t0
+    out = run_passes(scorer, gather, row_of, args.steps, args.warmup, args.gather, fence, gather_ring)
+    dt = out["dt"]
     if dist_on:
         tmax = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
-        nw = torch.tensor([len(windows)], dtype=torch.int64, device=cdev)
-        dist.all_reduce(nw, op=dist.ReduceOp.SUM)
-        total_windows = int(nw.item())
+
+    # what the job produced: on rank 0 the gathered rows of the last pass, merged over the global list
+    n_sets = len(wl.specs)
+    if dist_on:
+        res = None
+        if rank == 0:
+            per_rank = gather.decode(out["rows"])
+            res = merge_rank_results(per_rank, plan_shards(win_counts, world), n_sets)
+            own = scorer.results()  # rank 0's own share must be what it sent
+            n0 = own.records.shape[1]
+            assert res.records[:, :n0].tobytes() == own.records.tobytes(), "gathered records differ from rank 0's own"
     else:
-        total_windows = len(windows)
+        res = scorer.results()  # also checks the candidate buffers were large enough
 
-    res = scorer.results()  # also checks the candidate buffers were large enough
-    kernel_ms = [a.elapsed_time(b) for a, b in scorer.count_events]
-    avg_ms = sum(kernel_ms) / len(kernel_ms)
-    achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
-    # on-box ceiling: plain 16-B-per-lane streaming read of the ref block (outside the timed region)
-    stream_read = eng.probe_stream_read(block.pops[0].tiles)
-
-    path_bytes = alg_bytes + 4 * n_sites + 24 * len(windows)
     if rank == 0:
-        traffic = None
+        kernel_ms = [a.elapsed_time(b) for a, b in scorer.count_events]
+        avg_ms = sum(kernel_ms) / len(kernel_ms)
+        alg_bytes = block.genotype_bytes if args.layout == "int8" else block.packed2_bytes
+        achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
+        # on-box ceiling: plain 16-B-per-lane streaming read of the ref block (outside the timed region)
+        probe_buf = block.pops[0].tiles[: min(block.pops[0].tiles.numel(), 10_000_000_000)]
+        stream_read = eng.probe_stream_read(probe_buf)
+        n_sites_rank0 = block.n_real_sites
+        path_bytes = alg_bytes + 4 * n_sites_rank0 + 24 * n_sets * scorer.n_windows
+        traffic, traffic_source = None, None
         tfile = ROOT / "profiles" / "traffic.json"
-        if tfile.exists():
+        if tfile.exists() and world == 1 and not args.sites and not args.chroms:
             rec = json.loads(tfile.read_text())
-            key = f"{n_sites}x{args.ref}+{args.tgt}+{args.src}" + ("" if args.layout == "int8" else f":{args.layout}")
-            traffic = rec.get(key, {}).get("site_counts_hbm_bytes_per_launch")
+            key = wl.name + ("" if args.layout == "int8" else f":{args.layout}")
+            if key in rec:
+                traffic = rec[key].get("site_counts_hbm_bytes_per_launch")
+                traffic_source = f"profiles/traffic.json[{key}] ({rec[key].get('source', 'rocprofv3 --pmc passes of this command')}); not measured in this run"
+        score_path = None
+        want_sp = args.score_path == "on" or (args.score_path == "auto" and world == 1)
+        if want_sp and world == 1 and len(wl.chroms) == 1 and args.layout == "int8":
+            score_path = score_path_rate(eng, wl, block, lay)
         line = {
             "metric": METRIC,
             "value": round(total_windows * args.steps / dt, 1),
@@ -330,21 +504,35 @@ def main() -> None:
             "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "u8",
             "data": "synthetic",
             "config": {
-                "workload": f"synthetic chr: {n_sites:.0e} sites, {args.ref} ref/{args.tgt} tgt/{args.src} src diploids, "
-                "50kb/25kb windows, U+Q95 (BASELINE.json configs[2]); one chromosome per GPU",
+                "workload": wl.description,
+                "workload_id": wl.name,
                 "layout": args.layout,
                 "steps_pipelined": overlap,
-                "n_sites_per_gpu": n_sites,
-                "windows_per_gpu": len(windows),
+                "chromosomes": len(wl.chroms),
+                "n_sites_per_chromosome": wl.n_sites,
+                "parameter_sets": n_sets,
                 "windows_total": total_windows,
-                "sharding": f"windows sharded by chromosome, RCCL gather of records + candidate lists to rank 0 ({args.gather})" if dist_on else "none",
-                "u_sum_rank0": int(res.records["u_count"].sum()),
-                "q_finite_rank0": int(np.isfinite(res.records["q"]).sum()),
+                "windows_rank0": scorer.n_windows,
+                "sites_rank0": n_sites_rank0,
+                "pieces_rank0": len(lay.pieces),
+                "sharding": (
+                    f"global window list cut into {world} contiguous ranges (chunk_generator.py:130-142), each rank "
+                    f"holds its sites + the win-step halo, no data-path collective; ONE RCCL gather of 24-byte records "
+                    f"+ CSR candidate lists to rank 0 per {'pass' if args.gather == 'step' else 'run (rows of all passes)'}"
+                    if dist_on else "none"
+                ),
+                "gather": args.gather if dist_on else None,
+                "gather_row_bytes": gather.sizes if dist_on else None,
+                "setup_s": round(t_setup, 2),
+                "u_sum": int(res.records["u_count"].sum()),
+                "q_finite": int(np.isfinite(res.records["q"]).sum()),
+                "cdd_u_entries": int(res.cdd_u.size),
+                "cdd_q_entries": int(res.cdd_q.size),
             },
             "roofline": {
                 "kernel": "site_counts" if args.layout == "int8" else "site_counts_packed2",
@@ -354,8 +542,10 @@ def main() -> None:
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 4),
                 "traffic": traffic,
+                "traffic_source": traffic_source,
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "avg_launch_ms": round(avg_ms, 4),
+                "rank": 0,
                 "stream_read_probe_gbps": round(stream_read, 1),
                 "frac_of_stream_read_probe": round(achieved / stream_read, 4),
                 # genotypes + 4 B per position + 24 B per record, over the whole step
@@ -363,6 +553,7 @@ def main() -> None:
                 "whole_path_gbps_this_rank": round(path_bytes / (dt / args.steps) / 1e9, 1),
             },
             "cpu_baseline": cpu,
+            "score_path": score_path,
         }
         print(json.dumps(line), file=result_out, flush=True)
     if dist_on:

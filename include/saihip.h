@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define SAI_ABI_VERSION 3
+#define SAI_ABI_VERSION 4
 #define SAI_TILE_SITES 64
 #define SAI_MAX_SRC 6   /* source populations per call */
 #define SAI_MAX_SETS 16 /* parameter sets per call */
@@ -150,6 +150,15 @@ int sai_site_flags(sai_ctx* ctx, int64_t n_sites, int32_t n_pops, const int32_t*
 int sai_window_bounds(sai_ctx* ctx, const int32_t* pos, int64_t n_sites, int32_t n_windows,
                       const int64_t* win_start, const int64_t* win_end, int32_t* lo, int32_t* hi,
                       void* stream);
+
+/* The same search for a block that holds several chromosome pieces back to back (a rank's share of
+ * a whole-genome window list, chunk_generator.py:111-142 applied to the concatenated list): window
+ * w is searched only inside sites [seg_lo[w], seg_hi[w]) of the block -- positions ascend inside a
+ * piece, not across pieces -- and lo/hi are block-relative like sai_window_bounds'.  Segment bounds
+ * are clamped into [0, n_sites]. */
+int sai_window_bounds_seg(sai_ctx* ctx, const int32_t* pos, int64_t n_sites, int32_t n_windows,
+                          const int64_t* win_start, const int64_t* win_end, const int32_t* seg_lo,
+                          const int32_t* seg_hi, int32_t* lo, int32_t* hi, void* stream);
 
 /* Kernel 4 (four launches): one record per (set, window): U count (u_statistic.py:94-96),
  * numpy 'linear' nanquantile of the effective target frequency over condition sites

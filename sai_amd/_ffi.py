@@ -20,7 +20,7 @@ SAI_MAX_SETS = 16
 SAI_FUSED_SETS = 4
 SAI_ERR_UNSUPPORTED = -4  # enum sai_status
 FREQ_MODES = {"dense": 0, "candidates": 1}  # enum sai_freq_mode
-SAI_ABI_VERSION = 3
+SAI_ABI_VERSION = 4
 
 OPS = {"=": 0, "<": 1, ">": 2, "<=": 3, ">=": 4}
 
@@ -83,6 +83,7 @@ SIGNATURES = {
         [_p, _i64, _i32, C.POINTER(_i32), _p, _i32, C.POINTER(SaiParams), _p, _p, _p, _p],
     ),
     "sai_window_bounds": (C.c_int, [_p, _p, _i64, _i32, _p, _p, _p, _p, _p]),
+    "sai_window_bounds_seg": (C.c_int, [_p, _p, _i64, _i32, _p, _p, _p, _p, _p, _p, _p]),
     "sai_window_stats": (
         C.c_int,
         [_p, _i64, _p, _p, _i32, C.POINTER(SaiParams), _i32, _p, _p, _p, _p, _p, _p, _i64, _p, _i64, _p, _p],
@@ -113,7 +114,14 @@ SIGNATURES = {
     "sai_vcf_block_free": (C.c_int, [_p]),
 }
 
+# entry points that never touch the GPU (host_core.cpp, vcf_ingest.cpp)
+HOST_SYMBOLS = (
+    "sai_abi_version", "sai_build_arch", "sai_last_error", "sai_synth_fill_host", "sai_synth_gaps_host",
+    "sai_narrow_to_int8", "sai_vcf_scan", "sai_vcf_load", "sai_vcf_block_info", "sai_vcf_block_copy", "sai_vcf_block_free",
+)  # fmt: skip
+
 _lib = None
+_host_lib = None
 
 
 def load() -> C.CDLL:
@@ -146,9 +154,30 @@ def load() -> C.CDLL:
     return lib
 
 
-def check(status: int) -> None:
+def load_host() -> C.CDLL:
+    """The library that serves the host-only entry points (``HOST_SYMBOLS``): libsaihip.so itself,
+    or -- when ``SAI_AMD_HOST_LIB`` names one -- a separate build of host_core.cpp + vcf_ingest.cpp
+    (the sanitizer build of the CPU test suite), loaded without the HIP runtime or torch."""
+    global _host_lib
+    if _host_lib is not None:
+        return _host_lib
+    path = os.environ.get("SAI_AMD_HOST_LIB")
+    if not path:
+        _host_lib = load()
+        return _host_lib
+    lib = C.CDLL(path)
+    for name in HOST_SYMBOLS:
+        fn = getattr(lib, name)
+        fn.restype, fn.argtypes = SIGNATURES[name]
+    if lib.sai_abi_version() != SAI_ABI_VERSION:
+        raise RuntimeError(f"{path}: ABI {lib.sai_abi_version()} != expected {SAI_ABI_VERSION}")
+    _host_lib = lib
+    return lib
+
+
+def check(status: int, lib=None) -> None:
     if status != 0:
-        raise SaiHipError(status, load().sai_last_error().decode("utf-8", "replace"))
+        raise SaiHipError(status, (lib or load()).sai_last_error().decode("utf-8", "replace"))
 
 
 def make_params(w, x, quantile, y_list, anc_allele_available, n_src=None) -> SaiParams:

@@ -1,7 +1,9 @@
 // libsaihip: sai's sliding-window U/Q statistics as hand-written HIP for MI355X (gfx950, CDNA4).
 //
 // Translation units (see DESIGN.md for the roofline of each kernel):
-//   core.hip       errors, context, tile_from_site_major (ingest: [site][ind] int8 -> tiled SoA)
+//   host_core.cpp  errors, version, host side of the synthetic generator (plain C++, also built
+//                  alone with the sanitizers)
+//   core.hip       context, tile_from_site_major (ingest: [site][ind] int8 -> tiled SoA)
 //   site_pass.hip  site_counts (the HBM-bound byte reduction), site_flags, the fused site pass
 //   packed2.hip    the optional 2-bit layout and its site pass
 //   windows.hip    window_bounds, window statistics (U count, numpy-'linear' quantile, lists)
@@ -15,20 +17,6 @@
 // (separate multiply and add in the quantile lerp, IEEE division for the frequencies).
 
 #include "common.hpp"
-
-namespace {
-
-thread_local char g_err[512] = "";
-
-}  // namespace
-
-extern "C" int sai_set_error(int code, const char* fmt, ...) {
-  va_list ap;
-  va_start(ap, fmt);
-  vsnprintf(g_err, sizeof(g_err), fmt, ap);
-  va_end(ap);
-  return code;
-}
 
 namespace {
 
@@ -85,10 +73,6 @@ __global__ __launch_bounds__(256) void tile_from_site_major_kernel(const int8_t*
 // ------------------------------------------------------------------------------------------
 
 extern "C" {
-
-int sai_abi_version(void) { return SAI_ABI_VERSION; }
-const char* sai_build_arch(void) { return "gfx950"; }
-const char* sai_last_error(void) { return g_err; }
 
 int sai_device_count(int* count_out) {
   if (!count_out) return fail(SAI_ERR_ARG, "count_out is NULL");

@@ -9,6 +9,7 @@
 // The Python reader sai_amd/utils/vcf.py is the readable statement of the same rules; the two are
 // tested against each other and against the reference tests' expectations.
 
+#include <sys/stat.h>
 #include <zlib.h>
 
 #include <algorithm>
@@ -17,6 +18,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <exception>
+#include <memory>
 #include <new>
 #include <string>
 #include <thread>
@@ -26,9 +29,23 @@
 
 #include "saihip.h"
 
-extern "C" int sai_set_error(int code, const char* fmt, ...);  // defined in core.hip
+extern "C" int sai_set_error(int code, const char* fmt, ...);  // defined in host_core.cpp
 
 namespace {
+
+// Worker threads that are always joined, also when an exception unwinds the spawning scope (a
+// joinable std::thread that is destroyed calls std::terminate).
+struct ThreadGroup {
+  std::vector<std::thread> th;
+  template <typename F>
+  void spawn(F&& f) { th.emplace_back(std::forward<F>(f)); }
+  void join() {
+    for (auto& t : th)
+      if (t.joinable()) t.join();
+    th.clear();
+  }
+  ~ThreadGroup() { join(); }
+};
 
 constexpr int kScanThreads = 8;  // inflate threads of sai_vcf_scan (it has no thread argument)
 
@@ -68,6 +85,7 @@ struct ThreadOut {
   bool saw_chrom = false;        // a record line of the requested chromosome
   bool beyond_stop = false;      // ... with POS past the region
   bool last_line_other = false;  // the last record line of the piece is another chromosome
+  bool failed = false;           // an exception ended the piece and not even its text could be kept
   std::string error;
 };
 
@@ -282,7 +300,15 @@ bool read_all_gz(const std::string& path, std::vector<unsigned char>& out) {
 // false: no usable index (absent, unreadable, malformed) -- the caller falls back to a full pass
 bool load_tbi(const char* vcf_path, const std::string& chrom, TbiRef& ref) {
   std::vector<unsigned char> d;
-  if (!read_all_gz(std::string(vcf_path) + ".tbi", d)) return false;
+  const std::string tbi_path = std::string(vcf_path) + ".tbi";
+  {  // an index older than its file describes other bytes: a region would be silently cut short.
+     // Whole seconds, as htslib compares them: a checkout or copy writes both files within moments
+     // of each other in either order.
+    struct stat sv, si;
+    if (stat(vcf_path, &sv) != 0 || stat(tbi_path.c_str(), &si) != 0) return false;
+    if (si.st_mtim.tv_sec < sv.st_mtim.tv_sec) return false;
+  }
+  if (!read_all_gz(tbi_path, d)) return false;
   size_t o = 0;
   auto need = [&](size_t n) { return o + n <= d.size(); };
   auto i32 = [&]() { const int32_t v = static_cast<int32_t>(le32(d.data() + o)); o += 4; return v; };
@@ -421,6 +447,8 @@ int for_each_block_bgzf(FILE* f, const char* path, int n_threads, uint64_t voff_
       if (bsize == 0 || off + static_cast<size_t>(bsize) > chave) break;  // incomplete member
       if (static_cast<size_t>(bsize) < hlen + 8) return sai_set_error(SAI_ERR_ARG, "%s: corrupt BGZF block", path);
       const unsigned char* tail = cbuf.data() + off + bsize - 8;
+      // a BGZF member holds at most 64 KiB of data; the trailer is file content, not a promise
+      if (le32(tail + 4) > 65536u) return sai_set_error(SAI_ERR_ARG, "%s: corrupt BGZF block (ISIZE > 64 KiB)", path);
       members.push_back({off + hlen, static_cast<uint32_t>(static_cast<size_t>(bsize) - hlen - 8), le32(tail + 4),
                          le32(tail), out_total});
       out_total += le32(tail + 4);
@@ -442,16 +470,16 @@ int for_each_block_bgzf(FILE* f, const char* path, int n_threads, uint64_t voff_
     {
       const int nt = std::max(1, std::min<int>(n_threads, static_cast<int>(members.size())));
       std::vector<char> bad(static_cast<size_t>(nt), 0);
-      auto work = [&](int t) {
+      auto work = [&](int t) {  // inflate_member allocates nothing but zlib's own state: no throw
         const size_t lo = members.size() * static_cast<size_t>(t) / static_cast<size_t>(nt);
         const size_t hi = members.size() * static_cast<size_t>(t + 1) / static_cast<size_t>(nt);
         for (size_t i = lo; i < hi; ++i)
           if (!inflate_member(cbuf.data(), members[i], ubuf.data() + carry)) bad[static_cast<size_t>(t)] = 1;
       };
-      std::vector<std::thread> th;
-      for (int t = 1; t < nt; ++t) th.emplace_back(work, t);
+      ThreadGroup th;
+      for (int t = 1; t < nt; ++t) th.spawn([&work, t] { work(t); });
       work(0);
-      for (auto& x : th) x.join();
+      th.join();
       for (char b : bad)
         if (b) return sai_set_error(SAI_ERR_ARG, "%s: BGZF block fails to inflate or its CRC", path);
     }
@@ -606,9 +634,24 @@ struct sai_vcf_block {
   std::vector<int8_t> dosage;  // [record][sample]
 };
 
+// No C++ exception may cross the C ABI (the caller is ctypes: it would be std::terminate and the
+// Python process would die): allocation and thread-creation failures come back as a status.
+template <typename F>
+static int guarded(const char* what, F&& body) {
+  try {
+    return body();
+  } catch (const std::bad_alloc&) {
+    return sai_set_error(SAI_ERR_HIP, "%s: out of host memory", what);
+  } catch (const std::exception& e) {
+    return sai_set_error(SAI_ERR_HIP, "%s: %s", what, e.what());
+  } catch (...) {
+    return sai_set_error(SAI_ERR_HIP, "%s: unknown failure", what);
+  }
+}
+
 extern "C" {
 
-int sai_vcf_scan(const char* path, const char* chrom, int64_t* first_pos, int64_t* last_pos) {
+static int vcf_scan_impl(const char* path, const char* chrom, int64_t* first_pos, int64_t* last_pos) {
   if (!path || !chrom || !first_pos || !last_pos) return sai_set_error(SAI_ERR_ARG, "NULL argument");
   const std::string c(chrom);
   int64_t first = -1, last = -1;
@@ -668,9 +711,9 @@ int sai_vcf_scan(const char* path, const char* chrom, int64_t* first_pos, int64_
   return SAI_OK;
 }
 
-int sai_vcf_load(const char* path, const char* chrom, int64_t start, int64_t end, int32_t n_samples,
-                 const char* const* sample_names, const int32_t* ploidy, const char* anc_bed_path, int32_t n_threads,
-                 sai_vcf_block** block_out) {
+static int vcf_load_impl(const char* path, const char* chrom, int64_t start, int64_t end, int32_t n_samples,
+                         const char* const* sample_names, const int32_t* ploidy, const char* anc_bed_path,
+                         int32_t n_threads, sai_vcf_block** block_out) {
   if (!path || !chrom || !block_out) return sai_set_error(SAI_ERR_ARG, "NULL argument");
   *block_out = nullptr;
   if (n_samples < 1 || !sample_names || !ploidy) return sai_set_error(SAI_ERR_ARG, "empty sample selection");
@@ -678,12 +721,12 @@ int sai_vcf_load(const char* path, const char* chrom, int64_t start, int64_t end
     if (ploidy[s] < 1 || ploidy[s] > 64) return sai_set_error(SAI_ERR_ARG, "ploidy of sample %d out of range", s);
   if (n_threads < 1) n_threads = 1;
   const std::string c(chrom);
-  sai_vcf_block* blk = new (std::nothrow) sai_vcf_block;
-  if (!blk) return sai_set_error(SAI_ERR_HIP, "out of host memory");
+  std::unique_ptr<sai_vcf_block> holder(new sai_vcf_block);  // released to the caller only on success
+  sai_vcf_block* blk = holder.get();
   blk->n_samples = n_samples;
   AncMap anc;
   if (anc_bed_path) {
-    if (int rc = load_anc(anc_bed_path, c, start, end, anc, &blk->n_anc_entries)) { delete blk; return rc; }
+    if (int rc = load_anc(anc_bed_path, c, start, end, anc, &blk->n_anc_entries)) return rc;
   }
   Selection sel;
   bool header_seen = false;
@@ -720,17 +763,27 @@ int sai_vcf_load(const char* path, const char* chrom, int64_t start, int64_t end
       o.pos.clear();
       o.dosage.clear();
       o.matched = 0;
-      o.saw_chrom = o.beyond_stop = o.last_line_other = false;
+      o.saw_chrom = o.beyond_stop = o.last_line_other = o.failed = false;
     }
-    std::vector<std::thread> th;
+    auto piece = [&](int t) {  // an exception must not leave a worker thread (that is std::terminate)
+      ThreadOut& o = outs[static_cast<size_t>(t)];
+      try {
+        parse_lines(cut[static_cast<size_t>(t)], cut[static_cast<size_t>(t) + 1], c, start, end, sel, anc, true, o);
+      } catch (const std::exception& e) {
+        try { o.error = std::string("tokenizer failed: ") + e.what(); } catch (...) { o.failed = true; }
+      } catch (...) {
+        o.failed = true;
+      }
+    };
+    ThreadGroup th;
     for (int t = 1; t < n_threads; ++t) {
       if (cut[static_cast<size_t>(t)] >= cut[static_cast<size_t>(t) + 1]) continue;
-      th.emplace_back(parse_lines, cut[static_cast<size_t>(t)], cut[static_cast<size_t>(t) + 1], std::cref(c), start, end,
-                      std::cref(sel), std::cref(anc), true, std::ref(outs[static_cast<size_t>(t)]));
+      th.spawn([&piece, t] { piece(t); });
     }
-    if (cut[0] < cut[1]) parse_lines(cut[0], cut[1], c, start, end, sel, anc, true, outs[0]);  // this thread works too
-    for (auto& x : th) x.join();
+    if (cut[0] < cut[1]) piece(0);  // this thread works too
+    th.join();
     for (auto& o : outs) {  // pieces in file order
+      if (o.failed) return sai_set_error(SAI_ERR_HIP, "%s: tokenizer failed (out of memory)", path);
       if (!o.error.empty()) return sai_set_error(SAI_ERR_ARG, "%s: %s", path, o.error.c_str());
       blk->n_matched += o.matched;
       blk->pos.insert(blk->pos.end(), o.pos.begin(), o.pos.end());
@@ -762,13 +815,13 @@ int sai_vcf_load(const char* path, const char* chrom, int64_t start, int64_t end
       return on_records(p, endp);
     });
   }
-  if (rc) { delete blk; return rc; }
-  if (!header_seen) { delete blk; return sai_set_error(SAI_ERR_ARG, "%s: not a VCF (no #CHROM header)", path); }
-  *block_out = blk;
+  if (rc) return rc;
+  if (!header_seen) return sai_set_error(SAI_ERR_ARG, "%s: not a VCF (no #CHROM header)", path);
+  *block_out = holder.release();
   return SAI_OK;
 }
 
-int sai_narrow_to_int8(const void* src, int32_t itemsize, int32_t is_signed, int64_t n_rows, int64_t n_cols,
+static int narrow_impl(const void* src, int32_t itemsize, int32_t is_signed, int64_t n_rows, int64_t n_cols,
                        int64_t row_stride_bytes, int8_t* dst, int32_t n_threads) {
   if (n_rows < 0 || n_cols < 0) return sai_set_error(SAI_ERR_ARG, "negative shape");
   if (n_rows == 0 || n_cols == 0) return SAI_OK;
@@ -793,13 +846,32 @@ int sai_narrow_to_int8(const void* src, int32_t itemsize, int32_t is_signed, int
     }
     ok[static_cast<size_t>(t)] = good ? 1 : 0;
   };
-  std::vector<std::thread> th;
-  for (int t = 1; t < nt; ++t) th.emplace_back(work, t);
+  ThreadGroup th;  // narrow_rows touches only the caller's buffers: no throw inside the workers
+  for (int t = 1; t < nt; ++t) th.spawn([&work, t] { work(t); });
   work(0);
-  for (auto& x : th) x.join();
+  th.join();
   for (char g : ok)
     if (!g) return sai_set_error(SAI_ERR_UNSUPPORTED, "dosage above 127 is not representable in the int8 device layout");
   return SAI_OK;
+}
+
+int sai_vcf_scan(const char* path, const char* chrom, int64_t* first_pos, int64_t* last_pos) {
+  return guarded("sai_vcf_scan", [&] { return vcf_scan_impl(path, chrom, first_pos, last_pos); });
+}
+
+int sai_vcf_load(const char* path, const char* chrom, int64_t start, int64_t end, int32_t n_samples,
+                 const char* const* sample_names, const int32_t* ploidy, const char* anc_bed_path, int32_t n_threads,
+                 sai_vcf_block** block_out) {
+  return guarded("sai_vcf_load", [&] {
+    return vcf_load_impl(path, chrom, start, end, n_samples, sample_names, ploidy, anc_bed_path, n_threads, block_out);
+  });
+}
+
+int sai_narrow_to_int8(const void* src, int32_t itemsize, int32_t is_signed, int64_t n_rows, int64_t n_cols,
+                       int64_t row_stride_bytes, int8_t* dst, int32_t n_threads) {
+  return guarded("sai_narrow_to_int8", [&] {
+    return narrow_impl(src, itemsize, is_signed, n_rows, n_cols, row_stride_bytes, dst, n_threads);
+  });
 }
 
 int sai_vcf_block_info(const sai_vcf_block* block, int64_t* n_records, int64_t* n_matched, int64_t* n_anc_entries) {

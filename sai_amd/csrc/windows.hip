@@ -45,18 +45,27 @@ __device__ __forceinline__ int64_t group_search(const int32_t* __restrict__ pos,
 
 constexpr int kBoundsGroup = 8;  // lanes per window
 
-// lo = first site with pos >= start, hi = first site with pos > end.
+// lo = first site with pos >= start, hi = first site with pos > end, both searched inside the
+// window's segment [seg_lo[w], seg_hi[w]) of the block (the whole block when seg_lo is NULL): a
+// block that holds several chromosomes back to back has positions that ascend only per segment.
 __global__ __launch_bounds__(256) void window_bounds_kernel(const int32_t* __restrict__ pos,
                                                              int64_t n_sites, int32_t n_windows,
                                                              const int64_t* __restrict__ ws,
                                                              const int64_t* __restrict__ we,
+                                                             const int32_t* __restrict__ seg_lo,
+                                                             const int32_t* __restrict__ seg_hi,
                                                              int32_t* __restrict__ lo,
                                                              int32_t* __restrict__ hi) {
   const int lane = threadIdx.x & 63;
   const int w = (blockIdx.x * 256 + threadIdx.x) / kBoundsGroup;
   const bool live = w < n_windows;  // dead groups search an empty range: no loads, no stores
-  const int64_t first = group_search<kBoundsGroup>(pos, 0, live ? n_sites : 0, live ? ws[w] : 0, false, lane);
-  const int64_t last = group_search<kBoundsGroup>(pos, first, live ? n_sites : first, live ? we[w] : 0, true, lane);
+  int64_t a = 0, b = live ? n_sites : 0;
+  if (live && seg_lo) {  // clamped into the block, so a bad segment can never turn into a wild load
+    a = min(max(static_cast<int64_t>(seg_lo[w]), int64_t{0}), n_sites);
+    b = min(max(static_cast<int64_t>(seg_hi[w]), a), n_sites);
+  }
+  const int64_t first = group_search<kBoundsGroup>(pos, a, b, live ? ws[w] : 0, false, lane);
+  const int64_t last = group_search<kBoundsGroup>(pos, first, live ? b : first, live ? we[w] : 0, true, lane);
   if (live && lane % kBoundsGroup == 0) {
     lo[w] = static_cast<int32_t>(first);
     hi[w] = static_cast<int32_t>(last);
@@ -504,16 +513,29 @@ __global__ __launch_bounds__(256) void window_lists_kernel(WinArgs a) {
 
 extern "C" {
 
-int sai_window_bounds(sai_ctx* ctx, const int32_t* pos, int64_t n_sites, int32_t n_windows,
-                      const int64_t* win_start, const int64_t* win_end, int32_t* lo, int32_t* hi, void* stream) {
+static int launch_window_bounds(sai_ctx* ctx, const int32_t* pos, int64_t n_sites, int32_t n_windows,
+                                const int64_t* win_start, const int64_t* win_end, const int32_t* seg_lo,
+                                const int32_t* seg_hi, int32_t* lo, int32_t* hi, void* stream) {
   if (int rc = enter(ctx)) return rc;
   if (n_sites < 0 || n_sites >= 0x7FFFFFFFll || n_windows < 0) return fail(SAI_ERR_ARG, "size out of range");
   if (n_windows == 0) return SAI_OK;
   if ((n_sites > 0 && !pos) || !win_start || !win_end || !lo || !hi) return fail(SAI_ERR_ARG, "NULL buffer");
   const unsigned grid = static_cast<unsigned>((static_cast<int64_t>(n_windows) * kBoundsGroup + 255) / 256);
   hipLaunchKernelGGL(window_bounds_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), pos, n_sites,
-                     n_windows, win_start, win_end, lo, hi);
+                     n_windows, win_start, win_end, seg_lo, seg_hi, lo, hi);
   return check_launch("window_bounds");
+}
+
+int sai_window_bounds(sai_ctx* ctx, const int32_t* pos, int64_t n_sites, int32_t n_windows,
+                      const int64_t* win_start, const int64_t* win_end, int32_t* lo, int32_t* hi, void* stream) {
+  return launch_window_bounds(ctx, pos, n_sites, n_windows, win_start, win_end, nullptr, nullptr, lo, hi, stream);
+}
+
+int sai_window_bounds_seg(sai_ctx* ctx, const int32_t* pos, int64_t n_sites, int32_t n_windows,
+                          const int64_t* win_start, const int64_t* win_end, const int32_t* seg_lo,
+                          const int32_t* seg_hi, int32_t* lo, int32_t* hi, void* stream) {
+  if (n_windows > 0 && (!seg_lo || !seg_hi)) return fail(SAI_ERR_ARG, "NULL segment bounds");
+  return launch_window_bounds(ctx, pos, n_sites, n_windows, win_start, win_end, seg_lo, seg_hi, lo, hi, stream);
 }
 
 int sai_window_stats(sai_ctx* ctx, int64_t n_sites, const double* tgt_freq, const uint8_t* flags, int32_t n_sets,

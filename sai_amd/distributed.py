@@ -49,24 +49,76 @@ def my_chunk_indices(n_chunks: int, rank: int, world: int) -> range:
     return range(*bounds[rank])
 
 
+def _exchange_task_results(data_processor, mine: list, group=None) -> Optional[list]:
+    """Bring every rank's per-task results to rank 0, in rank (= task) order.
+
+    A processor that offers ``pack_result`` / ``unpack_result`` (ChunkPreprocessor: the numeric
+    ``WindowBatch`` -- fixed window records + CSR candidate lists) travels as ONE byte row per rank:
+    sizes are exchanged once, then a single padded ``gather`` moves the rows (RCCL over xGMI when
+    the backend is "nccl", the rows then live in HBM; gloo on the host).  Other processors -- user
+    plugins with arbitrary Python results -- fall back to ``gather_object`` (pickle), which is what
+    the reference's pool does with every result (mp_pool.py:67-73)."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    if not (hasattr(data_processor, "pack_result") and hasattr(data_processor, "unpack_result")):
+        gathered: Optional[list] = [None] * world if rank == 0 else None
+        dist.gather_object(mine, gathered, dst=0, group=group)
+        return None if rank != 0 else [res for per_rank in gathered for res in per_rank]
+    blobs = [data_processor.pack_result(r) for r in mine]
+    head = np.array([len(blobs), *map(len, blobs)], dtype=np.int64).tobytes()
+    row = np.frombuffer(head + b"".join(blobs), dtype=np.uint8)
+    on_gpu = dist.get_backend(group) == "nccl"
+    local = torch.from_numpy(row.copy())
+    if on_gpu:
+        local = local.to(torch.device("cuda", torch.cuda.current_device()))
+    per_rank = gather_window_records(local, group)
+    if rank != 0:
+        return None
+    out = []
+    for t in per_rank:
+        raw = t.cpu().numpy().tobytes()
+        n = int(np.frombuffer(raw, dtype=np.int64, count=1)[0])
+        sizes = np.frombuffer(raw, dtype=np.int64, count=n, offset=8).tolist()
+        o = 8 * (1 + n)
+        for sz in sizes:
+            out.append(data_processor.unpack_result(raw[o : o + sz]))
+            o += sz
+    return out
+
+
+def _finish(data_processor, results: list) -> list:
+    """Items of all tasks: a processor with the numeric protocol merges its batches into the
+    single-chunk order (combination-major, sai.py:146-151), others are concatenated task by task."""
+    if hasattr(data_processor, "items_from_results"):
+        return data_processor.items_from_results(results)
+    return [it for per_task in results for it in per_task]
+
+
 def run_sharded(data_processor, data_generator, group=None) -> Optional[list]:
-    """mp_pool's contract over ranks: every rank runs ``data_processor.run(**params)`` for its
-    share of ``data_generator.get()``, the item lists are gathered to rank 0 in generator order,
-    and rank 0 calls ``process_items`` on the concatenation.  Returns the items on rank 0."""
+    """mp_pool's decomposition over ranks: every rank runs its share of ``data_generator.get()``
+    (``run_compact`` when the processor has the numeric protocol, else ``run``), the per-task results
+    come to rank 0 in generator order, and rank 0 calls ``process_items`` on the items -- written in
+    the order a one-process run writes them, so the output files are byte-identical for any number
+    of ranks.  Returns the items on rank 0."""
     import torch.distributed as dist
 
     tasks = list(data_generator.get())
+    compute = getattr(data_processor, "run_compact", None) or data_processor.run
     if not (dist.is_available() and dist.is_initialized()):
-        items = [it for params in tasks for it in data_processor.run(**params)]
+        items = _finish(data_processor, [compute(**params) for params in tasks])
         data_processor.process_items(items)
         return items
     rank, world = dist.get_rank(group), dist.get_world_size(group)
-    mine = [data_processor.run(**tasks[i]) for i in my_chunk_indices(len(tasks), rank, world)]
-    gathered: Optional[list] = [None] * world if rank == 0 else None
-    dist.gather_object(mine, gathered, dst=0, group=group)
+    mine = [compute(**tasks[i]) for i in my_chunk_indices(len(tasks), rank, world)]
+    if hasattr(data_processor, "run_compact") and not hasattr(data_processor, "pack_result"):
+        raise TypeError("a processor with run_compact must also offer pack_result / unpack_result")
+    results = _exchange_task_results(data_processor, mine, group)
     if rank != 0:
         return None
-    items = [it for per_rank in gathered for per_task in per_rank for it in per_task]
+    items = _finish(data_processor, results)
     data_processor.process_items(items)
     return items
 
@@ -107,6 +159,55 @@ def gather_padded(local, sizes: Sequence[int], group=None):
     if rank != 0:
         return None
     return [t[:n] for t, n in zip(out, sizes)]
+
+
+class RowGather:
+    """The per-pass exchange of a sharded resident job: every rank owns a
+    ``RowLayout`` (records + CSR candidate lists of its windows; fixed for a resident block), the
+    layouts are exchanged ONCE at set-up with one small all_gather, and each pass then costs one
+    padded ``gather`` of the byte rows to rank 0 -- RCCL over xGMI for HBM rows (backend "nccl"),
+    gloo for host rows.  ``decode`` turns what rank 0 received into per-rank WindowResults."""
+
+    HEADER_LEN = 64  # int64 words: enough for 20 set chunks (320 parameter sets)
+
+    def __init__(self, layout, device, group=None):
+        import torch
+        import torch.distributed as dist
+
+        self.group = group
+        self.on = dist.is_available() and dist.is_initialized()
+        self.rank = dist.get_rank(group) if self.on else 0
+        self.world = dist.get_world_size(group) if self.on else 1
+        head = ([1] + layout.header()) if layout is not None else [0]
+        if len(head) > self.HEADER_LEN:
+            raise ValueError("too many set chunks for the gather header")
+        mine = torch.zeros((self.HEADER_LEN,), dtype=torch.int64)
+        mine[: len(head)] = torch.tensor(head, dtype=torch.int64)
+        if self.on:
+            mine = mine.to(device)
+            every = [torch.zeros_like(mine) for _ in range(self.world)]
+            dist.all_gather(every, mine, group=group)
+            heads = [h.cpu().tolist() for h in every]
+        else:
+            heads = [mine.tolist()]
+        from .resident import RowLayout
+
+        self.layouts = [RowLayout.from_header(h[1:]) if h[0] else None for h in heads]
+        self.sizes = [lay.nbytes if lay is not None else 0 for lay in self.layouts]
+
+    def gather(self, row):
+        """One pass: ``row`` = this rank's uint8 row (``sizes[rank]`` bytes; any tensor for a rank
+        without windows).  Returns the rank-ordered list of rows on rank 0, None elsewhere."""
+        if not self.on:
+            return [row[: self.sizes[0]]]
+        return gather_padded(row[: self.sizes[self.rank]], self.sizes, self.group)
+
+    def decode(self, rows) -> list:
+        """Rank 0: WindowResults per rank (None for a rank without windows)."""
+        out = []
+        for lay, t in zip(self.layouts, rows):
+            out.append(None if lay is None else lay.unpack(t.cpu().numpy()))
+        return out
 
 
 def score_sharded(vcf_file: str, chr_name: str, win_len: int, win_step: int, anc_allele_file, output_file: str,

@@ -49,14 +49,14 @@ def to_int8_dosage(gts) -> np.ndarray:
         # one multithreaded native pass (the reference holds int64: numpy's max / maximum / astype
         # chain costs three passes over 8x the bytes)
         out = np.empty(g.shape, dtype=np.int8)
-        lib = _ffi.load()
+        lib = _ffi.load_host()
         rc = lib.sai_narrow_to_int8(
             g.ctypes.data_as(C.c_void_p), g.itemsize, int(np.issubdtype(g.dtype, np.signedinteger)), g.shape[0], g.shape[1],
             g.strides[0], out.ctypes.data_as(C.c_void_p), min(os.cpu_count() or 1, 16),
         )
         if rc == _ffi.SAI_ERR_UNSUPPORTED:
             raise ValueError("dosage above 127 is not representable in the int8 device layout")
-        _ffi.check(rc)
+        _ffi.check(rc, lib)
         return out
     if g.size and g.max() > 127:
         raise ValueError("dosage above 127 is not representable in the int8 device layout")
@@ -445,10 +445,18 @@ class Engine:
 
     # -- synthetic data --------------------------------------------------------------------
 
-    def synth_population(self, seed, chrom, site0, n_sites, pop_stream, n_ind, ploidy=2, missing_per_million=0):
+    def synth_population(self, seed, chrom, site0, n_sites, pop_stream, n_ind, ploidy=2, missing_per_million=0, out=None):
+        """synth-v1 genotypes of sites [site0, site0 + n_sites) as a tiled block; ``out`` = an int8
+        device tensor of exactly ``sai_tiled_bytes`` bytes to fill instead of a fresh allocation (a
+        tile-aligned slice of a larger block that holds several pieces)."""
         torch = _torch()
         nbytes = self.lib.sai_tiled_bytes(n_sites, n_ind)
-        tiles = self._empty((nbytes,), torch.int8)
+        if out is None:
+            tiles = self._empty((nbytes,), torch.int8)
+        else:
+            if out.dtype != torch.int8 or out.numel() != nbytes or not out.is_contiguous():
+                raise ValueError("out must be a contiguous int8 tensor of sai_tiled_bytes(n_sites, n_ind) bytes")
+            tiles = out
         _ffi.check(
             self.lib.sai_synth_fill(
                 self.ctx, seed, chrom, site0, n_sites, pop_stream, n_ind, ploidy, missing_per_million,

@@ -16,6 +16,7 @@ from typing import Any, Iterator, Optional
 
 import numpy as np
 
+from ..utils.genomic_dataclasses import ChromosomeData
 from ..utils.read_data import read_data
 from ..utils.windows import split_genome
 from .data_generator import DataGenerator
@@ -90,6 +91,21 @@ class WindowGenerator(DataGenerator):
         )  # fmt: skip
         return self
 
+    @classmethod
+    def from_resident(cls, chr_name, pos: np.ndarray, pos_dev, ref: dict, tgt: dict, src: dict, win_len: int,
+                      win_step: int, ploidy_config, start: int = None, end: int = None, out: Optional[dict] = None):  # fmt: skip
+        """Build from blocks that already live in HBM: ``ref`` / ``tgt`` / ``src`` / ``out`` map
+        population -> TiledPop over the sites of ``pos`` (host int32 array; ``pos_dev`` its device
+        copy).  ``get()`` (per-window host matrices for the plugin classes) is not available on such
+        a generator; the batched path (FeaturePreprocessor.run_windows) is."""
+        data = lambda d: {k: ChromosomeData(POS=pos, REF=None, ALT=None, GT=v) for k, v in d.items()}  # noqa: E731
+        names = lambda d: {k: [f"{k}_{i}" for i in range(v.n_ind)] for k, v in d.items()}  # noqa: E731
+        self = object.__new__(cls)
+        self._setup(chr_name, win_len, win_step, ploidy_config, (data(ref), names(ref)), (data(tgt), names(tgt)),
+                    (data(src), names(src)), start, end, len(src), (data(out), names(out)) if out else (None, None))  # fmt: skip
+        self._device_pos = (pos, pos_dev)
+        return self
+
     def _setup(self, chr_name, win_len, win_step, ploidy_config, ref, tgt, src, start, end, num_src, out=(None, None)):
         self.win_len, self.win_step, self.num_src = win_len, win_step, num_src
         self.chr_name, self.ploidy_config = chr_name, ploidy_config
@@ -138,6 +154,34 @@ class WindowGenerator(DataGenerator):
             raise NotImplementedError("positions must be strictly increasing (duplicate or unsorted POS)")
         return pos
 
+    def device_blocks(self, eng) -> dict:
+        """{(group, population): TiledPop} of every loaded population: host matrices are uploaded
+        and re-tiled once per generator; blocks that already live in HBM (``from_resident``) are
+        handed through."""
+        from ..engine import TiledPop
+
+        cache = self.__dict__.setdefault("_device_blocks", {})
+        groups = [("ref", self.ref_data), ("tgt", self.tgt_data), ("src", self.src_data)]
+        if self.out_data:
+            groups.append(("outgroup", self.out_data))
+        for group, data in groups:
+            for pop, cd in data.items():
+                if (group, pop) not in cache:
+                    cache[(group, pop)] = cd.GT if isinstance(cd.GT, TiledPop) else eng.tile(cd.GT)
+        return cache
+
+    def device_positions(self, eng, pos: np.ndarray):
+        """int32 device tensor of a position array (resident blocks bring their own)."""
+        import torch
+
+        dev = self.__dict__.get("_device_pos")
+        if dev is not None and dev[0] is pos:
+            return dev[1]
+        return torch.as_tensor(np.ascontiguousarray(pos, dtype=np.int32)).to(eng.device)
+
+    def __getstate__(self):  # device handles never travel with a pickled generator
+        return {k: v for k, v in self.__dict__.items() if k not in ("_device_blocks", "_device_pos")}
+
     @staticmethod
     def window_range(pos: np.ndarray, start: int, end: int) -> tuple[int, int]:
         """[lo, hi) site indices of the inclusive window (window_generator.py:173-183)."""
@@ -153,6 +197,8 @@ class WindowGenerator(DataGenerator):
         }  # fmt: skip
 
     def _window_generator(self) -> Iterator[dict[str, Any]]:
+        if "_device_pos" in self.__dict__:
+            raise TypeError("a generator over HBM-resident blocks has no per-window host matrices; use run_windows")
         for ref_pop, tgt_pop, src_comb, out_pop in self.combinations():
             pos = self.common_positions(ref_pop, tgt_pop, src_comb, out_pop)
             for start, end in self.tgt_windows[tgt_pop]:

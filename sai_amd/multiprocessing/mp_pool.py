@@ -22,16 +22,24 @@ def mp_pool(data_processor: DataPreprocessor, data_generator: DataGenerator, npr
     """Same contract as the reference: one task per ``data_generator.get()`` entry, results in
     task order, ``data_processor.process_items(results)`` once at the end (on rank 0 of a
     multi-rank job).  ``nprocess`` is accepted for signature compatibility; the degree of
-    parallelism is the number of ranks (= GPUs) the job was launched with."""
+    parallelism is the number of ranks (= GPUs) the job was launched with.  Results travel to rank
+    0 as one byte row per rank when the processor has the numeric protocol (ChunkPreprocessor:
+    window records + CSR candidate lists through one RCCL gather), pickled otherwise."""
     import torch.distributed as dist
+
+    from ..distributed import _exchange_task_results
 
     tasks = [(data_processor, params) for params in data_generator.get()]
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         data_processor.process_items([mp_worker(t) for t in tasks])
         return
     rank, world = dist.get_rank(), dist.get_world_size()
-    mine = [mp_worker(tasks[i]) for i in my_chunk_indices(len(tasks), rank, world)]
-    gathered = [None] * world if rank == 0 else None
-    dist.gather_object(mine, gathered, dst=0)
+    compact = hasattr(data_processor, "run_compact") and hasattr(data_processor, "pack_result")
+    mine = []
+    for i in my_chunk_indices(len(tasks), rank, world):
+        mine.append(data_processor.run_compact(**tasks[i][1]) if compact else mp_worker(tasks[i]))
+    results = _exchange_task_results(data_processor, mine)
     if rank == 0:
-        data_processor.process_items([res for per_rank in gathered for res in per_rank])
+        if compact:  # per-task item lists, as ``run`` returns them
+            results = [data_processor.items_from_result(b) for b in results]
+        data_processor.process_items(results)

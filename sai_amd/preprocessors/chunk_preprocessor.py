@@ -46,6 +46,11 @@ class ChunkPreprocessor(DataPreprocessor):
 
     def run(self, chr_name: str, start: int, end: int) -> list[dict[str, Any]]:
         """Items of all windows of [start, end] (chunk_preprocessor.py:105-147)."""
+        return self.feature_preprocessor.items_from_batch(self.run_compact(chr_name, start, end))
+
+    def run_compact(self, chr_name: str, start: int, end: int):
+        """The same work unit in numeric form (a ``WindowBatch``): what a rank of a sharded run
+        computes and sends to rank 0, where ``unpack_results`` turns the batches into items."""
         window_generator = WindowGenerator(
             vcf_file=self.vcf_file,
             chr_name=chr_name,
@@ -61,7 +66,26 @@ class ChunkPreprocessor(DataPreprocessor):
             anc_allele_file=self.anc_allele_file,
             num_src=self.num_src,
         )
-        return self.feature_preprocessor.run_windows(window_generator)
+        return self.feature_preprocessor.score_windows(window_generator)
+
+    # transport hooks of sai_amd.distributed.run_sharded / sai_amd.multiprocessing.mp_pool
+    @staticmethod
+    def pack_result(batch) -> bytes:
+        return batch.to_bytes()
+
+    @staticmethod
+    def unpack_result(raw):
+        from .window_batch import WindowBatch
+
+        return WindowBatch.from_bytes(raw)
+
+    def items_from_result(self, batch) -> list[dict[str, Any]]:
+        """Items of one task's batch -- what ``run`` returns for that task."""
+        return self.feature_preprocessor.items_from_batch(batch)
+
+    def items_from_results(self, batches) -> list[dict[str, Any]]:
+        """All items of the tasks' batches in single-chunk order (combination-major)."""
+        return self.feature_preprocessor.items_from_batches(batches)
 
     def process_items(self, items: list[dict[str, Any]]) -> None:
         self.feature_preprocessor.process_items(items)

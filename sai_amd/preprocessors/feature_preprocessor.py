@@ -3,9 +3,10 @@ sai/preprocessors/feature_preprocessor.py:28-258).
 
 ``run`` keeps the reference's one-window plugin call (statistic classes looked up in
 STAT_REGISTRY).  ``run_windows`` is the batched MI355X path the chunk driver uses: every
-population block of the region is uploaded and reduced once (site_counts), and all windows of
-all population combinations are answered by a handful of launches; the item dictionaries it
-returns are the ones ``run`` would have produced window by window.
+population block of the region is uploaded once and all windows of a population combination are
+answered by ONE resident scoring pass (``score_windows`` -> ``WindowBatch``, the numeric form
+that also travels between GPUs); ``items_from_batch`` then builds the item dictionaries ``run``
+would have produced window by window.
 """
 
 from __future__ import annotations
@@ -17,6 +18,7 @@ import numpy as np
 
 from ..registries.stat_registry import STAT_REGISTRY
 from .data_preprocessor import DataPreprocessor
+from .window_batch import ComboBatch, WindowBatch
 
 _HIP_STATS = ("U", "Q")
 _FOURPOP = ("fd", "df", "Danc", "Dplus")
@@ -125,58 +127,63 @@ class FeaturePreprocessor(DataPreprocessor):
 
     def run_windows(self, wg) -> list[dict[str, Any]]:
         """Items for every (population combination, window) of a WindowGenerator, in its order."""
+        return self.items_from_batch(self.score_windows(wg))
+
+    def score_windows(self, wg) -> WindowBatch:
+        """The GPU part of ``run_windows``: every population block of the region is uploaded once
+        and U / Q are answered by a ``ResidentScorer`` -- the fused site pass (genotypes streamed
+        once, per-site decision in the same launch, tgt_freq only at candidate sites) followed by
+        the windows stage -- i.e. by the very path bench.py times.  When several population
+        combinations share blocks, or the ABBA-BABA family needs the per-population counts anyway,
+        each block is reduced once (site_counts) and the combinations start from those counts."""
         names = self._active_stats()
-        items: list[dict[str, Any]] = []
+        uq_names = [n for n in names if n in _HIP_STATS]
+        four_names = [n for n in names if n in _FOURPOP]
+        want_dd = "DD" in names
+        combos = list(wg.combinations())
+        batch = WindowBatch(wg.chr_name, [])
         if not wg.has_data():
-            for w in wg.get():
-                item = self._new_item(w["chr_name"], w["start"], w["end"], w["ref_pop"], w["tgt_pop"],
-                                      w["src_pop_list"], w["out_pop"], 0)  # fmt: skip
-                self._fill_missing(item, names)
-                items.append(item)
-            return items
+            for ref_pop, tgt_pop, src_comb, out_pop in combos:
+                win = np.asarray(wg.tgt_windows[tgt_pop], dtype=np.int64).reshape(-1, 2)
+                batch.combos.append(ComboBatch(ref_pop, tgt_pop, tuple(src_comb), out_pop, win, np.zeros(len(win), np.int32)))
+            return batch
 
         import torch
 
         from .. import _ffi
         from ..engine import Engine
+        from ..resident import ResidentBlock, ResidentScorer
         from ..stats.stat_utils import _check_ploidy, validate_thresholds
 
         eng = Engine.get()
         pc = wg.ploidy_config
-        # upload + reduce every population block once
-        blocks = {}
-        groups = [("ref", wg.ref_data), ("tgt", wg.tgt_data), ("src", wg.src_data)]
-        if wg.out_data:
-            groups.append(("outgroup", wg.out_data))
-        for group, data in groups:
-            for pop, cd in data.items():
-                blocks[(group, pop)] = eng.tile(cd.GT)
-        keys = list(blocks)
+        tiled = wg.device_blocks(eng)  # {(group, population): TiledPop}, uploaded (or already resident) once
+        shared = len(combos) > 1 or bool(four_names) or len(uq_names) > _ffi.SAI_FUSED_SETS
         counts_rows = {}
-        max_pops = 2 + _ffi.SAI_MAX_SRC
-        for i in range(0, len(keys), max_pops):
-            part = keys[i : i + max_pops]
-            counts = eng.site_counts([blocks[k] for k in part])
-            for j, k in enumerate(part):
-                counts_rows[k] = counts[j]
-        tiled = blocks if "DD" in names else None  # DD streams the genotype blocks again
-        del blocks
+
+        def counts_of(keys):
+            """int32 [len(keys)][n_sites][2]; every block is reduced at most once."""
+            todo = [k for k in dict.fromkeys(keys) if k not in counts_rows]
+            max_pops = 2 + _ffi.SAI_MAX_SRC
+            for i in range(0, len(todo), max_pops):
+                part = todo[i : i + max_pops]
+                c = eng.site_counts([tiled[k] for k in part])
+                for j, k in enumerate(part):
+                    counts_rows[k] = c[j]
+            return torch.stack([counts_rows[k] for k in keys])
 
         pos_dev_cache = {}
-        for ref_pop, tgt_pop, src_comb, out_pop in wg.combinations():
+        for ref_pop, tgt_pop, src_comb, out_pop in combos:
             pos = wg.common_positions(ref_pop, tgt_pop, src_comb, out_pop)
             windows = wg.tgt_windows[tgt_pop]
+            win = np.asarray(windows, dtype=np.int64).reshape(-1, 2)
             src_ploidies = pc.get_ploidy("src")
             ploidy = [pc.get_ploidy("ref", ref_pop), pc.get_ploidy("tgt", tgt_pop)] + list(src_ploidies)
             n_eff = min(len(src_comb), len(src_ploidies))
-            uq_names = [n for n in names if n in _HIP_STATS]
-            four_names = [n for n in names if n in _FOURPOP]
-            want_dd = "DD" in names
-            sets, kwargs = [], {}
+            sets = []
             for name in uq_names:
                 kw = self._stat_kwargs(name, ref_pop, tgt_pop)
                 validate_thresholds(kw["w"], kw["y_list"], len(src_comb))
-                kwargs[name] = kw
                 sets.append(
                     _ffi.make_params(kw["w"], kw.get("x", 0.0), kw.get("quantile", 0.5), kw["y_list"],
                                      kw["anc_allele_available"], n_src=n_eff)  # fmt: skip
@@ -184,70 +191,106 @@ class FeaturePreprocessor(DataPreprocessor):
             for p in ploidy[: 2 + len(src_comb)]:
                 _check_ploidy(p)
             n_sites = int(pos.size)
-            res = four = dd = nsnps_all = None
-            if names and windows and n_sites:
-                pid = id(pos)
-                if pid not in pos_dev_cache:
-                    pos_dev_cache[pid] = torch.as_tensor(np.ascontiguousarray(pos, dtype=np.int32)).to(eng.device)
-                pos_dev = pos_dev_cache[pid]
-                lo, hi = eng.window_bounds(pos_dev, [w[0] for w in windows], [w[1] for w in windows])
-                nsnps_all = (hi - lo).cpu().numpy()
-                if uq_names:
-                    counts = torch.stack(
-                        [counts_rows[("ref", ref_pop)], counts_rows[("tgt", tgt_pop)]]
-                        + [counts_rows[("src", s)] for s in src_comb[:n_eff]]
-                    )
-                    tgt_freq, flags, _ = eng.site_flags(counts, ploidy[: 2 + n_eff], sets)
-                    res = eng.window_stats(tgt_freq, flags, sets, lo, hi, pos=pos_dev)
-                if four_names:  # every source of the combination, with its own ploidy (fd_statistic.py:63-74)
-                    if len(src_ploidies) < len(src_comb):
-                        raise IndexError("list index out of range")
-                    rows = [counts_rows[("ref", ref_pop)], counts_rows[("tgt", tgt_pop)]] + [
-                        counts_rows[("src", s)] for s in src_comb
-                    ]
-                    pl4 = [ploidy[0], ploidy[1]] + list(src_ploidies[: len(src_comb)])
-                    if out_pop is not None:
-                        rows.append(counts_rows[("outgroup", out_pop)])
-                        pl4.append(pc.get_ploidy("outgroup", out_pop))
-                    for p in pl4:
-                        _check_ploidy(p)
-                    freqs = eng.site_freqs(torch.stack(rows), pl4)
-                    four = eng.window_fourpop(freqs, len(src_comb), out_pop is not None, lo, hi).cpu().numpy()
-                if want_dd:  # per source population: two streaming passes per pair of its individuals
-                    dd = np.stack(
-                        [
-                            eng.window_dd(
-                                eng.site_absdiff(tiled[("ref", ref_pop)], tiled[("src", s)]), tiled[("ref", ref_pop)].n_ind,
-                                eng.site_absdiff(tiled[("tgt", tgt_pop)], tiled[("src", s)]), tiled[("tgt", tgt_pop)].n_ind,
-                                lo, hi,
-                            ).cpu().numpy()
-                            for s in src_comb
-                        ],
-                        axis=1,
-                    )  # fmt: skip
-            for wi, (start, end) in enumerate(windows):
-                nsnps = int(nsnps_all[wi]) if nsnps_all is not None else 0
-                item = self._new_item(wg.chr_name, start, end, ref_pop, tgt_pop, src_comb, out_pop, nsnps)
+            cb = ComboBatch(ref_pop, tgt_pop, tuple(src_comb), out_pop, win, np.zeros(len(win), np.int32), list(uq_names),
+                            pos_dtype=np.dtype(pos.dtype).name)  # fmt: skip
+            batch.combos.append(cb)
+            if not (names and len(win) and n_sites):
+                continue
+            pid = id(pos)
+            if pid not in pos_dev_cache:
+                pos_dev_cache[pid] = wg.device_positions(eng, pos)
+            pos_dev = pos_dev_cache[pid]
+            uq_keys = [("ref", ref_pop), ("tgt", tgt_pop)] + [("src", s) for s in src_comb[:n_eff]]
+            lo = hi = None
+            if uq_names:
+                block = ResidentBlock([tiled[k] for k in uq_keys], ploidy[: 2 + n_eff], pos_dev)
+                scorer = ResidentScorer(eng, block, windows, sets, cap_u=1 << 16, cap_q=1 << 16,
+                                        counts_in=counts_of(uq_keys) if shared else None)  # fmt: skip
+                scorer.step()
+                cb.uq = scorer.results(grow=True)
+                lo, hi = scorer.lo, scorer.hi
+                cb.nsnps = cb.uq.records[0]["n_sites"].astype(np.int32)
+            else:
+                lo, hi = eng.window_bounds(pos_dev, win[:, 0], win[:, 1])
+                cb.nsnps = (hi - lo).cpu().numpy().astype(np.int32)
+            if four_names:  # every source of the combination, with its own ploidy (fd_statistic.py:63-74)
+                if len(src_ploidies) < len(src_comb):
+                    raise IndexError("list index out of range")
+                keys = [("ref", ref_pop), ("tgt", tgt_pop)] + [("src", s) for s in src_comb]
+                pl4 = [ploidy[0], ploidy[1]] + list(src_ploidies[: len(src_comb)])
+                if out_pop is not None:
+                    keys.append(("outgroup", out_pop))
+                    pl4.append(pc.get_ploidy("outgroup", out_pop))
+                for p in pl4:
+                    _check_ploidy(p)
+                freqs = eng.site_freqs(counts_of(keys), pl4)
+                cb.four = eng.window_fourpop(freqs, len(src_comb), out_pop is not None, lo, hi).cpu().numpy()
+            if want_dd:  # per source population: two streaming passes per pair of its individuals
+                ref_t, tgt_t = tiled[("ref", ref_pop)], tiled[("tgt", tgt_pop)]
+                cb.dd = np.stack(
+                    [
+                        eng.window_dd(eng.site_absdiff(ref_t, tiled[("src", s)]), ref_t.n_ind,
+                                      eng.site_absdiff(tgt_t, tiled[("src", s)]), tgt_t.n_ind, lo, hi).cpu().numpy()
+                        for s in src_comb
+                    ],
+                    axis=1,
+                )  # fmt: skip
+        return batch
+
+    def items_from_batch(self, batch: WindowBatch, combos=None) -> list[dict[str, Any]]:
+        """The reference's item dictionaries (feature_preprocessor.py:113-191) of a batch, in
+        (combination, window) order; ``combos`` restricts it to some ComboBatch objects."""
+        names = self._active_stats()
+        four_names = [n for n in names if n in _FOURPOP]
+        items: list[dict[str, Any]] = []
+        for cb in batch.combos if combos is None else combos:
+            pos_dtype = np.dtype(cb.pos_dtype)
+            src_comb = tuple(cb.src_comb)
+            starts, ends, nsnps_all = cb.windows[:, 0].tolist(), cb.windows[:, 1].tolist(), cb.nsnps.tolist()
+            res = cb.uq
+            if res is not None:
+                u_count, n_cond = res.records["u_count"].tolist(), res.records["n_cond"].tolist()
+                n_cdd_q, q_vals, off = res.records["n_cdd_q"].tolist(), res.records["q"], res.offsets.tolist()
+                cdd_u, cdd_q = res.cdd_u.astype(pos_dtype, copy=False), res.cdd_q.astype(pos_dtype, copy=False)
+            for wi, (start, end, nsnps) in enumerate(zip(starts, ends, nsnps_all)):
+                item = self._new_item(batch.chr_name, start, end, cb.ref_pop, cb.tgt_pop, src_comb, cb.out_pop, nsnps)
                 if nsnps == 0:  # window without sites: the reference's None-matrix branch
                     self._fill_missing(item, names)
                     items.append(item)
                     continue
                 for name in four_names:  # one value per source, Python floats like the reference
-                    item[name] = [float(v) for v in four[wi, :, _FOURPOP.index(name)]]
-                if want_dd:  # np.float64 values, as np.mean returns them (dd_statistic.py:74)
-                    item["DD"] = [np.float64(v) for v in dd[wi]]
-                for si, name in enumerate(uq_names):
-                    rec = res.records[si, wi]
+                    item[name] = [float(v) for v in cb.four[wi, :, _FOURPOP.index(name)]]
+                if cb.dd is not None:  # np.float64 values, as np.mean returns them (dd_statistic.py:74)
+                    item["DD"] = [np.float64(v) for v in cb.dd[wi]]
+                for si, name in enumerate(cb.uq_names):
                     if name == "U":
-                        item["cdd_pos"][name] = res.u_list(si, wi).astype(pos.dtype, copy=True)
-                        item[name] = int(rec["u_count"])
-                    elif int(rec["n_cond"]) == 0:
+                        o = off[si][wi][0]
+                        item["cdd_pos"][name] = cdd_u[o : o + u_count[si][wi]].copy()
+                        item[name] = u_count[si][wi]
+                    elif n_cond[si][wi] == 0:
                         item["cdd_pos"][name] = np.array([])
                         item[name] = np.nan
                     else:
-                        item["cdd_pos"][name] = res.q_list(si, wi).astype(pos.dtype, copy=True)
-                        item[name] = np.float64(rec["q"])
+                        o = off[si][wi][1]
+                        item["cdd_pos"][name] = cdd_q[o : o + n_cdd_q[si][wi]].copy()
+                        item[name] = q_vals[si, wi]
                 items.append(item)
+        return items
+
+    def items_from_batches(self, batches) -> list[dict[str, Any]]:
+        """Items of several chunks of ONE chromosome region list, in the order a single-chunk run
+        emits them: combination-major, and inside a combination the chunks' windows in chunk order
+        (sai.py:146-151 with ``num_chunks=1``) -- so a sharded run writes the same bytes."""
+        batches = list(batches)
+        if not batches:
+            return []
+        n_combos = len(batches[0].combos)
+        if any(len(b.combos) != n_combos for b in batches):
+            raise ValueError("chunks disagree about the population combinations")
+        items: list[dict[str, Any]] = []
+        for k in range(n_combos):
+            for b in batches:
+                items.extend(self.items_from_batch(b, [b.combos[k]]))
         return items
 
     # -- output ----------------------------------------------------------------------------

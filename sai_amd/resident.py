@@ -1,12 +1,17 @@
-"""A chromosome block resident in HBM and its repeated scoring (the path bench.py times and the
-multi-GPU driver shards): all buffers are allocated once, one ``step()`` enqueues the whole hot
-path -- site_counts (+ fused per-site decision) -> window_bounds -> window_stats -> async copy of
-the records to pinned host memory -- on the current HIP stream without any host synchronisation.
+"""A chromosome block resident in HBM and its repeated scoring (the path ``score``, bench.py and the
+multi-GPU driver all run): buffers are allocated once, one ``step()`` enqueues the whole hot path --
+site_counts (+ fused per-site decision) -> window_bounds -> window_stats -> async copy of the records
+to pinned host memory -- on the current HIP stream without any host synchronisation.
+
+A block may hold several chromosome *pieces* back to back (a rank's share of a whole-genome window
+list, sai_amd.sharding): positions then ascend only inside a piece, every window names the piece
+("segment") it is searched in, and one site pass + one windows stage still cover the whole block.
 """
 
 from __future__ import annotations
 
-from dataclasses import dataclass
+import time
+from dataclasses import dataclass, field
 from typing import Optional, Sequence
 
 import numpy as np
@@ -15,29 +20,42 @@ from . import _ffi
 from .engine import RECORD_DTYPE, Engine, TiledPop, WindowResults
 from .utils.windows import split_genome
 
+WAIT_DEADLINE_S = 30.0  # a step is milliseconds; an event that has not fired by then never will
+
 
 @dataclass
 class ResidentBlock:
-    """ref, tgt and source populations of one contiguous site range, plus positions."""
+    """ref, tgt and source populations of one contiguous site range (or of several pieces laid
+    end to end at tile boundaries), plus positions."""
 
     pops: list  # [ref, tgt, src...] TiledPop
     ploidies: list  # same order
     pos: "object"  # int32 device tensor [n_sites]
+    # block-relative [lo, hi) site range of every piece; None = the block is one ascending run
+    segments: Optional[list] = None
+    extra: dict = field(default_factory=dict)  # e.g. the outgroup block of the ABBA-BABA family
 
     @property
     def n_sites(self) -> int:
         return self.pops[0].n_sites
 
     @property
+    def n_real_sites(self) -> int:
+        """Sites that carry data (pieces are padded to whole tiles in between)."""
+        if self.segments is None:
+            return self.n_sites
+        return sum(hi - lo for lo, hi in self.segments)
+
+    @property
     def genotype_bytes(self) -> int:
         """Algorithmic bytes of one site_counts launch: every genotype byte once."""
-        return self.n_sites * sum(p.n_ind for p in self.pops)
+        return self.n_real_sites * sum(p.n_ind for p in self.pops)
 
     @property
     def packed2_bytes(self) -> int:
         """Algorithmic bytes of one packed2 launch: two bits per genotype, each site's row rounded
         up to whole bytes (the layout's padding of every site to 64-individual groups is not counted)."""
-        return self.n_sites * sum((p.n_ind + 3) // 4 for p in self.pops)
+        return self.n_real_sites * sum((p.n_ind + 3) // 4 for p in self.pops)
 
 
 def synth_block(eng: Engine, seed: int, chrom: int, n_sites: int, n_ref: int, n_tgt: int, n_src_list: Sequence[int],
@@ -52,16 +70,43 @@ def synth_block(eng: Engine, seed: int, chrom: int, n_sites: int, n_ref: int, n_
     return ResidentBlock(pops, [ploidy] * len(sizes), pos)
 
 
+class _SetChunk:
+    """Window-stage buffers of up to SAI_MAX_SETS parameter sets (one sai_window_stats call)."""
+
+    def __init__(self, eng: Engine, s0: int, s1: int, n_windows: int, cap_u: int, cap_q: int):
+        import torch
+
+        self.s0, self.s1 = s0, s1
+        self.bufs = eng.alloc_window_bufs(s1 - s0, n_windows, cap_u, cap_q)
+        # pinned mirror of the records | offsets | totals buffer: one copy per step
+        self.host_head = torch.empty((self.bufs[5].numel(),), dtype=torch.uint8).pin_memory()
+        rec_bytes = (s1 - s0) * n_windows * RECORD_DTYPE.itemsize
+        self.rec_bytes = rec_bytes
+        self.host_records = self.host_head[:rec_bytes]
+        self.host_offsets = self.host_head[rec_bytes:-16].view(torch.int64)
+        self.host_totals = self.host_head[-16:].view(torch.int64)
+
+
 class ResidentScorer:
     def __init__(self, eng: Engine, block: ResidentBlock, windows: Sequence[tuple], sets: Sequence[_ffi.SaiParams],
-                 cap_u: int = 1 << 20, cap_q: int = 1 << 20, layout: str = "int8", overlap: bool = False):  # fmt: skip
-        """``layout="packed2"`` re-encodes the block once into the 2-bit layout (dosages 0..2 only)
+                 cap_u: int = 1 << 20, cap_q: int = 1 << 20, layout: str = "int8", overlap: bool = False,
+                 window_segment: Optional[Sequence[int]] = None, counts_out=None, counts_in=None):  # fmt: skip
+        """``windows`` = inclusive ``(start, end)`` position pairs; for a block of several pieces
+        ``window_segment[w]`` is the index into ``block.segments`` of the piece window w lies in.
+
+        ``layout="packed2"`` re-encodes the block once into the 2-bit layout (dosages 0..2 only)
         and streams that instead: 4x fewer genotype bytes per step, identical results.
 
         ``overlap=True`` software-pipelines consecutive steps: the windows stage of step k
         (bounds, statistics, candidate lists, copy to the host) runs on a second HIP stream while
         the site pass of step k+1 already streams genotypes on the caller's stream; the per-site
-        arrays are double-buffered and events order every reuse.  Same kernels, same results."""
+        arrays are double-buffered and events order every reuse.  Same kernels, same results.
+
+        ``counts_out`` (int32 device tensor [P][n_sites][2]) additionally receives the per-population
+        ``{alt_sum, n_called}`` of the pass (what the ABBA-BABA family divides).  ``counts_in`` (same
+        shape) says the counts of these populations already exist -- several population combinations
+        share blocks that were reduced once -- so a step starts at the per-site decision and no
+        genotype byte is read."""
         import torch
 
         if layout not in ("int8", "packed2"):
@@ -69,8 +114,8 @@ class ResidentScorer:
         self.layout = layout
         self.packed = [eng.pack2(p) for p in block.pops] if layout == "packed2" else None
 
-        if not 1 <= len(sets) <= _ffi.SAI_MAX_SETS:
-            raise ValueError(f"1..{_ffi.SAI_MAX_SETS} parameter sets per scorer")
+        if len(sets) < 1:
+            raise ValueError("at least one parameter set per scorer")
         self.eng, self.block, self.sets = eng, block, list(sets)
         self.windows = list(windows)
         n, n_w, n_s = block.n_sites, len(self.windows), len(self.sets)
@@ -78,9 +123,31 @@ class ResidentScorer:
         dev = eng.device
         self.win_start = torch.as_tensor(np.array([w[0] for w in self.windows], dtype=np.int64)).to(dev)
         self.win_end = torch.as_tensor(np.array([w[1] for w in self.windows], dtype=np.int64)).to(dev)
+        self.seg_lo = self.seg_hi = None
+        if block.segments is not None:
+            if window_segment is None:
+                if len(block.segments) != 1:
+                    raise ValueError("a block of several pieces needs window_segment")
+                window_segment = np.zeros(n_w, dtype=np.int64)
+            seg = np.asarray(block.segments, dtype=np.int64).reshape(-1, 2)
+            ws = np.asarray(window_segment, dtype=np.int64)
+            if ws.shape != (n_w,) or (n_w and (ws.min() < 0 or ws.max() >= len(seg))):
+                raise ValueError("window_segment does not match the block's segments")
+            if len(seg) and (seg[:, 0].min() < 0 or seg[:, 1].max() > n or np.any(seg[:, 1] < seg[:, 0])):
+                raise ValueError("segment outside the block")
+            self.seg_lo = torch.as_tensor(seg[ws, 0].astype(np.int32)).to(dev)
+            self.seg_hi = torch.as_tensor(seg[ws, 1].astype(np.int32)).to(dev)
+        elif window_segment is not None:
+            raise ValueError("window_segment given for a block without segments")
         # at most SAI_FUSED_SETS sets: one fused launch, the per-population counts never leave the chip
-        self.fused = n_s <= _ffi.SAI_FUSED_SETS
-        self.counts = None if self.fused else torch.empty((len(block.pops), n, 2), dtype=torch.int32, device=dev)
+        if counts_in is not None and (counts_out is not None or layout != "int8"):
+            raise ValueError("counts_in excludes counts_out and the packed2 layout")
+        self.have_counts = counts_in is not None
+        self.fused = n_s <= _ffi.SAI_FUSED_SETS and not self.have_counts
+        self.counts_out = counts_out
+        self.counts = counts_in if self.have_counts else counts_out
+        if self.counts is None and not self.fused:
+            self.counts = torch.empty((len(block.pops), n, 2), dtype=torch.int32, device=dev)
         self.overlap = bool(overlap)
         # two sets: the windows stage of step k runs under site pass k+1 and is over long before the
         # host may enqueue site pass k+2 into the same buffers
@@ -97,14 +164,19 @@ class ResidentScorer:
         self._k = 0
         self.lo = torch.empty((n_w,), dtype=torch.int32, device=dev)
         self.hi = torch.empty((n_w,), dtype=torch.int32, device=dev)
-        self.bufs = eng.alloc_window_bufs(n_s, n_w, cap_u, cap_q)
-        # pinned mirror of the records | offsets | totals buffer: one copy per step
-        self.host_head = torch.empty((self.bufs[5].numel(),), dtype=torch.uint8).pin_memory()
-        rec_bytes = n_s * n_w * RECORD_DTYPE.itemsize
-        self.host_records = self.host_head[:rec_bytes]
-        self.host_offsets = self.host_head[rec_bytes:-16].view(torch.int64)
-        self.host_totals = self.host_head[-16:].view(torch.int64)
+        self._alloc_chunks(cap_u, cap_q)
         self.count_events: list = []  # (start, end) torch events around site_counts, when requested
+
+    def _alloc_chunks(self, cap_u: int, cap_q: int) -> None:
+        m = _ffi.SAI_MAX_SETS
+        self.cap_u, self.cap_q = int(cap_u), int(cap_q)
+        self.chunks = [
+            _SetChunk(self.eng, s0, min(s0 + m, self.n_sets), self.n_windows, cap_u, cap_q)
+            for s0 in range(0, self.n_sets, m)
+        ]
+        first = self.chunks[0]  # the whole scorer when n_sets <= SAI_MAX_SETS
+        self.bufs, self.host_head = first.bufs, first.host_head
+        self.host_records, self.host_offsets, self.host_totals = first.host_records, first.host_offsets, first.host_totals
 
     @property
     def tgt_freq(self):
@@ -117,7 +189,7 @@ class ResidentScorer:
 
     def window_stream(self):
         """Context manager selecting the stream on which window records are produced (for follow-up
-        work such as the multi-GPU gather of ``bufs[0]``).  In the pipelined form call ``flush()``
+        work such as the multi-GPU gather of the records).  In the pipelined form call ``flush()``
         first, or use ``after_stage``: the newest step's stage is enqueued one step late."""
         import contextlib
 
@@ -125,10 +197,25 @@ class ResidentScorer:
 
         return torch.cuda.stream(self.side) if self.overlap else contextlib.nullcontext()
 
-    @staticmethod
-    def _wait(event) -> None:
-        while not event.query():  # polling: Event.synchronize() was seen to oversleep by ~7 ms
-            pass
+    def _wait(self, event, what: str) -> None:
+        """Poll an event (Event.synchronize() was seen to oversleep by ~7 ms -- the runtime's
+        interrupt-driven wait -- which is longer than two whole steps).  Spins for the first
+        millisecond, then yields the core between polls; raises instead of spinning forever when the
+        GPU has stopped making progress, and surfaces a failed kernel's status (query() raises)."""
+        t0 = time.perf_counter()
+        spins = 0
+        while not event.query():
+            spins += 1
+            if spins & 0xFF:
+                continue
+            dt = time.perf_counter() - t0
+            if dt > WAIT_DEADLINE_S:
+                raise RuntimeError(
+                    f"ResidentScorer: {what} of step {self._k} did not finish within {WAIT_DEADLINE_S:.0f} s "
+                    f"(buffer set {self._k % len(self._flags)}); the GPU is hung or a kernel faulted"
+                )
+            if dt > 1e-3:
+                time.sleep(0)
 
     def _launch_pending(self) -> None:
         """Pipelined form: enqueue the windows stage of the pending step on the second stream, as soon
@@ -142,7 +229,7 @@ class ResidentScorer:
             return
         b, index = self._pending
         self._pending = None
-        self._wait(self._site_done[b])
+        self._wait(self._site_done[b], "site pass")
         with torch.cuda.stream(self.side):
             self._window_stage(self._tgt_freq[b], self._flags[b])
             if self.after_stage is not None:
@@ -164,18 +251,20 @@ class ResidentScorer:
         tgt_freq, flags = self._tgt_freq[b], self._flags[b]
         main = torch.cuda.current_stream(eng.device)
         if self.overlap and self._win_used[b]:
-            self._wait(self._win_done[b])  # the windows stage that last read buffer set b (2 steps ago) is done
+            self._wait(self._win_done[b], "windows stage")  # the stage that last read buffer set b (2 steps ago)
         if time_counts:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
         if self.packed is not None:
             if self.fused:
-                eng.site_pass_packed2(self.packed, blk.ploidies, self.sets, out=(tgt_freq, flags), freq_mode="candidates")
+                eng.site_pass_packed2(self.packed, blk.ploidies, self.sets, out=(tgt_freq, flags), counts=self.counts_out,
+                                      freq_mode="candidates")  # fmt: skip
             else:
                 eng.site_pass_packed2(self.packed, blk.ploidies, [], counts=self.counts)
         elif self.fused:
-            eng.site_pass(blk.pops, blk.ploidies, self.sets, out=(tgt_freq, flags), freq_mode="candidates")
-        else:
+            eng.site_pass(blk.pops, blk.ploidies, self.sets, out=(tgt_freq, flags), counts=self.counts_out,
+                          freq_mode="candidates")  # fmt: skip
+        elif not self.have_counts:
             eng.site_counts(blk.pops, out=self.counts)
         if time_counts:
             e1.record()
@@ -196,32 +285,141 @@ class ResidentScorer:
 
     def _window_stage(self, tgt_freq, flags) -> None:
         eng, blk = self.eng, self.block
-        _ffi.check(
-            eng.lib.sai_window_bounds(
-                eng.ctx, eng._ptr(blk.pos), blk.n_sites, self.n_windows, eng._ptr(self.win_start), eng._ptr(self.win_end),
-                eng._ptr(self.lo), eng._ptr(self.hi), eng._stream(),
-            )
-        )  # fmt: skip
-        eng.window_stats_async(tgt_freq, flags, self.sets, self.lo, self.hi, blk.pos, self.bufs)
-        self.host_head.copy_(self.bufs[5], non_blocking=True)
+        if self.seg_lo is None:
+            _ffi.check(
+                eng.lib.sai_window_bounds(
+                    eng.ctx, eng._ptr(blk.pos), blk.n_sites, self.n_windows, eng._ptr(self.win_start),
+                    eng._ptr(self.win_end), eng._ptr(self.lo), eng._ptr(self.hi), eng._stream(),
+                )
+            )  # fmt: skip
+        else:
+            _ffi.check(
+                eng.lib.sai_window_bounds_seg(
+                    eng.ctx, eng._ptr(blk.pos), blk.n_sites, self.n_windows, eng._ptr(self.win_start),
+                    eng._ptr(self.win_end), eng._ptr(self.seg_lo), eng._ptr(self.seg_hi), eng._ptr(self.lo),
+                    eng._ptr(self.hi), eng._stream(),
+                )
+            )  # fmt: skip
+        for ch in self.chunks:
+            eng.window_stats_async(tgt_freq, flags[ch.s0 : ch.s1], self.sets[ch.s0 : ch.s1], self.lo, self.hi, blk.pos,
+                                   ch.bufs)  # fmt: skip
+            ch.host_head.copy_(ch.bufs[5], non_blocking=True)
 
-    def results(self) -> WindowResults:
-        """Synchronise and return the last step's records and candidate lists."""
+    # -- results ---------------------------------------------------------------------------
+
+    def _sync(self) -> None:
         import torch
 
         self.flush()
         torch.cuda.current_stream(self.eng.device).synchronize()
         if self.side is not None:
             self.side.synchronize()
-        need_u, need_q = (int(v) for v in self.host_totals.tolist())
-        if need_u > self.bufs[2].numel() or need_q > self.bufs[3].numel():
-            raise RuntimeError(
-                f"candidate buffers too small (need {need_u}/{need_q}); rebuild the scorer with larger cap_u/cap_q"
-            )
-        rec = np.frombuffer(self.host_records.numpy().tobytes(), dtype=RECORD_DTYPE).reshape(self.n_sets, self.n_windows)
-        off = self.host_offsets.numpy().reshape(self.n_sets, self.n_windows, 2).copy()
-        with self.window_stream():
-            cdd_u, cdd_q = self.bufs[2][:need_u].cpu().numpy(), self.bufs[3][:need_q].cpu().numpy()
+
+    def list_totals(self) -> list[tuple[int, int]]:
+        """(entries of all U lists, entries of all Q lists) per set chunk, of the last step."""
+        self._sync()
+        return [tuple(int(v) for v in ch.host_totals.tolist()) for ch in self.chunks]
+
+    def results(self, grow: bool = False) -> WindowResults:
+        """Synchronise and return the last step's records and candidate lists.  When the candidate
+        buffers were too small: raise, or with ``grow=True`` enlarge them and repeat the windows
+        stage on the per-site arrays of the last step (the genotypes are not streamed again)."""
+        totals = self.list_totals()
+        need_u, need_q = max(t[0] for t in totals), max(t[1] for t in totals)
+        if need_u > self.cap_u or need_q > self.cap_q:
+            if not grow:
+                raise RuntimeError(
+                    f"candidate buffers too small (need {need_u}/{need_q}); rebuild the scorer with larger cap_u/cap_q"
+                )
+            self._alloc_chunks(max(need_u, self.cap_u), max(need_q, self.cap_q))
+            with self.window_stream():
+                self._window_stage(self.tgt_freq, self.flags)
+            totals = self.list_totals()
+        recs, offs, us, qs = [], [], [], []
+        base_u = base_q = 0
+        for ch, (nu, nq) in zip(self.chunks, totals):
+            n_s = ch.s1 - ch.s0
+            recs.append(np.frombuffer(ch.host_records.numpy().tobytes(), dtype=RECORD_DTYPE).reshape(n_s, self.n_windows))
+            off = ch.host_offsets.numpy().reshape(n_s, self.n_windows, 2).copy()
+            off[:, :, 0] += base_u
+            off[:, :, 1] += base_q
+            offs.append(off)
+            with self.window_stream():
+                us.append(ch.bufs[2][:nu].cpu().numpy())
+                qs.append(ch.bufs[3][:nq].cpu().numpy())
+            base_u += nu
+            base_q += nq
+        return WindowResults(np.concatenate(recs), np.concatenate(offs), np.concatenate(us), np.concatenate(qs))
+
+    # -- the row a rank contributes to the multi-GPU gather -------------------------------------
+
+    def row_layout(self) -> "RowLayout":
+        """Byte layout of this scorer's gather row, from the list sizes of the last step (they are
+        fixed for a resident block): records of every set chunk, then all U lists, then all Q lists."""
+        totals = self.list_totals()
+        for nu, nq in totals:
+            if nu > self.cap_u or nq > self.cap_q:
+                raise RuntimeError(f"candidate buffers too small (need {nu}/{nq})")
+        return RowLayout(self.n_sets, self.n_windows, [ch.s1 - ch.s0 for ch in self.chunks], [t[0] for t in totals],
+                         [t[1] for t in totals])  # fmt: skip
+
+    def pack_row(self, row, layout: "RowLayout") -> None:
+        """Copy records and both candidate lists into the uint8 device tensor ``row`` (enqueued on
+        the current stream -- call it on the stream the windows stage ran on)."""
+        import torch
+
+        o = 0
+        for ch in self.chunks:
+            row[o : o + ch.rec_bytes].copy_(ch.bufs[0], non_blocking=True)
+            o += ch.rec_bytes
+        for k, which in ((2, layout.n_u), (3, layout.n_q)):
+            for ch, n in zip(self.chunks, which):
+                row[o : o + 4 * n].copy_(ch.bufs[k][:n].view(torch.uint8), non_blocking=True)
+                o += 4 * n
+        assert o == layout.nbytes
+
+
+@dataclass
+class RowLayout:
+    """What one rank sends to rank 0 per pass: ``n_sets * n_windows`` 24-byte records ([set][window],
+    in chunks of at most SAI_MAX_SETS sets), then the int32 entries of all U candidate lists and of
+    all Q candidate lists in (set, window) order -- fixed records + CSR lists; the list
+    offsets are the prefix sums of the records' u_count / n_cdd_q, so they do not travel."""
+
+    n_sets: int
+    n_windows: int
+    chunk_sets: list
+    n_u: list
+    n_q: list
+
+    @property
+    def nbytes(self) -> int:
+        return self.n_sets * self.n_windows * RECORD_DTYPE.itemsize + 4 * (sum(self.n_u) + sum(self.n_q))
+
+    def header(self) -> list[int]:
+        return [self.n_sets, self.n_windows, len(self.chunk_sets), *self.chunk_sets, *self.n_u, *self.n_q]
+
+    @classmethod
+    def from_header(cls, h: Sequence[int]) -> "RowLayout":
+        n_sets, n_windows, n_chunks = int(h[0]), int(h[1]), int(h[2])
+        vals = [int(v) for v in h[3 : 3 + 3 * n_chunks]]
+        return cls(n_sets, n_windows, vals[:n_chunks], vals[n_chunks : 2 * n_chunks], vals[2 * n_chunks :])
+
+    def unpack(self, row: np.ndarray) -> WindowResults:
+        """Rebuild the WindowResults of the sending rank from its row bytes (host side, rank 0)."""
+        row = np.ascontiguousarray(row, dtype=np.uint8)
+        if row.size != self.nbytes:
+            raise ValueError(f"row of {row.size} bytes, layout says {self.nbytes}")
+        rec_bytes = self.n_sets * self.n_windows * RECORD_DTYPE.itemsize
+        rec = np.frombuffer(row[:rec_bytes].tobytes(), dtype=RECORD_DTYPE).reshape(self.n_sets, self.n_windows)
+        tail = np.frombuffer(row[rec_bytes:].tobytes(), dtype=np.int32)
+        cdd_u, cdd_q = tail[: sum(self.n_u)], tail[sum(self.n_u) :]
+        off = np.zeros((self.n_sets, self.n_windows, 2), dtype=np.int64)
+        for k, name in enumerate(("u_count", "n_cdd_q")):
+            flat = rec[name].reshape(-1).astype(np.int64)
+            off[:, :, k] = (np.cumsum(flat) - flat).reshape(self.n_sets, self.n_windows)
+        if int(rec["u_count"].sum()) != cdd_u.size or int(rec["n_cdd_q"].sum()) != cdd_q.size:
+            raise ValueError("row lists do not match the records' counts")
         return WindowResults(rec, off, cdd_u, cdd_q)
 
 

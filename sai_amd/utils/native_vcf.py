@@ -22,7 +22,7 @@ def default_threads() -> int:
 
 def scan_first_last(vcf_file: str, chr_name: str) -> tuple[Optional[int], Optional[int]]:
     """First and last POS of the first contiguous run of ``chr_name`` (None, None if absent)."""
-    lib = _ffi.load()
+    lib = _ffi.load_host()
     first, last = C.c_int64(-1), C.c_int64(-1)
     _check_io(lib.sai_vcf_scan(os.fsencode(vcf_file), str(chr_name).encode(), C.byref(first), C.byref(last)))
     if first.value < 0:
@@ -33,7 +33,7 @@ def scan_first_last(vcf_file: str, chr_name: str) -> tuple[Optional[int], Option
 def _check_io(status: int) -> None:
     """I/O and format problems of the ingest surface as ValueError, like the reference's readers."""
     if status != 0:
-        raise ValueError(_ffi.load().sai_last_error().decode("utf-8", "replace"))
+        raise ValueError(_ffi.load_host().sai_last_error().decode("utf-8", "replace"))
 
 
 def load_dosage(vcf_file: str, chr_name: str, samples: Sequence[str], ploidies: Sequence[int],
@@ -41,7 +41,7 @@ def load_dosage(vcf_file: str, chr_name: str, samples: Sequence[str], ploidies: 
                 n_threads: Optional[int] = None) -> tuple[np.ndarray, np.ndarray, int, int]:  # fmt: skip
     """(pos int32 [n], dosage int8 [n][len(samples)], n_matched, n_anc_entries) for one region;
     with ``anc_allele_file`` the rows are already polarised (kept / flipped)."""
-    lib = _ffi.load()
+    lib = _ffi.load_host()
     n = len(samples)
     names = (C.c_char_p * n)(*[s.encode() for s in samples])
     pl = (C.c_int32 * n)(*[int(p) for p in ploidies])

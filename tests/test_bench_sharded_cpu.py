@@ -1,0 +1,258 @@
+"""The N > 1 branch of bench.py end to end on CPU: ``gloo`` process groups of 2, 3 and 4 ranks run
+bench.run_passes -- shard plan (chunk_generator.py:111-142 applied to the whole job's window list),
+per-rank site ranges with the win-step halo, row packing, the per-pass gather (both forms),
+decoding and merging on rank 0 -- on tiny synthetic jobs, and what rank 0 ends up with is compared
+byte for byte with the one-rank run of the same job.
+
+There is no CPU compute path in the product, so the kernels' place is taken here by a test double
+with ResidentScorer's interface that answers every window with the oracle from the SAME synthetic
+bytes (the library's host generator).  The GPU counterpart (same job, real kernels, two ranks on the
+box's one GPU) is tests/test_hip_sharded.py."""
+
+import ctypes as C
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+
+def _free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def tiny_workload(name="c4"):
+    import bench
+
+    wl = bench.make_workload(name, sites=2600, chroms=5 if name == "c4" else 0)
+    wl.n_ref, wl.n_tgt = 12, 10
+    wl.win_len, wl.win_step = 3000, 1500  # ~120 sites per window, ~43 windows per chromosome
+    wl.missing_per_million = 20000
+    for s in wl.specs:  # thresholds that make the tiny populations produce candidates
+        s.update(w=0.3, x=0.3, quantile=0.9)
+    return wl
+
+
+class OracleScorer:
+    """ResidentScorer's interface (what bench.run_passes uses), computed by the oracle on host
+    copies of exactly the sites the shard layout says this rank holds."""
+
+    overlap = False
+
+    def __init__(self, wl, lay, all_pos):
+        from sai_amd import _ffi
+
+        lib = _ffi.load_host()
+        self.wl, self.lay = wl, lay
+        self.n_windows, self.n_sets = len(lay.windows), len(wl.specs)
+        self.pieces = []
+        for pc, a, n in zip(lay.pieces, lay.site0, lay.n_sites):
+            chrom = int(wl.chroms[pc.chrom_index])
+            mats = []
+            for stream, n_ind in enumerate(wl.pop_sizes):
+                m = np.empty((n, n_ind), dtype=np.int8)
+                _ffi.check(lib.sai_synth_fill_host(wl.seed, chrom, a, n, stream, n_ind, wl.ploidy, wl.missing_per_million,
+                                                   m.ctypes.data_as(C.c_void_p)), lib)  # fmt: skip
+                mats.append(m.astype(np.int64))
+            self.pieces.append((all_pos[pc.chrom_index][a : a + n], mats))
+        self.after_stage = None
+        self.count_events = []
+        self._res = None
+        self._k = 0
+
+    def window_stream(self):
+        import contextlib
+
+        return contextlib.nullcontext()
+
+    def flush(self):
+        pass
+
+    def step(self, time_counts=False):
+        from oracle import sai_oracle as O
+        from sai_amd.engine import RECORD_DTYPE, WindowResults
+
+        rec = np.zeros((self.n_sets, self.n_windows), dtype=RECORD_DTYPE)
+        lists_u = [[None] * self.n_windows for _ in range(self.n_sets)]
+        lists_q = [[None] * self.n_windows for _ in range(self.n_sets)]
+        for wi, ((_, start, end), k) in enumerate(zip(self.lay.windows, self.lay.window_segment)):
+            pos, mats = self.pieces[k]
+            lo, hi = np.searchsorted(pos, start, "left"), np.searchsorted(pos, end, "right")
+            sub = [m[lo:hi] for m in mats]
+            for si, s in enumerate(self.wl.specs):
+                kw = dict(ref_gts=sub[0], tgt_gts=sub[1], src_gts_list=sub[2:], ref_ploidy=self.wl.ploidy,
+                          tgt_ploidy=self.wl.ploidy, src_ploidy_list=[self.wl.ploidy] * (len(sub) - 2), pos=pos[lo:hi],
+                          w=s["w"], y_list=s["y_list"], anc_allele_available=s["anc"])  # fmt: skip
+                u = O.u_stat(x=s["x"], **kw)
+                q = O.q_stat(quantile=s["quantile"], **kw)
+                _, _, cond = O.matching_loci(sub[0], sub[1], sub[2:], s["w"], s["y_list"], [self.wl.ploidy] * len(sub), s["anc"])
+                rec[si, wi] = (hi - lo, u["value"], int(cond.sum()), len(q["cdd_pos"]), q["value"])
+                lists_u[si][wi] = np.asarray(u["cdd_pos"], dtype=np.int32)
+                lists_q[si][wi] = np.asarray(q["cdd_pos"], dtype=np.int32)
+        cat = lambda ll: np.concatenate([a for row in ll for a in row]) if self.n_windows else np.zeros(0, np.int32)  # noqa: E731
+        off = np.zeros((self.n_sets, self.n_windows, 2), dtype=np.int64)
+        for k, name in enumerate(("u_count", "n_cdd_q")):
+            flat = rec[name].reshape(-1).astype(np.int64)
+            off[:, :, k] = (np.cumsum(flat) - flat).reshape(self.n_sets, self.n_windows)
+        self._res = WindowResults(rec, off, cat(lists_u), cat(lists_q))
+        index, self._k = self._k, self._k + 1
+        if self.after_stage is not None:
+            self.after_stage(index)
+
+    def results(self):
+        return self._res
+
+    def row_layout(self):
+        from sai_amd import _ffi
+        from sai_amd.resident import RowLayout
+
+        m = _ffi.SAI_MAX_SETS
+        chunks = [min(m, self.n_sets - s0) for s0 in range(0, self.n_sets, m)]
+        nu, nq, s0 = [], [], 0
+        for c in chunks:
+            nu.append(int(self._res.records["u_count"][s0 : s0 + c].sum()))
+            nq.append(int(self._res.records["n_cdd_q"][s0 : s0 + c].sum()))
+            s0 += c
+        return RowLayout(self.n_sets, self.n_windows, chunks, nu, nq)
+
+    def pack_row(self, row, layout):
+        import torch
+
+        raw = self._res.records.tobytes() + self._res.cdd_u.tobytes() + self._res.cdd_q.tobytes()
+        assert len(raw) == layout.nbytes
+        row[: len(raw)].copy_(torch.frombuffer(bytearray(raw), dtype=torch.uint8))
+
+
+def run_job(wl, rank, world, gather_mode, steps=2, warmup=1):
+    """What bench.main does between set-up and the JSON line, with the oracle double: returns the
+    merged global WindowResults on rank 0."""
+    import torch
+    import torch.distributed as dist
+
+    import bench
+    from sai_amd import _ffi
+    from sai_amd.distributed import RowGather, gather_padded
+    from sai_amd.sharding import layout_shard, merge_rank_results, piece_site_range, plan_shards, synth_chrom_windows
+
+    all_pos, all_windows = synth_chrom_windows(_ffi.load_host(), wl)
+    counts = [len(w) for w in all_windows]
+    plan = plan_shards(counts, world)
+    lay = layout_shard(plan[rank], wl.chroms, all_windows,
+                       lambda pc: piece_site_range(all_pos[pc.chrom_index], all_windows[pc.chrom_index], pc.w0, pc.w1))  # fmt: skip
+    scorer = OracleScorer(wl, lay, all_pos) if plan[rank] else None
+    layout = None
+    if scorer is not None:
+        scorer.step()
+        layout = scorer.row_layout()
+    gather = RowGather(layout, torch.device("cpu"))
+    n_rows = max(steps, warmup, 1) if gather_mode == "end" else 1
+    ring = torch.zeros((n_rows, max(gather.sizes[gather.rank], 1)), dtype=torch.uint8)
+
+    def gather_ring(n):
+        if n == 0:
+            return None
+        rows = gather_padded(ring[:n, : gather.sizes[gather.rank]].reshape(-1), [n * s for s in gather.sizes])
+        return None if rows is None else [r.reshape(n, -1)[n - 1] if r.numel() else r for r in rows]
+
+    def fence():
+        if gather.on:
+            dist.barrier()
+
+    out = bench.run_passes(scorer, gather, lambda k: ring[k % n_rows], steps, warmup, gather_mode, fence, gather_ring)
+    if rank != 0:
+        assert out["rows"] is None or not gather.on
+        return None, plan, lay
+    if not gather.on:  # one rank: the scorer's own results are the job's results
+        return merge_rank_results([scorer.results()], plan, len(wl.specs)), plan, lay
+    return merge_rank_results(gather.decode(out["rows"]), plan, len(wl.specs)), plan, lay
+
+
+def _worker(rank, world, port, out_dir, name, gather_mode):
+    import torch.distributed as dist
+
+    sys.path.insert(0, str(ROOT))
+    sys.path.insert(0, str(ROOT / "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))  # fmt: skip
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from test_bench_sharded_cpu import run_job, tiny_workload
+
+    res, plan, lay = run_job(tiny_workload(name), rank, world, gather_mode)
+    if rank == 0:
+        np.savez(os.path.join(out_dir, "merged.npz"), rec=res.records.view(np.uint8), off=res.offsets, u=res.cdd_u, q=res.cdd_q)
+    # every rank holds its own range + the halo: neighbouring ranks overlap by < one window of sites
+    np.save(os.path.join(out_dir, f"sites{rank}.npy"), np.array([sum(lay.n_sites), len(lay.windows), len(lay.pieces)]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("name,world,gather_mode", [("c4", 2, "step"), ("c4", 4, "step"), ("c4", 3, "end"), ("c5", 2, "step")])
+def test_sharded_job_equals_one_rank_job(tmp_path, name, world, gather_mode):
+    import torch.multiprocessing as mp
+
+    wl = tiny_workload(name)
+    single, plan1, lay1 = run_job(wl, 0, 1, "step")
+    assert single.records.shape == (len(wl.specs), len(lay1.windows)) and single.records["u_count"].sum() > 0
+    assert np.isfinite(single.records["q"]).sum() > 0 and single.cdd_q.size > 0
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), name, gather_mode), nprocs=world, join=True)
+    got = np.load(tmp_path / "merged.npz")
+    assert got["rec"].tobytes() == single.records.tobytes()  # every record, every f64 bit
+    assert np.array_equal(got["off"], single.offsets)
+    assert got["u"].tobytes() == single.cdd_u.tobytes() and got["q"].tobytes() == single.cdd_q.tobytes()
+    # the shards: all windows exactly once, contiguous, balanced; each rank holds only its sites + halo
+    sites = [np.load(tmp_path / f"sites{r}.npy") for r in range(world)]
+    n_w = [int(s[1]) for s in sites]
+    assert sum(n_w) == len(lay1.windows) and max(n_w) - min(n_w) <= 1
+    total_sites = len(wl.chroms) * wl.n_sites
+    halo = 2 * (wl.win_len // 20)  # synth-v1: one site per ~25 bp; a piece re-reads < win_len of its neighbour
+    for s in sites:
+        assert int(s[0]) <= total_sites // world + (int(s[2]) + 1) * halo + wl.win_len // 10
+
+
+def test_plan_shards_matches_the_chunk_rule():
+    from sai_amd.sharding import plan_shards
+    from sai_amd.utils.windows import split_index_ranges
+
+    for counts in ([5000] * 22, [7, 0, 3, 11], [1], [0, 0], [3, 3, 3]):
+        for world in (1, 2, 3, 4, 8, 9):
+            plan = plan_shards(counts, world)
+            assert len(plan) == world
+            flat = [(pc.chrom_index, w) for pieces in plan for pc in pieces for w in range(pc.w0, pc.w1)]
+            assert flat == [(c, w) for c, n in enumerate(counts) for w in range(n)]
+            sizes = [sum(pc.n_windows for pc in pieces) for pieces in plan]
+            want = [b - a for a, b in split_index_ranges(sum(counts), world)] if sum(counts) else []
+            assert sizes[: len(want)] == want and not any(sizes[len(want) :])
+            for pieces in plan:  # g0 = position in the global list; pieces of a rank are consecutive
+                for a, b in zip(pieces, pieces[1:]):
+                    assert b.g0 == a.g0 + a.n_windows and b.chrom_index > a.chrom_index and b.w0 == 0
+
+
+def test_row_layout_round_trip():
+    from sai_amd.engine import RECORD_DTYPE
+    from sai_amd.resident import RowLayout
+
+    rng = np.random.default_rng(4)
+    n_sets, n_w = 18, 7
+    rec = np.zeros((n_sets, n_w), dtype=RECORD_DTYPE)
+    rec["u_count"] = rng.integers(0, 4, (n_sets, n_w))
+    rec["n_cdd_q"] = rng.integers(0, 3, (n_sets, n_w))
+    rec["q"] = rng.random((n_sets, n_w))
+    u = rng.integers(1, 10**6, int(rec["u_count"].sum())).astype(np.int32)
+    q = rng.integers(1, 10**6, int(rec["n_cdd_q"].sum())).astype(np.int32)
+    lay = RowLayout(n_sets, n_w, [16, 2], [int(rec["u_count"][:16].sum()), int(rec["u_count"][16:].sum())],
+                    [int(rec["n_cdd_q"][:16].sum()), int(rec["n_cdd_q"][16:].sum())])  # fmt: skip
+    assert RowLayout.from_header(lay.header() + [0] * 5).header() == lay.header()
+    row = np.frombuffer(rec.tobytes() + u.tobytes() + q.tobytes(), dtype=np.uint8)
+    res = lay.unpack(row)
+    assert res.records.tobytes() == rec.tobytes()
+    for s in range(n_sets):
+        for w in range(n_w):
+            assert len(res.u_list(s, w)) == rec["u_count"][s, w] and len(res.q_list(s, w)) == rec["n_cdd_q"][s, w]
+    assert np.array_equal(np.concatenate([res.u_list(s, w) for s in range(n_sets) for w in range(n_w)]), u)
+    with pytest.raises(ValueError):
+        lay.unpack(row[:-4])

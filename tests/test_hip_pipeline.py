@@ -277,7 +277,7 @@ def test_site_absdiff_exact_at_extremes(_gpu):
 # ---- sharded score: two ranks (both on this box's one GPU, gloo for the final gather) ---------
 
 
-def _sharded_worker(rank, world, port, out_file):
+def _sharded_worker(rank, world, port, out_file, chunks_per_rank):
     import os
 
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
@@ -288,17 +288,19 @@ def _sharded_worker(rank, world, port, out_file):
     from sai_amd.distributed import score_sharded
 
     items = score_sharded("tests/data/test.data.vcf", "21", 10000, 5000, None, out_file, "tests/data/test.uq.config.yaml",
-                          chunks_per_rank=2)  # fmt: skip
+                          chunks_per_rank=chunks_per_rank)  # fmt: skip
     assert (items is not None) == (rank == 0)
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_score_sharded_two_ranks_equals_single_process(in_repo_root, tmp_path):
-    """The multi-GPU decomposition (window-range chunks per rank, one gather, rank 0 writes) gives
-    the same rows as the single-process run.  Rows come out chunk by chunk (inside a chunk:
-    population combination, then window), exactly as the reference's chunked executor would emit
-    them, so with two target populations the comparison is on the sorted rows."""
+@pytest.mark.parametrize("world,chunks_per_rank", [(2, 2), (3, 1)])
+def test_score_sharded_equals_single_process_byte_for_byte(in_repo_root, tmp_path, world, chunks_per_rank):
+    """The multi-GPU decomposition (window-range chunks per rank, one gather of the numeric batches,
+    rank 0 writes) gives the single-process FILES: rank 0 re-orders the gathered chunks into the
+    order a one-chunk run emits (population combination, then window; sai.py:146-151 with
+    num_chunks=1), so TSV, .U.log and .Q.log are byte-identical for any number of ranks -- here two
+    target populations (two combinations) and, with 3 ranks over 10 windows, uneven chunks."""
     import socket
 
     import torch.multiprocessing as mp
@@ -313,12 +315,10 @@ def test_score_sharded_two_ranks_equals_single_process(in_repo_root, tmp_path):
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     sharded = tmp_path / "sharded.tsv"
-    mp.spawn(_sharded_worker, args=(2, port, str(sharded)), nprocs=2, join=True)
-    assert sharded.read_text().splitlines()[0] == single.read_text().splitlines()[0]
-    assert sorted(sharded.read_text().splitlines()) == sorted(single.read_text().splitlines())
+    mp.spawn(_sharded_worker, args=(world, port, str(sharded), chunks_per_rank), nprocs=world, join=True)
+    assert sharded.read_text() == single.read_text()
     for k in ("U", "Q"):
-        a, b = (tmp_path / f"sharded.{k}.log").read_text().splitlines(), (tmp_path / f"single.{k}.log").read_text().splitlines()
-        assert a[0] == b[0] and sorted(a) == sorted(b)
+        assert (tmp_path / f"sharded.{k}.log").read_text() == (tmp_path / f"single.{k}.log").read_text()
 
 
 import os

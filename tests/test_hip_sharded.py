@@ -1,0 +1,195 @@
+"""GPU tests of the sharded resident job: a rank's share of a whole-genome
+window list -- several chromosome pieces laid back to back in one block, searched per segment --
+gives, merged over the ranks, exactly the bytes of the one-GPU run of the same job; and bench.py's
+N > 1 branch runs end to end with two ranks on the box's one GPU (gloo moves the rows; RCCL refuses
+two ranks on one device) and with one rank on real RCCL."""
+
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    import torch
+
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    from sai_amd.engine import Engine
+
+    return Engine.get(0)
+
+
+def small_job(name, sites=60_000, chroms=5):
+    import bench
+
+    wl = bench.make_workload(name, sites=sites, chroms=chroms if name == "c4" else 0)
+    wl.n_ref, wl.n_tgt = 130, 70
+    wl.missing_per_million = 2000
+    for s in wl.specs:
+        s.update(w=0.05, x=0.3)
+    return wl
+
+
+def run_rank(eng, wl, rank, world, overlap=False, through_row=True):
+    """One rank's pass; returns (WindowResults or None, layout).  ``through_row`` sends the results
+    through pack_row / RowLayout.unpack, the bytes a gather moves."""
+    import torch
+
+    from sai_amd.resident import ResidentScorer
+    from sai_amd.sharding import build_synth_shard
+
+    block, lay, counts = build_synth_shard(eng, wl, rank, world)
+    if block is None:
+        return None, lay, counts
+    scorer = ResidentScorer(eng, block, [(s, e) for _, s, e in lay.windows], wl.params(), cap_u=1 << 18, cap_q=1 << 18,
+                            overlap=overlap, window_segment=lay.window_segment)  # fmt: skip
+    scorer.step()
+    scorer.step()  # the pipelined form needs a second step + flush to have run a stage
+    res = scorer.results()
+    if through_row:
+        layout = scorer.row_layout()
+        row = torch.empty((layout.nbytes,), dtype=torch.uint8, device=eng.device)
+        with scorer.window_stream():
+            scorer.pack_row(row, layout)
+        torch.cuda.synchronize()
+        from sai_amd.resident import RowLayout
+
+        back = RowLayout.from_header(layout.header()).unpack(row.cpu().numpy())
+        assert back.records.tobytes() == res.records.tobytes()
+        assert back.cdd_u.tobytes() == res.cdd_u.tobytes() and back.cdd_q.tobytes() == res.cdd_q.tobytes()
+        assert np.array_equal(back.offsets, res.offsets)
+        res = back
+    return res, lay, counts
+
+
+@pytest.mark.parametrize("name,world", [("c4", 3), ("c4", 8), ("c5", 4), ("c2", 2)])
+def test_merged_shards_equal_the_one_gpu_job(eng, name, world):
+    from sai_amd.sharding import merge_rank_results, plan_shards
+
+    wl = small_job(name)
+    one, lay1, counts = run_rank(eng, wl, 0, 1)
+    n_sets = len(wl.specs)
+    assert one.records.shape == (n_sets, sum(counts)) and one.records["u_count"].sum() > 0 and one.cdd_q.size > 0
+    per_rank, n_pieces = [], 0
+    for r in range(world):
+        res, lay, c = run_rank(eng, wl, r, world, overlap=(r % 2 == 1))
+        assert c == counts
+        per_rank.append(res)
+        n_pieces += len(lay.pieces)
+        # a rank holds only its own sites + halo
+        assert sum(lay.n_sites) < len(wl.chroms) * wl.n_sites / world + (len(lay.pieces) + 1) * 4000
+    merged = merge_rank_results(per_rank, plan_shards(counts, world), n_sets)
+    assert merged.records.tobytes() == one.records.tobytes()
+    assert merged.cdd_u.tobytes() == one.cdd_u.tobytes() and merged.cdd_q.tobytes() == one.cdd_q.tobytes()
+    assert np.array_equal(merged.offsets, one.offsets)
+    if name == "c4":
+        assert n_pieces >= world + len(wl.chroms) - 1  # ranks really span chromosome boundaries
+
+
+def test_multi_piece_block_equals_per_chromosome_blocks(eng):
+    """The one-rank block of a 4-chromosome job (4 segments, one site pass, one windows stage)
+    against four single-chromosome scorers on separately generated blocks."""
+    from sai_amd.resident import ResidentScorer, default_windows, synth_block
+
+    wl = small_job("c4", sites=50_000, chroms=4)
+    one, lay, counts = run_rank(eng, wl, 0, 1, through_row=False)
+    g = 0
+    for chrom, n_w in zip(wl.chroms, counts):
+        block = synth_block(eng, wl.seed, chrom, wl.n_sites, wl.n_ref, wl.n_tgt, wl.src_sizes,
+                            missing_per_million=wl.missing_per_million)  # fmt: skip
+        windows = default_windows(int(block.pos[0]), int(block.pos[-1]), wl.win_len, wl.win_step)
+        assert len(windows) == n_w
+        sc = ResidentScorer(eng, block, windows, wl.params(), cap_u=1 << 18, cap_q=1 << 18)
+        sc.step()
+        res = sc.results()
+        assert one.records[:, g : g + n_w].tobytes() == res.records.tobytes()
+        for w in range(n_w):
+            assert one.u_list(0, g + w).tolist() == res.u_list(0, w).tolist()
+            assert one.q_list(0, g + w).tolist() == res.q_list(0, w).tolist()
+        g += n_w
+
+
+def test_more_than_sixteen_sets_in_one_scorer(eng):
+    """C5's 18 parameter sets: one scorer (two set chunks) against engine-level calls."""
+    from sai_amd.resident import ResidentScorer, default_windows, synth_block
+
+    wl = small_job("c5", sites=80_000)
+    block = synth_block(eng, wl.seed, 1, wl.n_sites, wl.n_ref, wl.n_tgt, wl.src_sizes, missing_per_million=2000)
+    windows = default_windows(int(block.pos[0]), int(block.pos[-1]), wl.win_len, wl.win_step)
+    sets = wl.params()
+    assert len(sets) == 18
+    sc = ResidentScorer(eng, block, windows, sets, cap_u=16, cap_q=16)  # far too small: results(grow=True) enlarges
+    sc.step()
+    with pytest.raises(RuntimeError, match="too small"):
+        sc.results()
+    res = sc.results(grow=True)
+    counts = eng.site_counts(block.pops)
+    tgt_freq, flags, _ = eng.site_flags(counts, block.ploidies, sets)
+    lo, hi = eng.window_bounds(block.pos, [w[0] for w in windows], [w[1] for w in windows])
+    ref = eng.window_stats(tgt_freq, flags, sets, lo, hi, pos=block.pos)
+    assert res.records.tobytes() == ref.records.tobytes()
+    assert res.cdd_u.tobytes() == ref.cdd_u.tobytes() and res.cdd_q.tobytes() == ref.cdd_q.tobytes()
+    assert np.array_equal(res.offsets, ref.offsets)
+    assert len({r["u_count"].sum() for r in res.records}) > 3  # the sets really differ
+
+
+def _bench(args, env_extra=None, nproc=1):
+    env = dict(os.environ)
+    env.update(env_extra or {})
+    if nproc > 1:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr",
+               "127.0.0.1", "--master-port", "29577", "bench.py", "--gpus", str(nproc), *args]  # fmt: skip
+    else:
+        cmd = [sys.executable, "bench.py", *args]
+    res = subprocess.run(cmd, cwd=str(ROOT), env=env, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+REDUCED = ["--workload", "c4", "--sites", "200000", "--chroms", "5", "--steps", "3", "--warmup", "1", "--cpu-sites", "0"]
+
+
+@pytest.mark.parametrize("gather", ["step", "end"])
+def test_bench_two_ranks_on_one_gpu_equal_one_rank(gather):
+    """bench.py's N > 1 branch with two processes on the box's one GPU (real kernels; gloo moves
+    the rows) against the one-process run of the same reduced job."""
+    one = _bench(REDUCED)
+    two = _bench([*REDUCED, "--gather", gather], {"SAI_BENCH_DEVICE": "0", "SAI_BENCH_BACKEND": "gloo"}, nproc=2)
+    assert two["n_gpus"] == 2 and two["scaling"] == "strong" and two["config"]["gather"] == gather
+    for k in ("windows_total", "u_sum", "q_finite", "cdd_u_entries", "cdd_q_entries", "chromosomes", "parameter_sets"):
+        assert two["config"][k] == one["config"][k], k
+    assert one["config"]["u_sum"] > 0 and one["config"]["windows_total"] > 500
+    assert two["config"]["windows_rank0"] in (one["config"]["windows_total"] // 2, one["config"]["windows_total"] // 2 + 1)
+    assert two["config"]["pieces_rank0"] == 3 and one["config"]["pieces_rank0"] == 5
+    assert "configs[3]" in two["config"]["workload"] and "REDUCED" in two["config"]["workload"]
+    assert two["roofline"]["frac"] > 0 and two["value"] > 0
+
+
+def test_bench_one_rank_on_real_rccl():
+    """The same branches -- process group with device_id, header all_gather, the per-pass gather on
+    the window stream, the MAX reduction -- with one rank on real RCCL."""
+    one = _bench(REDUCED)
+    rccl = _bench(REDUCED, {"SAI_BENCH_FORCE_DIST": "1"})
+    for k in ("windows_total", "u_sum", "q_finite", "cdd_u_entries", "cdd_q_entries"):
+        assert rccl["config"][k] == one["config"][k], k
+    assert rccl["config"]["gather"] == "step" and rccl["config"]["gather_row_bytes"][0] > 24 * one["config"]["windows_total"]
+
+
+def test_bench_default_line_has_the_contract_fields():
+    line = _bench(["--workload", "c2", "--steps", "5", "--warmup", "1", "--cpu-sites", "20000"])
+    assert line["metric"].startswith("windows/sec") and line["unit"] == "windows/s" and line["n_gpus"] == 1
+    assert line["dtype"] == "u8" and line["vs_baseline"] is None and line["higher_is_better"] is True
+    assert set(line["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source"}
+    assert line["cpu_baseline"]["kind"] == "port" and line["cpu_baseline"]["cpu_model"] and line["cpu_baseline"]["cores"] >= 1
+    sp = line["score_path"]
+    assert sp["windows"] == line["config"]["windows_total"] and sp["value"] > 0

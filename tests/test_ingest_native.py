@@ -289,13 +289,38 @@ def test_tabix_index_seek_equals_full_pass(tmp_path, monkeypatch):
     victim = members[len(members) // 2][0]
     raw[victim + 30] ^= 0xFF
     path.write_bytes(bytes(raw))
+    os.utime(str(path) + ".tbi")  # the index stays newer than the rewritten file (a stale index is ignored)
     monkeypatch.setenv("SAI_VCF_BATCH_BYTES", "20000")  # the whole test file is smaller than a default batch
     for chrom, reg in (("7", (5000, 40000)), ("22", (5000, 40000))):
         got = load_dosage(str(path), chrom, names, [2] * len(names), reg[0], reg[1], None, 3)
         assert np.array_equal(got[1], plain[chrom, reg][1])
+    # an index older than the file is not trusted: the full pass runs and meets the damaged block
+    st = os.stat(path)
+    os.utime(str(path) + ".tbi", (st.st_atime - 100, st.st_mtime - 100))
+    with pytest.raises((ValueError, OSError), match="BGZF"):
+        load_dosage(str(path), "22", names, [2] * len(names), 5000, 40000, None, 3)
     os.remove(str(path) + ".tbi")
     with pytest.raises((ValueError, OSError), match="BGZF"):
         load_dosage(str(path), "22", names, [2] * len(names), 5000, 40000, None, 3)
+
+
+def test_oversized_bgzf_isize_is_rejected(tmp_path):
+    """A BGZF trailer is file content: a member that claims more than 64 KiB of data is corrupt,
+    not a reason to allocate what it says (up to 4 GiB per member)."""
+    from sai_amd.utils.native_vcf import load_dosage, scan_first_last
+
+    rng = np.random.default_rng(11)
+    path = tmp_path / "big.vcf.gz"
+    names = write_vcf(path, rng, 300, 5, gz="bgzf")
+    raw = bytearray(path.read_bytes())
+    bsize = (raw[16] | raw[17] << 8) + 1  # first member: BC subfield right after the 12-byte header + 4
+    assert raw[12:14] == b"BC"
+    raw[bsize - 4 : bsize] = (0xFFFFFFF0).to_bytes(4, "little")  # ISIZE of the first member
+    path.write_bytes(bytes(raw))
+    with pytest.raises((ValueError, OSError), match="BGZF"):
+        scan_first_last(str(path), "21")
+    with pytest.raises((ValueError, OSError), match="BGZF"):
+        load_dosage(str(path), "21", names, [2] * len(names), None, None, None, 2)
 
 
 @pytest.mark.parametrize("fixture,chroms", [("tests/data/test.with.outgroup.vcf.gz", ["1", "2"]),
