@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define SAI_ABI_VERSION 4
+#define SAI_ABI_VERSION 5
 #define SAI_TILE_SITES 64
 #define SAI_MAX_SRC 6   /* source populations per call */
 #define SAI_MAX_SETS 16 /* parameter sets per call */
@@ -201,6 +201,14 @@ int sai_site_freqs(sai_ctx* ctx, int64_t n_sites, int32_t n_pops, const int32_t*
 int sai_window_fourpop(sai_ctx* ctx, int64_t n_sites, int32_t n_src, int32_t has_outgroup,
                        const double* freqs, int32_t n_windows, const int32_t* lo, const int32_t* hi,
                        double* sums, double* stats, void* stream);
+
+/* calc_pattern_sum (stat_utils.py:220-272) for one arbitrary pattern over whole arrays: bit k of
+ * pattern_bits set = population k (0 ref, 1 tgt, 2 src, 3 out) contributes its frequency ('b'),
+ * clear = one minus it ('a'); *sum_out (device) = np.sum of the per-site products, in numpy's
+ * order.  One wavefront; the statistic classes use sai_window_fourpop instead. */
+int sai_pattern_sum(sai_ctx* ctx, int64_t n_sites, const double* ref_freq, const double* tgt_freq,
+                    const double* src_freq, const double* out_freq, int32_t pattern_bits, double* sum_out,
+                    void* stream);
 
 /* ---- DD --------------------------------------------------------- */
 

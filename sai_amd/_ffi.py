@@ -20,7 +20,7 @@ SAI_MAX_SETS = 16
 SAI_FUSED_SETS = 4
 SAI_ERR_UNSUPPORTED = -4  # enum sai_status
 FREQ_MODES = {"dense": 0, "candidates": 1}  # enum sai_freq_mode
-SAI_ABI_VERSION = 4
+SAI_ABI_VERSION = 5
 
 OPS = {"=": 0, "<": 1, ">": 2, "<=": 3, ">=": 4}
 
@@ -90,6 +90,7 @@ SIGNATURES = {
     ),
     "sai_site_freqs": (C.c_int, [_p, _i64, _i32, C.POINTER(_i32), _p, _p, _p]),
     "sai_window_fourpop": (C.c_int, [_p, _i64, _i32, _i32, _p, _i32, _p, _p, _p, _p, _p]),
+    "sai_pattern_sum": (C.c_int, [_p, _i64, _p, _p, _p, _p, _i32, _p, _p]),
     "sai_site_absdiff": (C.c_int, [_p, _i64, C.POINTER(SaiPop), C.POINTER(SaiPop), _p, _p]),
     "sai_window_dd": (C.c_int, [_p, _i64, _i32, _p, _i32, _p, _i32, _i32, _p, _p, _p, _p, _p]),
     "sai_packed2_bytes": (_i64, [_i64, _i32]),

@@ -1,35 +1,36 @@
-"""Population-file section of the YAML config (mirror of sai/configs/pop_config.py:31-82)."""
+"""``populations`` section of the YAML config: group -> sample-list file.  Interface of
+sai/configs/pop_config.py:31-82: groups ref, tgt and src are required, outgroup is optional, any
+other key is refused, every file must exist; ``get_population("outgroup")`` is None when no
+outgroup is configured."""
 
 from __future__ import annotations
 
-import os
-from typing import Dict
+from pathlib import Path
+from typing import Dict, Optional
 
-from pydantic import RootModel, field_validator
+from pydantic import RootModel, model_validator
 
-REQUIRED_KEYS = {"ref", "tgt", "src"}
-OPTIONAL_KEYS = {"outgroup"}
-ALLOWED_KEYS = REQUIRED_KEYS | OPTIONAL_KEYS
+_GROUPS = {"ref": True, "tgt": True, "src": True, "outgroup": False}  # group -> required?
 
 
 class PopConfig(RootModel[Dict[str, str]]):
-    """``{"ref": path, "tgt": path, "src": path[, "outgroup": path]}``; every file must exist."""
+    @model_validator(mode="after")
+    def _groups_and_files(self) -> "PopConfig":
+        given = self.root
+        absent = sorted(g for g, required in _GROUPS.items() if required and g not in given)
+        if absent:
+            raise ValueError(f"Missing required population keys: {absent}")
+        unknown = sorted(set(given) - set(_GROUPS))
+        if unknown:
+            raise ValueError(f"Unsupported population keys: {unknown}")
+        for group, file_name in given.items():
+            if not Path(file_name).is_file():
+                raise ValueError(f"{group} file does not exist: {file_name}")
+        return self
 
-    @field_validator("root")
-    def validate_population_keys_and_paths(cls, v):
-        keys = set(v.keys())
-        if missing := REQUIRED_KEYS - keys:
-            raise ValueError(f"Missing required population keys: {missing}")
-        if invalid := keys - ALLOWED_KEYS:
-            raise ValueError(f"Unsupported population keys: {invalid}")
-        for name, path in v.items():
-            if not os.path.isfile(path):
-                raise ValueError(f"{name} file does not exist: {path}")
-        return v
-
-    def get_population(self, group: str) -> str:
-        if group not in self.root:
-            if group == "outgroup":
-                return None
-            raise ValueError(f"Population group '{group}' not found in config.")
-        return self.root[group]
+    def get_population(self, group: str) -> Optional[str]:
+        if group in self.root:
+            return self.root[group]
+        if _GROUPS.get(group) is False:  # an optional group that was left out
+            return None
+        raise ValueError(f"Population group '{group}' not found in config.")

@@ -8,9 +8,9 @@ namespace {
 // ------------------------------------------------------------------------------------------
 // ABBA-BABA family (fd, df, Danc, Dplus; sai/stats/{fd,df,danc,dplus}_statistic.py and
 // stat_utils.py:171-272).  site_freqs turns the counts of site_counts into f64 frequencies;
-// window_pattern_sums evaluates, per (window, source, pattern), the per-site products
-// ((x0*x1)*x2)*x3 with x = f or 1 - f and adds them in numpy's np.sum order (pairwise within
-// 8192-element pieces, pieces accumulated in order), so the sums -- and the ratios formed from
+// window_pattern_sums evaluates, per (window, source), the per-site products ((x0*x1)*x2)*x3 with
+// x = f or 1 - f of all seven patterns and adds them in numpy's np.sum order (pairwise within
+// 8192-element pieces, pieces accumulated in order) with one wavefront, so the sums -- and the ratios formed from
 // them by window_fourpop -- are the reference's doubles bit for bit.  NaN frequencies (a
 // population with no called individual at a site) poison the window's sums, as np.sum does.
 // ------------------------------------------------------------------------------------------
@@ -36,30 +36,6 @@ __global__ __launch_bounds__(256) void site_freqs_kernel(FreqArgs a) {
 
 constexpr int kPatternSlots = 7;  // abba, baba, bbaa, baaa, abaa, abba_d, baba_d
 
-struct PatternElem {
-  const double* fr;
-  const double* ft;
-  const double* fs;
-  const double* fo;  // nullptr: outgroup frequency 0 everywhere (stat_utils.py:213-214)
-  int bits;          // bit k set: population k contributes f ('b'), else 1 - f ('a'); k = ref,tgt,src,out
-  bool donor;        // fd's denominators: tgt and src both replaced by max(tgt, src) (fd_statistic.py:80-83)
-  __device__ __forceinline__ double operator()(int i) const {
-    const double r = fr[i];
-    double t = ft[i], s = fs[i];
-    const double o = fo ? fo[i] : 0.0;
-    if (donor) {
-      const double d = (t != t || s != s) ? std::numeric_limits<double>::quiet_NaN() : (t > s ? t : s);
-      t = d;
-      s = d;
-    }
-    double p = (bits & 1) ? r : 1.0 - r;
-    p = p * ((bits & 2) ? t : 1.0 - t);
-    p = p * ((bits & 4) ? s : 1.0 - s);
-    p = p * ((bits & 8) ? o : 1.0 - o);
-    return p;
-  }
-};
-
 struct PatternArgs {
   int64_t n_sites;
   int32_t n_src;
@@ -72,24 +48,211 @@ struct PatternArgs {
   double* stats;  // [n_windows][n_src][4]: fd, df, Danc, Dplus
 };
 
-__global__ __launch_bounds__(64) void window_pattern_sums_kernel(PatternArgs a) {
-  const int64_t tid = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-  const int64_t total = static_cast<int64_t>(a.n_windows) * a.n_src * kPatternSlots;
-  if (tid >= total) return;
-  const int slot = static_cast<int>(tid % kPatternSlots);
-  const int src = static_cast<int>((tid / kPatternSlots) % a.n_src);
-  const int w = static_cast<int>(tid / (kPatternSlots * a.n_src));
-  PatternElem e;
+// The per-site products of one source population, all pattern slots at once: every product is
+// ((x0*x1)*x2)*x3 with x_k = f_k ('b') or 1 - f_k ('a'), k = ref, tgt, src, out -- calc_pattern_sum's
+// `product *= ...` chain (stat_utils.py:259-270; 1.0 * x0 is x0).  Shared prefixes are the same
+// operations, so sharing them changes no bit.
+struct FourPopElems {
+  static constexpr int kSlots = kPatternSlots;
+  const double* fr;
+  const double* ft;
+  const double* fs;
+  const double* fo;  // nullptr: outgroup frequency 0 everywhere (stat_utils.py:213-214)
+  __device__ __forceinline__ void operator()(int i, double (&p)[kSlots]) const {
+    const double r = fr[i], t = ft[i], s = fs[i];
+    const double o = fo ? fo[i] : 0.0;
+    // fd's denominators: tgt and src both replaced by max(tgt, src) (fd_statistic.py:80-83)
+    const double d = (t != t || s != s) ? std::numeric_limits<double>::quiet_NaN() : (t > s ? t : s);
+    const double nr = 1.0 - r, nt = 1.0 - t, ns = 1.0 - s, no = 1.0 - o, nd = 1.0 - d;
+    const double nr_t = nr * t, r_nt = r * nt;
+    p[0] = (nr_t * s) * no;          // abba
+    p[1] = (r_nt * s) * no;          // baba
+    p[2] = ((r * t) * ns) * no;      // bbaa
+    p[3] = (r_nt * ns) * no;         // baaa
+    p[4] = (nr_t * ns) * no;         // abaa
+    p[5] = ((nr * d) * d) * no;      // abba with the donor frequency
+    p[6] = ((r * nd) * d) * no;      // baba with the donor frequency
+  }
+};
+
+// One arbitrary pattern (calc_pattern_sum's public form): bit k set = population k contributes f.
+struct OnePatternElem {
+  static constexpr int kSlots = 1;
+  const double* f[4];
+  int bits;
+  __device__ __forceinline__ void operator()(int i, double (&p)[1]) const {
+    double v = (bits & 1) ? f[0][i] : 1.0 - f[0][i];
+#pragma unroll
+    for (int k = 1; k < 4; ++k) v = v * ((bits & (1 << k)) ? f[k][i] : 1.0 - f[k][i]);
+    p[0] = v;
+  }
+};
+
+// ------------------------------------------------------------------------------------------
+// np.sum's order, in parallel.  numpy adds an f64 array in 8192-element pieces (the ufunc buffer),
+// pieces accumulated in order; a piece is summed by recursive halving (n2 = n/2 rounded down to a
+// multiple of 8) down to leaves of <= 128 elements; a leaf keeps EIGHT running sums r[j] over the
+// elements j, j+8, j+16, ... and closes with ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)) plus a tail of
+// < 8 elements.  The order of every addition is fixed, but the eight running sums of a leaf and the
+// leaves of a piece are independent: one wavefront sums a window with lane = (leaf % 8, j) -- eight
+// leaves at a time, 16 dependent additions per lane for a full leaf instead of thousands for a
+// serial walk -- closes each leaf with an xor-butterfly over j (IEEE addition commutes, so the
+// butterfly forms exactly numpy's pairs), and one lane per slot then replays the recursion over
+// the leaf sums.  Same additions, same order, same bits (golden: fourpop_cases.json incl. windows
+// beyond 8192 sites).
+// ------------------------------------------------------------------------------------------
+
+constexpr int kMaxLeaves = 80;  // an 8192-element piece has at most 65 leaves (sizes 64..128)
+
+struct LeafList {
+  int off[kMaxLeaves];
+  int n[kMaxLeaves];
+  int count;
+};
+
+// the recursion of numpy's pairwise sum with a caller-supplied leaf action, unrolled to the depth
+// an 8192-element piece can reach (seven levels, see numpy_sum.hpp)
+template <int DEPTH, typename Leaf>
+struct PairwiseWalk {
+  static __device__ __noinline__ double run(Leaf& leaf, int off, int n) {
+    if (n <= 128) return leaf(off, n);
+    int n2 = n / 2;
+    n2 -= n2 % 8;
+    const double a = PairwiseWalk<DEPTH - 1, Leaf>::run(leaf, off, n2);
+    const double b = PairwiseWalk<DEPTH - 1, Leaf>::run(leaf, off + n2, n - n2);
+    return a + b;
+  }
+};
+template <typename Leaf>
+struct PairwiseWalk<0, Leaf> {
+  static __device__ __noinline__ double run(Leaf& leaf, int off, int n) { return leaf(off, n); }
+};
+
+struct ListLeaves {
+  LeafList* list;
+  __device__ __forceinline__ double operator()(int off, int n) {
+    const int k = list->count++;
+    if (k < kMaxLeaves) {
+      list->off[k] = off;
+      list->n[k] = n;
+    }
+    return 0.0;
+  }
+};
+
+struct ReplayLeaves {
+  const double* sums;  // this slot's leaf sums, in leaf order
+  int next;
+  __device__ __forceinline__ double operator()(int, int) { return sums[next++]; }
+};
+
+// np.sum over elements [off, off + n) for every slot of `e`; the whole wave calls it, lane 0..kSlots-1
+// return their slot's sum in `out`.  `list` and `leaf_sums` are this wave's LDS scratch.
+template <typename E>
+__device__ __forceinline__ double wave_numpy_sum(const E& e, int off, int n, int lane, LeafList* list,
+                                                 double (*leaf_sums)[kMaxLeaves]) {
+  constexpr int S = E::kSlots;
+  double total = 0.0;  // meaningful in lanes < S
+  for (int o = 0; o < n; o += 8192) {
+    const int m = min(8192, n - o);
+    if (lane == 0) {
+      list->count = 0;
+      ListLeaves ll{list};
+      PairwiseWalk<7, ListLeaves>::run(ll, off + o, m);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int n_leaves = list->count;  // <= kMaxLeaves by construction (at most 65 leaves)
+    const int j = lane & 7, g = lane >> 3;
+    for (int lb = 0; lb < n_leaves; lb += 8) {
+      const int leaf = lb + g;
+      const bool live = leaf < n_leaves;
+      const int lo = live ? list->off[leaf] : 0;
+      const int ln = live ? list->n[leaf] : 0;
+      double r[S];
+#pragma unroll
+      for (int s = 0; s < S; ++s) r[s] = 0.0;
+      if (ln >= 8) {
+        double p[S];
+        e(lo + j, p);
+#pragma unroll
+        for (int s = 0; s < S; ++s) r[s] = p[s];
+        const int body = ln - (ln % 8);
+        for (int i = 8; i < body; i += 8) {
+          e(lo + i + j, p);
+#pragma unroll
+          for (int s = 0; s < S; ++s) r[s] += p[s];
+        }
+      }
+      // close the eight running sums: ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)); lanes of dead or short
+      // leaves shuffle zeros
+#pragma unroll
+      for (int s = 0; s < S; ++s) {
+        r[s] = r[s] + __shfl_xor(r[s], 1, 64);
+        r[s] = r[s] + __shfl_xor(r[s], 2, 64);
+        r[s] = r[s] + __shfl_xor(r[s], 4, 64);
+      }
+      if (live && j == 0) {
+        double p[S];
+        if (ln < 8) {  // numpy's plain loop: res = 0.; res += a[i]
+#pragma unroll
+          for (int s = 0; s < S; ++s) r[s] = 0.0;
+          for (int i = 0; i < ln; ++i) {
+            e(lo + i, p);
+#pragma unroll
+            for (int s = 0; s < S; ++s) r[s] += p[s];
+          }
+        } else {
+          for (int i = ln - (ln % 8); i < ln; ++i) {  // the tail after the eight-way body
+            e(lo + i, p);
+#pragma unroll
+            for (int s = 0; s < S; ++s) r[s] += p[s];
+          }
+        }
+#pragma unroll
+        for (int s = 0; s < S; ++s) leaf_sums[s][leaf] = r[s];
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (lane < S) {  // replay the recursion over the leaf sums: the same tree, hence the same pairs
+      ReplayLeaves rl{leaf_sums[lane], 0};
+      total += PairwiseWalk<7, ReplayLeaves>::run(rl, off + o, m);
+    }
+    __builtin_amdgcn_wave_barrier();  // the next piece overwrites the scratch
+  }
+  return total;
+}
+
+constexpr int kSumWaves = 4;  // waves per workgroup, each with its own scratch
+
+__global__ __launch_bounds__(64 * kSumWaves) void window_pattern_sums_kernel(PatternArgs a) {
+  __shared__ LeafList lists[kSumWaves];
+  __shared__ double leaf_sums[kSumWaves][kPatternSlots][kMaxLeaves];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int64_t item = static_cast<int64_t>(blockIdx.x) * kSumWaves + wv;  // (window, source)
+  if (item >= static_cast<int64_t>(a.n_windows) * a.n_src) return;       // whole wave
+  const int src = static_cast<int>(item % a.n_src);
+  const int w = static_cast<int>(item / a.n_src);
+  FourPopElems e;
   e.fr = a.freqs;
   e.ft = a.freqs + a.n_sites;
   e.fs = a.freqs + static_cast<int64_t>(2 + src) * a.n_sites;
   e.fo = a.has_out ? a.freqs + static_cast<int64_t>(2 + a.n_src) * a.n_sites : nullptr;
-  //                 abba  baba  bbaa  baaa  abaa  abba_d baba_d   (bit0 ref, bit1 tgt, bit2 src, bit3 out)
-  const int bits[kPatternSlots] = {0x6, 0x5, 0x3, 0x1, 0x2, 0x6, 0x5};
-  e.bits = bits[slot];
-  e.donor = slot >= 5;
   const int lo = a.lo[w], hi = a.hi[w];
-  a.sums[tid] = numpy_sum(e, lo, hi - lo);
+  const double total = wave_numpy_sum(e, lo, hi - lo, lane, &lists[wv], leaf_sums[wv]);
+  if (lane < kPatternSlots) a.sums[item * kPatternSlots + lane] = total;
+}
+
+__global__ __launch_bounds__(64) void pattern_sum_kernel(OnePatternElem e, int64_t n, double* out) {
+  __shared__ LeafList list;
+  __shared__ double leaf_sums[1][kMaxLeaves];
+  const int lane = threadIdx.x;
+  // np.sum's buffer pieces are counted from the start of the array; int offsets cover 2^31 elements
+  const double total = wave_numpy_sum(e, 0, static_cast<int>(n), lane, &list, leaf_sums);
+  if (lane == 0) *out = total;
 }
 
 __device__ __forceinline__ double ratio_or_nan(double num, double den) {
@@ -157,13 +320,31 @@ int sai_window_fourpop(sai_ctx* ctx, int64_t n_sites, int32_t n_src, int32_t has
   a.hi = hi;
   a.sums = sums;
   a.stats = stats;
-  const int64_t n_sum = static_cast<int64_t>(n_windows) * n_src * kPatternSlots;
+  const int64_t n_items = static_cast<int64_t>(n_windows) * n_src;  // one wavefront each
   hipStream_t st = static_cast<hipStream_t>(stream);
-  hipLaunchKernelGGL(window_pattern_sums_kernel, dim3(static_cast<unsigned>((n_sum + 63) / 64)), dim3(64), 0, st, a);
+  hipLaunchKernelGGL(window_pattern_sums_kernel, dim3(static_cast<unsigned>((n_items + kSumWaves - 1) / kSumWaves)),
+                     dim3(64 * kSumWaves), 0, st, a);
   if (int rc = check_launch("window_pattern_sums")) return rc;
   const int64_t n_stat = static_cast<int64_t>(n_windows) * n_src;
   hipLaunchKernelGGL(window_fourpop_kernel, dim3(static_cast<unsigned>((n_stat + 255) / 256)), dim3(256), 0, st, a);
   return check_launch("window_fourpop");
+}
+
+int sai_pattern_sum(sai_ctx* ctx, int64_t n_sites, const double* ref_freq, const double* tgt_freq,
+                    const double* src_freq, const double* out_freq, int32_t pattern_bits, double* sum_out,
+                    void* stream) {
+  if (int rc = enter(ctx)) return rc;
+  if (n_sites < 0 || n_sites >= 0x7FFFFFFFll) return fail(SAI_ERR_ARG, "n_sites out of range");
+  if (pattern_bits < 0 || pattern_bits > 15) return fail(SAI_ERR_ARG, "pattern_bits must be 0..15");
+  if (!sum_out || (n_sites > 0 && (!ref_freq || !tgt_freq || !src_freq || !out_freq))) return fail(SAI_ERR_ARG, "NULL buffer");
+  OnePatternElem e;
+  e.f[0] = ref_freq;
+  e.f[1] = tgt_freq;
+  e.f[2] = src_freq;
+  e.f[3] = out_freq;
+  e.bits = pattern_bits;
+  hipLaunchKernelGGL(pattern_sum_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), e, n_sites, sum_out);
+  return check_launch("pattern_sum");
 }
 
 }  // extern "C"

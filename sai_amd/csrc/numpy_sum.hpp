@@ -26,7 +26,10 @@ __device__ __forceinline__ double pairwise_leaf(const E& e, int off, int n) {
   return res;
 }
 
-// recursion of numpy's pairwise sum unrolled to the depth an 8192-element piece can reach
+// recursion of numpy's pairwise sum unrolled to the depth an 8192-element piece can reach: SEVEN
+// levels -- the right halves are up to 7 elements larger than the left ones (n2 is rounded down to
+// a multiple of 8), so pieces of 7689..8191 elements still hold a node of 129..135 elements six
+// levels down, which numpy splits once more
 template <int DEPTH, typename E>
 struct PairwiseNode {
   static __device__ __noinline__ double run(const E& e, int off, int n) {
@@ -45,6 +48,6 @@ struct PairwiseNode<0, E> {
 template <typename E>
 __device__ __forceinline__ double numpy_sum(const E& e, int off, int n) {
   double res = 0.0;
-  for (int o = 0; o < n; o += 8192) res += PairwiseNode<6, E>::run(e, off + o, min(8192, n - o));
+  for (int o = 0; o < n; o += 8192) res += PairwiseNode<7, E>::run(e, off + o, min(8192, n - o));
   return res;
 }

@@ -313,6 +313,24 @@ class Engine:
         )  # fmt: skip
         return stats
 
+    def pattern_sum(self, ref_freq, tgt_freq, src_freq, out_freq, pattern_bits: int) -> float:
+        """np.sum over the sites of the per-site pattern product (calc_pattern_sum's arithmetic) of
+        four f64 frequency arrays (host numpy or device tensors of one length)."""
+        torch = _torch()
+        dev = []
+        for f in (ref_freq, tgt_freq, src_freq, out_freq):
+            t = f if isinstance(f, torch.Tensor) else torch.as_tensor(np.ascontiguousarray(f, dtype=np.float64))
+            dev.append(t.to(self.device, dtype=torch.float64).contiguous())
+        n = int(dev[0].numel())
+        if any(int(t.numel()) != n for t in dev):
+            raise ValueError("frequency arrays must have the same length")
+        out = self._empty((1,), torch.float64)
+        _ffi.check(
+            self.lib.sai_pattern_sum(self.ctx, n, self._ptr(dev[0]), self._ptr(dev[1]), self._ptr(dev[2]), self._ptr(dev[3]),
+                                     int(pattern_bits), self._ptr(out), self._stream())
+        )  # fmt: skip
+        return float(out.item())
+
     def site_absdiff(self, pop: TiledPop, src: TiledPop):
         """int32 [src.n_ind][n_sites]: per site, sum over pop's individuals of |src - g| (DD's
         per-site city-block terms)."""

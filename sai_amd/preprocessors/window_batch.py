@@ -68,7 +68,7 @@ class WindowBatch:
                  arrays=[dict(dtype=a.dtype.str, shape=list(a.shape)) for a in arrays])  # fmt: skip
         ).encode()
         parts = [_MAGIC, struct.pack("<q", len(head)), head]
-        parts.extend(b"\0" * (-sum(map(len, parts)) % 8))  # payload starts 8-byte aligned
+        parts.append(b"\0" * (-sum(map(len, parts)) % 8))  # payload starts 8-byte aligned
         for a in arrays:
             raw = a.tobytes()
             parts.append(raw)

@@ -83,3 +83,38 @@ def compute_matching_loci(
     adj = adj.cpu().numpy()
     cond = (flags[0].cpu().numpy() & FLAG_COND).astype(bool)
     return adj[0, 0].copy(), adj[0, 1].copy(), cond
+
+
+def calc_four_pops_freq(ref_gts, tgt_gts, src_gts, out_gts=None, ref_ploidy: int = 1, tgt_ploidy: int = 1,
+                        src_ploidy: int = 1, out_ploidy: int = 1):  # fmt: skip
+    """(ref_freq, tgt_freq, src_freq, out_freq) of one window (stat_utils.py:171-217): ``calc_freq``
+    of each population -- one site_counts + one site_freqs launch for all of them -- and an outgroup
+    frequency of 0 everywhere when ``out_gts`` is None."""
+    mats, ploidy = [ref_gts, tgt_gts, src_gts], [ref_ploidy, tgt_ploidy, src_ploidy]
+    if out_gts is not None:
+        mats.append(out_gts)
+        ploidy.append(out_ploidy)
+    for p in ploidy:
+        _check_ploidy(p)
+    eng = Engine.get()
+    pops = [eng.tile(m) for m in mats]
+    if len({p.n_sites for p in pops}) != 1:
+        raise ValueError("genotype matrices must have the same number of sites")
+    freqs = eng.site_freqs(eng.site_counts(pops), ploidy).cpu().numpy()
+    out_freq = freqs[3].copy() if out_gts is not None else np.zeros_like(freqs[0])
+    return freqs[0].copy(), freqs[1].copy(), freqs[2].copy(), out_freq
+
+
+def calc_pattern_sum(ref_freq, tgt_freq, src_freq, out_freq, pattern: str) -> float:
+    """Sum over sites of the product picked by a four-letter pattern over (ref, tgt, src, out):
+    'b' takes the frequency, 'a' one minus it (stat_utils.py:220-272, same ValueErrors); the
+    products and the sum are formed on the GPU in numpy's order, so the result is np.sum's double."""
+    if len(pattern) != 4:
+        raise ValueError("Pattern must be a four-character string.")
+    bits = 0
+    for k, c in enumerate(pattern.lower()):
+        if c == "b":
+            bits |= 1 << k
+        elif c != "a":
+            raise ValueError(f"Invalid character '{c}' in pattern. Only 'a' and 'b' allowed.")
+    return Engine.get().pattern_sum(ref_freq, tgt_freq, src_freq, out_freq, bits)

@@ -505,3 +505,73 @@ def test_window_bounds_equals_searchsorted(eng, n_sites):
     want_lo = np.searchsorted(pos, starts, side="left")
     want_hi = np.maximum(np.searchsorted(pos, ends, side="right"), want_lo)
     assert np.array_equal(lo.cpu().numpy(), want_lo) and np.array_equal(hi.cpu().numpy(), want_hi)
+
+
+# ---- np.sum's order in parallel (fourpop.hip: wave_numpy_sum) -------------------------------
+
+
+@pytest.mark.parametrize("n", [0, 1, 7, 8, 9, 127, 128, 129, 135, 136, 263, 1000, 2001, 4097, 7688, 7689, 7693, 8191, 8192,
+                               8193, 16384 + 7700, 3 * 8192 + 5])  # fmt: skip
+def test_pattern_sum_is_np_sum_bit_for_bit(eng, n):
+    """calc_pattern_sum on the GPU against numpy itself: the products in population order, the sum
+    in np.sum's order (8192-element pieces, pairwise halving, eight running sums per leaf).  Sizes
+    7689..8191 are the pieces whose halving tree is seven levels deep (a six-level unrolling summed a
+    129..135-element node as one leaf and differed from numpy in the last bits)."""
+    from oracle import sai_oracle as O
+    from sai_amd.stats import calc_pattern_sum
+
+    rng = np.random.default_rng(n + 1)
+    f = [rng.random(n) ** 3 for _ in range(4)]
+    for pattern in ("abba", "baba", "bbaa", "baaa", "abaa", "bbbb", "aaab"):
+        prod = np.ones_like(f[0])
+        for k, c in enumerate(pattern):
+            prod *= f[k] if c == "b" else 1 - f[k]
+        want = float(np.sum(prod))
+        got = calc_pattern_sum(f[0], f[1], f[2], f[3], pattern)
+        assert same_f64(got, want), (n, pattern, got.hex(), want.hex())
+        assert same_f64(O.numpy_sum(prod), want)  # the oracle's restatement agrees with numpy as well
+    with pytest.raises(ValueError, match="four-character"):
+        calc_pattern_sum(f[0], f[1], f[2], f[3], "abb")
+    with pytest.raises(ValueError, match="Invalid character 'c'"):
+        calc_pattern_sum(f[0], f[1], f[2], f[3], "abca")
+
+
+def test_window_pattern_sums_at_seven_level_sizes(eng):
+    """sai_window_fourpop on windows whose site counts need the seven-level tree, several sources,
+    NaN sites, against the oracle's four_pop_stats (pinned to the reference's golden capture)."""
+    import torch
+
+    from oracle import sai_oracle as O
+
+    rng = np.random.default_rng(77)
+    n_sites, n_src = 30_000, 2
+    mats = [rng.integers(0, 3, size=(n_sites, k)).astype(np.int8) for k in (9, 7, 2, 3, 5)]  # ref, tgt, s0, s1, out
+    mats[1][rng.random(mats[1].shape) < 0.01] = -2
+    mats[2][5000] = -2  # an all-missing source site: NaN poisons the windows that hold it
+    pops = [eng.tile(m) for m in mats]
+    freqs = eng.site_freqs(eng.site_counts(pops), [2] * 5)
+    bounds = [(0, 7689), (100, 100 + 8191), (3, 3 + 7700), (0, 30_000), (6000, 6000 + 8192 + 7693), (10, 17), (20, 20)]
+    lo = torch.tensor([b[0] for b in bounds], dtype=torch.int32, device=eng.device)
+    hi = torch.tensor([b[1] for b in bounds], dtype=torch.int32, device=eng.device)
+    got = eng.window_fourpop(freqs, n_src, True, lo, hi).cpu().numpy()
+    for wi, (a, b) in enumerate(bounds):
+        if b == a:
+            continue
+        sub = [m[a:b].astype(np.int64) for m in mats]
+        want = O.four_pop_stats(sub[0], sub[1], sub[2:4], sub[4], 2, 2, [2, 2], 2)
+        for si in range(n_src):
+            for k, name in enumerate(("fd", "df", "Danc", "Dplus")):
+                assert same_f64(got[wi, si, k], want[name][si]), (wi, si, name, got[wi, si, k], want[name][si])
+
+
+def test_calc_four_pops_freq_matches_calc_freq(eng):
+    from sai_amd.stats import calc_four_pops_freq, calc_freq
+
+    rng = np.random.default_rng(3)
+    mats = [rng.integers(-1, 3, size=(300, k)).astype(np.int64) for k in (5, 4, 2, 3)]
+    r, t, s, o = calc_four_pops_freq(mats[0], mats[1], mats[2], mats[3], 2, 2, 2, 2)
+    for got, m in zip((r, t, s, o), mats):
+        want = calc_freq(m, 2)
+        assert np.array_equal(np.isnan(got), np.isnan(want)) and np.array_equal(got[~np.isnan(got)], want[~np.isnan(want)])
+    r2, t2, s2, o2 = calc_four_pops_freq(mats[0], mats[1], mats[2], ref_ploidy=2, tgt_ploidy=2, src_ploidy=2)
+    assert np.array_equal(o2, np.zeros(300)) and np.array_equal(np.nan_to_num(r2), np.nan_to_num(r))

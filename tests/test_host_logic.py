@@ -415,3 +415,57 @@ def test_outlier_reference_pins_and_natural_order(in_repo_root, tmp_path):
     assert natsorted_df(pd.DataFrame(columns=["Chrom", "Start", "End"])).empty
     t = natsorted_df(pd.DataFrame({"Chrom": ["1", "2", "X"], "Start": ["100", "200", "300"], "End": ["150", "250", "350"]}))
     assert t["Start"].dtype == int and t["End"].dtype == int
+
+
+def test_window_batch_bytes_round_trip_and_single_chunk_order(tmp_path):
+    """The numeric batch a rank sends to rank 0 (records + CSR lists + optional f64 blocks) survives
+    to_bytes / from_bytes bit for bit, and items_from_batches emits several chunks in the order ONE
+    chunk would: combination-major, windows in chunk order."""
+    from sai_amd.configs import StatConfig
+    from sai_amd.engine import RECORD_DTYPE, WindowResults
+    from sai_amd.preprocessors import FeaturePreprocessor
+    from sai_amd.preprocessors.window_batch import ComboBatch, WindowBatch
+
+    rng = np.random.default_rng(12)
+
+    def combo(ref, tgt, w0, n_w, with_extra):
+        rec = np.zeros((2, n_w), dtype=RECORD_DTYPE)
+        rec["n_sites"] = rng.integers(0, 30, (1, n_w))
+        rec["u_count"][0] = rng.integers(0, 4, n_w)
+        rec["n_cond"][1] = rng.integers(0, 3, n_w)
+        rec["n_cdd_q"][1] = np.minimum(rec["n_cond"][1], rng.integers(1, 3, n_w))
+        rec["q"] = rng.random((2, n_w))
+        rec["q"][1][rec["n_cond"][1] == 0] = np.nan
+        off = np.zeros((2, n_w, 2), dtype=np.int64)
+        for k, name in enumerate(("u_count", "n_cdd_q")):
+            flat = rec[name].reshape(-1).astype(np.int64)
+            off[:, :, k] = (np.cumsum(flat) - flat).reshape(2, n_w)
+        uq = WindowResults(rec, off, rng.integers(1, 9999, int(rec["u_count"].sum())).astype(np.int32),
+                           rng.integers(1, 9999, int(rec["n_cdd_q"].sum())).astype(np.int32))  # fmt: skip
+        win = np.array([[1 + 100 * (w0 + i), 200 + 100 * (w0 + i)] for i in range(n_w)], dtype=np.int64)
+        return ComboBatch(ref, tgt, ("s1", "s2"), None, win, rec[0]["n_sites"].astype(np.int32), ["U", "Q"], uq,
+                          rng.random((n_w, 2, 4)) if with_extra else None, rng.random((n_w, 2)) if with_extra else None)  # fmt: skip
+
+    chunks = [WindowBatch("9", [combo("r", "t1", 0, 3, True), combo("r", "t2", 0, 3, False)]),
+              WindowBatch("9", [combo("r", "t1", 3, 2, True), combo("r", "t2", 3, 2, False)])]  # fmt: skip
+    for b in chunks:
+        back = WindowBatch.from_bytes(b.to_bytes())
+        assert back.chr_name == b.chr_name and len(back.combos) == len(b.combos)
+        for x, y in zip(back.combos, b.combos):
+            assert (x.ref_pop, x.tgt_pop, x.src_comb, x.out_pop, x.uq_names, x.pos_dtype) == (y.ref_pop, y.tgt_pop, y.src_comb, y.out_pop, y.uq_names, y.pos_dtype)
+            assert x.windows.tobytes() == y.windows.tobytes() and x.nsnps.tobytes() == y.nsnps.tobytes()
+            assert x.uq.records.tobytes() == y.uq.records.tobytes() and np.array_equal(x.uq.offsets, y.uq.offsets)
+            assert x.uq.cdd_u.tobytes() == y.uq.cdd_u.tobytes() and x.uq.cdd_q.tobytes() == y.uq.cdd_q.tobytes()
+            for a, c in ((x.four, y.four), (x.dd, y.dd)):
+                assert (a is None and c is None) or a.tobytes() == c.tobytes()
+    with pytest.raises(ValueError):
+        WindowBatch.from_bytes(b"nonsense")
+    sc = StatConfig({"U": {"ref": {"r": 0.1}, "tgt": {"t1": 0.5, "t2": 0.5}, "src": {"s1": "=1", "s2": "=1"}},
+                     "Q": {"ref": {"r": 0.1}, "tgt": {"t1": 0.9, "t2": 0.9}, "src": {"s1": "=1", "s2": "=1"}}})  # fmt: skip
+    fp = FeaturePreprocessor(str(tmp_path / "o.tsv"), sc)
+    merged = fp.items_from_batches([WindowBatch.from_bytes(b.to_bytes()) for b in chunks])
+    assert [(it["tgt_pop"], it["start"]) for it in merged] == [("t1", 1 + 100 * i) for i in range(5)] + [("t2", 1 + 100 * i) for i in range(5)]
+    per_chunk = [it for b in chunks for it in fp.items_from_batch(b)]
+    assert sorted((it["tgt_pop"], it["start"], it["U"]) for it in merged) == sorted((it["tgt_pop"], it["start"], it["U"]) for it in per_chunk)
+    for it in merged:
+        assert isinstance(it["U"], int) and len(it["cdd_pos"]["U"]) == it["U"] or it["nsnps"] == 0
