@@ -102,87 +102,93 @@ struct OnePatternElem {
 // beyond 8192 sites).
 // ------------------------------------------------------------------------------------------
 
-constexpr int kMaxLeaves = 80;  // an 8192-element piece has at most 65 leaves (sizes 64..128)
+constexpr int kMaxLeaves = 72;  // an 8192-element piece has at most 65 leaves (sizes 64..128)
+constexpr int kMaxDepth = 8;    // ... at most seven levels down (numpy_sum.hpp)
 
 struct LeafList {
   int off[kMaxLeaves];
-  int n[kMaxLeaves];
+  short n[kMaxLeaves];
+  short depth[kMaxLeaves];
+  int stack_off[kMaxDepth + 1];
+  short stack_n[kMaxDepth + 1];
+  short stack_depth[kMaxDepth + 1];
   int count;
 };
 
-// the recursion of numpy's pairwise sum with a caller-supplied leaf action, unrolled to the depth
-// an 8192-element piece can reach (seven levels, see numpy_sum.hpp)
-template <int DEPTH, typename Leaf>
-struct PairwiseWalk {
-  static __device__ __noinline__ double run(Leaf& leaf, int off, int n) {
-    if (n <= 128) return leaf(off, n);
-    int n2 = n / 2;
-    n2 -= n2 % 8;
-    const double a = PairwiseWalk<DEPTH - 1, Leaf>::run(leaf, off, n2);
-    const double b = PairwiseWalk<DEPTH - 1, Leaf>::run(leaf, off + n2, n - n2);
-    return a + b;
-  }
-};
-template <typename Leaf>
-struct PairwiseWalk<0, Leaf> {
-  static __device__ __noinline__ double run(Leaf& leaf, int off, int n) { return leaf(off, n); }
-};
-
-struct ListLeaves {
-  LeafList* list;
-  __device__ __forceinline__ double operator()(int off, int n) {
-    const int k = list->count++;
-    if (k < kMaxLeaves) {
-      list->off[k] = off;
-      list->n[k] = n;
+// Leaves of numpy's halving tree over elements [off, off + n), n <= 8192, in left-to-right order
+// with their depths (one lane; an explicit stack instead of the recursion).
+__device__ __forceinline__ void list_leaves(LeafList* L, int off, int n) {
+  int sp = 0, count = 0;
+  L->stack_off[0] = off;
+  L->stack_n[0] = static_cast<short>(n);
+  L->stack_depth[0] = 0;
+  while (sp >= 0) {
+    const int a = L->stack_off[sp];
+    const int len = L->stack_n[sp];
+    const int d = L->stack_depth[sp];
+    --sp;
+    if (len <= 128) {
+      if (count < kMaxLeaves) {
+        L->off[count] = a;
+        L->n[count] = static_cast<short>(len);
+        L->depth[count] = static_cast<short>(d);
+      }
+      ++count;
+    } else {
+      int n2 = len / 2;
+      n2 -= n2 % 8;
+      ++sp;  // right half waits on the stack, the left half is visited first
+      L->stack_off[sp] = a + n2;
+      L->stack_n[sp] = static_cast<short>(len - n2);
+      L->stack_depth[sp] = static_cast<short>(d + 1);
+      ++sp;
+      L->stack_off[sp] = a;
+      L->stack_n[sp] = static_cast<short>(n2);
+      L->stack_depth[sp] = static_cast<short>(d + 1);
     }
-    return 0.0;
   }
-};
+  L->count = count;
+}
 
-struct ReplayLeaves {
-  const double* sums;  // this slot's leaf sums, in leaf order
-  int next;
-  __device__ __forceinline__ double operator()(int, int) { return sums[next++]; }
-};
-
-// np.sum over elements [off, off + n) for every slot of `e`; the whole wave calls it, lane 0..kSlots-1
-// return their slot's sum in `out`.  `list` and `leaf_sums` are this wave's LDS scratch.
+// np.sum over elements [off, off + n) for every slot of `e`; the whole wave calls it, lanes
+// 0..kSlots-1 return their slot's sum.  `list` and `leaf_sums` are this wave's LDS scratch.
 template <typename E>
 __device__ __forceinline__ double wave_numpy_sum(const E& e, int off, int n, int lane, LeafList* list,
                                                  double (*leaf_sums)[kMaxLeaves]) {
   constexpr int S = E::kSlots;
-  double total = 0.0;  // meaningful in lanes < S
+  constexpr int kBatch = 4;  // leaf iterations whose loads are in flight together
+  double total = 0.0;        // meaningful in lanes < S
   for (int o = 0; o < n; o += 8192) {
     const int m = min(8192, n - o);
-    if (lane == 0) {
-      list->count = 0;
-      ListLeaves ll{list};
-      PairwiseWalk<7, ListLeaves>::run(ll, off + o, m);
-    }
+    if (lane == 0) list_leaves(list, off + o, m);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    const int n_leaves = list->count;  // <= kMaxLeaves by construction (at most 65 leaves)
+    const int n_leaves = list->count;  // <= 65
     const int j = lane & 7, g = lane >> 3;
     for (int lb = 0; lb < n_leaves; lb += 8) {
       const int leaf = lb + g;
       const bool live = leaf < n_leaves;
       const int lo = live ? list->off[leaf] : 0;
       const int ln = live ? list->n[leaf] : 0;
+      const int body = ln - (ln % 8);  // the part the eight running sums cover (0 when ln < 8)
       double r[S];
 #pragma unroll
       for (int s = 0; s < S; ++s) r[s] = 0.0;
-      if (ln >= 8) {
-        double p[S];
-        e(lo + j, p);
+      // r[j] = a[j]; r[j] += a[i + j] for i = 8, 16, ...: kBatch iterations' loads go out together
+      // (indices clamped into the leaf, results of iterations past its end dropped), so a lane
+      // waits for memory 4 times per full leaf instead of 16
+      for (int i0 = 0; i0 < body; i0 += 8 * kBatch) {
+        double p[kBatch][S];
 #pragma unroll
-        for (int s = 0; s < S; ++s) r[s] = p[s];
-        const int body = ln - (ln % 8);
-        for (int i = 8; i < body; i += 8) {
-          e(lo + i + j, p);
+        for (int u = 0; u < kBatch; ++u) e(lo + min(i0 + 8 * u, body - 8) + j, p[u]);
 #pragma unroll
-          for (int s = 0; s < S; ++s) r[s] += p[s];
+        for (int u = 0; u < kBatch; ++u) {
+          const int i = i0 + 8 * u;
+          if (i < body) {
+#pragma unroll
+            for (int s = 0; s < S; ++s) r[s] = (i == 0) ? p[u][s] : r[s] + p[u][s];
+          }
         }
       }
       // close the eight running sums: ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)); lanes of dead or short
@@ -198,17 +204,11 @@ __device__ __forceinline__ double wave_numpy_sum(const E& e, int off, int n, int
         if (ln < 8) {  // numpy's plain loop: res = 0.; res += a[i]
 #pragma unroll
           for (int s = 0; s < S; ++s) r[s] = 0.0;
-          for (int i = 0; i < ln; ++i) {
-            e(lo + i, p);
+        }
+        for (int i = body; i < ln; ++i) {  // the whole of a short leaf, or the tail after the eight-way body
+          e(lo + i, p);
 #pragma unroll
-            for (int s = 0; s < S; ++s) r[s] += p[s];
-          }
-        } else {
-          for (int i = ln - (ln % 8); i < ln; ++i) {  // the tail after the eight-way body
-            e(lo + i, p);
-#pragma unroll
-            for (int s = 0; s < S; ++s) r[s] += p[s];
-          }
+          for (int s = 0; s < S; ++s) r[s] += p[s];
         }
 #pragma unroll
         for (int s = 0; s < S; ++s) leaf_sums[s][leaf] = r[s];
@@ -217,9 +217,31 @@ __device__ __forceinline__ double wave_numpy_sum(const E& e, int off, int n, int
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    if (lane < S) {  // replay the recursion over the leaf sums: the same tree, hence the same pairs
-      ReplayLeaves rl{leaf_sums[lane], 0};
-      total += PairwiseWalk<7, ReplayLeaves>::run(rl, off + o, m);
+    if (lane < S) {
+      // Rebuild the tree from the leaves' depths: a finished subtree at depth d either waits as a
+      // left child (pend[d]) or meets the left sibling waiting there and becomes left + right, one
+      // level up -- the recursion's `run(left) + run(right)`, pair for pair.
+      double pend[kMaxDepth];
+      unsigned waiting = 0;
+      double piece = 0.0;
+      for (int k = 0; k < n_leaves; ++k) {
+        double v = leaf_sums[lane][k];
+        int d = list->depth[k];
+#pragma unroll
+        for (int lv = kMaxDepth - 1; lv >= 1; --lv) {
+          if (d == lv && (waiting >> lv & 1u)) {
+            v = pend[lv] + v;
+            waiting ^= 1u << lv;
+            d = lv - 1;
+          }
+        }
+#pragma unroll
+        for (int lv = kMaxDepth - 1; lv >= 1; --lv)
+          if (d == lv) pend[lv] = v;
+        if (d > 0) waiting |= 1u << d;
+        else piece = v;
+      }
+      total += piece;
     }
     __builtin_amdgcn_wave_barrier();  // the next piece overwrites the scratch
   }
@@ -232,7 +254,8 @@ __global__ __launch_bounds__(64 * kSumWaves) void window_pattern_sums_kernel(Pat
   __shared__ LeafList lists[kSumWaves];
   __shared__ double leaf_sums[kSumWaves][kPatternSlots][kMaxLeaves];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int64_t item = static_cast<int64_t>(blockIdx.x) * kSumWaves + wv;  // (window, source)
+  // (window, source); each XCD works on a run of neighbouring windows, which share their sites
+  const int64_t item = static_cast<int64_t>(xcd_contiguous(blockIdx.x, gridDim.x)) * kSumWaves + wv;
   if (item >= static_cast<int64_t>(a.n_windows) * a.n_src) return;       // whole wave
   const int src = static_cast<int>(item % a.n_src);
   const int w = static_cast<int>(item / a.n_src);

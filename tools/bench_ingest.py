@@ -1,7 +1,7 @@
 """Throughput of the native VCF tokenizer vs the Python reader on a synthetic VCF (host only)."""
 import os, sys, time, tempfile
 import numpy as np
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from sai_amd.utils.native_vcf import load_dosage, default_threads
 from sai_amd.utils.read_data import _load_python
 

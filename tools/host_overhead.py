@@ -1,7 +1,7 @@
 """Host time of one ResidentScorer.step() (enqueue only): tiny block, so the GPU never limits."""
 import sys, time
 import torch
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from sai_amd import _ffi
 from sai_amd.engine import Engine
 from sai_amd.resident import ResidentScorer, default_windows, synth_block

@@ -2,7 +2,7 @@
 pays when it keeps the reference's one-window-at-a-time API.  Never the bench `value`."""
 import sys, time
 import numpy as np
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import sai_amd.stats
 from sai_amd.stats import QStatistic, UStatistic
 rng = np.random.default_rng(0)

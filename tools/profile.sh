@@ -1,15 +1,20 @@
 #!/bin/bash
 # Run on the GPU box (via gpurun): kernel trace + the two PMC passes of the bench command.
-# Usage: bash tools/profile.sh <tag> [extra bench flags]   -> gpurun_out/prof_<tag>/...
+# Usage: bash tools/profile.sh <tag> <workload> [extra bench flags]   -> gpurun_out/prof_<tag>/...
+# Counters are collected in their own passes (--pmc with --kernel-trace only), as the guide's
+# HBM / rocprofv3 section prescribes; the program itself follows `--` (no env/bash hop).
 set -o pipefail
-TAG=${1:-r01}
-shift
+TAG=${1:-r02_c3}
+WL=${2:-c3}
+shift; shift
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-CMD="python3 $ROOT/bench.py --steps 10 --warmup 2 --cpu-sites 0 $*"
+CMD="python3 $ROOT/bench.py --workload $WL --steps 10 --warmup 2 --cpu-sites 0 --score-path off $*"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $CMD > $OUT/trace.log 2>&1 || exit 1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- $CMD > $OUT/pmc_fetch.log 2>&1 || exit 2
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- $CMD > $OUT/pmc_write.log 2>&1 || exit 3
+# keep what the summariser reads (the raw traces of a C4 run are large)
+find $OUT -name "*.csv" -size +40M -delete
 find $OUT -name "*.csv" | head -20

@@ -1,7 +1,7 @@
 """Scratch timing of the packed2 site pass on the C3-shaped block."""
 import sys
 import torch
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from sai_amd.engine import Engine
 from sai_amd import _ffi
 

@@ -1,7 +1,7 @@
 """End-to-end `score` on a synthetic VCF (host parse -> GPU -> TSV): where does the time go?"""
 import cProfile, io, os, pstats, sys, tempfile, time
 import numpy as np
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 
 n_sites = int(float(sys.argv[1])) if len(sys.argv) > 1 else 50000
 n_ref, n_tgt, n_src = 1000, 1000, 2

@@ -8,9 +8,10 @@ import csv, glob, json, shutil, sys
 from collections import defaultdict
 from pathlib import Path
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
-workload_key = sys.argv[2] if len(sys.argv) > 2 else "10000000x1000+1000+2"
-warmup = int(sys.argv[3]) if len(sys.argv) > 3 else 2
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02_c3"
+workload_key = sys.argv[2] if len(sys.argv) > 2 else "c3"  # bench.py's workload id (+ ":packed2")
+# launches before the timed region: the set-up pass that fixes the row layout + the warm-up steps
+warmup = int(sys.argv[3]) if len(sys.argv) > 3 else 3
 dominant = sys.argv[4] if len(sys.argv) > 4 else "site_counts"
 src = Path("gpurun_out") / f"prof_{tag}"
 dst = Path("profiles")

@@ -1,5 +1,5 @@
 import os, sys, torch
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from sai_amd.engine import Engine
 n_sites = 10_000_000
 eng = Engine.get(0)

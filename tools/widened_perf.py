@@ -3,7 +3,7 @@ outgroup: 1e7 sites, 1000 ref / 1000 tgt / 2 src / 100 outgroup diploids, 50 kb 
 import sys
 import numpy as np
 import torch
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from sai_amd.engine import Engine
 
 n_sites = int(float(sys.argv[1])) if len(sys.argv) > 1 else 10_000_000
