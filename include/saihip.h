@@ -11,7 +11,8 @@
  *   - every function returns an int status: 0 = ok, <0 = error class (enum sai_status);
  *     sai_last_error() returns thread-local text for the last failure on the calling thread;
  *   - the caller owns every buffer; all data pointers are DEVICE pointers unless the name ends in
- *     _host; the library allocates nothing but the small sai_ctx;
+ *     _host; the library allocates nothing but the small sai_ctx and, inside it, the scratch of
+ *     sai_single_window;
  *   - `stream` is a hipStream_t passed as void* (NULL = default stream); all work is enqueued on
  *     it and no entry point synchronises unless documented;
  *   - a ctx is bound to one device and is not thread-safe; distinct ctxs are independent;
@@ -38,7 +39,7 @@
 extern "C" {
 #endif
 
-#define SAI_ABI_VERSION 5
+#define SAI_ABI_VERSION 6
 #define SAI_TILE_SITES 64
 #define SAI_MAX_SRC 6   /* source populations per call */
 #define SAI_MAX_SETS 16 /* parameter sets per call */
@@ -181,6 +182,19 @@ int sai_window_stats(sai_ctx* ctx, int64_t n_sites, const double* tgt_freq, cons
                      const int32_t* lo, const int32_t* hi, const int32_t* pos,
                      sai_window_record* records, int64_t* cdd_off, int32_t* cdd_u, int64_t cap_u,
                      int32_t* cdd_q, int64_t cap_q, int64_t* cdd_total, void* stream);
+
+/* One window per call -- the whole of UStatistic.compute (u_statistic.py:79-99) and
+ * QStatistic.compute (q_statistic.py:79-104) for the plugin classes: the fused site pass over the
+ * window's blocks (`pops` = ref, tgt, sources as DEVICE tiled blocks of exactly the window's
+ * n_sites sites), the window statistics over all of them, and the results in the caller's HOST
+ * buffers: *record_host, and the U / Q candidates as 0-based site indices (ascending) in
+ * cdd_u_host / cdd_q_host, each with room for n_sites entries (record_host->u_count and
+ * ->n_cdd_q say how many were written).  Unlike the other entry points this one SYNCHRONISES
+ * `stream` before it returns and keeps its device and pinned-host scratch in the ctx (grown on
+ * demand, released by sai_ctx_destroy).  n_sites == 0 gives U = 0 and Q = NaN. */
+int sai_single_window(sai_ctx* ctx, int64_t n_sites, int32_t n_pops, const sai_pop* pops,
+                      const sai_params* set_host, sai_window_record* record_host, int32_t* cdd_u_host,
+                      int32_t* cdd_q_host, void* stream);
 
 /* ---- ABBA-BABA family: fd, df, Danc, Dplus --------------------- */
 

@@ -20,7 +20,7 @@ SAI_MAX_SETS = 16
 SAI_FUSED_SETS = 4
 SAI_ERR_UNSUPPORTED = -4  # enum sai_status
 FREQ_MODES = {"dense": 0, "candidates": 1}  # enum sai_freq_mode
-SAI_ABI_VERSION = 5
+SAI_ABI_VERSION = 6
 
 OPS = {"=": 0, "<": 1, ">": 2, "<=": 3, ">=": 4}
 
@@ -87,6 +87,10 @@ SIGNATURES = {
     "sai_window_stats": (
         C.c_int,
         [_p, _i64, _p, _p, _i32, C.POINTER(SaiParams), _i32, _p, _p, _p, _p, _p, _p, _i64, _p, _i64, _p, _p],
+    ),
+    "sai_single_window": (
+        C.c_int,
+        [_p, _i64, _i32, C.POINTER(SaiPop), C.POINTER(SaiParams), C.POINTER(SaiWindowRecord), _p, _p, _p],
     ),
     "sai_site_freqs": (C.c_int, [_p, _i64, _i32, C.POINTER(_i32), _p, _p, _p]),
     "sai_window_fourpop": (C.c_int, [_p, _i64, _i32, _i32, _p, _i32, _p, _p, _p, _p, _p]),

@@ -37,7 +37,12 @@ constexpr int kStreamWavesPerCu = 16;
 struct sai_ctx {
   int device;
   int n_cu;
-  uint32_t* probe_partials;  // n_cu * kProbeWavesPerCu words, the only scratch the library owns
+  uint32_t* probe_partials;  // n_cu * kProbeWavesPerCu words (stream-read probe)
+  // scratch of sai_single_window, grown on demand, freed by sai_ctx_destroy
+  void* sw_dev;
+  size_t sw_dev_cap;
+  void* sw_host;  // pinned
+  size_t sw_host_cap;
 };
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));

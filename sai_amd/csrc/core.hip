@@ -7,6 +7,7 @@
 //   site_pass.hip  site_counts (the HBM-bound byte reduction), site_flags, the fused site pass
 //   packed2.hip    the optional 2-bit layout and its site pass
 //   windows.hip    window_bounds, window statistics (U count, numpy-'linear' quantile, lists)
+//   single_window.hip  one window per call: the plugin classes' U / Q evaluation in one entry
 //   fourpop.hip    fd / df / Danc / Dplus: frequencies and numpy-ordered pattern sums
 //   dd.hip         DD: per-site city-block terms and their window means
 //   synth.hip      counter-based synthetic data (synth-v1) and the stream-read probe
@@ -104,6 +105,8 @@ int sai_ctx_create(int device, sai_ctx** ctx_out) {
   c->device = device;
   c->n_cu = prop.multiProcessorCount;
   c->probe_partials = nullptr;
+  c->sw_dev = c->sw_host = nullptr;
+  c->sw_dev_cap = c->sw_host_cap = 0;
   if (hipMalloc(&c->probe_partials, sizeof(uint32_t) * c->n_cu * kProbeWavesPerCu) != hipSuccess) {
     delete c;
     return fail(SAI_ERR_HIP, "hipMalloc of the context scratch failed");
@@ -114,6 +117,8 @@ int sai_ctx_create(int device, sai_ctx** ctx_out) {
 
 int sai_ctx_destroy(sai_ctx* ctx) {
   if (ctx && ctx->probe_partials) (void)hipFree(ctx->probe_partials);
+  if (ctx && ctx->sw_dev) (void)hipFree(ctx->sw_dev);
+  if (ctx && ctx->sw_host) (void)hipHostFree(ctx->sw_host);
   delete ctx;
   return SAI_OK;
 }

@@ -123,6 +123,9 @@ class Engine:
         ctx = C.c_void_p()
         _ffi.check(self.lib.sai_ctx_create(self.device_index, C.byref(ctx)))
         self.ctx = ctx
+        self._tile_cache = None  # {id(matrix): (matrix, TiledPop)} while an upload_scope is open
+        self._scope_depth = 0
+        self._staging = None  # pinned int8 buffer the host matrices are narrowed into
 
     def close(self) -> None:
         if getattr(self, "ctx", None):
@@ -150,16 +153,96 @@ class Engine:
 
     # -- layout ----------------------------------------------------------------------------
 
+    def upload_scope(self):
+        """Context manager: inside it, a host matrix handed to ``tile`` more than once (the same
+        object: FeaturePreprocessor.run passes one window's matrices to every configured statistic)
+        is narrowed, uploaded and re-tiled ONCE.  The caller promises not to modify the matrices
+        while the scope is open; nothing is remembered after it closes."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def scope():
+            if self._scope_depth == 0:
+                self._tile_cache = {}
+            self._scope_depth += 1
+            try:
+                yield self
+            finally:
+                self._scope_depth -= 1
+                if self._scope_depth == 0:
+                    self._tile_cache = None
+
+        return scope()
+
+    def _stage_host(self, g: np.ndarray, offset: int):
+        """Narrow a host matrix to int8 [sites][individuals] straight into the engine's pinned
+        staging buffer at ``offset`` (one multithreaded native pass); returns the torch view, or None
+        when the matrix needs the general numpy path (bools, column-strided views, ...)."""
+        native = (g.size and np.issubdtype(g.dtype, np.integer) and g.dtype != np.bool_ and g.strides[1] == g.itemsize
+                  and g.strides[0] > 0 and g.dtype.isnative)  # fmt: skip
+        if not native:
+            return None
+        out = self._staging[offset : offset + g.size].view(g.shape[0], g.shape[1])
+        lib = _ffi.load_host()
+        rc = lib.sai_narrow_to_int8(
+            g.ctypes.data_as(C.c_void_p), g.itemsize, int(np.issubdtype(g.dtype, np.signedinteger)), g.shape[0], g.shape[1],
+            g.strides[0], C.c_void_p(out.data_ptr()), min(os.cpu_count() or 1, 16),
+        )  # fmt: skip
+        if rc == _ffi.SAI_ERR_UNSUPPORTED:
+            raise ValueError("dosage above 127 is not representable in the int8 device layout")
+        _ffi.check(rc, lib)
+        return out
+
     def tile(self, gts) -> TiledPop:
         """Upload a [sites][individuals] matrix (host numpy, any int dtype, or a device int8
         tensor) and re-tile it on the GPU."""
+        return self.tile_many([gts])[0]
+
+    def tile_many(self, mats: Sequence) -> list:
+        """``tile`` for several matrices with ONE host synchronisation: every host matrix is narrowed
+        into its own part of the pinned staging buffer, the H2D copies and the re-tiling kernels are
+        enqueued back to back, and the host waits once at the end (the staging buffer must not be
+        rewritten before the copies have left it).  Matrices already seen in the open
+        ``upload_scope`` are not uploaded again."""
         torch = _torch()
-        if isinstance(gts, torch.Tensor):
-            if gts.dtype != torch.int8 or gts.dim() != 2:
-                raise TypeError("device genotype matrix must be a 2-D int8 tensor")
-            src = gts.to(self.device).contiguous()
-        else:
-            src = torch.from_numpy(to_int8_dosage(gts)).to(self.device)
+        cache = self._tile_cache
+        out: list = [None] * len(mats)
+        host = []  # (index, array)
+        for i, m in enumerate(mats):
+            if isinstance(m, torch.Tensor):
+                if m.dtype != torch.int8 or m.dim() != 2:
+                    raise TypeError("device genotype matrix must be a 2-D int8 tensor")
+                out[i] = self._tile_device(m.to(self.device).contiguous())
+            elif cache is not None and id(m) in cache:
+                out[i] = cache[id(m)][1]
+            else:
+                g = np.asarray(m)
+                if g.ndim != 2:
+                    raise ValueError("genotype matrix must be 2-D [sites][individuals]")
+                host.append((i, g))
+        if not host:
+            return out
+        total = sum(int(g.size) for _, g in host)
+        if self._staging is None or self._staging.numel() < total:
+            self._staging = torch.empty((max(int(total * 1.25), 1 << 20),), dtype=torch.int8).pin_memory()
+        offset, staged = 0, False
+        for i, g in host:
+            view = self._stage_host(g, offset)
+            if view is None:
+                src = torch.from_numpy(to_int8_dosage(g)).to(self.device)
+            else:
+                src = view.to(self.device, non_blocking=True)
+                offset += int(g.size)
+                staged = True
+            out[i] = self._tile_device(src)
+            if cache is not None:
+                cache[id(mats[i])] = (mats[i], out[i])  # holding the matrix keeps its id from being reused
+        if staged:
+            torch.cuda.current_stream(self.device).synchronize()
+        return out
+
+    def _tile_device(self, src) -> TiledPop:
+        torch = _torch()
         n_sites, n_ind = int(src.shape[0]), int(src.shape[1])
         nbytes = self.lib.sai_tiled_bytes(n_sites, n_ind)
         dst = self._empty((max(nbytes, 0),), torch.int8)
@@ -171,6 +254,26 @@ class Engine:
         return TiledPop(dst, n_sites, n_ind)
 
     # -- kernels ---------------------------------------------------------------------------
+
+    def single_window(self, pops: Sequence[TiledPop], ploidies: Sequence[int], prm: _ffi.SaiParams):
+        """U and Q of ONE window = the whole blocks (sai_single_window: one C call, one
+        synchronisation).  Returns (record, U site indices, Q site indices) on the host."""
+        n_sites = pops[0].n_sites
+        if any(p.n_sites != n_sites for p in pops):
+            raise ValueError("all populations of one call must cover the same sites")
+        arr = (_ffi.SaiPop * len(pops))()
+        for i, p in enumerate(pops):
+            arr[i].tiles = p.tiles.data_ptr() if p.tiles.numel() else 0
+            arr[i].n_ind = p.n_ind
+            arr[i].ploidy = int(ploidies[i])
+        rec = _ffi.SaiWindowRecord()
+        cdd_u = np.empty(max(n_sites, 1), dtype=np.int32)
+        cdd_q = np.empty(max(n_sites, 1), dtype=np.int32)
+        _ffi.check(
+            self.lib.sai_single_window(self.ctx, n_sites, len(pops), arr, C.byref(prm), C.byref(rec),
+                                       cdd_u.ctypes.data_as(C.c_void_p), cdd_q.ctypes.data_as(C.c_void_p), self._stream())
+        )  # fmt: skip
+        return rec, cdd_u[: rec.u_count].astype(np.int64), cdd_q[: rec.n_cdd_q].astype(np.int64)
 
     def site_counts(self, pops: Sequence[TiledPop], out=None):
         """{alt_sum, n_called} per population and site: int32 tensor [P][n_sites][2]."""

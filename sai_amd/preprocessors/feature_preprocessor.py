@@ -104,6 +104,16 @@ class FeaturePreprocessor(DataPreprocessor):
         if ref_gts is None or tgt_gts is None or src_gts_list is None or ploidy_config is None:
             self._fill_missing(item, names)
             return [item]
+        from ..engine import Engine
+
+        # one upload of the window's matrices serves every configured statistic
+        with Engine.get().upload_scope():
+            self._run_statistics(item, names, ref_pop, tgt_pop, pos, ref_gts, tgt_gts, src_gts_list, out_gts, out_pop,
+                                 ploidy_config)  # fmt: skip
+        return [item]
+
+    def _run_statistics(self, item, names, ref_pop, tgt_pop, pos, ref_gts, tgt_gts, src_gts_list, out_gts, out_pop,
+                        ploidy_config) -> None:  # fmt: skip
         for name in names:
             stat = STAT_REGISTRY.get(name)(
                 ref_gts=ref_gts,
@@ -121,7 +131,6 @@ class FeaturePreprocessor(DataPreprocessor):
             else:
                 res = stat.compute()
             item[name] = res["value"]
-        return [item]
 
     # -- all windows of a resident region, batched on the GPU -------------------------------
 
