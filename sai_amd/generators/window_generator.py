@@ -22,6 +22,18 @@ from ..utils.windows import split_genome
 from .data_generator import DataGenerator
 
 
+class AlignedSites:
+    """Row selection of one population combination (``WindowGenerator.aligned``)."""
+
+    __slots__ = ("keys", "pos_rows", "uniq", "rows")
+
+    def __init__(self, keys, pos_rows, uniq, rows):
+        self.keys = keys  # [(group, population)] in ref, tgt, sources, outgroup order
+        self.pos_rows = pos_rows  # position of every selected row, non-decreasing
+        self.uniq = uniq  # the unique common positions when rows repeat a position, else None
+        self.rows = rows  # {(group, population): selected row indices}, or None when every row is kept
+
+
 class WindowGenerator(DataGenerator):
     def __init__(
         self,
@@ -139,20 +151,52 @@ class WindowGenerator(DataGenerator):
         """(ref_pop, tgt_pop, src_comb, out_pop) in the reference's product order (:162-166)."""
         return product(self.ref_samples, self.tgt_samples, self.src_combinations, self.out_samples or [None])
 
-    def common_positions(self, ref_pop, tgt_pop, src_comb, out_pop=None) -> np.ndarray:
-        """Positions shared by the populations of one combination.  All populations come from
-        the same VCF region (and the same polarisation), so their site sets are identical; that
-        is what the resident, index-range design relies on and it is checked here."""
-        blocks = [self.ref_data[ref_pop], self.tgt_data[tgt_pop]] + [self.src_data[s] for s in src_comb]
+    def aligned(self, ref_pop, tgt_pop, src_comb, out_pop=None) -> "AlignedSites":
+        """The rows of every population of one combination that the reference would select
+        (window_generator.py:193-231: per window, ``intersect1d`` over the populations' positions,
+        then ``isin`` per population).  Selecting by position set commutes with cutting a window
+        out, so the intersection is taken ONCE for the whole region and a window is a row range.
+
+        Usual case -- all populations come from one VCF region: identical, strictly increasing
+        positions, nothing to gather.  Otherwise (populations lacking sites, repeated positions)
+        each population gets the index array of its selected rows; positions must be sorted."""
+        keys = [("ref", ref_pop), ("tgt", tgt_pop)] + [("src", s) for s in src_comb]
         if out_pop is not None:
-            blocks.append(self.out_data[out_pop])
+            keys.append(("outgroup", out_pop))
+        cache = self.__dict__.setdefault("_aligned", {})
+        if tuple(keys) in cache:
+            return cache[tuple(keys)]
+        group_data = {"ref": self.ref_data, "tgt": self.tgt_data, "src": self.src_data, "outgroup": self.out_data}
+        blocks = [group_data[g][p] for g, p in keys]
         pos = blocks[0].POS
-        for b in blocks[1:]:
-            if b.POS.shape != pos.shape or not np.array_equal(b.POS, pos):
-                raise NotImplementedError("populations with different site sets are not supported")
-        if pos.size > 1 and not np.all(pos[1:] > pos[:-1]):
-            raise NotImplementedError("positions must be strictly increasing (duplicate or unsorted POS)")
-        return pos
+        same = all(b.POS is pos or (b.POS.shape == pos.shape and np.array_equal(b.POS, pos)) for b in blocks[1:])
+        if same and (pos.size < 2 or np.all(pos[1:] > pos[:-1])):
+            out = AlignedSites(keys, pos, None, None)
+        else:
+            for b in blocks:
+                if b.POS.size > 1 and not np.all(b.POS[1:] >= b.POS[:-1]):
+                    raise NotImplementedError("positions must be sorted within a population")
+            common = np.unique(pos)
+            for b in blocks[1:]:
+                common = np.intersect1d(common, b.POS)
+            rows = [np.flatnonzero(np.isin(b.POS, common)) for b in blocks]
+            row_pos = [b.POS[r] for b, r in zip(blocks, rows)]
+            for rp in row_pos[1:]:
+                if rp.shape != row_pos[0].shape or not np.array_equal(rp, row_pos[0]):
+                    # a position repeated in some populations only: the reference's matrices of a window
+                    # then have different numbers of rows and numpy refuses to combine them
+                    raise ValueError(
+                        f"operands could not be broadcast together with shapes ({row_pos[0].size},) ({rp.size},) "
+                    )
+            identity = all(r.size == b.POS.size for r, b in zip(rows, blocks))
+            uniq = common if common.size != row_pos[0].size else None
+            out = AlignedSites(keys, row_pos[0], uniq, None if identity else dict(zip(keys, rows)))
+        cache[tuple(keys)] = out
+        return out
+
+    def common_positions(self, ref_pop, tgt_pop, src_comb, out_pop=None) -> np.ndarray:
+        """Positions of the rows shared by the populations of one combination."""
+        return self.aligned(ref_pop, tgt_pop, src_comb, out_pop).pos_rows
 
     def device_blocks(self, eng) -> dict:
         """{(group, population): TiledPop} of every loaded population: host matrices are uploaded
@@ -180,7 +224,7 @@ class WindowGenerator(DataGenerator):
         return torch.as_tensor(np.ascontiguousarray(pos, dtype=np.int32)).to(eng.device)
 
     def __getstate__(self):  # device handles never travel with a pickled generator
-        return {k: v for k, v in self.__dict__.items() if k not in ("_device_blocks", "_device_pos")}
+        return {k: v for k, v in self.__dict__.items() if k not in ("_device_blocks", "_device_pos", "_aligned")}
 
     @staticmethod
     def window_range(pos: np.ndarray, start: int, end: int) -> tuple[int, int]:
@@ -199,20 +243,27 @@ class WindowGenerator(DataGenerator):
     def _window_generator(self) -> Iterator[dict[str, Any]]:
         if "_device_pos" in self.__dict__:
             raise TypeError("a generator over HBM-resident blocks has no per-window host matrices; use run_windows")
+        group_data = {"ref": self.ref_data, "tgt": self.tgt_data, "src": self.src_data, "outgroup": self.out_data}
         for ref_pop, tgt_pop, src_comb, out_pop in self.combinations():
-            pos = self.common_positions(ref_pop, tgt_pop, src_comb, out_pop)
+            al = self.aligned(ref_pop, tgt_pop, src_comb, out_pop)
+            mats = {}
+            for key in al.keys:
+                gt = group_data[key[0]][key[1]].GT
+                mats[key] = gt if al.rows is None else gt[al.rows[key]]
             for start, end in self.tgt_windows[tgt_pop]:
-                lo, hi = self.window_range(pos, start, end)
+                lo, hi = self.window_range(al.pos_rows, start, end)
                 if hi <= lo:  # window_generator.py:199-215
                     yield self._empty_item(ref_pop, tgt_pop, src_comb, out_pop, start, end)
                     continue
                 item = self._empty_item(ref_pop, tgt_pop, src_comb, out_pop, start, end)
                 item.update(
-                    pos=pos[lo:hi],
-                    ref_gts=self.ref_data[ref_pop].GT[lo:hi],
-                    tgt_gts=self.tgt_data[tgt_pop].GT[lo:hi],
-                    src_gts_list=[self.src_data[s].GT[lo:hi] for s in src_comb],
-                    out_gts=None if out_pop is None else self.out_data[out_pop].GT[lo:hi],
+                    # the reference hands over the UNIQUE common positions next to matrices that keep
+                    # every row of a repeated position (window_generator.py:193-197 vs :217-231)
+                    pos=al.pos_rows[lo:hi] if al.uniq is None else al.uniq[slice(*self.window_range(al.uniq, start, end))],
+                    ref_gts=mats[("ref", ref_pop)][lo:hi],
+                    tgt_gts=mats[("tgt", tgt_pop)][lo:hi],
+                    src_gts_list=[mats[("src", s)][lo:hi] for s in src_comb],
+                    out_gts=None if out_pop is None else mats[("outgroup", out_pop)][lo:hi],
                 )
                 yield item
 

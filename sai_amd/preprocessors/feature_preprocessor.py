@@ -25,6 +25,48 @@ _FOURPOP = ("fd", "df", "Danc", "Dplus")
 _LIST_STATS = _FOURPOP + ("DD",)  # one value per source population
 
 
+def _repeated_position_semantics(res, uq_names, lo, win, uniq) -> np.ndarray:
+    """What the reference does when a position occurs more than once (a VCF with split multiallelic
+    records): a window's matrices keep every row (window_generator.py:217-231) but its ``pos`` is the
+    UNIQUE common positions (:193-197).  N(Variants) therefore counts unique positions; U's
+    ``pos[idx]`` (u_statistic.py:95) reads the k-th unique position for the k-th row -- shifted after a
+    repeat, and an IndexError when k runs past the end; Q's ``pos[condition]`` (q_statistic.py:93) is
+    a boolean index of the wrong length, an IndexError as soon as a window holds a repeat.
+
+    ``res`` holds row indices in its lists (block-relative); they are replaced by those positions in
+    place.  Returns the per-window unique-position counts."""
+    ulo = np.searchsorted(uniq, win[:, 0], "left")
+    uhi = np.searchsorted(uniq, win[:, 1], "right")
+    n_uniq = (uhi - ulo).astype(np.int64)
+    n_rows = res.records[0]["n_sites"].astype(np.int64)
+    first_bad = None  # (window, order of the statistic, message)
+    for si, name in enumerate(uq_names):
+        count_field, col, flat = ("u_count", 0, res.cdd_u) if name == "U" else ("n_cdd_q", 1, res.cdd_q)
+        counts = res.records[si][count_field].astype(np.int64)
+        a = int(res.offsets[si, 0, col]) if counts.size else 0
+        rows = flat[a : a + int(counts.sum())].astype(np.int64)
+        w_of = np.repeat(np.arange(counts.size), counts)
+        k = rows - lo[w_of].astype(np.int64)
+        if name == "Q":
+            bad = np.flatnonzero((n_rows != n_uniq) & (n_uniq > 0))
+            if bad.size and (first_bad is None or (bad[0], si) < first_bad[:2]):
+                w = int(bad[0])
+                first_bad = (w, si, f"boolean index did not match indexed array along axis 0; size of axis is "
+                                    f"{n_uniq[w]} but size of corresponding boolean axis is {n_rows[w]}")  # fmt: skip
+        else:
+            over = np.flatnonzero(k >= n_uniq[w_of])
+            if over.size and (first_bad is None or (w_of[over[0]], si) < first_bad[:2]):
+                w = int(w_of[over[0]])
+                first_bad = (w, si, f"index {int(k[over[0]])} is out of bounds for axis 0 with size {int(n_uniq[w])}")
+        ok = k < n_uniq[w_of]
+        shifted = np.zeros(rows.size, dtype=np.int64)
+        shifted[ok] = uniq[ulo[w_of[ok]] + k[ok]]
+        flat[a : a + rows.size] = shifted.astype(flat.dtype)
+    if first_bad is not None:
+        raise IndexError(first_bad[2])
+    return n_uniq.astype(np.int32)
+
+
 class FeaturePreprocessor(DataPreprocessor):
     def __init__(self, output_file: str, stat_config, anc_allele_available: bool = False):
         self.output_file = output_file
@@ -166,9 +208,10 @@ class FeaturePreprocessor(DataPreprocessor):
 
         eng = Engine.get()
         pc = wg.ploidy_config
-        tiled = wg.device_blocks(eng)  # {(group, population): TiledPop}, uploaded (or already resident) once
+        shared_tiled = wg.device_blocks(eng)  # {(group, population): TiledPop}, uploaded (or already resident) once
         shared = len(combos) > 1 or bool(four_names) or len(uq_names) > _ffi.SAI_FUSED_SETS
-        counts_rows = {}
+        shared_counts = {}
+        tiled, counts_rows = shared_tiled, shared_counts
 
         def counts_of(keys):
             """int32 [len(keys)][n_sites][2]; every block is reduced at most once."""
@@ -182,8 +225,17 @@ class FeaturePreprocessor(DataPreprocessor):
             return torch.stack([counts_rows[k] for k in keys])
 
         pos_dev_cache = {}
+        group_data = {"ref": wg.ref_data, "tgt": wg.tgt_data, "src": wg.src_data, "outgroup": wg.out_data}
         for ref_pop, tgt_pop, src_comb, out_pop in combos:
-            pos = wg.common_positions(ref_pop, tgt_pop, src_comb, out_pop)
+            al = wg.aligned(ref_pop, tgt_pop, src_comb, out_pop)
+            pos = al.pos_rows
+            if al.rows is not None:
+                # populations with different site sets (window_generator.py:193-231): this combination
+                # works on its own row-gathered copies of the blocks
+                tiled = dict(zip(al.keys, eng.tile_many([group_data[g][p].GT[al.rows[(g, p)]] for g, p in al.keys])))
+                counts_rows = {}
+            else:
+                tiled, counts_rows = shared_tiled, shared_counts
             windows = wg.tgt_windows[tgt_pop]
             win = np.asarray(windows, dtype=np.int64).reshape(-1, 2)
             src_ploidies = pc.get_ploidy("src")
@@ -214,14 +266,19 @@ class FeaturePreprocessor(DataPreprocessor):
             if uq_names:
                 block = ResidentBlock([tiled[k] for k in uq_keys], ploidy[: 2 + n_eff], pos_dev)
                 scorer = ResidentScorer(eng, block, windows, sets, cap_u=1 << 16, cap_q=1 << 16,
-                                        counts_in=counts_of(uq_keys) if shared else None)  # fmt: skip
+                                        counts_in=counts_of(uq_keys) if shared else None,
+                                        lists_as_indices=al.uniq is not None)  # fmt: skip
                 scorer.step()
                 cb.uq = scorer.results(grow=True)
                 lo, hi = scorer.lo, scorer.hi
                 cb.nsnps = cb.uq.records[0]["n_sites"].astype(np.int32)
+                if al.uniq is not None:
+                    cb.nsnps = _repeated_position_semantics(cb.uq, uq_names, lo.cpu().numpy(), win, al.uniq)
             else:
                 lo, hi = eng.window_bounds(pos_dev, win[:, 0], win[:, 1])
                 cb.nsnps = (hi - lo).cpu().numpy().astype(np.int32)
+                if al.uniq is not None:
+                    cb.nsnps = (np.searchsorted(al.uniq, win[:, 1], "right") - np.searchsorted(al.uniq, win[:, 0], "left")).astype(np.int32)
             if four_names:  # every source of the combination, with its own ploidy (fd_statistic.py:63-74)
                 if len(src_ploidies) < len(src_comb):
                     raise IndexError("list index out of range")

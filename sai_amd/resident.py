@@ -90,7 +90,8 @@ class _SetChunk:
 class ResidentScorer:
     def __init__(self, eng: Engine, block: ResidentBlock, windows: Sequence[tuple], sets: Sequence[_ffi.SaiParams],
                  cap_u: int = 1 << 20, cap_q: int = 1 << 20, layout: str = "int8", overlap: bool = False,
-                 window_segment: Optional[Sequence[int]] = None, counts_out=None, counts_in=None):  # fmt: skip
+                 window_segment: Optional[Sequence[int]] = None, counts_out=None, counts_in=None,
+                 lists_as_indices: bool = False):  # fmt: skip
         """``windows`` = inclusive ``(start, end)`` position pairs; for a block of several pieces
         ``window_segment[w]`` is the index into ``block.segments`` of the piece window w lies in.
 
@@ -106,7 +107,8 @@ class ResidentScorer:
         ``{alt_sum, n_called}`` of the pass (what the ABBA-BABA family divides).  ``counts_in`` (same
         shape) says the counts of these populations already exist -- several population combinations
         share blocks that were reduced once -- so a step starts at the per-site decision and no
-        genotype byte is read."""
+        genotype byte is read.  ``lists_as_indices``: the candidate lists hold block-relative
+        site indices instead of positions."""
         import torch
 
         if layout not in ("int8", "packed2"):
@@ -148,6 +150,7 @@ class ResidentScorer:
         self.counts = counts_in if self.have_counts else counts_out
         if self.counts is None and not self.fused:
             self.counts = torch.empty((len(block.pops), n, 2), dtype=torch.int32, device=dev)
+        self.list_pos = None if lists_as_indices else block.pos
         self.overlap = bool(overlap)
         # two sets: the windows stage of step k runs under site pass k+1 and is over long before the
         # host may enqueue site pass k+2 into the same buffers
@@ -301,8 +304,8 @@ class ResidentScorer:
                 )
             )  # fmt: skip
         for ch in self.chunks:
-            eng.window_stats_async(tgt_freq, flags[ch.s0 : ch.s1], self.sets[ch.s0 : ch.s1], self.lo, self.hi, blk.pos,
-                                   ch.bufs)  # fmt: skip
+            eng.window_stats_async(tgt_freq, flags[ch.s0 : ch.s1], self.sets[ch.s0 : ch.s1], self.lo, self.hi,
+                                   self.list_pos, ch.bufs)  # fmt: skip
             ch.host_head.copy_(ch.bufs[5], non_blocking=True)
 
     # -- results ---------------------------------------------------------------------------

@@ -26,6 +26,13 @@ class QStatistic(GenericStatistic):
         rec, _, idx_q = run_single_window(
             self, kwargs["w"], 0.0, kwargs["quantile"], kwargs["y_list"], kwargs["anc_allele_available"]
         )
+        if len(pos) != int(rec["n_sites"]):
+            # the reference's `pos[condition]` (q_statistic.py:93) with a boolean mask over the matrix rows:
+            # numpy's IndexError when `pos` is not as long as the matrices
+            raise IndexError(
+                f"boolean index did not match indexed array along axis 0; size of axis is {len(pos)} "
+                f"but size of corresponding boolean axis is {int(rec['n_sites'])}"
+            )
         if int(rec["n_cond"]) == 0:  # q_statistic.py:96-98
             return {"name": self.STAT_NAME, "value": np.nan, "cdd_pos": np.array([])}
         # q_statistic.py:100-104

@@ -776,3 +776,68 @@ def make_pipeline_fuzz():
 
 if __name__ == "__main__" and os.path.isdir(REF):
     make_pipeline_fuzz()
+
+
+# ---------------------------------------------------------------------------
+# 10. populations with different site sets / repeated positions through the
+#     reference's WindowGenerator._window_generator + FeaturePreprocessor
+#     (window_generator.py:193-231): output text, or the exception the
+#     reference raises (type and message -- the message depends on the numpy
+#     version, the tests compare the type)
+# ---------------------------------------------------------------------------
+
+SITESET_CASES = [("ragged", 1), ("ragged", 2), ("ragged", 3), ("dup_u", 4), ("dup_u", 5), ("dup_u", 6), ("dup_uq", 7),
+                 ("dup_uq", 8), ("dup_uneven", 9), *[("dup_rare", s) for s in range(10, 18)]]
+
+
+def make_sitesets():
+    sys.path.insert(0, str(OUT))
+    from itertools import combinations
+
+    from seeded import siteset_scenario
+    from sai.configs import PloidyConfig, StatConfig
+    from sai.generators import WindowGenerator
+    from sai.preprocessors import FeaturePreprocessor
+    from sai.utils import split_genome
+    from sai.utils.genomic_dataclasses import ChromosomeData
+
+    out = []
+    for kind, seed in SITESET_CASES:
+        sc = siteset_scenario(kind, seed)
+        wg = object.__new__(WindowGenerator)
+        wg.win_len, wg.win_step, wg.chr_name, wg.ploidy_config = sc["win"], sc["step"], "5", PloidyConfig(sc["pl"])
+        for g in ("ref", "tgt", "src"):
+            setattr(wg, f"{g}_data", {k: ChromosomeData(POS=sc["pos"][g][k].copy(), REF=None, ALT=None, GT=v.copy())
+                                      for k, v in sc["gts"][g].items()})
+            setattr(wg, f"{g}_samples", {k: [] for k in sc["gts"][g]})
+        wg.out_data = wg.out_samples = None
+        wg.num_src = len(sc["gts"]["src"])
+        wg.src_combinations = list(combinations(wg.src_samples.keys(), wg.num_src))
+        wg.tgt_windows = {t: split_genome(pos=wg.tgt_data[t].POS, window_size=sc["win"], step_size=sc["step"])
+                          for t in wg.tgt_samples}
+        stat_config = StatConfig(json.loads(json.dumps(sc["stats"])))
+        rec = dict(kind=kind, seed=seed)
+        with tempfile.TemporaryDirectory() as td:
+            tsv = os.path.join(td, "o.tsv")
+            fp = FeaturePreprocessor(output_file=tsv, stat_config=stat_config, anc_allele_available=sc["anc"])
+            items = []
+            try:
+                for item in wg.get():
+                    items.extend(fp.run(**item))
+                fp.process_items(items)
+                rec["text"] = {"tsv": open(tsv).read()}
+                for k in ("U", "Q"):
+                    f = os.path.join(td, f"o.{k}.log")
+                    if os.path.exists(f):
+                        rec["text"][k] = open(f).read()
+                rec["n_items"] = len(items)
+            except Exception as e:  # noqa: BLE001 -- the capture IS the reference's behaviour
+                rec["error"] = [type(e).__name__, str(e)]
+                rec["items_before_error"] = len(items)
+        out.append(rec)
+        print("siteset", kind, seed, rec.get("n_items"), rec.get("error"))
+    (OUT / "sitesets.json").write_text(json.dumps(out, separators=(",", ":")) + "\n")
+
+
+if __name__ == "__main__" and os.path.isdir(REF):
+    make_sitesets()

@@ -74,3 +74,57 @@ def fuzz_scenario(seed):
         start = int(pos[n_sites // 4] // step * step + 1)
         end = start + int(rng.integers(1, 6)) * step + win - step - 1
     return dict(pos=pos, gts=gts, pl=pl, stats=stats, win=win, step=step, start=start, end=end, anc=anc, with_out=with_out)
+
+
+def siteset_scenario(kind, seed):
+    """Populations whose site sets differ and / or repeat a position (what the reference's
+    WindowGenerator resolves per window with intersect1d + isin, window_generator.py:193-231).
+
+    kind: "ragged"      every population lacks a random ~12 % of the base sites (no repeats)
+          "dup_u"       all populations share positions, some positions occur twice (a VCF with split
+                        multiallelic records); U only
+          "dup_rare"    the same with few repeats and few candidates (the reference then often runs
+                        through and reports candidate positions shifted by the repeats)
+          "dup_uq"      the same with U and Q configured
+          "dup_uneven"  a position repeated in the target population only
+    Returns dict(pos={group: {pop: int32}}, gts={group: {pop: int64}}, pl, stats, win, step, anc)."""
+    rng = np.random.default_rng(seed)
+    n_sites = int(rng.integers(300, 700))
+    base = np.cumsum(rng.integers(1, 40, n_sites)).astype(np.int32) + 50
+    p = rng.random(n_sites) ** 2
+    intro = rng.random(n_sites) < (0.02 if kind == "dup_rare" else 0.15)
+    dup = np.zeros(n_sites, bool)
+    if kind.startswith("dup"):
+        dup = rng.random(n_sites) < (0.012 if kind == "dup_rare" else 0.06)
+    rows = np.repeat(np.arange(n_sites), 1 + dup.astype(np.int64))  # a duplicated site contributes two rows
+
+    def pop(n_ind, ploidy, role):
+        pp = p.copy()
+        if role == "ref":
+            pp[intro] = 0.0
+        elif role == "src":
+            pp[intro] = 1.0
+        g = rng.binomial(ploidy, np.broadcast_to(pp[rows][:, None], (len(rows), n_ind))).astype(np.int64)
+        g[rng.random(g.shape) < 0.02] = -ploidy
+        return g
+
+    pl = {"ref": {"R": 2}, "tgt": {"T0": 2, "T1": 1}, "src": {"S0": 2, "S1": 2}}
+    sizes = {"R": 9, "T0": 8, "T1": 6, "S0": 1, "S1": 2}
+    pos, gts = {}, {}
+    for grp, role in (("ref", "ref"), ("tgt", "tgt"), ("src", "src")):
+        pos[grp], gts[grp] = {}, {}
+        for name, ploidy in pl[grp].items():
+            g = pop(sizes[name], ploidy, role)
+            keep = np.ones(len(rows), bool)
+            if kind == "ragged":
+                drop_site = rng.random(n_sites) < 0.12
+                keep = ~drop_site[rows]
+            elif kind == "dup_uneven" and name != "T0":
+                keep = np.concatenate([[True], rows[1:] != rows[:-1]])  # only T0 keeps the second rows
+            pos[grp][name] = base[rows][keep]
+            gts[grp][name] = g[keep]
+    uq = lambda tgt: {"ref": {"R": 0.3}, "tgt": dict(tgt), "src": {"S0": "=1", "S1": ">=0.5"}}  # noqa: E731
+    stats = {"U": uq({"T0": 0.2, "T1": 0.0})}
+    if kind not in ("dup_u", "dup_rare"):
+        stats["Q"] = uq({"T0": 0.9, "T1": 0.5})
+    return dict(pos=pos, gts=gts, pl=pl, stats=stats, win=1500, step=500, anc=bool(seed % 2))

@@ -384,3 +384,59 @@ def test_pipeline_fuzz_against_oracle(seed, tmp_path):
         assert out.read_text() == O.header_line(names, list(sc["pl"]["src"])) + ref_text["tsv"]
         for k in ("U", "Q"):
             assert (tmp_path / f"o.{k}.log").read_text() == O.log_header_line(k) + ref_text[k]
+
+
+# ---- populations with different site sets / repeated positions (window_generator.py:193-231) ----
+
+from test_oracle_golden import SITESETS, siteset_inputs  # noqa: E402
+
+
+@pytest.mark.parametrize("case", SITESETS, ids=[f"{c['kind']}-{c['seed']}" for c in SITESETS])
+def test_ragged_and_repeated_positions_equal_the_reference(case, tmp_path):
+    """The batched path and the per-window plugin path on populations that lack sites (rows gathered
+    per combination) and on repeated positions (the reference's unique-`pos` semantics: shifted
+    candidate positions or IndexError; ValueError when only some populations repeat a position):
+    the reference's own output text / exception type (golden capture)."""
+    from sai_amd.configs import PloidyConfig, StatConfig
+    from sai_amd.generators import WindowGenerator
+    from sai_amd.preprocessors import FeaturePreprocessor
+    from sai_amd.utils import ChromosomeData
+
+    sc = siteset_inputs(case)
+    data = {g: {k: ChromosomeData(sc["pos"][g][k], None, None, v.astype(np.int8)) for k, v in sc["gts"][g].items()}
+            for g in ("ref", "tgt", "src")}  # fmt: skip
+    pc = PloidyConfig(sc["pl"])
+    names = list(sc["stats"])
+
+    def fresh():
+        wg = WindowGenerator.from_arrays("5", data["ref"], data["tgt"], data["src"], sc["win"], sc["step"], pc)
+        out = tmp_path / f"o{len(list(tmp_path.iterdir()))}.tsv"
+        return wg, out, FeaturePreprocessor(str(out), StatConfig(json.loads(json.dumps(sc["stats"]))), sc["anc"])
+
+    def plugin_items(wg, fp):
+        items = []
+        for w in wg.get():
+            items.extend(fp.run(**w))
+        return items
+
+    if "error" in case:
+        exc = {"IndexError": IndexError, "ValueError": ValueError}[case["error"][0]]
+        wg, out, fp = fresh()
+        with pytest.raises(exc):
+            fp.run_windows(wg)
+        wg, out, fp = fresh()
+        with pytest.raises(exc):
+            plugin_items(wg, fp)
+        return
+    for route in ("batched", "plugin"):
+        wg, out, fp = fresh()
+        items = fp.run_windows(wg) if route == "batched" else plugin_items(wg, fp)
+        assert len(items) == case["n_items"]
+        fp.process_items(items)
+        assert out.read_text() == case["text"]["tsv"], route
+        for k in names:
+            assert out.with_suffix(f".{k}.log").read_text() == case["text"][k], (route, k)
+    if case["kind"] == "dup_rare":  # the capture really exercises the shift: not what per-row positions would give
+        wg, out, fp = fresh()
+        al = wg.aligned("R", "T0", ("S0", "S1"))
+        assert al.uniq is not None and al.uniq.size < al.pos_rows.size

@@ -324,3 +324,35 @@ def test_pipeline_fuzz_text_equals_reference(rec):
     assert "".join(O.score_lines(items, names)) == rec["text"]["tsv"]
     for k in ("U", "Q"):
         assert "".join(O.log_lines(items, k)) == rec["text"][k]
+
+
+# ---- populations with different site sets / repeated positions (make_golden.py section 10) ----
+
+SITESETS = load_golden("sitesets.json")
+
+
+def siteset_inputs(case):
+    from seeded import siteset_scenario
+
+    return siteset_scenario(case["kind"], case["seed"])
+
+
+@pytest.mark.parametrize("case", SITESETS, ids=[f"{c['kind']}-{c['seed']}" for c in SITESETS])
+def test_oracle_on_ragged_and_repeated_positions(case):
+    """intersect1d + isin per window (window_generator.py:193-231): the oracle writes the reference's
+    text when populations lack sites, and fails with the reference's exception type when a position
+    is repeated (IndexError from `pos[idx]` / `pos[condition]`, ValueError when only some
+    populations repeat it)."""
+    sc = siteset_inputs(case)
+    data = {g: {k: O.Chrom(sc["pos"][g][k], v) for k, v in sc["gts"][g].items()} for g in ("ref", "tgt", "src")}
+    stats = _validated(sc["stats"])
+    names = list(sc["stats"])
+    if "error" in case:
+        with pytest.raises({"IndexError": IndexError, "ValueError": ValueError}[case["error"][0]]):
+            O.run_chunk("5", data["ref"], data["tgt"], data["src"], sc["win"], sc["step"], stats, sc["pl"], sc["anc"])
+        return
+    items = O.run_chunk("5", data["ref"], data["tgt"], data["src"], sc["win"], sc["step"], stats, sc["pl"], sc["anc"])
+    assert len(items) == case["n_items"]
+    assert "".join(O.score_lines(items, names)) == case["text"]["tsv"]
+    for k in names:
+        assert "".join(O.log_lines(items, k)) == case["text"][k]
