@@ -43,6 +43,7 @@ extern "C" {
 #define SAI_TILE_SITES 64
 #define SAI_MAX_SRC 6   /* source populations per call */
 #define SAI_MAX_SETS 16 /* parameter sets per call */
+#define SAI_FUSED_SETS 20 /* parameter sets the fused site pass carries (C5's 18-set sweep fits) */
 
 enum sai_status {
   SAI_OK = 0,
@@ -119,7 +120,7 @@ int sai_tile_from_site_major(sai_ctx* ctx, const int8_t* src, int64_t n_sites, i
 int sai_site_counts(sai_ctx* ctx, int64_t n_sites, int32_t n_pops, const sai_pop* pops,
                     uint32_t* counts, void* stream);
 
-/* Kernels 1+2 fused (the fast path when there are at most 4 parameter sets): one pass over the
+/* Kernels 1+2 fused (the fast path when there are at most SAI_FUSED_SETS parameter sets): one pass over the
  * genotypes that also evaluates sai_site_flags' per-site decision for each set at the end of every
  * tile, while the counts are still on chip.  `counts` may be NULL (then the 8 bytes per site and
  * population are neither written nor re-read); pops[p].ploidy is used.  Results are identical to

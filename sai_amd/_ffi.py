@@ -17,7 +17,7 @@ LIB_PATH = Path(__file__).resolve().parent / "lib" / LIB_NAME
 SAI_TILE_SITES = 64
 SAI_MAX_SRC = 6
 SAI_MAX_SETS = 16
-SAI_FUSED_SETS = 4
+SAI_FUSED_SETS = 20
 SAI_ERR_UNSUPPORTED = -4  # enum sai_status
 FREQ_MODES = {"dense": 0, "candidates": 1}  # enum sai_freq_mode
 SAI_ABI_VERSION = 6

@@ -61,7 +61,7 @@ inline int check_launch(const char* what) {
 }
 
 // site_pass.hip: argument checks of a parameter-set array (n_src < 0: any number of sources)
-int check_sets(int32_t n_sets, const sai_params* sets, int32_t n_src);
+int check_sets(int32_t n_sets, const sai_params* sets, int32_t n_src, int32_t max_sets = SAI_MAX_SETS);
 
 inline unsigned stream_grid(const sai_ctx* ctx, int64_t n_tiles) {
   const int64_t max_grid = static_cast<int64_t>(ctx->n_cu) * kStreamWavesPerCu;  // grid-stride beyond this

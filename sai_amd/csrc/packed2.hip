@@ -170,7 +170,7 @@ int sai_site_pass_packed2(sai_ctx* ctx, int64_t n_sites, int32_t n_pops, const s
   if (n_sets < 0 || n_sets > kFusedSets) return fail(SAI_ERR_UNSUPPORTED, "at most %d parameter sets", kFusedSets);
   if (n_sets > 0) {
     if (n_pops < 2) return fail(SAI_ERR_ARG, "n_pops must be >= 2 (ref, tgt, sources)");
-    if (int rc = check_sets(n_sets, sets_host, n_pops - 2)) return rc;
+    if (int rc = check_sets(n_sets, sets_host, n_pops - 2, kFusedSets)) return rc;
     if (n_sites > 0 && (!tgt_freq || !flags)) return fail(SAI_ERR_ARG, "NULL buffer");
   } else if (!counts && n_sites > 0) {
     return fail(SAI_ERR_ARG, "nothing to compute: no parameter sets and counts is NULL");

@@ -75,7 +75,9 @@ __device__ __forceinline__ void eval_site(int n_pops, const int32_t* ploidy, Get
   if (!sparse_freq || any_cond) __builtin_nontemporal_store(f[1], tgt_freq + site);
 }
 
-constexpr int kFusedSets = 4;  // parameter sets the fused tail of site_counts can carry in its arguments
+// parameter sets the fused tail of site_counts carries in its kernel arguments (20 x 152 B + the
+// rest stay below the 4 KiB kernarg segment)
+constexpr int kFusedSets = SAI_FUSED_SETS;
 
 struct FusedArgs {
   int32_t n_sets;  // 0 = plain site_counts

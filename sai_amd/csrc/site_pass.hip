@@ -51,6 +51,7 @@ struct CountsArgs {
   PopArg pop[kMaxPops];
   uint2* counts;
 };
+static_assert(sizeof(CountsArgs) + sizeof(FusedArgs) <= 4096, "kernel arguments exceed the kernarg segment");
 
 // MULTI: some population has more than 16 * kChunkIters individuals, so the packed fields are
 // widened several times per population (keeps 32 more registers live across the load loop).
@@ -112,8 +113,8 @@ __global__ __launch_bounds__(64) void site_counts_kernel(CountsArgs a, FusedArgs
 
 }  // namespace
 
-int check_sets(int32_t n_sets, const sai_params* sets, int32_t n_src) {
-  if (n_sets < 1 || n_sets > SAI_MAX_SETS) return fail(SAI_ERR_ARG, "n_sets must be 1..%d", SAI_MAX_SETS);
+int check_sets(int32_t n_sets, const sai_params* sets, int32_t n_src, int32_t max_sets) {
+  if (n_sets < 1 || n_sets > max_sets) return fail(SAI_ERR_ARG, "n_sets must be 1..%d", max_sets);
   if (!sets) return fail(SAI_ERR_ARG, "sets_host is NULL");
   for (int s = 0; s < n_sets; ++s) {
     if (n_src >= 0 && sets[s].n_src != n_src)
@@ -192,7 +193,7 @@ int sai_site_pass(sai_ctx* ctx, int64_t n_sites, int32_t n_pops, const sai_pop* 
   if (n_sets > kFusedSets)
     return fail(SAI_ERR_UNSUPPORTED, "sai_site_pass carries at most %d parameter sets; use sai_site_counts + sai_site_flags",
                 kFusedSets);
-  if (int rc = check_sets(n_sets, sets_host, n_pops - 2)) return rc;
+  if (int rc = check_sets(n_sets, sets_host, n_pops - 2, kFusedSets)) return rc;
   if (pops)
     for (int p = 0; p < n_pops && p < kMaxPops; ++p)
       if (pops[p].ploidy <= 0) return fail(SAI_ERR_ARG, "ploidy[%d] must be positive", p);

@@ -241,7 +241,8 @@ def test_synth_device_equals_host(eng):
 
 def test_fused_site_pass_equals_two_kernels(eng):
     """sai_site_pass (counts kept on chip) == sai_site_counts + sai_site_flags, bit for bit, with
-    and without the optional counts output, for 1..4 parameter sets and 1..3 sources."""
+    and without the optional counts output, for 1, 4 and 18 parameter sets (C5's sweep rides in
+    the fused pass too) and 1..3 sources."""
     import torch
 
     from sai_amd import _ffi
@@ -253,7 +254,7 @@ def test_fused_site_pass_equals_two_kernels(eng):
         mats = [rng.integers(-2, 3, size=(n_sites, n)).astype(np.int8) for n in [33, 4100, *([2] * n_src)]]
         pl = [2, 2] + [int(rng.integers(1, 4)) for _ in range(n_src)]
         pops = [eng.tile(m) for m in mats]
-        for n_sets in (1, 4):
+        for n_sets in (1, 4, 18):
             sets = [
                 _ffi.make_params(float(rng.choice([0.1, 0.5, 1.0])), float(rng.choice([0.0, 0.4])), 0.9,
                                  [(str(rng.choice(["=", ">=", "<"])), float(rng.choice([0.0, 0.5, 1.0]))) for _ in range(n_src)],
@@ -273,7 +274,7 @@ def test_fused_site_pass_equals_two_kernels(eng):
             out = (torch.full_like(tf, sentinel), torch.zeros_like(fl))
             eng.site_pass(pops, pl, sets, out=out, freq_mode="candidates")
             cand = ((fl & 1) != 0).any(dim=0)
-            assert torch.equal(out[1], fl) and int(cand.sum()) < n_sites
+            assert torch.equal(out[1], fl) and (int(cand.sum()) < n_sites or n_sets == 18)
             n_cand_seen += int(cand.sum())
             assert out[0][cand].cpu().numpy().tobytes() == tf[cand].cpu().numpy().tobytes()
             assert bool((out[0][~cand] == sentinel).all())
