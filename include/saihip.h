@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define SAI_ABI_VERSION 6
+#define SAI_ABI_VERSION 7
 #define SAI_TILE_SITES 64
 #define SAI_MAX_SRC 6   /* source populations per call */
 #define SAI_MAX_SETS 16 /* parameter sets per call */
@@ -311,6 +311,47 @@ int sai_vcf_block_info(const sai_vcf_block* block, int64_t* n_records, int64_t* 
                        int64_t* n_anc_entries);
 int sai_vcf_block_copy(const sai_vcf_block* block, int32_t* pos_host, int8_t* dosage_host);
 int sai_vcf_block_free(sai_vcf_block* block);
+
+/* Streaming form of the ingest for the GPU tokenizer: a producer thread walks the file exactly as
+ * sai_vcf_load does (plain / gzip / bgzip with parallel inflate, tabix seek, early stop after the
+ * region) but only INDEXES the record lines -- chromosome and region filter, POS, the
+ * ancestral-allele decision of check_anc_allele (utils.py:492-555: keep, flip or drop; it needs the
+ * fixed columns only), the index of GT inside FORMAT, where the sample columns start -- and copies
+ * the text as it is into the caller's two pinned buffers alternately; sai_tokenize_gt then turns the
+ * text into dosages on the GPU.  sai_vcf_stream_next hands out batch k (it blocks until the batch is
+ * ready) and releases the buffer of batch k-1, so the caller must have finished its H2D copy of
+ * batch k-1 by then; the line arrays stay valid until the following call.  line_off = offset of the
+ * first sample column inside the batch text, line_len = bytes from there to the end of the line
+ * (without "\r").  *done = 1 (and no batch) once everything has been handed out, or the producer's
+ * error as the status.  sai_vcf_stream_selection: slot_of_col[c] = output slot of VCF sample column
+ * c or -1 (valid once a batch has been returned), n_matched / n_anc_entries as sai_vcf_block_info
+ * (complete once done was reported). */
+typedef struct sai_vcf_stream sai_vcf_stream;
+int sai_vcf_stream_open(const char* path, const char* chrom, int64_t start, int64_t end, int32_t n_samples,
+                        const char* const* sample_names, const int32_t* ploidy, const char* anc_bed_path,
+                        int32_t n_threads, void* pinned0_host, void* pinned1_host, int64_t buffer_bytes,
+                        sai_vcf_stream** stream_out);
+int sai_vcf_stream_next(sai_vcf_stream* stream, int32_t* buffer_index, int64_t* n_text_bytes, int64_t* n_lines,
+                        const int64_t** line_off_host, const int32_t** line_len_host, const int32_t** line_pos_host,
+                        const uint8_t** line_flip_host, const uint8_t** line_gi_host, int32_t* done);
+int sai_vcf_stream_selection(sai_vcf_stream* stream, int32_t* slot_of_col_host, int32_t capacity, int32_t* n_cols,
+                             int64_t* n_matched, int64_t* n_anc_entries);
+int sai_vcf_stream_close(sai_vcf_stream* stream);
+
+/* The GPU half: the sample columns of n_lines record lines -> dosages.  text = the batch text in
+ * HBM; line_off / line_len / line_flip / line_gi = the index of sai_vcf_stream_next (device copies);
+ * slot_of_col (n_cols entries) and ploidy_of_slot (n_out entries) = the sample selection.  For every
+ * selected column the GT sub-field is read exactly as read_geno_data + reshape_genotypes do
+ * (utils.py:78-186, 389-410): alleles separated by | or /, '.' or an empty allele = -1, the call
+ * padded / cut to the slot's ploidy, alleles summed; a flipped line stores sum |a - 1| instead
+ * (utils.py:531-555).  out[(line * n_out + slot)] = int8 dosage, [record][sample] like
+ * sai_vcf_block_copy.  status[line] = 0, or non-zero where the host reader would have refused the
+ * line (unparsable genotype, too few sample columns, dosage outside int8): the caller then lets
+ * sai_vcf_load produce the reference error text.  One wavefront per line. */
+int sai_tokenize_gt(sai_ctx* ctx, const char* text, int64_t n_text_bytes, int64_t n_lines, const int64_t* line_off,
+                    const int32_t* line_len, const uint8_t* line_flip, const uint8_t* line_gi, int32_t n_cols,
+                    const int32_t* slot_of_col, int32_t n_out, const int32_t* ploidy_of_slot, int8_t* out,
+                    int32_t* status, void* stream);
 
 /* In-memory counterpart of the ingest: narrow a reference-style [rows][cols] integer matrix (the
  * reference holds genotypes as int64 after utils.py:410) to the int8 the device layout uses, in one

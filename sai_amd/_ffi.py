@@ -20,7 +20,7 @@ SAI_MAX_SETS = 16
 SAI_FUSED_SETS = 20
 SAI_ERR_UNSUPPORTED = -4  # enum sai_status
 FREQ_MODES = {"dense": 0, "candidates": 1}  # enum sai_freq_mode
-SAI_ABI_VERSION = 6
+SAI_ABI_VERSION = 7
 
 OPS = {"=": 0, "<": 1, ">": 2, "<=": 3, ">=": 4}
 
@@ -114,6 +114,19 @@ SIGNATURES = {
         C.c_int,
         [C.c_char_p, C.c_char_p, _i64, _i64, _i32, C.POINTER(C.c_char_p), C.POINTER(_i32), C.c_char_p, _i32, C.POINTER(_p)],
     ),
+    "sai_vcf_stream_open": (
+        C.c_int,
+        [C.c_char_p, C.c_char_p, _i64, _i64, _i32, C.POINTER(C.c_char_p), C.POINTER(_i32), C.c_char_p, _i32, _p, _p, _i64,
+         C.POINTER(_p)],
+    ),
+    "sai_vcf_stream_next": (
+        C.c_int,
+        [_p, C.POINTER(_i32), C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_p), C.POINTER(_p), C.POINTER(_p), C.POINTER(_p),
+         C.POINTER(_p), C.POINTER(_i32)],
+    ),
+    "sai_vcf_stream_selection": (C.c_int, [_p, _p, _i32, C.POINTER(_i32), C.POINTER(_i64), C.POINTER(_i64)]),
+    "sai_vcf_stream_close": (C.c_int, [_p]),
+    "sai_tokenize_gt": (C.c_int, [_p, _p, _i64, _i64, _p, _p, _p, _p, _i32, _p, _i32, _p, _p, _p, _p]),
     "sai_vcf_block_info": (C.c_int, [_p, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)]),
     "sai_vcf_block_copy": (C.c_int, [_p, _p, _p]),
     "sai_vcf_block_free": (C.c_int, [_p]),
@@ -123,6 +136,7 @@ SIGNATURES = {
 HOST_SYMBOLS = (
     "sai_abi_version", "sai_build_arch", "sai_last_error", "sai_synth_fill_host", "sai_synth_gaps_host",
     "sai_narrow_to_int8", "sai_vcf_scan", "sai_vcf_load", "sai_vcf_block_info", "sai_vcf_block_copy", "sai_vcf_block_free",
+    "sai_vcf_stream_open", "sai_vcf_stream_next", "sai_vcf_stream_selection", "sai_vcf_stream_close",
 )  # fmt: skip
 
 _lib = None

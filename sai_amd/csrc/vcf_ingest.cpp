@@ -9,10 +9,14 @@
 // The Python reader sai_amd/utils/vcf.py is the readable statement of the same rules; the two are
 // tested against each other and against the reference tests' expectations.
 
+#include <fcntl.h>
 #include <sys/stat.h>
+#include <unistd.h>
 #include <zlib.h>
 
 #include <algorithm>
+#include <condition_variable>
+#include <mutex>
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
@@ -526,6 +530,72 @@ int for_each_block_from(const char* path, int n_threads, uint64_t voff, size_t b
   return rc;
 }
 
+// Uncompressed text: the batch is read by `n_threads` preads side by side (zlib's transparent
+// gzread is a serial copy through its own buffer, ~1.5 GB/s; the page cache delivers far more).
+bool file_is_plain_text(const char* path) {
+  FILE* f = fopen(path, "rb");
+  if (!f) return false;
+  unsigned char head[2] = {0, 0};
+  const size_t n = fread(head, 1, 2, f);
+  fclose(f);
+  return !(n == 2 && head[0] == 0x1f && head[1] == 0x8b);
+}
+
+template <typename F>
+int for_each_block_plain(const char* path, int n_threads, F&& consume) {
+  const int fd = open(path, O_RDONLY);
+  if (fd < 0) return sai_set_error(SAI_ERR_ARG, "cannot open VCF %s", path);
+  struct FdGuard { int fd; ~FdGuard() { close(fd); } } guard{fd};
+  struct stat st;
+  if (fstat(fd, &st) != 0) return sai_set_error(SAI_ERR_ARG, "cannot stat %s", path);
+  const size_t total = static_cast<size_t>(st.st_size);
+  const size_t batch = batch_out_bytes();
+  std::vector<char> buf;
+  size_t have = 0, file_off = 0;
+  for (;;) {
+    const size_t want = std::min(batch, total - file_off);
+    if (buf.size() < have + want) buf.resize(have + want);
+    const int nt = std::max(1, std::min<int>(n_threads, static_cast<int>(want / (size_t(4) << 20)) + 1));
+    std::vector<char> bad(static_cast<size_t>(nt), 0);
+    auto work = [&](int t) {  // pread loops touch only the caller's buffer: no throw
+      size_t lo = want * static_cast<size_t>(t) / static_cast<size_t>(nt), hi = want * static_cast<size_t>(t + 1) / static_cast<size_t>(nt);
+      while (lo < hi) {
+        const ssize_t got = pread(fd, buf.data() + have + lo, hi - lo, static_cast<off_t>(file_off + lo));
+        if (got <= 0) { bad[static_cast<size_t>(t)] = 1; return; }
+        lo += static_cast<size_t>(got);
+      }
+    };
+    {
+      ThreadGroup th;
+      for (int t = 1; t < nt; ++t) th.spawn([&work, t] { work(t); });
+      work(0);
+      th.join();
+    }
+    for (char b : bad)
+      if (b) return sai_set_error(SAI_ERR_ARG, "read error in %s", path);
+    have += want;
+    file_off += want;
+    const bool eof = file_off >= total;
+    size_t usable = have;
+    if (!eof) {
+      usable = 0;
+      for (size_t i = have; i > 0; --i)
+        if (buf[i - 1] == '\n') { usable = i; break; }
+      if (usable == 0) continue;  // no complete line yet: read on
+    }
+    if (usable) {
+      const int rc = consume(buf.data(), buf.data() + usable);
+      if (rc < 0) return rc;
+      if (rc > 0) return SAI_OK;  // consumer has seen enough
+    }
+    const size_t rest = have - usable;
+    if (rest) memmove(buf.data(), buf.data() + usable, rest);
+    have = rest;
+    if (eof) break;
+  }
+  return SAI_OK;
+}
+
 // Streams the file in blocks of whole lines and hands each block to `consume(begin, end)`; bgzip
 // files are inflated by `n_threads` threads, plain gzip and uncompressed text go through zlib's
 // gzread.  Returns 0, or a negative status after sai_set_error.
@@ -542,6 +612,7 @@ int for_each_block(const char* path, int n_threads, F&& consume) {
     }
     fclose(f);
   }
+  if (file_is_plain_text(path)) return for_each_block_plain(path, n_threads, consume);
   GzReader r(path);
   if (!r.f) return sai_set_error(SAI_ERR_ARG, "cannot open VCF %s", path);
   std::vector<char> buf(size_t(8) << 20);
@@ -622,6 +693,291 @@ bool narrow_rows(const char* src, int64_t row_stride, int64_t r0, int64_t r1, in
     too_big = too_big || hi > static_cast<T>(127);
   }
   return !too_big;
+}
+
+}  // namespace
+
+namespace {
+
+// ------------------------------------------------------------------------------------------
+// Streaming ingest for the GPU tokenizer (sai_vcf_stream_*): the host reads / inflates the file and
+// INDEXES its record lines -- chromosome and region filter, POS, the ancestral-allele decision
+// (keep / flip / drop: it needs only the fixed columns), the GT sub-field index, where the sample
+// columns start -- while the genotype text itself crosses PCIe untouched and is tokenised by
+// sai_tokenize_gt on the GPU.  A producer thread runs the same file walk as sai_vcf_load (plain,
+// gzip, bgzip with parallel inflate, tabix seek, early stop) and fills the caller's two pinned
+// buffers alternately; the consumer takes batch k while batch k+1 is being read.
+// ------------------------------------------------------------------------------------------
+
+struct IndexOut {
+  std::vector<int64_t> off;   // first byte of the first sample column, relative to the batch text
+  std::vector<int32_t> len;   // bytes from there to the end of the line (without "\r")
+  std::vector<int32_t> pos;
+  std::vector<uint8_t> flip, gi;
+  int64_t matched = 0;
+  bool saw_chrom = false, beyond_stop = false, last_line_other = false, failed = false;
+  std::string error;
+  void clear() {
+    off.clear(); len.clear(); pos.clear(); flip.clear(); gi.clear();
+    matched = 0;
+    saw_chrom = beyond_stop = last_line_other = failed = false;
+    error.clear();
+  }
+};
+
+// The fixed columns of the record lines of [begin, end): parse_lines without the sample loop.
+void index_lines(const char* begin, const char* end, const char* text0, const std::string& chrom, int64_t start,
+                 int64_t stop, const AncMap& anc, IndexOut& out) {
+  const char* p = begin;
+  while (p < end) {
+    const char* eol = static_cast<const char*>(memchr(p, '\n', static_cast<size_t>(end - p)));
+    if (!eol) eol = end;
+    const char* line = p;
+    p = eol + 1;
+    const char* le = eol;
+    if (le > line && le[-1] == '\r') --le;
+    if (le == line || *line == '#') continue;
+    const char* t1 = find_tab(line, le);
+    if (static_cast<size_t>(t1 - line) != chrom.size() || memcmp(line, chrom.data(), chrom.size()) != 0) {
+      out.last_line_other = true;
+      continue;
+    }
+    if (t1 >= le) continue;
+    out.last_line_other = false;
+    out.saw_chrom = true;
+    const char* f = t1 + 1;
+    int64_t pos = 0;
+    while (f < le && *f >= '0' && *f <= '9') pos = pos * 10 + (*f++ - '0');
+    if (stop >= 0 && pos > stop) out.beyond_stop = true;
+    if ((start >= 0 && pos < start) || (stop >= 0 && pos > stop)) continue;
+    ++out.matched;
+    const char* col[10];
+    col[0] = line;
+    col[1] = t1 + 1;
+    const char* q = find_tab(f, le);
+    bool ok = true;
+    for (int c = 2; c <= 9; ++c) {
+      if (q >= le) { ok = false; break; }
+      col[c] = q + 1;
+      q = find_tab(col[c], le);
+    }
+    if (!ok) { out.error = "record with fewer than 10 columns at " + chrom + ":" + std::to_string(pos); return; }
+    bool flip = false;
+    if (anc.active) {
+      auto it = anc.allele.find(pos);
+      if (it == anc.allele.end()) continue;
+      const char* ref = col[3];
+      const size_t ref_len = static_cast<size_t>(col[4] - 1 - col[3]);
+      const char* alt = col[4];
+      const char* alt_end = col[5] - 1;
+      const void* comma = memchr(alt, ',', static_cast<size_t>(alt_end - alt));
+      const size_t alt_len = static_cast<size_t>((comma ? static_cast<const char*>(comma) : alt_end) - alt);
+      const std::string& a = it->second;
+      if (a.size() == alt_len && memcmp(a.data(), alt, alt_len) == 0) flip = true;
+      else if (!(a.size() == ref_len && memcmp(a.data(), ref, ref_len) == 0)) continue;
+    }
+    int gi = -1;
+    {
+      const char* fs = col[8];
+      const char* fe = col[9] - 1;
+      int k = 0;
+      while (fs <= fe) {
+        const void* c = memchr(fs, ':', static_cast<size_t>(fe - fs));
+        const char* ce = c ? static_cast<const char*>(c) : fe;
+        if (ce - fs == 2 && fs[0] == 'G' && fs[1] == 'T') { gi = k; break; }
+        if (!c) break;
+        fs = ce + 1;
+        ++k;
+      }
+    }
+    if (gi < 0) { out.error = "record " + chrom + ":" + std::to_string(pos) + " has no GT field"; return; }
+    if (gi > 255 || le - col[9] > 0x7FFFFFFF) { out.error = "record " + chrom + ":" + std::to_string(pos) + " is outside the streaming limits"; return; }
+    out.off.push_back(static_cast<int64_t>(col[9] - text0));
+    out.len.push_back(static_cast<int32_t>(le - col[9]));
+    out.pos.push_back(static_cast<int32_t>(pos));
+    out.flip.push_back(flip ? 1 : 0);
+    out.gi.push_back(static_cast<uint8_t>(gi));
+  }
+}
+
+}  // namespace
+
+struct sai_vcf_stream {
+  std::string path, chrom, anc_path;
+  int64_t start = -1, end = -1;
+  int n_threads = 1;
+  std::vector<std::string> names;
+  std::vector<int32_t> ploidy;
+  char* bufs[2] = {nullptr, nullptr};
+  size_t cap = 0;
+  // producer state
+  Selection sel;
+  AncMap anc;
+  bool header_seen = false;
+  int64_t n_matched = 0, n_anc = 0;
+  // hand-over: batch k lives in buffer k % 2
+  std::mutex m;
+  std::condition_variable cv;
+  IndexOut batch[2];
+  size_t batch_bytes[2] = {0, 0};
+  int state[2] = {0, 0};  // 0 free, 1 full, 2 held by the consumer
+  int64_t produced = 0, consumed = 0;
+  int held = -1;
+  bool finished = false, cancel = false;
+  int rc = 0;
+  std::string err;
+  std::thread producer;
+};
+
+namespace {
+
+// Copy + index [p, endp) (whole lines) into the next free buffer(s).  Returns 0, or a negative status.
+int stream_emit(sai_vcf_stream* st, const char* p, const char* endp, bool* done, bool* seen_chrom) {
+  const int nt = std::max(1, st->n_threads);
+  std::vector<IndexOut> outs(static_cast<size_t>(nt));
+  while (p < endp) {
+    // the part of [p, endp) that fits a buffer, cut at a line boundary
+    const char* cut = endp;
+    if (static_cast<size_t>(endp - p) > st->cap) {
+      cut = p + st->cap;
+      while (cut > p && cut[-1] != '\n') --cut;
+      if (cut == p) return sai_set_error(SAI_ERR_UNSUPPORTED, "%s: a line is longer than the staging buffer", st->path.c_str());
+    }
+    int b;
+    {
+      std::unique_lock<std::mutex> lk(st->m);
+      b = static_cast<int>(st->produced % 2);
+      st->cv.wait(lk, [&] { return st->state[b] == 0 || st->cancel; });
+      if (st->cancel) return 1;
+    }
+    char* dst = st->bufs[b];
+    const size_t total = static_cast<size_t>(cut - p);
+    std::vector<const char*> edge(static_cast<size_t>(nt) + 1, cut);
+    edge[0] = p;
+    for (int t = 1; t < nt; ++t) {
+      const char* guess = p + total * static_cast<size_t>(t) / static_cast<size_t>(nt);
+      if (guess < edge[static_cast<size_t>(t) - 1]) guess = edge[static_cast<size_t>(t) - 1];
+      const char* nl = static_cast<const char*>(memchr(guess, '\n', static_cast<size_t>(cut - guess)));
+      edge[static_cast<size_t>(t)] = nl ? nl + 1 : cut;
+    }
+    for (auto& o : outs) o.clear();
+    auto piece = [&](int t) {
+      IndexOut& o = outs[static_cast<size_t>(t)];
+      const char* a = edge[static_cast<size_t>(t)];
+      const char* z = edge[static_cast<size_t>(t) + 1];
+      if (a >= z) return;
+      try {
+        memcpy(dst + (a - p), a, static_cast<size_t>(z - a));  // the text goes to the pinned buffer as it is
+        index_lines(a, z, p, st->chrom, st->start, st->end, st->anc, o);
+      } catch (...) {
+        o.failed = true;
+      }
+    };
+    {
+      ThreadGroup th;
+      for (int t = 1; t < nt; ++t) th.spawn([&piece, t] { piece(t); });
+      piece(0);
+      th.join();
+    }
+    IndexOut& out = st->batch[b];
+    out.clear();
+    for (auto& o : outs) {
+      if (o.failed) return sai_set_error(SAI_ERR_HIP, "%s: indexing failed (out of memory)", st->path.c_str());
+      if (!o.error.empty()) return sai_set_error(SAI_ERR_ARG, "%s: %s", st->path.c_str(), o.error.c_str());
+      st->n_matched += o.matched;
+      out.off.insert(out.off.end(), o.off.begin(), o.off.end());
+      out.len.insert(out.len.end(), o.len.begin(), o.len.end());
+      out.pos.insert(out.pos.end(), o.pos.begin(), o.pos.end());
+      out.flip.insert(out.flip.end(), o.flip.begin(), o.flip.end());
+      out.gi.insert(out.gi.end(), o.gi.begin(), o.gi.end());
+      *seen_chrom = *seen_chrom || o.saw_chrom;
+      if (o.beyond_stop || (*seen_chrom && o.last_line_other)) *done = true;
+    }
+    {
+      std::lock_guard<std::mutex> lk(st->m);
+      st->batch_bytes[b] = total;
+      st->state[b] = 1;
+      ++st->produced;
+    }
+    st->cv.notify_all();
+    p = cut;
+  }
+  return 0;
+}
+
+int stream_run(sai_vcf_stream* st) {
+  const char* path = st->path.c_str();
+  if (!st->anc_path.empty()) {
+    if (int rc = load_anc(st->anc_path.c_str(), st->chrom, st->start, st->end, st->anc, &st->n_anc)) return rc;
+  }
+  std::vector<const char*> names;
+  for (auto& n : st->names) names.push_back(n.c_str());
+  bool done = false, seen_chrom = false;
+  auto on_header = [&](const char*& p, const char* endp) -> int {
+    while (!st->header_seen && p < endp) {
+      const char* eol = static_cast<const char*>(memchr(p, '\n', static_cast<size_t>(endp - p)));
+      if (!eol) eol = endp;
+      if (*p != '#') return sai_set_error(SAI_ERR_ARG, "%s: no #CHROM header line before the records", path);
+      if (eol - p > 6 && memcmp(p, "#CHROM", 6) == 0) {
+        if (int hrc = parse_header(p, eol, path, static_cast<int32_t>(names.size()), names.data(), st->ploidy.data(), st->sel))
+          return hrc;
+        std::lock_guard<std::mutex> lk(st->m);
+        st->header_seen = true;
+      }
+      p = eol + 1;
+    }
+    return 0;
+  };
+  auto on_records = [&](const char* p, const char* endp) -> int {
+    if (p >= endp) return 0;
+    const int rc = stream_emit(st, p, endp, &done, &seen_chrom);
+    if (rc < 0) return rc;
+    return (rc > 0 || done) ? 1 : 0;
+  };
+  int rc;
+  TbiRef idx;
+  if (st->start >= 0 && file_is_bgzf(path) && load_tbi(path, st->chrom, idx)) {
+    rc = for_each_block_from(path, 1, 0, size_t(1) << 16, [&](const char* p, const char* endp) -> int {
+      if (int hrc = on_header(p, endp)) return hrc;
+      return (st->header_seen || p < endp) ? 1 : 0;
+    });
+    const uint64_t window = static_cast<uint64_t>(st->start > 0 ? st->start - 1 : 0) >> 14;
+    if (rc == SAI_OK && st->header_seen && idx.present && window < idx.ioff.size())
+      rc = for_each_block_from(path, st->n_threads, idx.ioff[window], 0, on_records);
+  } else {
+    rc = for_each_block(path, st->n_threads, [&](const char* p, const char* endp) -> int {
+      if (int hrc = on_header(p, endp)) return hrc;
+      return on_records(p, endp);
+    });
+  }
+  if (rc) return rc;
+  if (!st->header_seen) return sai_set_error(SAI_ERR_ARG, "%s: not a VCF (no #CHROM header)", path);
+  return SAI_OK;
+}
+
+void stream_producer(sai_vcf_stream* st) {
+  int rc;
+  std::string err;
+  try {
+    rc = stream_run(st);
+    if (rc) err = sai_last_error();  // the producer thread's own message
+  } catch (const std::bad_alloc&) {
+    rc = SAI_ERR_HIP;
+    err = "sai_vcf_stream: out of host memory";
+  } catch (const std::exception& e) {
+    rc = SAI_ERR_HIP;
+    err = std::string("sai_vcf_stream: ") + e.what();
+  } catch (...) {
+    rc = SAI_ERR_HIP;
+    err = "sai_vcf_stream: unknown failure";
+  }
+  {
+    std::lock_guard<std::mutex> lk(st->m);
+    st->rc = rc;
+    st->err = err;
+    st->finished = true;
+  }
+  st->cv.notify_all();
 }
 
 }  // namespace
@@ -889,6 +1245,107 @@ int sai_vcf_block_copy(const sai_vcf_block* block, int32_t* pos_host, int8_t* do
     memcpy(pos_host, block->pos.data(), block->pos.size() * sizeof(int32_t));
     memcpy(dosage_host, block->dosage.data(), block->dosage.size());
   }
+  return SAI_OK;
+}
+
+int sai_vcf_stream_open(const char* path, const char* chrom, int64_t start, int64_t end, int32_t n_samples,
+                        const char* const* sample_names, const int32_t* ploidy, const char* anc_bed_path,
+                        int32_t n_threads, void* pinned0_host, void* pinned1_host, int64_t buffer_bytes,
+                        sai_vcf_stream** stream_out) {
+  return guarded("sai_vcf_stream_open", [&]() -> int {
+    if (!path || !chrom || !stream_out) return sai_set_error(SAI_ERR_ARG, "NULL argument");
+    *stream_out = nullptr;
+    if (n_samples < 1 || !sample_names || !ploidy) return sai_set_error(SAI_ERR_ARG, "empty sample selection");
+    if (!pinned0_host || !pinned1_host || buffer_bytes < (1 << 16)) return sai_set_error(SAI_ERR_ARG, "two staging buffers of at least 64 KiB are needed");
+    for (int32_t s = 0; s < n_samples; ++s)
+      if (ploidy[s] < 1 || ploidy[s] > 64) return sai_set_error(SAI_ERR_ARG, "ploidy of sample %d out of range", s);
+    {
+      FILE* f = fopen(path, "rb");
+      if (!f) return sai_set_error(SAI_ERR_ARG, "cannot open VCF %s", path);
+      fclose(f);
+    }
+    std::unique_ptr<sai_vcf_stream> st(new sai_vcf_stream);
+    st->path = path;
+    st->chrom = chrom;
+    st->start = start;
+    st->end = end;
+    st->n_threads = n_threads < 1 ? 1 : n_threads;
+    if (anc_bed_path) st->anc_path = anc_bed_path;
+    for (int32_t s = 0; s < n_samples; ++s) {
+      st->names.emplace_back(sample_names[s]);
+      st->ploidy.push_back(ploidy[s]);
+    }
+    st->bufs[0] = static_cast<char*>(pinned0_host);
+    st->bufs[1] = static_cast<char*>(pinned1_host);
+    st->cap = static_cast<size_t>(buffer_bytes);
+    sai_vcf_stream* raw = st.get();
+    st->producer = std::thread(stream_producer, raw);
+    *stream_out = st.release();
+    return SAI_OK;
+  });
+}
+
+int sai_vcf_stream_next(sai_vcf_stream* st, int32_t* buffer_index, int64_t* n_text_bytes, int64_t* n_lines,
+                        const int64_t** line_off_host, const int32_t** line_len_host, const int32_t** line_pos_host,
+                        const uint8_t** line_flip_host, const uint8_t** line_gi_host, int32_t* done) {
+  if (!st || !buffer_index || !n_text_bytes || !n_lines || !line_off_host || !line_len_host || !line_pos_host ||
+      !line_flip_host || !line_gi_host || !done)
+    return sai_set_error(SAI_ERR_ARG, "NULL argument");
+  std::unique_lock<std::mutex> lk(st->m);
+  if (st->held >= 0) {  // the caller is done with the batch it got last time
+    st->state[st->held] = 0;
+    st->held = -1;
+    st->cv.notify_all();
+  }
+  const int b = static_cast<int>(st->consumed % 2);
+  st->cv.wait(lk, [&] { return st->state[b] == 1 || st->finished; });
+  if (st->state[b] != 1) {  // nothing more will come
+    *done = 1;
+    *n_lines = *n_text_bytes = 0;
+    *buffer_index = -1;
+    if (st->rc) return sai_set_error(st->rc, "%s", st->err.c_str());
+    return SAI_OK;
+  }
+  const IndexOut& o = st->batch[b];
+  st->state[b] = 2;
+  st->held = b;
+  ++st->consumed;
+  *done = 0;
+  *buffer_index = b;
+  *n_text_bytes = static_cast<int64_t>(st->batch_bytes[b]);
+  *n_lines = static_cast<int64_t>(o.off.size());
+  *line_off_host = o.off.data();
+  *line_len_host = o.len.data();
+  *line_pos_host = o.pos.data();
+  *line_flip_host = o.flip.data();
+  *line_gi_host = o.gi.data();
+  return SAI_OK;
+}
+
+int sai_vcf_stream_selection(sai_vcf_stream* st, int32_t* slot_of_col_host, int32_t capacity, int32_t* n_cols,
+                             int64_t* n_matched, int64_t* n_anc_entries) {
+  if (!st || !n_cols) return sai_set_error(SAI_ERR_ARG, "NULL argument");
+  std::lock_guard<std::mutex> lk(st->m);
+  if (!st->header_seen) return sai_set_error(SAI_ERR_ARG, "the header has not been read yet");
+  *n_cols = st->sel.max_col + 1;
+  if (slot_of_col_host) {
+    if (capacity < *n_cols) return sai_set_error(SAI_ERR_ARG, "slot_of_col capacity %d < %d", capacity, *n_cols);
+    for (int32_t c = 0; c < *n_cols; ++c) slot_of_col_host[c] = st->sel.slot_of_col[static_cast<size_t>(c)];
+  }
+  if (n_matched) *n_matched = st->n_matched;  // complete once sai_vcf_stream_next has reported done
+  if (n_anc_entries) *n_anc_entries = st->n_anc;
+  return SAI_OK;
+}
+
+int sai_vcf_stream_close(sai_vcf_stream* st) {
+  if (!st) return SAI_OK;
+  {
+    std::lock_guard<std::mutex> lk(st->m);
+    st->cancel = true;
+  }
+  st->cv.notify_all();
+  if (st->producer.joinable()) st->producer.join();
+  delete st;
   return SAI_OK;
 }
 

@@ -241,6 +241,23 @@ class Engine:
             torch.cuda.current_stream(self.device).synchronize()
         return out
 
+    def tile_columns(self, block, cols: Sequence[int]) -> TiledPop:
+        """Tiled block of the columns ``cols`` of a device int8 [records][samples] block (what the GPU
+        tokenizer leaves behind): a contiguous run of columns is re-tiled in place with the block's
+        row stride, anything else is gathered first."""
+        torch = _torch()
+        cols = [int(c) for c in cols]
+        n_sites, width = int(block.shape[0]), int(block.shape[1])
+        if cols and cols == list(range(cols[0], cols[0] + len(cols))):
+            n_ind = len(cols)
+            nbytes = self.lib.sai_tiled_bytes(n_sites, n_ind)
+            dst = self._empty((max(nbytes, 0),), torch.int8)
+            src_ptr = C.c_void_p(block.data_ptr() + cols[0]) if block.numel() else C.c_void_p(0)
+            _ffi.check(self.lib.sai_tile_from_site_major(self.ctx, src_ptr, n_sites, n_ind, width, self._ptr(dst), self._stream()))
+            return TiledPop(dst, n_sites, n_ind)
+        idx = torch.tensor(cols, dtype=torch.int64, device=self.device)
+        return self._tile_device(block.index_select(1, idx).contiguous())
+
     def _tile_device(self, src) -> TiledPop:
         torch = _torch()
         n_sites, n_ind = int(src.shape[0]), int(src.shape[1])

@@ -50,29 +50,36 @@ class WindowGenerator(DataGenerator):
         end: int = None,
         anc_allele_file: str = None,
         num_src: int = 1,
+        resident: bool = False,
     ):
+        """``resident=True`` (the batched GPU driver, ChunkPreprocessor): the region is streamed to
+        the GPU and tokenised there, the populations exist only as tiled blocks in HBM and ``get()``
+        is not available; otherwise the populations are host matrices, as in the reference."""
         if win_len <= 0:
             raise ValueError("`win_len` must be greater than 0.")
         if win_step < 0:
             raise ValueError("`win_step` must be non-negative.")
         if num_src < 1:
             raise ValueError("`num_src` must be at least 1.")
-        results = read_data(
-            vcf_file=vcf_file,
-            chr_name=chr_name,
-            start=start,
-            end=end,
-            ref_ind_file=ref_ind_file,
-            tgt_ind_file=tgt_ind_file,
-            src_ind_file=src_ind_file,
-            out_ind_file=out_ind_file,
-            ploidy_config=ploidy_config,
-            anc_allele_file=anc_allele_file,
-        )
+        kw = dict(vcf_file=vcf_file, chr_name=chr_name, start=start, end=end, ref_ind_file=ref_ind_file,
+                  tgt_ind_file=tgt_ind_file, src_ind_file=src_ind_file, out_ind_file=out_ind_file,
+                  ploidy_config=ploidy_config, anc_allele_file=anc_allele_file)  # fmt: skip
+        pos_dev = None
+        if resident:
+            from ..engine import Engine
+            from ..utils.read_data import read_data_device
+
+            results, pos_dev = read_data_device(Engine.get(), **kw)
+        else:
+            results = read_data(**kw)
         self._setup(
             chr_name, win_len, win_step, ploidy_config, results["ref"], results["tgt"], results["src"], start, end, num_src,
             results["outgroup"],
         )
+        if pos_dev is not None:
+            first = next(iter(self.ref_data.values())) if self.ref_data else None
+            if first is not None:
+                self._device_pos = (first.POS, pos_dev)
 
     @classmethod
     def from_arrays(

@@ -3,6 +3,7 @@ region -> all its windows, computed in batched launches on the GPU."""
 
 from __future__ import annotations
 
+import os
 from typing import Any
 
 from ..generators.window_generator import WindowGenerator
@@ -65,6 +66,7 @@ class ChunkPreprocessor(DataPreprocessor):
             ploidy_config=self.ploidy_config,
             anc_allele_file=self.anc_allele_file,
             num_src=self.num_src,
+            resident=os.environ.get("SAI_AMD_INGEST", "device") != "host",
         )
         return self.feature_preprocessor.score_windows(window_generator)
 

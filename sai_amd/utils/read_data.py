@@ -123,6 +123,88 @@ def read_data(
     return results
 
 
+def read_data_device(eng, vcf_file: str, chr_name: str, ploidy_config, ref_ind_file, tgt_ind_file, src_ind_file,
+                     out_ind_file=None, anc_allele_file=None, start: int = None, end: int = None):
+    """``read_data`` with the genotypes left in HBM: one streaming pass over the file (text over PCIe,
+    tokenised on the GPU, ``device_vcf.load_dosage_device``) for all populations and ploidies, then one
+    re-tiling launch per population straight from the shared [record][sample] block.  Returns
+    ``(results, pos_dev)``: ``results`` as ``read_data`` gives it, except that every ``GT`` is a
+    ``TiledPop``; ``pos_dev`` = the int32 device copy of the positions (None without data)."""
+    import torch
+
+    from .device_vcf import load_dosage_device
+
+    chr_name = str(chr_name)
+    groups = [("ref", ref_ind_file), ("tgt", tgt_ind_file), ("src", src_ind_file)]
+    if out_ind_file is not None and "outgroup" in ploidy_config.root:
+        groups.append(("outgroup", out_ind_file))
+    samples_by_group, column, names, ploidies = {}, {}, [], []
+    for group, ind_file in groups:
+        if ind_file is None:
+            samples_by_group[group] = None
+            continue
+        samples = parse_ind_file(ind_file)
+        if group not in ploidy_config.root:
+            raise ValueError(f"Ploidy configuration missing group '{group}'.")
+        for population in ploidy_config.root[group]:
+            if population not in samples:
+                raise ValueError(
+                    f"Population '{population}' in ploidy_config[{group}] not found in sample file: {ind_file}"
+                )
+        samples_by_group[group] = samples
+        for population, pop_names in samples.items():
+            if population not in ploidy_config.root[group]:
+                continue
+            ploidy = ploidy_config.root[group][population]
+            for nme in pop_names:  # one output column per (sample, ploidy): the first occurrence keeps its place
+                if (nme, ploidy) not in column:
+                    column[(nme, ploidy)] = len(names)
+                    names.append(nme)
+                    ploidies.append(ploidy)
+    results: dict = {"outgroup": (None, None)}
+    if not names:
+        for group, _ in groups:
+            results[group] = (None, samples_by_group[group])
+        return results, None
+    if len(set(names)) != len(names):
+        # a sample read at two ploidies: the streaming reader maps a VCF column to one slot
+        raise NotImplementedError("a sample that belongs to populations of different ploidy needs the host reader")
+    where = chr_name if start is None and end is None else f"{chr_name}:{start}-{end}"
+    if not os.path.exists(vcf_file):
+        raise ValueError(f"Failed to read VCF file {vcf_file} from {where}: cannot open VCF {vcf_file}")
+    try:
+        pos, dos, n_matched, n_anc = load_dosage_device(eng, vcf_file, chr_name, names, ploidies, start, end, anc_allele_file)
+    except FileNotFoundError:
+        raise
+    except Exception as e:  # utils.py:139-140
+        raise ValueError(f"Failed to read VCF file {vcf_file} from {where}: {e}") from e
+    if anc_allele_file and n_matched and n_anc == 0:  # read_anc_allele, utils.py:480-487
+        if start is not None or end is not None:
+            raise ValueError(f"No ancestral allele is found for chromosome {chr_name} in the region {start}-{end}.")
+        raise ValueError(f"No ancestral allele is found for chromosome {chr_name}.")
+    pos_dev = torch.from_numpy(pos).to(eng.device) if n_matched else None
+    for group, _ in groups:
+        samples = samples_by_group[group]
+        if samples is None:
+            results[group] = (None, None)
+            continue
+        data: dict[str, ChromosomeData] = {}
+        for population, pop_names in samples.items():
+            if population not in ploidy_config.root[group]:
+                warnings.warn(
+                    f"Population '{population}' found in sample file but not in ploidy_config[{group}]; skipping.",
+                    RuntimeWarning,
+                )
+                continue
+            if n_matched == 0:
+                continue
+            ploidy = ploidy_config.root[group][population]
+            cols = [column[(nme, ploidy)] for nme in pop_names]
+            data[population] = ChromosomeData(POS=pos, REF=None, ALT=None, GT=eng.tile_columns(dos, cols))
+        results[group] = (data if data else None, samples)
+    return results, pos_dev
+
+
 def _load_native(vcf_file, chr_name, names, ploidy, start, end, anc_allele_file):
     """libsaihip's multithreaded tokenizer (sai_amd/csrc/vcf_ingest.cpp)."""
     from .native_vcf import load_dosage

@@ -1,0 +1,156 @@
+"""The GPU ingest (sai_vcf_stream_* + sai_tokenize_gt, sai_amd.utils.device_vcf): the text of a VCF
+region crosses PCIe as it is and is tokenised on the GPU -- same positions, same dosage bytes, same
+errors as the host tokenizer (sai_vcf_load), which test_ingest_native.py pins to the Python
+statement of the reference's rules."""
+
+import numpy as np
+import pytest
+
+from test_ingest_native import write_tbi, write_vcf
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    import torch
+
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    from sai_amd.engine import Engine
+
+    return Engine.get(0)
+
+
+def untile(pop):
+    raw = pop.tiles.cpu().numpy()
+    n_tiles = (pop.n_sites + 63) // 64
+    return raw.reshape(n_tiles, pop.n_ind, 64).transpose(0, 2, 1).reshape(-1, pop.n_ind)[: pop.n_sites]
+
+
+@pytest.mark.parametrize("gz,crlf", [(False, False), (True, False), (False, True), ("bgzf", False), ("bgzf", True)])
+def test_device_reader_equals_host_reader(eng, tmp_path, gz, crlf, monkeypatch):
+    from sai_amd.utils.device_vcf import load_dosage_device
+    from sai_amd.utils.native_vcf import load_dosage
+    from sai_amd.utils.vcf import read_region
+
+    rng = np.random.default_rng(41 + bool(gz) + 2 * crlf)
+    path = tmp_path / ("t.vcf.gz" if gz else "t.vcf")
+    names = write_vcf(path, rng, 500, 37, gz=gz, crlf=crlf)
+    bed = tmp_path / "anc.bed"
+    reg = read_region(str(path), "21", names[:1])
+    with open(bed, "w") as f:
+        for p, r, a in zip(reg.pos, reg.ref, reg.alt):
+            u = rng.random()
+            if u >= 0.3:
+                f.write(f"21\t{p - 1}\t{p}\t{r if u < 0.6 else (a if u < 0.9 else '-')}\n")
+    pick = [names[i] for i in rng.permutation(37)[:29]]
+    ploidies = [int(rng.choice([1, 2, 2, 3, 4])) for _ in pick]
+    for batch_env in ("20000", None):  # tiny reader batches, then the default
+        if batch_env:
+            monkeypatch.setenv("SAI_VCF_BATCH_BYTES", batch_env)
+        else:
+            monkeypatch.delenv("SAI_VCF_BATCH_BYTES")
+        for start, end in ((None, None), (500, 9000), (9001, 9001), (10**7, None)):
+            for anc in (None, str(bed)):
+                for cap in (1 << 16, None):
+                    pos, dos, nm, na = load_dosage_device(eng, str(path), "21", pick, ploidies, start, end, anc, 3, cap)
+                    want = load_dosage(str(path), "21", pick, ploidies, start, end, anc, 2)
+                    assert pos.dtype == np.int32 and pos.tolist() == want[0].tolist()
+                    assert tuple(dos.shape) == want[1].shape and np.array_equal(dos.cpu().numpy(), want[1])
+                    assert nm == want[2]
+                    if anc and want[2]:
+                        assert na == want[3]
+
+
+def test_device_reader_edge_lines_and_errors(eng, tmp_path):
+    from sai_amd.utils.device_vcf import load_dosage_device
+    from sai_amd.utils.native_vcf import load_dosage
+
+    head = "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\ta\tb\tc\n"
+    ok = tmp_path / "edge.vcf"
+    ok.write_text(
+        head
+        + "1\t10\t.\tA\tT\t.\t.\t.\tGT\t0|1\t1/1\t.\n"          # a lone '.'
+        + "1\t20\t.\tA\tT\t.\t.\t.\tGT\t\t1\t\n"                # empty fields, the line ends in a tab
+        + "1\t30\t.\tA\tT\t.\t.\t.\tDP:GT\t5:1|1\t7\t3:0|0|1\n"  # a field without its GT sub-field, extra alleles
+        + "1\t40\t.\tA\tT,G\t.\t.\t.\tGT:DP\t2|10:4\t0|2\t1\n"    # allele indices 2 and 10
+        + "1\t50\t.\tA\tT\t.\t.\t.\tGT\t0|1\t1|1\t0/0"            # no newline at the end of the file
+    )
+    for ploidies in ([2, 2, 2], [1, 3, 4]):
+        got = load_dosage_device(eng, str(ok), "1", ["a", "b", "c"], ploidies)
+        want = load_dosage(str(ok), "1", ["a", "b", "c"], ploidies)
+        assert got[0].tolist() == want[0].tolist() == [10, 20, 30, 40, 50]
+        assert np.array_equal(got[1].cpu().numpy(), want[1])
+    # a subset in another order, the last VCF column not selected
+    got = load_dosage_device(eng, str(ok), "1", ["b", "a"], [2, 2])
+    want = load_dosage(str(ok), "1", ["b", "a"], [2, 2])
+    assert np.array_equal(got[1].cpu().numpy(), want[1])
+    for body, msg in (("1\t10\t.\tA\tT\t.\t.\t.\tGT\t0|1\t0|x\t0|0\n", "unparsable genotype"),
+                      ("1\t10\t.\tA\tT\t.\t.\t.\tGT\t0|1\t0|1\n", "too few sample columns"),
+                      ("1\t10\t.\tA\tT\t.\t.\t.\tGT\t0|1\t99|99\t0|0\n", "int8")):  # fmt: skip
+        bad = tmp_path / "bad.vcf"
+        bad.write_text(head + "1\t5\t.\tA\tT\t.\t.\t.\tGT\t0|0\t0|0\t0|0\n" + body)
+        with pytest.raises(ValueError, match=msg):
+            load_dosage(str(bad), "1", ["a", "b", "c"], [2, 2, 2])
+        with pytest.raises(ValueError, match=msg):
+            load_dosage_device(eng, str(bad), "1", ["a", "b", "c"], [2, 2, 2])
+    # a line longer than the staging buffer: the stream refuses, the caller sees a ValueError
+    rng = np.random.default_rng(2)
+    wide = tmp_path / "wide.vcf"
+    wnames = write_vcf(wide, rng, 3, 30000, chroms=("21",))
+    with pytest.raises(ValueError, match="staging buffer"):
+        load_dosage_device(eng, str(wide), "21", wnames[:2], [2, 2], buffer_bytes=1 << 16)
+    got = load_dosage_device(eng, str(wide), "21", wnames[5:9], [2] * 4)  # the default buffer holds it
+    assert np.array_equal(got[1].cpu().numpy(), load_dosage(str(wide), "21", wnames[5:9], [2] * 4)[1])
+
+
+def test_tabix_region_through_the_device_reader(eng, tmp_path):
+    from sai_amd.utils.device_vcf import load_dosage_device
+    from sai_amd.utils.native_vcf import load_dosage
+
+    rng = np.random.default_rng(5)
+    path = tmp_path / "i.vcf.gz"
+    names = write_vcf(path, rng, 1500, 7, gz="bgzf")
+    write_tbi(path)
+    for chrom in ("7", "22", "nope"):
+        for reg in ((1, 10**9), (5000, 40000), (16385, 32768), (70000, 70010), (33000, None)):
+            got = load_dosage_device(eng, str(path), chrom, names, [2] * 7, reg[0], reg[1])
+            want = load_dosage(str(path), chrom, names, [2] * 7, reg[0], reg[1], None, 3)
+            assert got[0].tolist() == want[0].tolist() and np.array_equal(got[1].cpu().numpy(), want[1]) and got[2] == want[2]
+
+
+@pytest.mark.parametrize("vcf,chrom,cfgfile,anc", [
+    ("tests/data/test.with.outgroup.vcf.gz", "1", "tests/data/test.with.outgroup.config.yaml", "tests/data/test.with.outgroup.anc.alleles"),
+    ("tests/data/test.mixed.ploidy.data.vcf.gz", "21", "tests/data/test_mixed_ploidy.config.yaml", "tests/data/test.mixed.ploidy.data.anc.alleles"),
+    ("tests/data/example.vcf", "21", "tests/data/example.u_and_q.config.yaml", None),
+])  # fmt: skip
+def test_read_data_device_and_score_equal_the_host_path(eng, in_repo_root, tmp_path, monkeypatch, vcf, chrom, cfgfile, anc):
+    """The reference's fixtures: every population block read on the GPU equals the host reader's
+    matrix, and `score` writes byte-identical files with either reader."""
+    import os
+
+    from sai_amd.sai import load_config, score
+    from sai_amd.utils.read_data import read_data, read_data_device
+
+    if not os.path.exists(cfgfile):
+        pytest.skip("fixture config not present")
+    cfg = load_config(cfgfile)
+    kw = dict(vcf_file=vcf, chr_name=chrom, ploidy_config=cfg.ploidies, ref_ind_file=cfg.populations.get_population("ref"),
+              tgt_ind_file=cfg.populations.get_population("tgt"), src_ind_file=cfg.populations.get_population("src"),
+              out_ind_file=cfg.populations.get_population("outgroup"), anc_allele_file=anc)  # fmt: skip
+    host = read_data(**kw)
+    dev, pos_dev = read_data_device(eng, **kw)
+    for group in ("ref", "tgt", "src", "outgroup"):
+        hd, dd = host[group][0], dev[group][0]
+        assert (hd is None) == (dd is None)
+        for pop in hd or {}:
+            assert hd[pop].POS.tolist() == dd[pop].POS.tolist() == pos_dev.cpu().numpy().tolist()
+            assert np.array_equal(untile(dd[pop].GT), hd[pop].GT)
+    outs = {}
+    for mode in ("device", "host"):
+        monkeypatch.setenv("SAI_AMD_INGEST", mode)
+        out = tmp_path / f"{mode}.tsv"
+        score(vcf_file=vcf, chr_name=chrom, win_len=20000, win_step=10000, anc_allele_file=anc, output_file=str(out),
+              config=cfgfile, num_workers=1)  # fmt: skip
+        outs[mode] = {p.suffixes[-2] if len(p.suffixes) > 1 else "": p.read_text() for p in tmp_path.glob(f"{mode}*")}
+    assert outs["device"] == outs["host"] and len(outs["device"][""].splitlines()) > 1

@@ -1,0 +1,147 @@
+"""The streaming half of the GPU ingest (libsaihip: sai_vcf_stream_*): the host indexes the record
+lines (region, POS, ancestral-allele keep / flip / drop, GT sub-field, where the sample columns
+start) while the text goes to the caller's staging buffers untouched.  Host-side only: the indexed
+text is tokenised here by a few lines of Python following the reader's rules and compared with the
+host tokenizer (sai_vcf_load), on the awkward files of test_ingest_native.py; the GPU half
+(sai_tokenize_gt) is tests/test_ingest_device.py."""
+
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from test_ingest_native import write_tbi, write_vcf
+
+
+def stream_batches(path, chrom, names, ploidies, start=None, end=None, anc=None, threads=3, cap=1 << 16):
+    """[(text bytes, off, len, pos, flip, gi)] per batch + (slot_of_col, n_matched, n_anc)."""
+    from sai_amd import _ffi
+
+    lib = _ffi.load_host()
+    bufs = [np.zeros(cap, dtype=np.uint8) for _ in range(2)]
+    n = len(names)
+    c_names = (C.c_char_p * n)(*[s.encode() for s in names])
+    c_pl = (C.c_int32 * n)(*ploidies)
+    h = C.c_void_p()
+    rc = lib.sai_vcf_stream_open(os.fsencode(str(path)), chrom.encode(), -1 if start is None else start, -1 if end is None else end,
+                                 n, c_names, c_pl, os.fsencode(anc) if anc else None, threads, bufs[0].ctypes.data_as(C.c_void_p),
+                                 bufs[1].ctypes.data_as(C.c_void_p), cap, C.byref(h))  # fmt: skip
+    if rc:
+        raise ValueError(lib.sai_last_error().decode())
+    out, sel = [], None
+    try:
+        b, nb, nl, done = C.c_int32(), C.c_int64(), C.c_int64(), C.c_int32()
+        ptrs = [C.c_void_p() for _ in range(5)]
+        while True:
+            if lib.sai_vcf_stream_next(h, C.byref(b), C.byref(nb), C.byref(nl), *[C.byref(p) for p in ptrs], C.byref(done)):
+                raise ValueError(lib.sai_last_error().decode())
+            if done.value:
+                break
+            k = int(nl.value)
+            get = lambda p, ct: np.ctypeslib.as_array(C.cast(p, C.POINTER(ct)), shape=(k,)).copy() if k else np.zeros(0, np.int64)  # noqa: E731
+            out.append((bufs[b.value][: nb.value].tobytes(), get(ptrs[0], C.c_int64), get(ptrs[1], C.c_int32), get(ptrs[2], C.c_int32),
+                        get(ptrs[3], C.c_uint8), get(ptrs[4], C.c_uint8)))  # fmt: skip
+        cols, nm, na = C.c_int32(), C.c_int64(), C.c_int64()
+        if lib.sai_vcf_stream_selection(h, None, 0, C.byref(cols), C.byref(nm), C.byref(na)) == 0:
+            slots = np.empty(max(cols.value, 1), dtype=np.int32)
+            assert lib.sai_vcf_stream_selection(h, slots.ctypes.data_as(C.c_void_p), cols.value, C.byref(cols), None, None) == 0
+            sel = (slots[: cols.value].tolist(), int(nm.value), int(na.value))
+    finally:
+        lib.sai_vcf_stream_close(h)
+    return out, sel
+
+
+def python_tokenize(batches, slot_of_col, ploidies):
+    """The reader's rules on the indexed text: GT sub-field, alleles split at | and /, '.' or empty
+    = -1, padded / cut to the ploidy, summed; a flipped line sums |a - 1|."""
+    pos, rows = [], []
+    for text, off, ln, p, flip, gi in batches:
+        for o, n, pp, fl, g in zip(off, ln, p, flip, gi):
+            fields = text[o : o + n].decode().split("\t")
+            row = [None] * len(ploidies)
+            for c, slot in enumerate(slot_of_col):
+                if slot < 0:
+                    continue
+                sub = fields[c].split(":")
+                gt = sub[g] if g < len(sub) else ""
+                alle = [(-1 if a in (".", "") else int(a)) for a in gt.replace("/", "|").split("|")]
+                alle = (alle + [-1] * ploidies[slot])[: ploidies[slot]]
+                row[slot] = sum(abs(a - 1) for a in alle) if fl else sum(alle)
+            pos.append(int(pp))
+            rows.append(row)
+    return np.array(pos, dtype=np.int32), np.array(rows, dtype=np.int8).reshape(len(rows), len(ploidies))
+
+
+@pytest.mark.parametrize("gz,crlf", [(False, False), (True, False), (False, True), ("bgzf", False), ("bgzf", True)])
+def test_stream_index_plus_python_tokenizer_equals_host_reader(tmp_path, gz, crlf, monkeypatch):
+    from sai_amd.utils.native_vcf import load_dosage
+    from sai_amd.utils.vcf import read_region
+
+    rng = np.random.default_rng(31 + bool(gz) + 2 * crlf)
+    path = tmp_path / ("t.vcf.gz" if gz else "t.vcf")
+    names = write_vcf(path, rng, 300, 11, gz=gz, crlf=crlf)
+    bed = tmp_path / "anc.bed"
+    reg = read_region(str(path), "21", names[:1])
+    with open(bed, "w") as f:
+        for p, r, a in zip(reg.pos, reg.ref, reg.alt):
+            u = rng.random()
+            if u >= 0.3:
+                f.write(f"21\t{p - 1}\t{p}\t{r if u < 0.6 else (a if u < 0.9 else '-')}\n")
+    pick = [names[i] for i in (4, 0, 10, 3)]
+    ploidies = [2, 1, 4, 3]
+    monkeypatch.setenv("SAI_VCF_BATCH_BYTES", "30000")  # several reader batches per file
+    for start, end in ((None, None), (500, 9000), (10**7, None)):
+        for anc in (None, str(bed)):
+            for cap in (1 << 16, 1 << 20):
+                batches, sel = stream_batches(path, "21", pick, ploidies, start, end, anc, cap=cap)
+                want = load_dosage(str(path), "21", pick, ploidies, start, end, anc, 2)
+                pos, dos = python_tokenize(batches, sel[0], ploidies)
+                assert pos.tolist() == want[0].tolist()
+                assert np.array_equal(dos, want[1]) and sel[1] == want[2]
+                if anc and want[2]:
+                    assert sel[2] == want[3]
+                if cap == 1 << 16 and start is None and not anc:
+                    assert len(batches) > 1  # the hand-over between the two staging buffers really ran
+    # the text in the staging buffer is the file's text: every indexed slice ends where its line ends
+    batches, _ = stream_batches(path, "7", names[:2], [2, 2])
+    for text, off, ln, *_ in batches:
+        for o, n in zip(off, ln):
+            assert text[o + n : o + n + 1] in (b"\n", b"\r")
+
+
+def test_stream_errors_and_tabix_region(tmp_path, monkeypatch):
+    from sai_amd.utils.native_vcf import load_dosage
+
+    rng = np.random.default_rng(5)
+    path = tmp_path / "i.vcf.gz"
+    names = write_vcf(path, rng, 1500, 5, gz="bgzf")
+    write_tbi(path)
+    for reg in ((5000, 40000), (16385, 32768), (10**6, 10**7)):
+        batches, sel = stream_batches(path, "21", names, [2] * 5, reg[0], reg[1])
+        want = load_dosage(str(path), "21", names, [2] * 5, reg[0], reg[1], None, 2)
+        pos, dos = python_tokenize(batches, sel[0], [2] * 5)
+        assert pos.tolist() == want[0].tolist() and np.array_equal(dos, want[1]) and sel[1] == want[2]
+    with pytest.raises(ValueError, match="samples not found"):
+        stream_batches(path, "21", ["nobody"], [2])
+    with pytest.raises(ValueError, match="cannot open"):
+        stream_batches(tmp_path / "missing.vcf", "21", names, [2] * 5)
+    bad = tmp_path / "short.vcf"
+    bad.write_text("#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\ta\n21\t5\t.\tA\tT\t.\t.\n")
+    with pytest.raises(ValueError, match="fewer than 10 columns"):
+        stream_batches(bad, "21", ["a"], [2])
+    # a line longer than the staging buffer is refused (the caller falls back to the host reader)
+    wide = tmp_path / "wide.vcf"
+    wnames = write_vcf(wide, rng, 3, 30000, chroms=("21",))
+    with pytest.raises(ValueError, match="longer than the staging buffer"):
+        stream_batches(wide, "21", wnames[:2], [2, 2], cap=1 << 16)
+    # closing early (consumer gives up after one batch) joins the producer without a hang
+    from sai_amd import _ffi
+
+    lib = _ffi.load_host()
+    bufs = [np.zeros(1 << 16, dtype=np.uint8) for _ in range(2)]
+    h = C.c_void_p()
+    c_names = (C.c_char_p * 1)(names[0].encode())
+    assert lib.sai_vcf_stream_open(os.fsencode(str(path)), b"21", -1, -1, 1, c_names, (C.c_int32 * 1)(2), None, 2,
+                                   bufs[0].ctypes.data_as(C.c_void_p), bufs[1].ctypes.data_as(C.c_void_p), 1 << 16, C.byref(h)) == 0  # fmt: skip
+    assert lib.sai_vcf_stream_close(h) == 0
