@@ -905,6 +905,146 @@ int stream_emit(sai_vcf_stream* st, const char* p, const char* endp, bool* done,
   return 0;
 }
 
+// Uncompressed text: the batches are pread straight into the staging buffers (no intermediate copy)
+// and indexed where they lie.
+int stream_run_plain(sai_vcf_stream* st, const std::vector<const char*>& names) {
+  const char* path = st->path.c_str();
+  const int fd = open(path, O_RDONLY);
+  if (fd < 0) return sai_set_error(SAI_ERR_ARG, "cannot open VCF %s", path);
+  struct FdGuard { int fd; ~FdGuard() { close(fd); } } guard{fd};
+  struct stat sb;
+  if (fstat(fd, &sb) != 0) return sai_set_error(SAI_ERR_ARG, "cannot stat %s", path);
+  const size_t total = static_cast<size_t>(sb.st_size);
+  // header: read from the top until the #CHROM line has been seen
+  size_t data_off = 0;
+  {
+    std::vector<char> head;
+    size_t have = 0;
+    while (!st->header_seen) {
+      const size_t want = std::min(total - have, std::max<size_t>(size_t(1) << 20, have));
+      if (want == 0) break;
+      head.resize(have + want);
+      size_t got_all = 0;
+      while (got_all < want) {
+        const ssize_t got = pread(fd, head.data() + have + got_all, want - got_all, static_cast<off_t>(have + got_all));
+        if (got <= 0) return sai_set_error(SAI_ERR_ARG, "read error in %s", path);
+        got_all += static_cast<size_t>(got);
+      }
+      have += want;
+      const char* p = head.data() + data_off;
+      const char* endp = head.data() + have;
+      while (p < endp) {
+        const char* eol = static_cast<const char*>(memchr(p, '\n', static_cast<size_t>(endp - p)));
+        if (!eol) {
+          if (have < total) break;  // an incomplete line: read more
+          eol = endp;
+        }
+        if (*p != '#') return sai_set_error(SAI_ERR_ARG, "%s: no #CHROM header line before the records", path);
+        const bool is_chrom = eol - p > 6 && memcmp(p, "#CHROM", 6) == 0;
+        if (is_chrom) {
+          if (int hrc = parse_header(p, eol, path, static_cast<int32_t>(names.size()), names.data(), st->ploidy.data(), st->sel))
+            return hrc;
+        }
+        p = eol < endp ? eol + 1 : endp;
+        data_off = static_cast<size_t>(p - head.data());
+        if (is_chrom) {
+          std::lock_guard<std::mutex> lk(st->m);
+          st->header_seen = true;
+          break;
+        }
+      }
+      if (have >= total) break;
+    }
+  }
+  if (!st->header_seen) return sai_set_error(SAI_ERR_ARG, "%s: not a VCF (no #CHROM header)", path);
+  const int nt = std::max(1, st->n_threads);
+  std::vector<IndexOut> outs(static_cast<size_t>(nt));
+  bool done = false, seen_chrom = false;
+  size_t file_off = data_off;
+  while (file_off < total && !done) {
+    int b;
+    {
+      std::unique_lock<std::mutex> lk(st->m);
+      b = static_cast<int>(st->produced % 2);
+      st->cv.wait(lk, [&] { return st->state[b] == 0 || st->cancel; });
+      if (st->cancel) return SAI_OK;
+    }
+    char* dst = st->bufs[b];
+    const size_t want = std::min(st->cap, total - file_off);
+    std::vector<char> bad(static_cast<size_t>(nt), 0);
+    auto reader = [&](int t) {
+      size_t lo = want * static_cast<size_t>(t) / static_cast<size_t>(nt), hi = want * static_cast<size_t>(t + 1) / static_cast<size_t>(nt);
+      while (lo < hi) {
+        const ssize_t got = pread(fd, dst + lo, hi - lo, static_cast<off_t>(file_off + lo));
+        if (got <= 0) { bad[static_cast<size_t>(t)] = 1; return; }
+        lo += static_cast<size_t>(got);
+      }
+    };
+    {
+      ThreadGroup th;
+      for (int t = 1; t < nt; ++t) th.spawn([&reader, t] { reader(t); });
+      reader(0);
+      th.join();
+    }
+    for (char x : bad)
+      if (x) return sai_set_error(SAI_ERR_ARG, "read error in %s", path);
+    size_t usable = want;
+    if (file_off + want < total) {  // cut at the last complete line; the rest is read again next time
+      while (usable > 0 && dst[usable - 1] != '\n') --usable;
+      if (usable == 0) return sai_set_error(SAI_ERR_UNSUPPORTED, "%s: a line is longer than the staging buffer", path);
+    }
+    const char* p = dst;
+    const char* cut = dst + usable;
+    std::vector<const char*> edge(static_cast<size_t>(nt) + 1, cut);
+    edge[0] = p;
+    for (int t = 1; t < nt; ++t) {
+      const char* guess = p + usable * static_cast<size_t>(t) / static_cast<size_t>(nt);
+      if (guess < edge[static_cast<size_t>(t) - 1]) guess = edge[static_cast<size_t>(t) - 1];
+      const char* nl = static_cast<const char*>(memchr(guess, '\n', static_cast<size_t>(cut - guess)));
+      edge[static_cast<size_t>(t)] = nl ? nl + 1 : cut;
+    }
+    for (auto& o : outs) o.clear();
+    auto piece = [&](int t) {
+      IndexOut& o = outs[static_cast<size_t>(t)];
+      if (edge[static_cast<size_t>(t)] >= edge[static_cast<size_t>(t) + 1]) return;
+      try {
+        index_lines(edge[static_cast<size_t>(t)], edge[static_cast<size_t>(t) + 1], p, st->chrom, st->start, st->end, st->anc, o);
+      } catch (...) {
+        o.failed = true;
+      }
+    };
+    {
+      ThreadGroup th;
+      for (int t = 1; t < nt; ++t) th.spawn([&piece, t] { piece(t); });
+      piece(0);
+      th.join();
+    }
+    IndexOut& out = st->batch[b];
+    out.clear();
+    for (auto& o : outs) {
+      if (o.failed) return sai_set_error(SAI_ERR_HIP, "%s: indexing failed (out of memory)", path);
+      if (!o.error.empty()) return sai_set_error(SAI_ERR_ARG, "%s: %s", path, o.error.c_str());
+      st->n_matched += o.matched;
+      out.off.insert(out.off.end(), o.off.begin(), o.off.end());
+      out.len.insert(out.len.end(), o.len.begin(), o.len.end());
+      out.pos.insert(out.pos.end(), o.pos.begin(), o.pos.end());
+      out.flip.insert(out.flip.end(), o.flip.begin(), o.flip.end());
+      out.gi.insert(out.gi.end(), o.gi.begin(), o.gi.end());
+      seen_chrom = seen_chrom || o.saw_chrom;
+      if (o.beyond_stop || (seen_chrom && o.last_line_other)) done = true;
+    }
+    {
+      std::lock_guard<std::mutex> lk(st->m);
+      st->batch_bytes[b] = usable;
+      st->state[b] = 1;
+      ++st->produced;
+    }
+    st->cv.notify_all();
+    file_off += usable;
+  }
+  return SAI_OK;
+}
+
 int stream_run(sai_vcf_stream* st) {
   const char* path = st->path.c_str();
   if (!st->anc_path.empty()) {
@@ -912,6 +1052,7 @@ int stream_run(sai_vcf_stream* st) {
   }
   std::vector<const char*> names;
   for (auto& n : st->names) names.push_back(n.c_str());
+  if (file_is_plain_text(path)) return stream_run_plain(st, names);
   bool done = false, seen_chrom = false;
   auto on_header = [&](const char*& p, const char* endp) -> int {
     while (!st->header_seen && p < endp) {
@@ -1033,6 +1174,72 @@ static int vcf_scan_impl(const char* path, const char* chrom, int64_t* first_pos
     }
     return 0;
   };
+  // the full pass, a batch at a time with kScanThreads pieces side by side: a piece reports the first
+  // run of the chromosome inside it, the pieces are merged in file order
+  struct ScanPiece {
+    int64_t first = -1, last = -1;
+    bool other_before = false, ended = false, header = false;
+  };
+  auto scan_piece = [&c](const char* p, const char* end, ScanPiece& r) {
+    while (p < end) {
+      const char* eol = static_cast<const char*>(memchr(p, '\n', static_cast<size_t>(end - p)));
+      if (!eol) eol = end;
+      if (*p == '#') {
+        if (eol - p > 6 && memcmp(p, "#CHROM", 6) == 0) r.header = true;
+      } else if (eol > p) {
+        const char* t1 = find_tab(p, eol);
+        if (static_cast<size_t>(t1 - p) == c.size() && memcmp(p, c.data(), c.size()) == 0 && t1 < eol) {
+          int64_t v = 0;
+          for (const char* f = t1 + 1; f < eol && *f >= '0' && *f <= '9'; ++f) v = v * 10 + (*f - '0');
+          if (r.first < 0) r.first = v;
+          r.last = v;
+        } else if (r.first >= 0) {
+          r.ended = true;
+          return;
+        } else {
+          r.other_before = true;
+        }
+      }
+      p = eol + 1;
+    }
+  };
+  auto scan_parallel = [&](const char* p, const char* end) -> int {
+    const size_t total = static_cast<size_t>(end - p);
+    const int nt = total < (size_t(1) << 20) ? 1 : kScanThreads;
+    std::vector<const char*> edge(static_cast<size_t>(nt) + 1, end);
+    edge[0] = p;
+    for (int t = 1; t < nt; ++t) {
+      const char* guess = p + total * static_cast<size_t>(t) / static_cast<size_t>(nt);
+      if (guess < edge[static_cast<size_t>(t) - 1]) guess = edge[static_cast<size_t>(t) - 1];
+      const char* nl = static_cast<const char*>(memchr(guess, '\n', static_cast<size_t>(end - guess)));
+      edge[static_cast<size_t>(t)] = nl ? nl + 1 : end;
+    }
+    std::vector<ScanPiece> res(static_cast<size_t>(nt));
+    {
+      ThreadGroup th;  // scan_piece allocates nothing: no throw inside the workers
+      for (int t = 1; t < nt; ++t)
+        th.spawn([&, t] { scan_piece(edge[static_cast<size_t>(t)], edge[static_cast<size_t>(t) + 1], res[static_cast<size_t>(t)]); });
+      scan_piece(edge[0], edge[1], res[0]);
+      th.join();
+    }
+    for (const ScanPiece& r : res) {
+      header_seen = header_seen || r.header;
+      if (first < 0) {
+        if (r.first >= 0) {
+          first = r.first;
+          last = r.last;
+          if (r.ended) return 1;
+        }
+      } else {
+        if (r.other_before) return 1;  // the run ended where the previous piece ended
+        if (r.first >= 0) {
+          last = r.last;
+          if (r.ended) return 1;
+        }
+      }
+    }
+    return 0;
+  };
   TbiRef idx;
   if (file_is_bgzf(path) && load_tbi(path, c, idx)) {
     // indexed: the first record sits at the smallest chunk start, the last one inside the chunk that
@@ -1059,7 +1266,7 @@ static int vcf_scan_impl(const char* path, const char* chrom, int64_t* first_pos
       return SAI_OK;
     }
   }
-  const int rc = for_each_block(path, kScanThreads, scan);
+  const int rc = for_each_block(path, kScanThreads, scan_parallel);
   if (rc) return rc;
   if (!header_seen && first < 0) return sai_set_error(SAI_ERR_ARG, "%s: not a VCF (no #CHROM header)", path);
   *first_pos = first;
