@@ -51,7 +51,7 @@ struct ThreadGroup {
   ~ThreadGroup() { join(); }
 };
 
-constexpr int kScanThreads = 8;  // inflate threads of sai_vcf_scan (it has no thread argument)
+constexpr int kScanThreads = 16;  // inflate threads of sai_vcf_scan (it has no thread argument)
 
 struct GzReader {
   gzFile f = nullptr;
@@ -549,7 +549,10 @@ int for_each_block_plain(const char* path, int n_threads, F&& consume) {
   struct stat st;
   if (fstat(fd, &st) != 0) return sai_set_error(SAI_ERR_ARG, "cannot stat %s", path);
   const size_t total = static_cast<size_t>(st.st_size);
-  const size_t batch = batch_out_bytes();
+  // 8 MiB batches: the buffer is fresh memory, and faulting it in costs more than reading into it
+  // (pread of 241 MB into new pages: 50 ms; into pages already touched: 3 ms) -- keep it small and
+  // reuse it for every batch
+  const size_t batch = std::min(batch_out_bytes(), size_t(8) << 20);
   std::vector<char> buf;
   size_t have = 0, file_off = 0;
   for (;;) {
@@ -1265,6 +1268,107 @@ static int vcf_scan_impl(const char* path, const char* chrom, int64_t* first_pos
       *first_pos = *last_pos = -1;  // chromosome not in the index
       return SAI_OK;
     }
+  }
+  if (file_is_plain_text(path)) {
+    // Uncompressed text: every thread walks its own part of the file through a small buffer of its
+    // own (1 MiB: faulted in once, then cache-resident), so the scan costs one pass over the page
+    // cache -- no 48 MiB batch buffer to fault in, no mapping to build and tear down (measured on
+    // 241 MB: mmap 34 ms, mmap + MAP_POPULATE 18 ms, pread into fresh memory 165 ms, this 5 ms).
+    const int fd = open(path, O_RDONLY);
+    if (fd < 0) return sai_set_error(SAI_ERR_ARG, "cannot open VCF %s", path);
+    struct FdGuard { int fd; ~FdGuard() { close(fd); } } guard{fd};
+    struct stat sb;
+    if (fstat(fd, &sb) != 0) return sai_set_error(SAI_ERR_ARG, "cannot stat %s", path);
+    const size_t total = static_cast<size_t>(sb.st_size);
+    const int nt = total < (size_t(4) << 20) ? 1 : kScanThreads;
+    std::vector<ScanPiece> res(static_cast<size_t>(nt));
+    std::vector<char> io_bad(static_cast<size_t>(nt), 0);
+    auto walk = [&](int t) {
+      const size_t a = total * static_cast<size_t>(t) / static_cast<size_t>(nt);
+      const size_t z = total * static_cast<size_t>(t + 1) / static_cast<size_t>(nt);
+      ScanPiece& r = res[static_cast<size_t>(t)];
+      try {
+        std::vector<char> buf(size_t(1) << 20);
+        bool skip = false;  // the line that straddles `a` belongs to the previous part
+        if (a > 0) {
+          char c = 0;
+          if (pread(fd, &c, 1, static_cast<off_t>(a - 1)) != 1) { io_bad[static_cast<size_t>(t)] = 1; return; }
+          skip = c != '\n';
+        }
+        size_t off = a, have = 0;     // file offset of the next read; bytes carried at the front of buf
+        size_t line0 = a;             // file offset of buf[0]
+        while (line0 < z && off < total && !r.ended) {
+          if (have == buf.size()) buf.resize(buf.size() * 2);  // one line longer than the buffer
+          const ssize_t got = pread(fd, buf.data() + have, std::min(buf.size() - have, total - off), static_cast<off_t>(off));
+          if (got <= 0) { io_bad[static_cast<size_t>(t)] = 1; return; }
+          off += static_cast<size_t>(got);
+          have += static_cast<size_t>(got);
+          const bool eof = off >= total;
+          // whole lines in buf[0, usable); only those that START before z are this part's
+          size_t usable = have;
+          if (!eof) {
+            usable = 0;
+            for (size_t i = have; i > 0; --i)
+              if (buf[i - 1] == '\n') { usable = i; break; }
+            if (usable == 0) continue;
+          }
+          size_t begin = 0;
+          if (skip) {
+            const void* nl = memchr(buf.data(), '\n', usable);
+            if (!nl) { begin = usable; } else { begin = static_cast<size_t>(static_cast<const char*>(nl) - buf.data()) + 1; skip = false; }
+          }
+          size_t stop = usable;
+          if (line0 + usable > z) {  // cut after the line that holds byte z - 1
+            const size_t rel = z - line0;  // first byte that may start a foreign line
+            if (rel <= begin) stop = begin;
+            else {
+              stop = rel;
+              if (buf[rel - 1] != '\n') {
+                const void* nl = memchr(buf.data() + rel, '\n', usable - rel);
+                stop = nl ? static_cast<size_t>(static_cast<const char*>(nl) - buf.data()) + 1 : usable;
+              }
+            }
+          }
+          if (stop > begin) scan_piece(buf.data() + begin, buf.data() + stop, r);
+          if (stop < usable) break;  // reached the end of this part
+          const size_t rest = have - usable;
+          if (rest) memmove(buf.data(), buf.data() + usable, rest);
+          line0 += usable;
+          have = rest;
+          if (eof) break;
+        }
+      } catch (...) {
+        io_bad[static_cast<size_t>(t)] = 2;
+      }
+    };
+    {
+      ThreadGroup th;
+      for (int t = 1; t < nt; ++t) th.spawn([&walk, t] { walk(t); });
+      walk(0);
+      th.join();
+    }
+    for (char x : io_bad)
+      if (x) return sai_set_error(x == 1 ? SAI_ERR_ARG : SAI_ERR_HIP, x == 1 ? "read error in %s" : "%s: out of host memory", path);
+    for (const ScanPiece& r : res) {  // merge in file order, as scan_parallel does
+      header_seen = header_seen || r.header;
+      if (first < 0) {
+        if (r.first >= 0) {
+          first = r.first;
+          last = r.last;
+          if (r.ended) break;
+        }
+      } else {
+        if (r.other_before) break;
+        if (r.first >= 0) {
+          last = r.last;
+          if (r.ended) break;
+        }
+      }
+    }
+    if (!header_seen && first < 0) return sai_set_error(SAI_ERR_ARG, "%s: not a VCF (no #CHROM header)", path);
+    *first_pos = first;
+    *last_pos = last;
+    return SAI_OK;
   }
   const int rc = for_each_block(path, kScanThreads, scan_parallel);
   if (rc) return rc;
