@@ -347,3 +347,28 @@ def test_htslib_written_index_equals_unindexed_copy(in_repo_root, tmp_path, fixt
             a = load_dosage(fixture, chrom, pick, [2] * len(pick), reg[0], reg[1], None, 4)
             b = load_dosage(str(plain), chrom, pick, [2] * len(pick), reg[0], reg[1], None, 4)
             assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2] == b[2], (chrom, reg)
+
+
+def test_bgzf_through_zlib_when_libdeflate_is_switched_off(tmp_path):
+    """BGZF members are inflated by libdeflate when its runtime library is present (bound with
+    dlopen); SAI_NO_LIBDEFLATE=1 keeps zlib.  Both give the same rows; a child interpreter is used
+    because the choice is made once per process."""
+    import os
+    import subprocess
+    import sys
+
+    from conftest import ROOT
+    from sai_amd.utils.native_vcf import load_dosage
+
+    rng = np.random.default_rng(21)
+    path = tmp_path / "z.vcf.gz"
+    names = write_vcf(path, rng, 400, 6, gz="bgzf")
+    want = load_dosage(str(path), "21", names, [2] * 6, None, None, None, 3)
+    code = (
+        "import sys, numpy as np; sys.path.insert(0, %r); from sai_amd.utils.native_vcf import load_dosage; "
+        "r = load_dosage(%r, '21', %r, [2] * 6, None, None, None, 3); np.save(%r, r[1]); print(len(r[0]))"
+        % (str(ROOT), str(path), names, str(tmp_path / "z.npy"))
+    )
+    res = subprocess.run([sys.executable, "-c", code], env={**os.environ, "SAI_NO_LIBDEFLATE": "1"}, capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr
+    assert int(res.stdout.strip()) == len(want[0]) and np.array_equal(np.load(tmp_path / "z.npy"), want[1])

@@ -1,4 +1,5 @@
-"""Throughput of the native VCF tokenizer vs the Python reader on a synthetic VCF (host only)."""
+"""Throughput of the native VCF tokenizer (host), of the Python reader and of the GPU reader on a
+synthetic VCF, plain and bgzip."""
 import os, sys, time, tempfile
 import numpy as np
 sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
@@ -52,6 +53,25 @@ for th in (1, 4, default_threads()):
     t0 = time.perf_counter(); pos_g, dos_g, _, _ = load_dosage(gzpath, "1", names, [2] * n_samples, n_threads=th); dt = time.perf_counter() - t0
     print(f"native bgzip, {th:2d} threads: {dt:.3f} s  {size / dt / 1e6:8.1f} MB/s of text  {gzsize / dt / 1e6:8.1f} MB/s of file")
 assert np.array_equal(dos_g, dos_n) and np.array_equal(pos_g, pos_n)
+# the GPU reader (text over PCIe, tokenised on the GPU, the dosages stay in HBM) when a GPU is there
+try:
+    import torch
+    have_gpu = torch.cuda.is_available()
+except Exception:
+    have_gpu = False
+if have_gpu:
+    from sai_amd.engine import Engine
+    from sai_amd.utils.device_vcf import load_dosage_device
+    eng = Engine.get(0)
+    for label, pth in (("plain", path), ("bgzip", gzpath)):
+        load_dosage_device(eng, pth, "1", names, [2] * n_samples)  # staging buffers are allocated once per engine
+        best = 1e9
+        for _ in range(3):
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            pos_d, dos_d, _, _ = load_dosage_device(eng, pth, "1", names, [2] * n_samples)
+            torch.cuda.synchronize(); best = min(best, time.perf_counter() - t0)
+        assert np.array_equal(pos_d, pos_n) and np.array_equal(dos_d.cpu().numpy(), dos_n)
+        print(f"GPU reader, {label}: {best:.3f} s  {size / best / 1e6:8.1f} MB/s of text (dosages left in HBM)")
 import gzip
 t0 = time.perf_counter()
 with gzip.open(gzpath, "rb") as f:
