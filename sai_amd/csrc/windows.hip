@@ -173,10 +173,14 @@ __global__ __launch_bounds__(256) void window_stats_wave_kernel(WinArgs a) {
   const unsigned long long lt_mask = (1ull << lane) - 1ull;
 
   // pass 1: counts + order-preserving compaction of the qualifying effective frequencies into LDS
-  uint32_t n_c = 0, n_u_lane = 0;
+  uint32_t n_c = 0, n_u_lane = 0, n_c_lane = 0;
   walk_flags(fl, lo, hi, lane, [&](uint32_t v, int site) {
     n_u_lane += __popc(v & 0x02020202u);
     const uint32_t cm = v & 0x01010101u;
+    if (n_c >= kWaveCap) {  // uniform: this window goes to the workgroup kernel, only the count matters
+      n_c_lane += __popc(cm);
+      return;
+    }
     if (__ballot(cm != 0u) == 0ull) return;  // no condition site among these 256: the usual case
     uint32_t below = 0, total = 0;
 #pragma unroll
@@ -197,7 +201,11 @@ __global__ __launch_bounds__(256) void window_stats_wave_kernel(WinArgs a) {
   });
   uint32_t n_u = n_u_lane;
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) n_u += __shfl_xor(n_u, o, 64);
+  for (int o = 32; o > 0; o >>= 1) {
+    n_u += __shfl_xor(n_u, o, 64);
+    n_c_lane += __shfl_xor(n_c_lane, o, 64);
+  }
+  n_c += n_c_lane;
   double q = std::numeric_limits<double>::quiet_NaN();
   uint32_t n_q = 0;
   if (n_c > kWaveCap) {
@@ -243,15 +251,36 @@ __global__ __launch_bounds__(256) void window_stats_wave_kernel(WinArgs a) {
 }
 
 // ---- heavy fallback ------------------------------------------------------------------------
+//
+// Windows with more than kWaveCap qualifying sites (loose source conditions: C5's ("=0", "=0") or
+// (">=0", ">=0") sets select hundreds of sites per window) are finished by one 256-thread workgroup
+// each.  The k-th smallest value is found by a radix select ON THE VALUE: all values lie in [0, 1],
+// so digit l of a value is floor(frac_l * 1024) with frac_0 = v, frac_{l+1} = frac_l * 1024 - digit_l
+// -- multiplications by a power of two and subtractions of the integer part, all exact in binary
+// floating point -- which makes the digits a monotone, lossless code of the value (six digits use
+// up the 53-bit mantissa).  One histogram pass per level narrows the candidates to one of 1025 bins
+// (bin 1024 holds exactly 1.0); frequencies k / (called * ploidy) separate within two or three
+// levels, then the few members of the bin are gathered and ranked directly.  The first version
+// selected on the f64 bit pattern, 8 bits per pass: 8 passes per order statistic, two statistics per
+// window, the first two passes spent on exponent bits that hardly differ (0.63 ms per 16-set chunk
+// of C5 against 0.2 ms now).
+
+constexpr int kBins = 1025;      // digits 0..1023, and 1024 for the value 1.0
+constexpr int kMaxLevels = 6;    // 6 x 10 bits cover the mantissa
+constexpr int kSmallBin = 256;   // members ranked directly
 
 struct WinShared {
   double vals[kSelCap];
-  uint32_t hist[256];
+  uint32_t hist[kBins + 3];
+  double small[kSmallBin];
   uint32_t wave_tot[4];
   uint32_t red[4];
+  double redf[4];
   uint32_t n_stored;
+  uint32_t n_small;
   uint32_t digit;
   uint32_t k_rem;
+  uint32_t bin_count;
 };
 
 __device__ __forceinline__ uint32_t block_sum(uint32_t v, uint32_t* red, int tid) {
@@ -263,34 +292,74 @@ __device__ __forceinline__ uint32_t block_sum(uint32_t v, uint32_t* red, int tid
   return red[0] + red[1] + red[2] + red[3];
 }
 
-// k-th smallest (0-based) of the selected values: MSB-first radix select on the f64 bit pattern
-// (all selected values are finite and >= 0, so the unsigned order of the bits is the numeric order).
+__device__ __forceinline__ double block_min(double v, double* red, int tid) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const double w = __shfl_xor(v, o, 64);
+    v = w < v ? w : v;
+  }
+  __syncthreads();
+  if ((tid & 63) == 0) red[tid >> 6] = v;
+  __syncthreads();
+  double m = red[0];
+#pragma unroll
+  for (int k = 1; k < 4; ++k) m = red[k] < m ? red[k] : m;
+  return m;
+}
+
+// digit `level` of v, or -1 when v left the chosen path at an earlier level
+__device__ __forceinline__ int digit_on_path(double v, int level, const int (&path)[kMaxLevels]) {
+  double f = v;
+  for (int l = 0;; ++l) {
+    const double t = f * 1024.0;
+    int d = static_cast<int>(t);
+    d = d > 1024 ? 1024 : d;
+    if (l == level) return d;
+    if (d != path[l]) return -1;
+    f = t - static_cast<double>(d);
+  }
+}
+
+// calls use(v) for every selected value of the window: from LDS, or from the per-site arrays when
+// the window holds more than kSelCap of them
+template <bool IN_LDS, typename F>
+__device__ __forceinline__ void for_each_selected(const WinShared& sh, const double* tgt_freq, const uint8_t* fl, int lo,
+                                                  int hi, uint32_t n_sel, int tid, F&& use) {
+  if (IN_LDS) {
+    for (uint32_t i = tid; i < n_sel; i += kWinThreads) use(sh.vals[i]);
+  } else {
+    for (int i = lo + tid; i < hi; i += kWinThreads) {
+      const uint8_t f = fl[i];
+      if (f & 1) use(eff_freq(tgt_freq, f, i));
+    }
+  }
+}
+
+// k-th smallest (0-based) of the selected values
 template <bool IN_LDS>
 __device__ double select_kth(WinShared& sh, const double* tgt_freq, const uint8_t* fl, int lo, int hi,
                              uint32_t n_sel, uint32_t k, int tid) {
-  unsigned long long prefix = 0;
-  for (int shift = 56; shift >= 0; shift -= 8) {
-    sh.hist[tid] = 0;
+  int path[kMaxLevels];
+#pragma unroll
+  for (int l = 0; l < kMaxLevels; ++l) path[l] = 0;
+  for (int level = 0; level < kMaxLevels; ++level) {
+    for (int i = tid; i < kBins; i += kWinThreads) sh.hist[i] = 0;
     __syncthreads();
-    const unsigned long long himask = shift == 56 ? 0ull : (~0ull << (shift + 8));
-    if (IN_LDS) {
-      for (uint32_t i = tid; i < n_sel; i += kWinThreads) {
-        const unsigned long long key = __double_as_longlong(sh.vals[i]);
-        if ((key & himask) == prefix) atomicAdd(&sh.hist[(key >> shift) & 255u], 1u);
-      }
-    } else {
-      for (int i = lo + tid; i < hi; i += kWinThreads) {
-        const uint8_t f = fl[i];
-        if (f & 1) {
-          const unsigned long long key = __double_as_longlong(eff_freq(tgt_freq, f, i));
-          if ((key & himask) == prefix) atomicAdd(&sh.hist[(key >> shift) & 255u], 1u);
-        }
-      }
+    for_each_selected<IN_LDS>(sh, tgt_freq, fl, lo, hi, n_sel, tid, [&](double v) {
+      const int d = digit_on_path(v, level, path);
+      if (d >= 0) atomicAdd(&sh.hist[d], 1u);
+    });
+    __syncthreads();
+    // the bin that holds rank k: every thread owns 5 consecutive bins (256 x 5 >= 1025), exclusive
+    // scan of the per-thread sums with shuffles inside each wave and wave totals through LDS
+    uint32_t h[5], mine = 0;
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      const int bin = tid * 5 + j;
+      h[j] = bin < kBins ? sh.hist[bin] : 0u;
+      mine += h[j];
     }
-    __syncthreads();
-    // inclusive scan of the 256 bins: shuffles inside each wave, wave totals through LDS
-    const uint32_t h = sh.hist[tid];
-    uint32_t inc = h;
+    uint32_t inc = mine;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
       const uint32_t t = __shfl_up(inc, o, 64);
@@ -298,20 +367,56 @@ __device__ double select_kth(WinShared& sh, const double* tgt_freq, const uint8_
     }
     if ((tid & 63) == 63) sh.wave_tot[tid >> 6] = inc;
     __syncthreads();
-    uint32_t before = 0;
+    uint32_t before = inc - mine;
     for (int wv = 0; wv < (tid >> 6); ++wv) before += sh.wave_tot[wv];
-    inc += before;
-    const uint32_t exc = inc - h;
-    if (h != 0 && k >= exc && k < inc) {  // exactly one bin satisfies this
-      sh.digit = tid;
-      sh.k_rem = k - exc;
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      if (h[j] != 0 && k >= before && k < before + h[j]) {  // exactly one bin of one thread
+        sh.digit = static_cast<uint32_t>(tid * 5 + j);
+        sh.k_rem = k - before;
+        sh.bin_count = h[j];
+      }
+      before += h[j];
     }
     __syncthreads();
-    prefix |= static_cast<unsigned long long>(sh.digit) << shift;
+    path[level] = static_cast<int>(sh.digit);
     k = sh.k_rem;
+    const uint32_t members = sh.bin_count;
     __syncthreads();
+    if (members <= kSmallBin || level == kMaxLevels - 1) {
+      // gather the bin (at the last level all its members are the same number) and rank directly
+      if (tid == 0) sh.n_small = 0;
+      __syncthreads();
+      for_each_selected<IN_LDS>(sh, tgt_freq, fl, lo, hi, n_sel, tid, [&](double v) {
+        if (digit_on_path(v, level, path) == path[level]) {  // on the chosen path through this level
+          const uint32_t slot = atomicAdd(&sh.n_small, 1u);
+          if (slot < kSmallBin) sh.small[slot] = v;
+        }
+      });
+      __syncthreads();
+      const uint32_t n = sh.n_small < kSmallBin ? sh.n_small : kSmallBin;
+      if (members > kSmallBin) return sh.small[0];  // last level: all equal
+      // rank counting with ties broken by slot: ranks are a permutation of 0..n-1
+      double found = 0.0;
+      bool have = false;
+      for (uint32_t e = tid; e < n; e += kWinThreads) {
+        const double ve = sh.small[e];
+        uint32_t rank = 0;
+        for (uint32_t j = 0; j < n; ++j) {
+          const double vj = sh.small[j];
+          rank += (vj < ve) || (vj == ve && j < e);
+        }
+        if (rank == k) { found = ve; have = true; }
+      }
+      __syncthreads();
+      if (have) sh.small[0] = found;  // exactly one thread
+      __syncthreads();
+      const double res = sh.small[0];
+      __syncthreads();
+      return res;
+    }
   }
-  return __longlong_as_double(static_cast<long long>(prefix));
+  return 0.0;  // not reached
 }
 
 // The grid covers every window; those not marked by the wave kernel exit at once.
@@ -336,23 +441,36 @@ __global__ __launch_bounds__(kWinThreads) void window_stats_heavy_kernel(WinArgs
   }
   __syncthreads();
   const double v = static_cast<double>(n_c - 1) * a.quantile[set];
-  double q;
-  if (v >= static_cast<double>(n_c - 1)) {
-    q = in_lds ? select_kth<true>(sh, a.tgt_freq, fl, lo, hi, n_c, n_c - 1, tid)
-               : select_kth<false>(sh, a.tgt_freq, fl, lo, hi, n_c, n_c - 1, tid);
-  } else {
-    const double fl_v = floor(v);
-    const uint32_t k = static_cast<uint32_t>(fl_v);
-    const double x0 = in_lds ? select_kth<true>(sh, a.tgt_freq, fl, lo, hi, n_c, k, tid)
-                             : select_kth<false>(sh, a.tgt_freq, fl, lo, hi, n_c, k, tid);
-    const double x1 = in_lds ? select_kth<true>(sh, a.tgt_freq, fl, lo, hi, n_c, k + 1, tid)
-                             : select_kth<false>(sh, a.tgt_freq, fl, lo, hi, n_c, k + 1, tid);
+  const bool take_max = v >= static_cast<double>(n_c - 1);
+  const double fl_v = floor(v);
+  const uint32_t k = take_max ? n_c - 1 : static_cast<uint32_t>(fl_v);
+  const double x0 = in_lds ? select_kth<true>(sh, a.tgt_freq, fl, lo, hi, n_c, k, tid)
+                           : select_kth<false>(sh, a.tgt_freq, fl, lo, hi, n_c, k, tid);
+  double q = x0;
+  if (!take_max) {
+    // the next order statistic: x0 again when more than k + 1 values are <= x0, else the smallest
+    // value above x0 -- one pass instead of a second selection
+    uint32_t c_le = 0;
+    double m_gt = std::numeric_limits<double>::infinity();
+    auto look = [&](double u) {
+      c_le += u <= x0 ? 1u : 0u;
+      if (u > x0 && u < m_gt) m_gt = u;
+    };
+    if (in_lds) for_each_selected<true>(sh, a.tgt_freq, fl, lo, hi, n_c, tid, look);
+    else for_each_selected<false>(sh, a.tgt_freq, fl, lo, hi, n_c, tid, look);
+    const uint32_t n_le = block_sum(c_le, sh.red, tid);
+    const double above = block_min(m_gt, sh.redf, tid);
+    const double x1 = n_le > k + 1 ? x0 : above;
     q = numpy_lerp(x0, x1, v, fl_v);
   }
   uint32_t c_q = 0;
-  for (int i = lo + tid; i < hi; i += kWinThreads) {
-    const uint8_t f = fl[i];
-    if ((f & 1u) && eff_freq(a.tgt_freq, f, i) >= q) ++c_q;
+  if (in_lds) {
+    for (uint32_t i = tid; i < n_c; i += kWinThreads) c_q += sh.vals[i] >= q ? 1u : 0u;
+  } else {
+    for (int i = lo + tid; i < hi; i += kWinThreads) {
+      const uint8_t f = fl[i];
+      if ((f & 1u) && eff_freq(a.tgt_freq, f, i) >= q) ++c_q;
+    }
   }
   const uint32_t n_q = block_sum(c_q, sh.red, tid);
   if (tid == 0) {

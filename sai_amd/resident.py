@@ -20,7 +20,10 @@ from . import _ffi
 from .engine import RECORD_DTYPE, Engine, TiledPop, WindowResults
 from .utils.windows import split_genome
 
-WAIT_DEADLINE_S = 30.0  # a step is milliseconds; an event that has not fired by then never will
+# A step is milliseconds, but in a multi-GPU job a windows stage ends with a gather, and the first
+# gather of a job waits for RCCL to build its channels (seconds on 8 ranks): the deadline only has
+# to beat "forever".  SAI_AMD_WAIT_DEADLINE_S overrides it.
+WAIT_DEADLINE_S = float(__import__("os").environ.get("SAI_AMD_WAIT_DEADLINE_S", "300"))
 
 
 @dataclass

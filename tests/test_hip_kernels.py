@@ -576,3 +576,36 @@ def test_calc_four_pops_freq_matches_calc_freq(eng):
         assert np.array_equal(np.isnan(got), np.isnan(want)) and np.array_equal(got[~np.isnan(got)], want[~np.isnan(want)])
     r2, t2, s2, o2 = calc_four_pops_freq(mats[0], mats[1], mats[2], ref_ploidy=2, tgt_ploidy=2, src_ploidy=2)
     assert np.array_equal(o2, np.zeros(300)) and np.array_equal(np.nan_to_num(r2), np.nan_to_num(r))
+
+
+def test_heavy_windows_value_radix_select(eng):
+    """The workgroup fallback on many distinct values: large target population with missing calls
+    (frequencies k / (2 * called): thousands of distinct rationals, some a few 1e-7 apart, some
+    repeated hundreds of times), inversion on and off, every kind of quantile position -- numpy's
+    'linear' quantile bit for bit and the same candidate lists."""
+    from oracle import sai_oracle as O
+    from sai_amd import _ffi
+
+    rng = np.random.default_rng(9)
+    n_sites = 9000
+    ref = np.zeros((n_sites, 3), dtype=np.int64)
+    p = rng.random(n_sites) ** 2
+    tgt = rng.binomial(2, p[:, None], size=(n_sites, 700)).astype(np.int64)
+    tgt[rng.random(tgt.shape) < 0.1] = -2
+    tgt[:2500] = rng.integers(0, 2, size=(2500, 1))  # a block of sites with only a handful of distinct values
+    src = np.where(rng.random((n_sites, 1)) < 0.5, 2, 0).astype(np.int64)
+    pos = np.arange(1, n_sites + 1, dtype=np.int64) * 2
+    ends = [18000, 9000, 5000, 4600, 700, 12000]
+    for anc in (True, False):
+        for quantile in (0.0, 0.001, 0.25, 0.5, 0.777, 0.95, 0.999, 1.0):
+            sets = [_ffi.make_params(0.5, 0.5, quantile, [(">=", 0.0)], anc)]
+            res, _, _ = _window_pass(eng, [ref, tgt, src], [2, 2, 2], sets, pos, np.ones(len(ends), dtype=np.int64), np.array(ends))
+            assert res.records[0]["n_cond"].min() > 256  # every window takes the workgroup path
+            for wi, we in enumerate(ends):
+                m = pos <= we
+                kw = dict(ref_gts=ref[m], tgt_gts=tgt[m], src_gts_list=[src[m]], ref_ploidy=2, tgt_ploidy=2,
+                          src_ploidy_list=[2], pos=pos[m], w=0.5, y_list=[(">=", 0.0)], anc_allele_available=anc)  # fmt: skip
+                eq = O.q_stat(quantile=quantile, **kw)
+                rec = res.records[0, wi]
+                assert same_f64(rec["q"], eq["value"]), (anc, quantile, wi, rec["q"], eq["value"])
+                assert rec["n_cdd_q"] == len(eq["cdd_pos"]) and res.q_list(0, wi).tolist() == eq["cdd_pos"].tolist()
