@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define SAI_ABI_VERSION 7
+#define SAI_ABI_VERSION 8
 #define SAI_TILE_SITES 64
 #define SAI_MAX_SRC 6   /* source populations per call */
 #define SAI_MAX_SETS 16 /* parameter sets per call */
@@ -173,11 +173,13 @@ int sai_window_bounds_seg(sai_ctx* ctx, const int32_t* pos, int64_t n_sites, int
  *     (-1 when the list would end beyond the buffer's capacity; such lists are not written);
  *   list entries are pos[site] when `pos` is non-NULL, else block-relative site indices;
  *   cdd_total[0..1] = entries needed for all U / Q lists: when a total exceeds its capacity,
- *     re-run with larger buffers.
+ *     re-run with larger buffers.  cdd_total must hold sai_window_total_words(n_sets, n_windows)
+ *     int64 words: the two totals, then scratch of the parallel prefix sum (one pair per 1024 records).
  * `quantile` is taken from sets_host[set].quantile.  `flags` is read as aligned 32-bit words, so up
  * to 3 bytes on either side of the n_sets * n_sites bytes are loaded (never used): inside the
  * same aligned word as a valid byte, hence always inside the same page.  tgt_freq is read only
  * at sites whose flags bit 0 is set (see SAI_FREQ_CANDIDATES). */
+int64_t sai_window_total_words(int32_t n_sets, int32_t n_windows); /* -1 on bad arguments */
 int sai_window_stats(sai_ctx* ctx, int64_t n_sites, const double* tgt_freq, const uint8_t* flags,
                      int32_t n_sets, const sai_params* sets_host, int32_t n_windows,
                      const int32_t* lo, const int32_t* hi, const int32_t* pos,

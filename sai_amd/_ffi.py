@@ -20,7 +20,7 @@ SAI_MAX_SETS = 16
 SAI_FUSED_SETS = 20
 SAI_ERR_UNSUPPORTED = -4  # enum sai_status
 FREQ_MODES = {"dense": 0, "candidates": 1}  # enum sai_freq_mode
-SAI_ABI_VERSION = 7
+SAI_ABI_VERSION = 8
 
 OPS = {"=": 0, "<": 1, ">": 2, "<=": 3, ">=": 4}
 
@@ -84,6 +84,7 @@ SIGNATURES = {
     ),
     "sai_window_bounds": (C.c_int, [_p, _p, _i64, _i32, _p, _p, _p, _p, _p]),
     "sai_window_bounds_seg": (C.c_int, [_p, _p, _i64, _i32, _p, _p, _p, _p, _p, _p, _p]),
+    "sai_window_total_words": (_i64, [_i32, _i32]),
     "sai_window_stats": (
         C.c_int,
         [_p, _i64, _p, _p, _i32, C.POINTER(SaiParams), _i32, _p, _p, _p, _p, _p, _p, _i64, _p, _i64, _p, _p],

@@ -49,8 +49,9 @@ extern "C" int sai_single_window(sai_ctx* ctx, int64_t n_sites, int32_t n_pops, 
   const size_t o_freq = o;   o = align_up(o + n * sizeof(double), 256);
   const size_t o_flags = o;  o = align_up(o + n + 8, 256);
   const size_t o_lohi = o;   o = align_up(o + 2 * sizeof(int32_t), 256);
-  const size_t o_head = o;   // record (24) | offsets (16) | totals (16): one copy brings them back
-  const size_t head_bytes = sizeof(sai_window_record) + 2 * sizeof(int64_t) + 2 * sizeof(int64_t);
+  const size_t o_head = o;   // record (24) | offsets (16) | totals (16 + scratch): one copy brings them back
+  // record | offsets (2) | totals (2) + the prefix sum's scratch pair for the one record
+  const size_t head_bytes = sizeof(sai_window_record) + 2 * sizeof(int64_t) + static_cast<size_t>(sai_window_total_words(1, 1)) * sizeof(int64_t);
   o = align_up(o + head_bytes, 256);
   const size_t o_u = o;      o = align_up(o + n * sizeof(int32_t), 256);
   const size_t o_q = o;      o = align_up(o + n * sizeof(int32_t), 256);

@@ -481,91 +481,102 @@ __global__ __launch_bounds__(kWinThreads) void window_stats_heavy_kernel(WinArgs
 
 // ---- CSR offsets ---------------------------------------------------------------------------
 
-// One 256-thread workgroup: exclusive prefix sums of u_count and n_cdd_q over the records in
-// (set, window) order.  cdd_off[2r] / cdd_off[2r+1] = start of record r's U / Q list (or -1 when
-// the list would not fit its buffer); cdd_total[0..1] = entries needed in all.  Each of the 4 waves
-// owns a contiguous run of 64-record rows and reads them lane-consecutive: 12 cache lines per wave
-// load of the 24-byte records and 8 per store, where a thread-owns-a-chunk mapping touched 64.
-// The workgroup is one wave per SIMD with < 128 registers on purpose: the pipelined scorer runs this
-// kernel under the next step's site pass, whose 4 waves per SIMD leave exactly that much free -- a
-// 512-thread version could not be placed on any CU until the site pass retired (2.4 ms instead
-// of 20 us, which made the whole windows stage as long as the site pass it was hiding under).
-// Pass 1 adds each wave's run up, one LDS hop gives every wave its base, pass 2 re-reads the rows
-// (L2 hits), scans each with wave shuffles and stores the offset pairs.
+// Exclusive prefix sums of u_count and n_cdd_q over the records in (set, window) order:
+// cdd_off[2r] / cdd_off[2r+1] = start of record r's U / Q list (or -1 when the list would not fit
+// its buffer); cdd_total[0..1] = entries needed in all.  Two small launches: every workgroup adds up
+// its 1024 records (window_scan_partials), then every workgroup sums the partials before it -- at
+// most a few hundred numbers -- and scans its own records (window_scan_apply).  The first version
+// was ONE workgroup walking all records: 20 us for C3's 9 999 records but 0.2 ms for a 16-set chunk
+// of C5 and 1.4 ms for C4's 110 017 windows on one GPU, the longest kernel of the windows stage.
+// Workgroups are 256 threads with few registers on purpose: the pipelined scorer runs this stage
+// under the next step's site pass, whose 4 waves per SIMD leave one wave slot per SIMD free.
 constexpr int kScanThreads = 256;
-constexpr int kScanRows = 8;  // rows of 64 records loaded together
+constexpr int kScanPerThread = 4;
+constexpr int kScanBlock = kScanThreads * kScanPerThread;  // records per workgroup
 
-__global__ __launch_bounds__(kScanThreads) void window_scan_kernel(WinArgs a) {
-  __shared__ long long wave_tot[2][kScanThreads / 64];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int64_t n = static_cast<int64_t>(a.n_sets) * a.n_windows;
-  const int64_t rows = (n + 63) / 64;
-  const int64_t rows_per_wave = (rows + kScanThreads / 64 - 1) / (kScanThreads / 64);
-  const int64_t row0 = wave * rows_per_wave, row1 = min(rows, row0 + rows_per_wave);
-  // loads are unconditional from a clamped index (a load under a per-element condition is branched
-  // around and waited for one at a time); records past the end count as empty
-  auto load_rows = [&](int64_t first_row, int32_t (&nu)[kScanRows], int32_t (&nq)[kScanRows]) {
+__device__ __forceinline__ long long block_sum_ll(long long v, long long* red, int tid) {
 #pragma unroll
-    for (int k = 0; k < kScanRows; ++k) {
-      const int64_t r = (first_row + k) * 64 + lane;
-      const sai_window_record& rec = a.records[min(r, n - 1)];
-      nu[k] = rec.u_count;
-      nq[k] = rec.n_cdd_q;
-    }
-#pragma unroll
-    for (int k = 0; k < kScanRows; ++k) {
-      const int64_t r = (first_row + k) * 64 + lane;
-      if (first_row + k >= row1 || r >= n) nu[k] = nq[k] = 0;
-    }
-  };
-  long long su = 0, sq = 0;  // pass 1: this lane's share of the wave's run
-  for (int64_t row = row0; row < row1; row += kScanRows) {
-    int32_t nu[kScanRows], nq[kScanRows];
-    load_rows(row, nu, nq);
-#pragma unroll
-    for (int k = 0; k < kScanRows; ++k) {
-      su += nu[k];
-      sq += nq[k];
-    }
-  }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    su += __shfl_xor(su, o, 64);
-    sq += __shfl_xor(sq, o, 64);
-  }
-  if (lane == 0) { wave_tot[0][wave] = su; wave_tot[1][wave] = sq; }
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   __syncthreads();
-  long long carry_u = 0, carry_q = 0, all_u = 0, all_q = 0;
+  if ((tid & 63) == 0) red[tid >> 6] = v;
+  __syncthreads();
+  return red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ __launch_bounds__(kScanThreads) void window_scan_partials_kernel(WinArgs a, long long* partials) {
+  __shared__ long long red[2][kScanThreads / 64];
+  const int tid = threadIdx.x;
+  const int64_t n = static_cast<int64_t>(a.n_sets) * a.n_windows;
+  const int64_t base = static_cast<int64_t>(blockIdx.x) * kScanBlock;
+  long long su = 0, sq = 0;
+#pragma unroll
+  for (int k = 0; k < kScanPerThread; ++k) {  // lane-consecutive records: coalesced 24-byte loads
+    const int64_t r = base + k * kScanThreads + tid;
+    if (r < n) {
+      su += a.records[r].u_count;
+      sq += a.records[r].n_cdd_q;
+    }
+  }
+  const long long tu = block_sum_ll(su, red[0], tid);
+  const long long tq = block_sum_ll(sq, red[1], tid);
+  if (tid == 0) {
+    partials[2 * blockIdx.x] = tu;
+    partials[2 * blockIdx.x + 1] = tq;
+  }
+}
+
+__global__ __launch_bounds__(kScanThreads) void window_scan_apply_kernel(WinArgs a, const long long* partials) {
+  __shared__ long long red[2][kScanThreads / 64];
+  __shared__ long long wave_tot[2][kScanThreads / 64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t n = static_cast<int64_t>(a.n_sets) * a.n_windows;
+  // everything before this workgroup
+  long long bu = 0, bq = 0;
+  for (int j = tid; j < static_cast<int>(blockIdx.x); j += kScanThreads) {
+    bu += partials[2 * j];
+    bq += partials[2 * j + 1];
+  }
+  const long long base_u = block_sum_ll(bu, red[0], tid);
+  const long long base_q = block_sum_ll(bq, red[1], tid);
+  // thread t owns records first .. first+3 (consecutive), so that one shuffle scan orders the block
+  const int64_t first = static_cast<int64_t>(blockIdx.x) * kScanBlock + static_cast<int64_t>(tid) * kScanPerThread;
+  int32_t nu[kScanPerThread], nq[kScanPerThread];
+  long long su = 0, sq = 0;
+#pragma unroll
+  for (int k = 0; k < kScanPerThread; ++k) {
+    const int64_t r = first + k;
+    nu[k] = r < n ? a.records[r].u_count : 0;
+    nq[k] = r < n ? a.records[r].n_cdd_q : 0;
+    su += nu[k];
+    sq += nq[k];
+  }
+  long long iu = su, iq = sq;  // inclusive scan over the threads of a wave
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const long long tu = __shfl_up(iu, o, 64), tq = __shfl_up(iq, o, 64);
+    if (lane >= o) { iu += tu; iq += tq; }
+  }
+  if (lane == 63) { wave_tot[0][wave] = iu; wave_tot[1][wave] = iq; }
+  __syncthreads();
+  long long ou = base_u + iu - su, oq = base_q + iq - sq;
+  long long block_u = 0, block_q = 0;
 #pragma unroll
   for (int v = 0; v < kScanThreads / 64; ++v) {
-    const long long tu = wave_tot[0][v], tq = wave_tot[1][v];
-    if (v < wave) { carry_u += tu; carry_q += tq; }
-    all_u += tu;
-    all_q += tq;
+    if (v < wave) { ou += wave_tot[0][v]; oq += wave_tot[1][v]; }
+    block_u += wave_tot[0][v];
+    block_q += wave_tot[1][v];
   }
   longlong2* out = reinterpret_cast<longlong2*>(a.cdd_off);
-  for (int64_t row = row0; row < row1; row += kScanRows) {  // pass 2
-    int32_t nu[kScanRows], nq[kScanRows];
-    load_rows(row, nu, nq);
 #pragma unroll
-    for (int k = 0; k < kScanRows; ++k) {
-      if (row + k >= row1) break;  // uniform
-      long long iu = nu[k], iq = nq[k];  // inclusive scan over the row
-#pragma unroll
-      for (int o = 1; o < 64; o <<= 1) {
-        const long long tu = __shfl_up(iu, o, 64), tq = __shfl_up(iq, o, 64);
-        if (lane >= o) { iu += tu; iq += tq; }
-      }
-      const long long ou = carry_u + iu - nu[k], oq = carry_q + iq - nq[k];
-      const int64_t r = (row + k) * 64 + lane;
-      if (r < n) out[r] = make_longlong2((ou + nu[k] <= a.cap_u) ? ou : -1, (oq + nq[k] <= a.cap_q) ? oq : -1);
-      carry_u += __shfl(iu, 63, 64);
-      carry_q += __shfl(iq, 63, 64);
-    }
+  for (int k = 0; k < kScanPerThread; ++k) {
+    const int64_t r = first + k;
+    if (r < n) out[r] = make_longlong2((ou + nu[k] <= a.cap_u) ? ou : -1, (oq + nq[k] <= a.cap_q) ? oq : -1);
+    ou += nu[k];
+    oq += nq[k];
   }
-  if (threadIdx.x == 0) {
-    a.cdd_total[0] = all_u;
-    a.cdd_total[1] = all_q;
+  if (blockIdx.x == gridDim.x - 1 && tid == 0) {
+    a.cdd_total[0] = base_u + block_u;
+    a.cdd_total[1] = base_q + block_q;
   }
 }
 
@@ -630,6 +641,12 @@ __global__ __launch_bounds__(256) void window_lists_kernel(WinArgs a) {
 // ------------------------------------------------------------------------------------------
 
 extern "C" {
+
+int64_t sai_window_total_words(int32_t n_sets, int32_t n_windows) {
+  if (n_sets < 0 || n_windows < 0) return -1;
+  const int64_t n_rec = static_cast<int64_t>(n_sets) * n_windows;
+  return 2 + 2 * ((n_rec + kScanBlock - 1) / kScanBlock);
+}
 
 static int launch_window_bounds(sai_ctx* ctx, const int32_t* pos, int64_t n_sites, int32_t n_windows,
                                 const int64_t* win_start, const int64_t* win_end, const int32_t* seg_lo,
@@ -697,8 +714,13 @@ int sai_window_stats(sai_ctx* ctx, int64_t n_sites, const double* tgt_freq, cons
   if (int rc = check_launch("window_stats_wave")) return rc;
   hipLaunchKernelGGL(window_stats_heavy_kernel, block_grid, dim3(kWinThreads), 0, st, a);
   if (int rc = check_launch("window_stats_heavy")) return rc;
-  hipLaunchKernelGGL(window_scan_kernel, dim3(1), dim3(kScanThreads), 0, st, a);
-  if (int rc = check_launch("window_scan")) return rc;
+  const int64_t n_rec = static_cast<int64_t>(n_sets) * n_windows;
+  const unsigned scan_grid = static_cast<unsigned>((n_rec + kScanBlock - 1) / kScanBlock);
+  long long* partials = reinterpret_cast<long long*>(cdd_total) + 2;  // the caller's scratch behind the two totals
+  hipLaunchKernelGGL(window_scan_partials_kernel, dim3(scan_grid), dim3(kScanThreads), 0, st, a, partials);
+  if (int rc = check_launch("window_scan_partials")) return rc;
+  hipLaunchKernelGGL(window_scan_apply_kernel, dim3(scan_grid), dim3(kScanThreads), 0, st, a, partials);
+  if (int rc = check_launch("window_scan_apply")) return rc;
   hipLaunchKernelGGL(window_lists_kernel, wave_grid, dim3(256), 0, st, a);
   return check_launch("window_lists");
 }

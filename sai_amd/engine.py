@@ -517,7 +517,8 @@ class Engine:
         torch = _torch()
         n_rec = n_sets * n_windows
         rec_bytes, off_bytes = n_rec * RECORD_DTYPE.itemsize, n_rec * 16  # 24 B records keep 8-byte alignment
-        head = self._empty((rec_bytes + off_bytes + 16,), torch.uint8)
+        tot_bytes = 8 * int(self.lib.sai_window_total_words(n_sets, n_windows))  # 2 totals + the scan's scratch
+        head = self._empty((rec_bytes + off_bytes + tot_bytes,), torch.uint8)
         return (
             head[:rec_bytes],
             head[rec_bytes : rec_bytes + off_bytes].view(torch.int64),
@@ -539,7 +540,7 @@ class Engine:
             while True:
                 bufs = self.alloc_window_bufs(len(chunk), n_w, cap_u, cap_q)
                 self.window_stats_async(tgt_freq, fl, chunk, lo, hi, pos, bufs)
-                need_u, need_q = (int(v) for v in bufs[4].cpu().tolist())
+                need_u, need_q = (int(v) for v in bufs[4][:2].cpu().tolist())
                 if need_u <= bufs[2].numel() and need_q <= bufs[3].numel():
                     break
                 cap_u, cap_q = max(need_u, 1), max(need_q, 1)

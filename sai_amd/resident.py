@@ -86,8 +86,9 @@ class _SetChunk:
         rec_bytes = (s1 - s0) * n_windows * RECORD_DTYPE.itemsize
         self.rec_bytes = rec_bytes
         self.host_records = self.host_head[:rec_bytes]
-        self.host_offsets = self.host_head[rec_bytes:-16].view(torch.int64)
-        self.host_totals = self.host_head[-16:].view(torch.int64)
+        off_bytes = (s1 - s0) * n_windows * 16
+        self.host_offsets = self.host_head[rec_bytes : rec_bytes + off_bytes].view(torch.int64)
+        self.host_totals = self.host_head[rec_bytes + off_bytes : rec_bytes + off_bytes + 16].view(torch.int64)
 
 
 class ResidentScorer:
