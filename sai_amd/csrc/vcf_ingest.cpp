@@ -463,7 +463,7 @@ inline size_t batch_out_bytes() {
 
 template <typename F>
 int for_each_block_bgzf(FILE* f, const char* path, int n_threads, uint64_t voff_start, size_t batch_out, F&& consume) {
-  std::vector<unsigned char> cbuf(size_t(16) << 20);
+  std::vector<unsigned char> cbuf(size_t(2) << 20);  // compressed bytes of a batch (grown when a batch needs more)
   std::vector<char> ubuf;
   std::vector<BgzfMember> members;
   size_t chave = 0, carry = 0;
@@ -471,7 +471,9 @@ int for_each_block_bgzf(FILE* f, const char* path, int n_threads, uint64_t voff_
   bool ceof = false;
   // batches grow from `batch_out` (default 1 MiB) to the maximum: a small indexed region or the
   // header is not charged for 48 MiB of inflating
-  const size_t batch_max = batch_out_bytes();
+  // 8 MiB of text per batch at most: the buffers are fresh memory and faulting them in costs more
+  // than inflating into them (see for_each_block_plain); small buffers are reused batch after batch
+  const size_t batch_max = std::min(batch_out_bytes(), size_t(8) << 20);
   size_t batch_now = std::min(batch_max, batch_out ? batch_out : size_t(1) << 20);
   if (fseeko(f, static_cast<off_t>(voff_start >> 16), SEEK_SET) != 0) return sai_set_error(SAI_ERR_ARG, "seek failed in %s", path);
   for (;;) {

@@ -100,7 +100,6 @@ def score(
         stat_config=stat_config,
         anc_allele_file=anc_allele_file,
     )
-    preprocessor.feature_preprocessor._active_stats()  # reject statistics outside the U/Q path early
     write_headers(output_file, stat_config, ploidy_config)
 
     items = []
