@@ -24,6 +24,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <exception>
+#include <functional>
 #include <memory>
 #include <new>
 #include <string>
@@ -50,6 +51,77 @@ struct ThreadGroup {
     th.clear();
   }
   ~ThreadGroup() { join(); }
+};
+
+
+// Persistent workers for loops that fan the same job out batch after batch (a thread costs tens of
+// microseconds to create; a 160 MB bgzip file is ~20 batches x 2 phases x 15 threads).  run(nt, fn)
+// executes fn(0) .. fn(nt-1), fn(0) on the calling thread, and returns when all are done.  fn must
+// not throw (the callers' jobs catch inside).
+class WorkerPool {
+ public:
+  explicit WorkerPool(int n) : n_(n < 1 ? 1 : n) {
+    for (int t = 1; t < n_; ++t) threads_.emplace_back([this, t] { loop(t); });
+  }
+  ~WorkerPool() {
+    {
+      std::lock_guard<std::mutex> lk(m_);
+      stop_ = true;
+    }
+    cv_.notify_all();
+    for (auto& t : threads_)
+      if (t.joinable()) t.join();
+  }
+  int size() const { return n_; }
+  template <typename F>
+  void run(int nt, F&& fn) {
+    if (nt > n_) nt = n_;
+    if (nt <= 1) {
+      fn(0);
+      return;
+    }
+    std::function<void(int)> job = [&fn](int t) { fn(t); };
+    {
+      std::lock_guard<std::mutex> lk(m_);
+      job_ = &job;
+      active_ = nt;
+      pending_ = nt - 1;
+      ++gen_;
+    }
+    cv_.notify_all();
+    fn(0);
+    std::unique_lock<std::mutex> lk(m_);
+    done_.wait(lk, [this] { return pending_ == 0; });
+    job_ = nullptr;
+  }
+
+ private:
+  void loop(int t) {
+    uint64_t seen = 0;
+    for (;;) {
+      std::function<void(int)>* job = nullptr;
+      {
+        std::unique_lock<std::mutex> lk(m_);
+        cv_.wait(lk, [&] { return stop_ || gen_ != seen; });
+        if (stop_) return;
+        seen = gen_;
+        if (t < active_) job = job_;
+      }
+      if (job) {
+        (*job)(t);
+        std::lock_guard<std::mutex> lk(m_);
+        if (--pending_ == 0) done_.notify_one();
+      }
+    }
+  }
+  int n_;
+  std::vector<std::thread> threads_;
+  std::mutex m_;
+  std::condition_variable cv_, done_;
+  std::function<void(int)>* job_ = nullptr;
+  int active_ = 0, pending_ = 0;
+  uint64_t gen_ = 0;
+  bool stop_ = false;
 };
 
 constexpr int kScanThreads = 16;  // inflate threads of sai_vcf_scan (it has no thread argument)
@@ -463,6 +535,7 @@ inline size_t batch_out_bytes() {
 
 template <typename F>
 int for_each_block_bgzf(FILE* f, const char* path, int n_threads, uint64_t voff_start, size_t batch_out, F&& consume) {
+  WorkerPool pool(n_threads);
   std::vector<unsigned char> cbuf(size_t(2) << 20);  // compressed bytes of a batch (grown when a batch needs more)
   std::vector<char> ubuf;
   std::vector<BgzfMember> members;
@@ -524,10 +597,7 @@ int for_each_block_bgzf(FILE* f, const char* path, int n_threads, uint64_t voff_
         for (size_t i = lo; i < hi; ++i)
           if (!inflate_member(cbuf.data(), members[i], ubuf.data() + carry, inf)) bad[static_cast<size_t>(t)] = 1;
       };
-      ThreadGroup th;
-      for (int t = 1; t < nt; ++t) th.spawn([&work, t] { work(t); });
-      work(0);
-      th.join();
+      pool.run(nt, work);
       for (char b : bad)
         if (b) return sai_set_error(SAI_ERR_ARG, "%s: BGZF block fails to inflate or its CRC", path);
     }
@@ -873,6 +943,7 @@ struct sai_vcf_stream {
   bool finished = false, cancel = false;
   int rc = 0;
   std::string err;
+  std::unique_ptr<WorkerPool> pool;  // the producer's indexing / copying workers
   std::thread producer;
 };
 
@@ -881,6 +952,7 @@ namespace {
 // Copy + index [p, endp) (whole lines) into the next free buffer(s).  Returns 0, or a negative status.
 int stream_emit(sai_vcf_stream* st, const char* p, const char* endp, bool* done, bool* seen_chrom) {
   const int nt = std::max(1, st->n_threads);
+  if (!st->pool) st->pool.reset(new WorkerPool(nt));
   std::vector<IndexOut> outs(static_cast<size_t>(nt));
   while (p < endp) {
     // the part of [p, endp) that fits a buffer, cut at a line boundary
@@ -920,12 +992,7 @@ int stream_emit(sai_vcf_stream* st, const char* p, const char* endp, bool* done,
         o.failed = true;
       }
     };
-    {
-      ThreadGroup th;
-      for (int t = 1; t < nt; ++t) th.spawn([&piece, t] { piece(t); });
-      piece(0);
-      th.join();
-    }
+    st->pool->run(nt, piece);
     IndexOut& out = st->batch[b];
     out.clear();
     for (auto& o : outs) {
@@ -1005,6 +1072,7 @@ int stream_run_plain(sai_vcf_stream* st, const std::vector<const char*>& names) 
   }
   if (!st->header_seen) return sai_set_error(SAI_ERR_ARG, "%s: not a VCF (no #CHROM header)", path);
   const int nt = std::max(1, st->n_threads);
+  if (!st->pool) st->pool.reset(new WorkerPool(nt));
   std::vector<IndexOut> outs(static_cast<size_t>(nt));
   bool done = false, seen_chrom = false;
   size_t file_off = data_off;
@@ -1027,12 +1095,7 @@ int stream_run_plain(sai_vcf_stream* st, const std::vector<const char*>& names) 
         lo += static_cast<size_t>(got);
       }
     };
-    {
-      ThreadGroup th;
-      for (int t = 1; t < nt; ++t) th.spawn([&reader, t] { reader(t); });
-      reader(0);
-      th.join();
-    }
+    st->pool->run(nt, reader);
     for (char x : bad)
       if (x) return sai_set_error(SAI_ERR_ARG, "read error in %s", path);
     size_t usable = want;
@@ -1060,12 +1123,7 @@ int stream_run_plain(sai_vcf_stream* st, const std::vector<const char*>& names) 
         o.failed = true;
       }
     };
-    {
-      ThreadGroup th;
-      for (int t = 1; t < nt; ++t) th.spawn([&piece, t] { piece(t); });
-      piece(0);
-      th.join();
-    }
+    st->pool->run(nt, piece);
     IndexOut& out = st->batch[b];
     out.clear();
     for (auto& o : outs) {
@@ -1444,6 +1502,7 @@ static int vcf_load_impl(const char* path, const char* chrom, int64_t start, int
   // per-thread scratch lives across blocks: clear() keeps the capacity, so the allocator (and the
   // page-fault cost of fresh memory) is paid once, not per block
   std::vector<ThreadOut> outs(static_cast<size_t>(n_threads));
+  WorkerPool tok_pool(n_threads);
   bool done = false, seen_chrom = false;  // early stop of an indexed (hence sorted) region read
   auto on_header = [&](const char*& p, const char* endp) -> int {
     while (!header_seen && p < endp) {  // header lines (serial)
@@ -1486,13 +1545,9 @@ static int vcf_load_impl(const char* path, const char* chrom, int64_t start, int
         o.failed = true;
       }
     };
-    ThreadGroup th;
-    for (int t = 1; t < n_threads; ++t) {
-      if (cut[static_cast<size_t>(t)] >= cut[static_cast<size_t>(t) + 1]) continue;
-      th.spawn([&piece, t] { piece(t); });
-    }
-    if (cut[0] < cut[1]) piece(0);  // this thread works too
-    th.join();
+    tok_pool.run(n_threads, [&](int t) {
+      if (cut[static_cast<size_t>(t)] < cut[static_cast<size_t>(t) + 1]) piece(t);
+    });
     for (auto& o : outs) {  // pieces in file order
       if (o.failed) return sai_set_error(SAI_ERR_HIP, "%s: tokenizer failed (out of memory)", path);
       if (!o.error.empty()) return sai_set_error(SAI_ERR_ARG, "%s: %s", path, o.error.c_str());
