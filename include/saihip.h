@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define SAI_ABI_VERSION 8
+#define SAI_ABI_VERSION 9
 #define SAI_TILE_SITES 64
 #define SAI_MAX_SRC 6   /* source populations per call */
 #define SAI_MAX_SETS 16 /* parameter sets per call */
@@ -247,11 +247,14 @@ int sai_window_dd(sai_ctx* ctx, int64_t n_sites, int32_t n_src_ind, const uint32
 /* ---- packed2: optional 2-bit layout ----------------------------- */
 
 /* For dosages in {0, 1, 2} plus missing (unphased diploid or haploid biallelic calls) a block can
- * be held 4x denser: 2 bits per individual (0, 1, 2 = dosage, 3 = missing), in 1 KiB blocks of
- * 64 consecutive sites (a tile) x 64 consecutive individuals (a group), site-major inside the
- * block (16 bytes per site), blocks ordered by tile, then group; n_groups = ceil(n_ind / 64):
+ * be held 4x denser: 2 bits per individual (0, 1, 2 = dosage, 3 = missing).  Per tile of 64
+ * consecutive sites the individuals form n_full = n_ind / 64 full groups of 64 (16 bytes per site:
+ * a 1 KiB block, site-major) and one tail group of the remaining n_ind % 64 in
+ * w_tail = ceil((n_ind % 64) / 16) words per site (a 256 * w_tail byte block), tiles back to back;
+ * with W = n_full * 256 + w_tail * 64 words per tile:
  *   field(site, ind) = bits [2 * (ind % 16), +2) of uint32 word
- *                      ((site / 64 * n_groups + ind / 64) * 64 + site % 64) * 4 + (ind % 64) / 16.
+ *       (site / 64) * W + (ind / 64) * 256 + (site % 64) * 4 + (ind % 64) / 16         (full group)
+ *       (site / 64) * W + n_full * 256 + (site % 64) * w_tail + (ind % 64) / 16        (tail group)
  * Padding individuals hold code 0, padding sites of the last tile code 3.  The byte count of a
  * launch is 4x smaller, so throughput figures on this layout are always reported separately from
  * the int8 ones. */

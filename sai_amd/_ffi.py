@@ -20,7 +20,7 @@ SAI_MAX_SETS = 16
 SAI_FUSED_SETS = 20
 SAI_ERR_UNSUPPORTED = -4  # enum sai_status
 FREQ_MODES = {"dense": 0, "candidates": 1}  # enum sai_freq_mode
-SAI_ABI_VERSION = 8
+SAI_ABI_VERSION = 9
 
 OPS = {"=": 0, "<": 1, ">": 2, "<=": 3, ">=": 4}
 

@@ -9,10 +9,14 @@ namespace {
 // packed2: an optional 4x denser layout for dosages in {0, 1, 2} (+ missing), i.e. unphased
 // diploid (or haploid) biallelic calls -- SURVEY.md section 8f #4.  2 bits per individual
 // (0, 1, 2 = dosage, 3 = missing), blocked so that one lane owns one site:
-//     tile t = 64 consecutive sites, group g = 64 consecutive individuals (16 bytes per site);
-//     block (t, g) = 64 sites x 16 B = 1 KiB at byte offset (t * n_groups + g) * 1024, site-major;
+//     tile t = 64 consecutive sites; the individuals form n_full = n_ind / 64 full groups of 64
+//     (16 bytes per site: a 1 KiB block per tile, site-major) and one TAIL group of the remaining
+//     n_ind % 64, held in w_tail = ceil(rem / 16) words per site (a 256 * w_tail byte block): a
+//     2-individual source population costs 4 bytes per site, not 16;
+//     words per tile W = n_full * 256 + w_tail * 64;
 //     field(site, ind) = bits [2*(ind%16), +2) of uint32 word
-//                        ((site/64 * n_groups + ind/64) * 64 + site%64) * 4 + (ind%64)/16.
+//         (site/64) * W + (ind/64) * 256 + (site%64) * 4 + (ind%64)/16        in a full group,
+//         (site/64) * W + n_full * 256 + (site%64) * w_tail + (ind%64)/16     in the tail group.
 // A wave instruction reads one block: lane l gets the 64 individuals of site l of the tile, counts
 // the three codes with v_bcnt_u32_b32 (popcount with accumulate) and keeps the totals in its own
 // registers across the groups -- no cross-lane step at all, and the per-site tail (eval_site) runs
@@ -21,14 +25,18 @@ namespace {
 // numbers.  Padding individuals carry code 0 (n_called = n_ind - missing), padding sites code 3.
 // ------------------------------------------------------------------------------------------
 
-__host__ __device__ __forceinline__ int packed2_groups(int n_ind) { return (n_ind + 63) / 64; }
+__host__ __device__ __forceinline__ int packed2_full_groups(int n_ind) { return n_ind / 64; }
+__host__ __device__ __forceinline__ int packed2_tail_words(int n_ind) { return ((n_ind % 64) + 15) / 16; }
+__host__ __device__ __forceinline__ int64_t packed2_tile_words(int n_ind) {
+  return static_cast<int64_t>(packed2_full_groups(n_ind)) * 256 + packed2_tail_words(n_ind) * 64;
+}
 
 constexpr int kPackedUnroll = 8;  // wave loads in flight per batch
 constexpr int kPackedMaxInd = 1 << 24;  // as for the int8 layout: per-site totals are 32-bit
 
 // tiled int8 -> packed2.  One workgroup per (tile, group); n_bad counts words holding a byte above 2.
 __global__ __launch_bounds__(256) void pack2_from_tiles_kernel(const int8_t* __restrict__ tiles, int64_t n_sites,
-                                                                int32_t n_ind, int32_t n_groups,
+                                                                int32_t n_ind,
                                                                 uint32_t* __restrict__ packed, int32_t* n_bad) {
   __shared__ int8_t blk[kTile][kTile + 4];  // [individual of the group][site]
   const int64_t tile = blockIdx.x;
@@ -57,14 +65,19 @@ __global__ __launch_bounds__(256) void pack2_from_tiles_kernel(const int8_t* __r
       w |= static_cast<uint32_t>(g < 0 ? 3 : (g & 3)) << (2 * k);
     }
   }
-  packed[((tile * n_groups + blockIdx.y) * kTile + s) * 4 + j] = w;  // the workgroup writes its 1 KiB block in order
+  const int n_full = packed2_full_groups(n_ind), w_tail = packed2_tail_words(n_ind);
+  uint32_t* tile_words = packed + tile * packed2_tile_words(n_ind);
+  if (static_cast<int>(blockIdx.y) < n_full) tile_words[blockIdx.y * 256 + s * 4 + j] = w;  // a 1 KiB block, in order
+  else if (j < w_tail) tile_words[n_full * 256 + s * w_tail + j] = w;                       // the narrow tail block
   if (bad) atomicAdd(n_bad, 1);
 }
 
 struct PackedPop {
-  const u32x4* data;
+  const uint32_t* data;
   int32_t n_ind;
-  int32_t n_groups;
+  int32_t n_full;   // full groups of 64 individuals
+  int32_t w_tail;   // words per site of the tail group (0..3)
+  int32_t pad;
 };
 
 struct PackedArgs {
@@ -94,8 +107,9 @@ __global__ __launch_bounds__(64) void site_counts_packed2_kernel(PackedArgs a, F
   for (int64_t tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
     const int64_t site = tile * kTile + lane;
     for (int p = 0; p < a.n_pops; ++p) {
-      const int n_groups = a.pop[p].n_groups;
-      const u32x4* base = a.pop[p].data + tile * n_groups * kTile + lane;
+      const int n_groups = a.pop[p].n_full, w_tail = a.pop[p].w_tail;
+      const uint32_t* tile_words = a.pop[p].data + tile * (static_cast<int64_t>(n_groups) * 256 + w_tail * 64);
+      const u32x4* base = reinterpret_cast<const u32x4*>(tile_words) + lane;
       uint32_t ones = 0, twos = 0, miss = 0;
       int g = 0;
       for (; g + kPackedUnroll <= n_groups; g += kPackedUnroll) {
@@ -105,7 +119,15 @@ __global__ __launch_bounds__(64) void site_counts_packed2_kernel(PackedArgs a, F
 #pragma unroll
         for (int u = 0; u < kPackedUnroll; ++u) count_codes(v[u], ones, twos, miss);
       }
-      if (g + 1 == n_groups) {  // one group left (small source populations): a single load
+      // the tail group's words of this lane's site go out together with the remaining full groups
+      u32x4 tail = {0u, 0u, 0u, 0u};
+      if (w_tail) {
+        const uint32_t* tw = tile_words + n_groups * 256 + lane * w_tail;
+        tail.x = __builtin_nontemporal_load(tw);
+        if (w_tail > 1) tail.y = __builtin_nontemporal_load(tw + 1);
+        if (w_tail > 2) tail.z = __builtin_nontemporal_load(tw + 2);
+      }
+      if (g + 1 == n_groups) {  // one full group left: a single load
         count_codes(__builtin_nontemporal_load(base + g * kTile), ones, twos, miss);
       } else if (g < n_groups) {  // 2 .. kPackedUnroll-1 groups as one batch: clamped addresses, zeroed extras
         u32x4 v[kPackedUnroll - 1];
@@ -117,6 +139,7 @@ __global__ __launch_bounds__(64) void site_counts_packed2_kernel(PackedArgs a, F
           count_codes(v[u], ones, twos, miss);
         }
       }
+      count_codes(tail, ones, twos, miss);  // padding individuals carry code 0
       const uint2 cnt = make_uint2(ones + 2u * twos, static_cast<uint32_t>(a.pop[p].n_ind) - miss);
       if (a.counts && site < a.n_sites) store_counts_nt(a.counts + static_cast<int64_t>(p) * a.n_sites + site, cnt);
       if (FUSED) stash[p][lane] = cnt;
@@ -139,7 +162,7 @@ extern "C" {
 int64_t sai_packed2_bytes(int64_t n_sites, int32_t n_ind) {
   if (n_sites < 0 || n_ind < 0 || n_ind > kPackedMaxInd) return -1;
   const int64_t n_tiles = (n_sites + kTile - 1) / kTile;
-  return n_tiles * packed2_groups(n_ind) * 1024;  // whole 1 KiB blocks: 64 sites x 64 individuals
+  return n_tiles * packed2_tile_words(n_ind) * 4;  // 1 KiB per full group + 256 B per word of the tail group
 }
 
 int sai_pack2_from_tiles(sai_ctx* ctx, const int8_t* tiles, int64_t n_sites, int32_t n_ind, uint8_t* packed,
@@ -154,7 +177,7 @@ int sai_pack2_from_tiles(sai_ctx* ctx, const int8_t* tiles, int64_t n_sites, int
   if (!tiles || !packed) return fail(SAI_ERR_ARG, "NULL buffer");
   const int64_t n_tiles = (n_sites + kTile - 1) / kTile;
   const dim3 grid(static_cast<unsigned>(n_tiles), static_cast<unsigned>((n_ind + kTile - 1) / kTile));
-  hipLaunchKernelGGL(pack2_from_tiles_kernel, grid, dim3(256), 0, st, tiles, n_sites, n_ind, packed2_groups(n_ind),
+  hipLaunchKernelGGL(pack2_from_tiles_kernel, grid, dim3(256), 0, st, tiles, n_sites, n_ind,
                      reinterpret_cast<uint32_t*>(packed), n_unrepresentable);
   return check_launch("pack2_from_tiles");
 }
@@ -188,9 +211,11 @@ int sai_site_pass_packed2(sai_ctx* ctx, int64_t n_sites, int32_t n_pops, const s
     if (!pops[p].tiles || (reinterpret_cast<uintptr_t>(pops[p].tiles) & 15u))
       return fail(SAI_ERR_ARG, "population %d: packed block must be a 16-byte aligned device pointer", p);
     if (n_sets > 0 && pops[p].ploidy <= 0) return fail(SAI_ERR_ARG, "ploidy[%d] must be positive", p);
-    a.pop[p].data = reinterpret_cast<const u32x4*>(pops[p].tiles);
+    a.pop[p].data = reinterpret_cast<const uint32_t*>(pops[p].tiles);
     a.pop[p].n_ind = pops[p].n_ind;
-    a.pop[p].n_groups = packed2_groups(pops[p].n_ind);
+    a.pop[p].n_full = packed2_full_groups(pops[p].n_ind);
+    a.pop[p].w_tail = packed2_tail_words(pops[p].n_ind);
+    a.pop[p].pad = 0;
     fa.ploidy[p] = pops[p].ploidy;
   }
   a.counts = reinterpret_cast<uint2*>(counts);

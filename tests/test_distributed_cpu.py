@@ -145,3 +145,110 @@ def test_mp_pool_single_process():
     pre = Pre()
     mp_pool(pre, Gen(), nprocess=2)
     assert pre.items == [0, 3, 6, 9, 12]
+
+
+# ---- the numeric transport of the product path (WindowBatch rows) over gloo --------------------
+
+
+def _batch_worker(rank: int, world: int, port: int, out_dir: str) -> None:
+    import torch.distributed as dist
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))  # fmt: skip
+    from sai_amd.distributed import init_process_group, run_sharded
+    from sai_amd.multiprocessing import mp_pool
+
+    init_process_group("gloo")
+    pre, gen = _FakeChunkPreprocessor(), _FakeChunks()
+    items = run_sharded(pre, gen)
+    pre2 = _FakeChunkPreprocessor()
+    mp_pool(pre2, _FakeChunks(), nprocess=3)
+    if rank == 0:
+        with open(os.path.join(out_dir, "items.json"), "w") as f:
+            json.dump([items, pre.written, pre2.written], f)
+    else:
+        assert items is None and pre.written is None and pre2.written is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+class _FakeChunks:
+    def get(self):
+        for i in range(7):
+            yield {"chr_name": "3", "start": 1 + 100 * i, "end": 100 * (i + 1)}
+
+    def __len__(self):
+        return 7
+
+
+class _FakeChunkPreprocessor:
+    """ChunkPreprocessor's numeric protocol (run_compact / pack_result / unpack_result /
+    items_from_results) with made-up numbers instead of kernels: two population combinations, three
+    windows per chunk."""
+
+    def __init__(self):
+        self.written = None
+
+    def run_compact(self, chr_name, start, end):
+        from sai_amd.engine import RECORD_DTYPE, WindowResults
+        from sai_amd.preprocessors.window_batch import ComboBatch, WindowBatch
+
+        combos = []
+        for ci, tgt in enumerate(("t1", "t2")):
+            win = np.array([[start + 10 * k, start + 10 * k + 29] for k in range(3)], dtype=np.int64)
+            rec = np.zeros((1, 3), dtype=RECORD_DTYPE)
+            rec["n_sites"] = 5
+            rec["u_count"][0] = [(start + k + ci) % 3 for k in range(3)]
+            off = np.zeros((1, 3, 2), dtype=np.int64)
+            off[0, :, 0] = np.cumsum(rec["u_count"][0]) - rec["u_count"][0]
+            lists = np.arange(int(rec["u_count"].sum()), dtype=np.int32) + start
+            combos.append(ComboBatch("r", tgt, ("s",), None, win, np.full(3, 5, np.int32), ["U"],
+                                     WindowResults(rec, off, lists, np.zeros(0, np.int32))))  # fmt: skip
+        return WindowBatch(chr_name, combos)
+
+    def run(self, **params):
+        return self.items_from_result(self.run_compact(**params))
+
+    @staticmethod
+    def pack_result(batch):
+        return batch.to_bytes()
+
+    @staticmethod
+    def unpack_result(raw):
+        from sai_amd.preprocessors.window_batch import WindowBatch
+
+        return WindowBatch.from_bytes(raw)
+
+    @staticmethod
+    def items_from_result(batch):
+        out = []
+        for cb in batch.combos:
+            for wi in range(len(cb.windows)):
+                out.append([cb.tgt_pop, int(cb.windows[wi, 0]), int(cb.uq.records[0, wi]["u_count"]), cb.uq.u_list(0, wi).tolist()])
+        return out
+
+    def items_from_results(self, batches):
+        out = []
+        for k in range(2):  # combination-major, chunks in order: what ONE chunk would emit
+            for b in batches:
+                out.extend(it for it in self.items_from_result(b) if it[0] == ("t1", "t2")[k])
+        return out
+
+    def process_items(self, items):
+        self.written = items
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_numeric_rows_through_run_sharded_and_mp_pool(tmp_path, world):
+    """A processor with the numeric protocol travels as ONE byte row per rank (sizes exchanged,
+    one padded gather) and rank 0 emits the items in single-chunk order, for 2 and 4 ranks over 7
+    uneven chunks; mp_pool keeps the reference's per-task, task-ordered contract."""
+    import torch.multiprocessing as mp
+
+    mp.spawn(_batch_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    items, written, pooled = json.load(open(tmp_path / "items.json"))
+    pre, chunks = _FakeChunkPreprocessor(), list(_FakeChunks().get())
+    serial = pre.items_from_results([pre.run_compact(**c) for c in chunks])
+    assert items == written == serial
+    assert [it[0] for it in items] == ["t1"] * 21 + ["t2"] * 21 and [it[1] for it in items[:4]] == [1, 11, 21, 101]
+    assert pooled == [pre.run(**c) for c in chunks]  # one list per task, in task order

@@ -340,7 +340,7 @@ def test_randomized_windows_against_oracle(eng):
                 assert res.q_list(si, wi).tolist() == np.asarray(eq["cdd_pos"]).astype(np.int64).tolist()
 
 
-@pytest.mark.parametrize("sizes", [[1, 1, 1], [64, 65, 2], [200, 129, 1, 3], [1000, 1008, 2], [4097, 513, 2]])
+@pytest.mark.parametrize("sizes", [[1, 1, 1], [64, 65, 2], [200, 129, 1, 3], [1000, 1008, 2], [4097, 513, 2], [17, 33, 49, 128]])
 def test_packed2_layout_equals_int8_path(eng, sizes):
     """The optional 2-bit layout: packing is exact, the packed site pass gives the same counts,
     frequencies and flags as the int8 kernels, and blocks with dosages above 2 are refused."""
@@ -362,20 +362,30 @@ def test_packed2_layout_equals_int8_path(eng, sizes):
     tiled = [eng.tile(m) for m in mats]
     packed = [eng.pack2(t) for t in tiled]
     for m, pk in zip(mats, packed):  # the documented bit layout
-        n_groups = (m.shape[1] + 63) // 64
+        n_ind = m.shape[1]
+        n_full, w_tail = n_ind // 64, (n_ind % 64 + 15) // 16
         n_tiles = (n_sites + 63) // 64
-        words = pk.data.cpu().numpy().view(np.uint32).reshape(n_tiles, n_groups, 64, 4)
-        assert pk.data.numel() == n_tiles * n_groups * 1024
+        tile_words = n_full * 256 + w_tail * 64
+        assert pk.data.numel() == n_tiles * tile_words * 4
+        words = pk.data.cpu().numpy().view(np.uint32).reshape(n_tiles, tile_words)
         codes = np.where(m < 0, 3, m).astype(np.uint32)
         sites = np.arange(n_sites)
-        for ind in (0, m.shape[1] // 2, m.shape[1] - 1):
-            got = (words[sites // 64, ind // 64, sites % 64, (ind % 64) // 16] >> (2 * (ind % 16))) & 3
-            assert np.array_equal(got, codes[:, ind])
-        if m.shape[1] % 64:  # padding individuals: code 0
-            ind = m.shape[1]
-            assert not ((words[sites // 64, ind // 64, sites % 64, (ind % 64) // 16] >> (2 * (ind % 16))) & 3).any()
+
+        def field(ind):
+            if ind // 64 < n_full:
+                w = words[sites // 64, (ind // 64) * 256 + (sites % 64) * 4 + (ind % 64) // 16]
+            else:
+                w = words[sites // 64, n_full * 256 + (sites % 64) * w_tail + (ind % 64) // 16]
+            return (w >> (2 * (ind % 16))) & 3
+
+        for ind in (0, n_ind // 2, n_ind - 1):
+            assert np.array_equal(field(ind), codes[:, ind])
+        if n_ind % 16:  # padding individuals inside the last word: code 0
+            assert not field(n_ind).any()
         if n_sites % 64:  # padding sites of the last tile: code 3 everywhere
-            assert (words[-1, :, n_sites % 64:, :] == 0xFFFFFFFF).all()
+            full = words[-1, : n_full * 256].reshape(n_full, 64, 4)[:, n_sites % 64 :, :]
+            tail = words[-1, n_full * 256 :].reshape(64, max(w_tail, 1))[n_sites % 64 :, :w_tail]
+            assert (full == 0xFFFFFFFF).all() and (tail == 0xFFFFFFFF).all()
     n_src = len(sizes) - 2
     sets = [_ffi.make_params(0.4, 0.3, 0.9, [(">=", 0.5)] * n_src, False), _ffi.make_params(1.0, 0.0, 0.5, [("<=", 1.0)] * n_src, True)]
     counts = eng.site_counts(tiled)
