@@ -76,7 +76,7 @@ struct PackedPop {
   const uint32_t* data;
   int32_t n_ind;
   int32_t n_full;   // full groups of 64 individuals
-  int32_t w_tail;   // words per site of the tail group (0..3)
+  int32_t w_tail;   // words per site of the tail group (0..4)
   int32_t pad;
 };
 
@@ -126,6 +126,7 @@ __global__ __launch_bounds__(64) void site_counts_packed2_kernel(PackedArgs a, F
         tail.x = __builtin_nontemporal_load(tw);
         if (w_tail > 1) tail.y = __builtin_nontemporal_load(tw + 1);
         if (w_tail > 2) tail.z = __builtin_nontemporal_load(tw + 2);
+        if (w_tail > 3) tail.w = __builtin_nontemporal_load(tw + 3);  // 49..63 individuals
       }
       if (g + 1 == n_groups) {  // one full group left: a single load
         count_codes(__builtin_nontemporal_load(base + g * kTile), ones, twos, miss);
