@@ -218,26 +218,14 @@ def score_sharded(vcf_file: str, chr_name: str, win_len: int, win_step: int, anc
     import torch.distributed as dist
 
     from .generators import ChunkGenerator
-    from .preprocessors import ChunkPreprocessor
-    from .sai import load_config, write_headers
+    from .sai import chunk_preprocessor_for, load_config, require_polarised_input, write_headers
 
     rank, world = init_process_group()
     cfg = load_config(config)
+    require_polarised_input(cfg.statistics, anc_allele_file)
     generator = ChunkGenerator(vcf_file=vcf_file, chr_name=chr_name, window_size=win_len, step_size=win_step,
                                num_chunks=max(world * chunks_per_rank, 1))  # fmt: skip
-    preprocessor = ChunkPreprocessor(
-        vcf_file=vcf_file,
-        ref_ind_file=cfg.populations.get_population("ref"),
-        tgt_ind_file=cfg.populations.get_population("tgt"),
-        src_ind_file=cfg.populations.get_population("src"),
-        out_ind_file=cfg.populations.get_population("outgroup"),
-        win_len=win_len,
-        win_step=win_step,
-        output_file=output_file,
-        ploidy_config=cfg.ploidies,
-        stat_config=cfg.statistics,
-        anc_allele_file=anc_allele_file,
-    )
+    preprocessor = chunk_preprocessor_for(cfg, vcf_file, win_len, win_step, output_file, anc_allele_file)
     if rank == 0:
         write_headers(output_file, cfg.statistics, cfg.ploidies)
     if world > 1:

@@ -58,54 +58,37 @@ def write_headers(output_file: str, stat_config, ploidy_config) -> None:
                 f.write(f"Chrom\tStart\tEnd\t{key}_SNP\n")
 
 
-def score(
-    vcf_file: str,
-    chr_name: str,
-    win_len: int,
-    win_step: int,
-    anc_allele_file: str,
-    output_file: str,
-    config: str,
-    num_workers: int,
-) -> None:
-    """Sliding-window U/Q scores of one chromosome, written as the reference writes them
-    (TSV + ``.U.log`` + ``.Q.log``).  ``num_workers`` is accepted for signature compatibility;
-    the windows of the chromosome are computed in batched GPU launches by one process (use
-    ``sai_amd.distributed`` under torchrun to shard window ranges over several GPUs)."""
-    global_config = load_config(config)
-    stat_config = global_config.statistics
-    ploidy_config = global_config.ploidies
-    pop_config = global_config.populations
+def require_polarised_input(stat_config, anc_allele_file) -> None:
+    """fd, df, Danc and Dplus need polarised data (sai.py:79-84)."""
+    if anc_allele_file is not None:
+        return
+    wanted = [name for name in stat_config.root if name in _POLARISED]
+    if wanted:
+        raise ValueError(
+            f"The {wanted[0]} statistic requires polarized data, please provide the ancestral allele information with `--anc-alleles`."
+        )
 
-    if anc_allele_file is None:  # sai.py:79-84
-        for stat_name in stat_config.root.keys():
-            if stat_name in _POLARISED:
-                raise ValueError(
-                    f"The {stat_name} statistic requires polarized data, please provide the ancestral allele information with `--anc-alleles`."
-                )
 
-    generator = ChunkGenerator(
-        vcf_file=vcf_file, chr_name=chr_name, window_size=win_len, step_size=win_step, num_chunks=1
-    )
-    preprocessor = ChunkPreprocessor(
-        vcf_file=vcf_file,
-        ref_ind_file=pop_config.get_population("ref"),
-        tgt_ind_file=pop_config.get_population("tgt"),
-        src_ind_file=pop_config.get_population("src"),
-        out_ind_file=pop_config.get_population("outgroup"),
-        win_len=win_len,
-        win_step=win_step,
-        output_file=output_file,
-        ploidy_config=ploidy_config,
-        stat_config=stat_config,
-        anc_allele_file=anc_allele_file,
-    )
-    write_headers(output_file, stat_config, ploidy_config)
+def chunk_preprocessor_for(cfg: GlobalConfig, vcf_file, win_len, win_step, output_file, anc_allele_file) -> ChunkPreprocessor:
+    """The chunk driver of a run: the sample lists come from the configuration's ``populations``
+    section (sai.py:95-107).  Shared by ``score`` and ``sai_amd.distributed.score_sharded``."""
+    files = {group: cfg.populations.get_population(group) for group in ("ref", "tgt", "src", "outgroup")}
+    return ChunkPreprocessor(vcf_file, files["ref"], files["tgt"], files["src"], files["outgroup"], win_len, win_step,
+                             output_file, cfg.ploidies, cfg.statistics, anc_allele_file=anc_allele_file)  # fmt: skip
 
-    items = []
-    for params in generator.get():
-        items.extend(preprocessor.run(**params))
-    preprocessor.process_items(items)
+
+def score(vcf_file: str, chr_name: str, win_len: int, win_step: int, anc_allele_file: str, output_file: str, config: str,
+          num_workers: int) -> None:  # fmt: skip
+    """Sliding-window scores of one chromosome, written as the reference writes them (TSV +
+    ``.U.log`` + ``.Q.log``; interface of sai.py:33-42).  ``num_workers`` is accepted for signature
+    compatibility: the windows of the chromosome are computed in batched GPU launches by one process
+    (``sai_amd.distributed.score_sharded`` under torchrun shards window ranges over several GPUs)."""
+    cfg = load_config(config)
+    require_polarised_input(cfg.statistics, anc_allele_file)
+    chunks = ChunkGenerator(vcf_file=vcf_file, chr_name=chr_name, window_size=win_len, step_size=win_step, num_chunks=1)
+    driver = chunk_preprocessor_for(cfg, vcf_file, win_len, win_step, output_file, anc_allele_file)
+    write_headers(output_file, cfg.statistics, cfg.ploidies)
+    driver.process_items([item for chunk in chunks.get() for item in driver.run(**chunk)])
 
 
 def outlier(score_file: str, output_prefix: str, quantile: float) -> None:
