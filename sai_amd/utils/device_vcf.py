@@ -106,7 +106,7 @@ def load_dosage_device(eng, vcf_file: str, chr_name: str, samples: Sequence[str]
         have_header = lib.sai_vcf_stream_selection(handle, None, 0, C.byref(cols), C.byref(n_match), C.byref(n_anc)) == 0
     finally:
         lib.sai_vcf_stream_close(handle)
-    side.synchronize()
+        side.synchronize()  # also on an error: the staging buffers are reused by the next call
     if stats and bool(torch.cat(stats).any()):
         # a line the host reader refuses: let it say why, in the reference's words
         load_dosage(vcf_file, chr_name, samples, ploidies, start, end, anc_allele_file, n_threads)
