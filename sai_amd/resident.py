@@ -23,6 +23,12 @@ from .utils.windows import split_genome
 # A step is milliseconds, but in a multi-GPU job a windows stage ends with a gather, and the first
 # gather of a job waits for RCCL to build its channels (seconds on 8 ranks): the deadline only has
 # to beat "forever".  SAI_AMD_WAIT_DEADLINE_S overrides it.
+# How the host waits for an event of the pipelined scorer: "sync" = Event.synchronize() (the runtime
+# wakes the thread 8-12 us after the kernel ends, tools/event_wait_probe.py, and no core spins);
+# "poll" = busy-poll Event.query() with a deadline that raises instead of waiting forever -- for
+# hunting a hang.  (Round 1 polled because synchronize() seemed to oversleep by milliseconds; that
+# belonged to the stream-side-wait arrangement it had at the time and does not reproduce.)
+_WAIT_MODE = __import__("os").environ.get("SAI_AMD_WAIT", "sync")
 WAIT_DEADLINE_S = float(__import__("os").environ.get("SAI_AMD_WAIT_DEADLINE_S", "300"))
 
 
@@ -205,10 +211,12 @@ class ResidentScorer:
         return torch.cuda.stream(self.side) if self.overlap else contextlib.nullcontext()
 
     def _wait(self, event, what: str) -> None:
-        """Poll an event (Event.synchronize() was seen to oversleep by ~7 ms -- the runtime's
-        interrupt-driven wait -- which is longer than two whole steps).  Spins for the first
-        millisecond, then yields the core between polls; raises instead of spinning forever when the
-        GPU has stopped making progress, and surfaces a failed kernel's status (query() raises)."""
+        """Wait for an event on the host (see _WAIT_MODE).  The polling form spins for the first
+        millisecond, then yields the core between polls; it raises instead of spinning forever when
+        the GPU has stopped making progress, and surfaces a failed kernel's status (query() raises)."""
+        if _WAIT_MODE == "sync":
+            event.synchronize()
+            return
         t0 = time.perf_counter()
         spins = 0
         while not event.query():
