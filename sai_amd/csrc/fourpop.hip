@@ -156,7 +156,7 @@ template <typename E>
 __device__ __forceinline__ double wave_numpy_sum(const E& e, int off, int n, int lane, LeafList* list,
                                                  double (*leaf_sums)[kMaxLeaves]) {
   constexpr int S = E::kSlots;
-  constexpr int kBatch = 4;  // leaf iterations whose loads are in flight together
+  constexpr int kBatch = 8;  // leaf iterations whose loads are in flight together
   double total = 0.0;        // meaningful in lanes < S
   for (int o = 0; o < n; o += 8192) {
     const int m = min(8192, n - o);
