@@ -17,7 +17,7 @@ from typing import Optional, Sequence
 import numpy as np
 
 from . import _ffi
-from .engine import RECORD_DTYPE, Engine, TiledPop, WindowResults
+from .engine import RECORD_DTYPE, Engine, WindowResults
 from .utils.windows import split_genome
 
 # A step is milliseconds, but in a multi-GPU job a windows stage ends with a gather, and the first
