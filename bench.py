@@ -31,8 +31,8 @@ memory (+ the gather).  Rank 0 prints one JSON line.
 algorithmic bytes = resident sites x (n_ref + n_tgt + n_src) genotype bytes per launch of rank 0.
 `cpu_baseline` times the numpy oracle (the reference's per-window structure) on the host cores over
 a bounded site prefix of the same chromosome, before the GPU is initialised.  `score_path` is the
-rate of the product entry point on the same resident block: FeaturePreprocessor.run_windows (the
-same fused pass and windows stage) + item dictionaries + process_items' TSV / log text.
+rate of the product entry point on the same resident block: FeaturePreprocessor.score_windows (the
+same fused pass and windows stage) + the native TSV / log writer, next to the item-dictionary route.
 """
 
 from __future__ import annotations
@@ -292,35 +292,50 @@ def score_path_rate(eng, wl, block, lay, repeats: int = 3) -> dict:
     )  # fmt: skip
     times = []
     with tempfile.TemporaryDirectory() as tmp:
-        out = os.path.join(tmp, "scores.tsv")
+        out, out_items = os.path.join(tmp, "scores.tsv"), os.path.join(tmp, "items.tsv")
         fp = FeaturePreprocessor(out, stats, anc_allele_available=s0["anc"])
-        n_items = 0
+        fp_items = FeaturePreprocessor(out_items, stats, anc_allele_available=s0["anc"])
+        n_rows = 0
         for _ in range(repeats + 1):
             write_headers(out, stats, ploidies)
+            write_headers(out_items, stats, ploidies)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             batch = fp.score_windows(wg)
             t1 = time.perf_counter()
-            items = fp.items_from_batch(batch)
+            fp.write_batches([batch])  # what `score` does: text straight from the numeric batch
             t2 = time.perf_counter()
-            fp.process_items(items)
+            items = fp_items.items_from_batch(batch)  # the reference's item protocol, for comparison
             t3 = time.perf_counter()
-            times.append((t3 - t0, t1 - t0, t2 - t1, t3 - t2))
-            n_items = len(items)
-        text_bytes = sum(os.path.getsize(os.path.join(tmp, f)) for f in os.listdir(tmp))
-    total, gpu, build, write = min(times[1:])
+            fp_items.process_items(items)
+            t4 = time.perf_counter()
+            times.append((t2 - t0, t1 - t0, t2 - t1, t3 - t2, t4 - t3))
+            n_rows = len(items)
+        same = all(open(out + sfx, "rb").read() == open(out_items + sfx, "rb").read() for sfx in ("",))
+        same = same and all(
+            open(os.path.join(tmp, f"scores.{k}.log"), "rb").read() == open(os.path.join(tmp, f"items.{k}.log"), "rb").read()
+            for k in ("U", "Q")
+        )
+        text_bytes = sum(os.path.getsize(os.path.join(tmp, f)) for f in os.listdir(tmp) if f.startswith("scores"))
+    total, gpu, write, build, items_write = min(times[1:])
     return {
-        "value": round(n_items / total, 1),
+        "value": round(n_rows / total, 1),
         "unit": "windows/s",
-        "windows": n_items,
+        "windows": n_rows,
         "ms_total": round(total * 1e3, 2),
         "ms_gpu_score_windows": round(gpu * 1e3, 2),
-        "ms_item_dicts": round(build * 1e3, 2),
-        "ms_process_items_text": round(write * 1e3, 2),
-        "host_us_per_window": round((build + write) / max(n_items, 1) * 1e6, 2),
+        "ms_native_text": round(write * 1e3, 2),
+        "host_us_per_window": round(write / max(n_rows, 1) * 1e6, 3),
         "output_bytes": text_bytes,
-        "what": "FeaturePreprocessor.score_windows + items_from_batch + process_items on the resident block "
-        "(U and Q as two statistics, one fused pass); best of %d" % repeats,
+        "item_protocol": {
+            "ms_item_dicts": round(build * 1e3, 2),
+            "ms_process_items_text": round(items_write * 1e3, 2),
+            "windows_per_s": round(n_rows / (gpu + build + items_write), 1),
+            "same_bytes_as_native": bool(same),
+        },
+        "what": "FeaturePreprocessor.score_windows + write_batches on the resident block = what `score` runs after the "
+        "ingest (U and Q as two statistics, one fused pass, TSV + .U.log + .Q.log); item_protocol = the same batch "
+        "through items_from_batch + process_items; best of %d" % repeats,
     }
 
 

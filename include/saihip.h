@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define SAI_ABI_VERSION 9
+#define SAI_ABI_VERSION 10
 #define SAI_TILE_SITES 64
 #define SAI_MAX_SRC 6   /* source populations per call */
 #define SAI_MAX_SETS 16 /* parameter sets per call */
@@ -357,6 +357,38 @@ int sai_tokenize_gt(sai_ctx* ctx, const char* text, int64_t n_text_bytes, int64_
                     const int32_t* line_len, const uint8_t* line_flip, const uint8_t* line_gi, int32_t n_cols,
                     const int32_t* slot_of_col, int32_t n_out, const int32_t* ploidy_of_slot, int8_t* out,
                     int32_t* status, void* stream);
+
+/* ---- output text (host side) -------------------------------------------------------------- */
+
+/* The rows FeaturePreprocessor.process_items writes (feature_preprocessor.py:193-258), formatted
+ * straight from the numeric window results: one TSV row per window
+ *     chr \t start \t end \t <pop_columns> \t nsnps \t col_0 \t ... \n
+ * where pop_columns is the caller's "ref\ttgt\tsrc1,src2\tout" and column c of window w is read at
+ * cols[c].data + w * cols[c].stride_bytes as an int32 or a double (U's count and Q's value inside the
+ * 24-byte records, the f64 blocks of the ABBA-BABA family and DD); a window with nsnps == 0 prints
+ * "nan" in every column.  Numbers print as Python's str() prints them (shortest round-trip digits,
+ * fixed notation for 1e-4 <= |x| < 1e16, "nan").  sai_format_log_rows writes the .U.log / .Q.log
+ * rows "chr \t start \t end \t chr:pos,chr:pos,...|NA \n" from a CSR list: count of window w at
+ * counts + w * count_stride_bytes (int32), its first entry at positions[offsets[w * offset_stride_words]].
+ * The text is owned by the library until sai_text_free. */
+enum sai_text_kind { SAI_TEXT_I32 = 0, SAI_TEXT_F64 = 1 };
+typedef struct sai_text_column {
+  const void* data;
+  int64_t stride_bytes;
+  int32_t kind;
+  int32_t reserved;
+} sai_text_column;
+typedef struct sai_text sai_text;
+int sai_format_score_rows(const char* chr_name_host, const char* pop_columns_host, int32_t n_windows,
+                          const int64_t* windows_host, const int32_t* nsnps_host, int32_t n_cols,
+                          const sai_text_column* cols_host, sai_text** text_out);
+int sai_format_log_rows(const char* chr_name_host, int32_t n_windows, const int64_t* windows_host,
+                        const void* counts_host, int64_t count_stride_bytes, const int64_t* offsets_host,
+                        int64_t offset_stride_words, const void* positions_host, int32_t position_bytes,
+                        sai_text** text_out);
+int sai_format_doubles(const double* values_host, int64_t n, sai_text** text_out); /* one str(x) per line */
+const char* sai_text_data(const sai_text* text, int64_t* n_bytes);
+int sai_text_free(sai_text* text);
 
 /* In-memory counterpart of the ingest: narrow a reference-style [rows][cols] integer matrix (the
  * reference holds genotypes as int64 after utils.py:410) to the int8 the device layout uses, in one

@@ -20,7 +20,7 @@ SAI_MAX_SETS = 16
 SAI_FUSED_SETS = 20
 SAI_ERR_UNSUPPORTED = -4  # enum sai_status
 FREQ_MODES = {"dense": 0, "candidates": 1}  # enum sai_freq_mode
-SAI_ABI_VERSION = 9
+SAI_ABI_VERSION = 10
 
 OPS = {"=": 0, "<": 1, ">": 2, "<=": 3, ">=": 4}
 
@@ -48,6 +48,10 @@ class SaiParams(C.Structure):
         ("y", C.c_double * SAI_MAX_SRC),
         ("one_minus_y", C.c_double * SAI_MAX_SRC),
     ]
+
+
+class SaiTextColumn(C.Structure):
+    _fields_ = [("data", C.c_void_p), ("stride_bytes", C.c_int64), ("kind", C.c_int32), ("reserved", C.c_int32)]
 
 
 class SaiWindowRecord(C.Structure):
@@ -128,6 +132,14 @@ SIGNATURES = {
     "sai_vcf_stream_selection": (C.c_int, [_p, _p, _i32, C.POINTER(_i32), C.POINTER(_i64), C.POINTER(_i64)]),
     "sai_vcf_stream_close": (C.c_int, [_p]),
     "sai_tokenize_gt": (C.c_int, [_p, _p, _i64, _i64, _p, _p, _p, _p, _i32, _p, _i32, _p, _p, _p, _p]),
+    "sai_format_score_rows": (
+        C.c_int,
+        [C.c_char_p, C.c_char_p, _i32, _p, _p, _i32, C.POINTER(SaiTextColumn), C.POINTER(_p)],
+    ),
+    "sai_format_log_rows": (C.c_int, [C.c_char_p, _i32, _p, _p, _i64, _p, _i64, _p, _i32, C.POINTER(_p)]),
+    "sai_format_doubles": (C.c_int, [_p, _i64, C.POINTER(_p)]),
+    "sai_text_data": (_p, [_p, C.POINTER(_i64)]),
+    "sai_text_free": (C.c_int, [_p]),
     "sai_vcf_block_info": (C.c_int, [_p, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)]),
     "sai_vcf_block_copy": (C.c_int, [_p, _p, _p]),
     "sai_vcf_block_free": (C.c_int, [_p]),
@@ -138,6 +150,7 @@ HOST_SYMBOLS = (
     "sai_abi_version", "sai_build_arch", "sai_last_error", "sai_synth_fill_host", "sai_synth_gaps_host",
     "sai_narrow_to_int8", "sai_vcf_scan", "sai_vcf_load", "sai_vcf_block_info", "sai_vcf_block_copy", "sai_vcf_block_free",
     "sai_vcf_stream_open", "sai_vcf_stream_next", "sai_vcf_stream_selection", "sai_vcf_stream_close",
+    "sai_format_score_rows", "sai_format_log_rows", "sai_format_doubles", "sai_text_data", "sai_text_free",
 )  # fmt: skip
 
 _lib = None

@@ -1,0 +1,216 @@
+// Output text of `sai score` straight from the numeric window results (host only): the TSV rows and
+// the .U.log / .Q.log rows FeaturePreprocessor.process_items writes (reference:
+// sai/preprocessors/feature_preprocessor.py:193-258), formatted without building a Python object per
+// window.  Numbers print as Python's str() prints them -- ints in decimal, doubles with the shortest
+// digits that round-trip, fixed notation for 1e-4 <= |x| < 1e16 and d.ddde+XX otherwise, "nan",
+// "inf" -- which tests/test_text_out.py checks against str() itself on millions of doubles.
+
+#include <charconv>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <exception>
+#include <new>
+#include <string>
+
+#include "saihip.h"
+
+extern "C" int sai_set_error(int code, const char* fmt, ...);
+
+namespace {
+
+// str(float) / str(numpy.float64): repr with the shortest round-trip digits
+void append_double(std::string& out, double v) {
+  if (v != v) { out += "nan"; return; }
+  if (std::isinf(v)) { out += v < 0 ? "-inf" : "inf"; return; }
+  char buf[40];
+  const auto res = std::to_chars(buf, buf + sizeof(buf), v, std::chars_format::scientific);
+  const char* p = buf;
+  const char* end = res.ptr;
+  if (*p == '-') { out += '-'; ++p; }
+  // d[.ddd]e[+-]XX
+  const char* e = p;
+  while (e < end && *e != 'e') ++e;
+  char digits[24];
+  int nd = 0;
+  for (const char* q = p; q < e; ++q)
+    if (*q != '.') digits[nd++] = *q;
+  int exp10 = 0;
+  {
+    const char* q = e + 1;
+    const bool neg = *q == '-';
+    if (*q == '+' || *q == '-') ++q;
+    for (; q < end; ++q) exp10 = exp10 * 10 + (*q - '0');
+    if (neg) exp10 = -exp10;
+  }
+  if (exp10 >= -4 && exp10 < 16) {  // fixed notation
+    if (exp10 >= 0) {
+      for (int i = 0; i <= exp10; ++i) out += i < nd ? digits[i] : '0';
+      out += '.';
+      if (nd > exp10 + 1) out.append(digits + exp10 + 1, static_cast<size_t>(nd - exp10 - 1));
+      else out += '0';
+    } else {
+      out += "0.";
+      out.append(static_cast<size_t>(-exp10 - 1), '0');
+      out.append(digits, static_cast<size_t>(nd));
+    }
+  } else {  // to_chars' scientific form is Python's: d[.ddd]e+XX with at least two exponent digits
+    out.append(p, static_cast<size_t>(end - p));
+  }
+}
+
+void append_int(std::string& out, long long v) {
+  char buf[24];
+  const auto res = std::to_chars(buf, buf + sizeof(buf), v);
+  out.append(buf, static_cast<size_t>(res.ptr - buf));
+}
+
+template <typename F>
+int guarded_text(const char* what, F&& body) {
+  try {
+    return body();
+  } catch (const std::bad_alloc&) {
+    return sai_set_error(SAI_ERR_HIP, "%s: out of host memory", what);
+  } catch (const std::exception& e) {
+    return sai_set_error(SAI_ERR_HIP, "%s: %s", what, e.what());
+  } catch (...) {
+    return sai_set_error(SAI_ERR_HIP, "%s: unknown failure", what);
+  }
+}
+
+}  // namespace
+
+struct sai_text {
+  std::string s;
+};
+
+extern "C" {
+
+int sai_format_score_rows(const char* chr_name_host, const char* pop_columns_host, int32_t n_windows,
+                          const int64_t* windows_host, const int32_t* nsnps_host, int32_t n_cols,
+                          const sai_text_column* cols_host, sai_text** text_out) {
+  return guarded_text("sai_format_score_rows", [&]() -> int {
+    if (!chr_name_host || !pop_columns_host || !text_out) return sai_set_error(SAI_ERR_ARG, "NULL argument");
+    *text_out = nullptr;
+    if (n_windows < 0 || n_cols < 0) return sai_set_error(SAI_ERR_ARG, "negative size");
+    if (n_windows > 0 && (!windows_host || !nsnps_host)) return sai_set_error(SAI_ERR_ARG, "NULL buffer");
+    for (int32_t c = 0; c < n_cols; ++c) {
+      if (!cols_host || (cols_host[c].kind != SAI_TEXT_I32 && cols_host[c].kind != SAI_TEXT_F64))
+        return sai_set_error(SAI_ERR_ARG, "column %d: bad kind", c);
+      if (n_windows > 0 && !cols_host[c].data) return sai_set_error(SAI_ERR_ARG, "column %d: NULL data", c);
+    }
+    sai_text* t = new sai_text;
+    std::string& out = t->s;
+    out.reserve(static_cast<size_t>(n_windows) * (48 + 12 * static_cast<size_t>(n_cols)));
+    const std::string chr(chr_name_host), pops(pop_columns_host);
+    for (int32_t w = 0; w < n_windows; ++w) {
+      out += chr;
+      out += '\t';
+      append_int(out, windows_host[2 * w]);
+      out += '\t';
+      append_int(out, windows_host[2 * w + 1]);
+      out += '\t';
+      out += pops;
+      out += '\t';
+      append_int(out, nsnps_host[w]);
+      const bool empty = nsnps_host[w] == 0;  // no site in the window: every statistic prints nan
+      for (int32_t c = 0; c < n_cols; ++c) {
+        out += '\t';
+        if (empty) { out += "nan"; continue; }
+        const char* p = static_cast<const char*>(cols_host[c].data) + static_cast<int64_t>(w) * cols_host[c].stride_bytes;
+        if (cols_host[c].kind == SAI_TEXT_I32) {
+          int32_t v;
+          std::memcpy(&v, p, sizeof(v));
+          append_int(out, v);
+        } else {
+          double v;
+          std::memcpy(&v, p, sizeof(v));
+          append_double(out, v);
+        }
+      }
+      out += '\n';
+    }
+    *text_out = t;
+    return SAI_OK;
+  });
+}
+
+int sai_format_log_rows(const char* chr_name_host, int32_t n_windows, const int64_t* windows_host,
+                        const void* counts_host, int64_t count_stride_bytes, const int64_t* offsets_host,
+                        int64_t offset_stride_words, const void* positions_host, int32_t position_bytes,
+                        sai_text** text_out) {
+  return guarded_text("sai_format_log_rows", [&]() -> int {
+    if (!chr_name_host || !text_out) return sai_set_error(SAI_ERR_ARG, "NULL argument");
+    *text_out = nullptr;
+    if (n_windows < 0) return sai_set_error(SAI_ERR_ARG, "negative size");
+    if (position_bytes != 4 && position_bytes != 8) return sai_set_error(SAI_ERR_ARG, "positions must be int32 or int64");
+    if (n_windows > 0 && (!windows_host || !counts_host || !offsets_host)) return sai_set_error(SAI_ERR_ARG, "NULL buffer");
+    sai_text* t = new sai_text;
+    std::string& out = t->s;
+    const std::string chr(chr_name_host);
+    for (int32_t w = 0; w < n_windows; ++w) {
+      out += chr;
+      out += '\t';
+      append_int(out, windows_host[2 * w]);
+      out += '\t';
+      append_int(out, windows_host[2 * w + 1]);
+      out += '\t';
+      int32_t n;
+      std::memcpy(&n, static_cast<const char*>(counts_host) + static_cast<int64_t>(w) * count_stride_bytes, sizeof(n));
+      if (n <= 0) {
+        out += "NA\n";
+        continue;
+      }
+      if (!positions_host) { delete t; return sai_set_error(SAI_ERR_ARG, "NULL candidate list"); }
+      const int64_t o = offsets_host[static_cast<int64_t>(w) * offset_stride_words];
+      for (int32_t k = 0; k < n; ++k) {
+        if (k) out += ',';
+        out += chr;
+        out += ':';
+        long long p;
+        if (position_bytes == 4) {
+          int32_t v;
+          std::memcpy(&v, static_cast<const char*>(positions_host) + (o + k) * 4, 4);
+          p = v;
+        } else {
+          int64_t v;
+          std::memcpy(&v, static_cast<const char*>(positions_host) + (o + k) * 8, 8);
+          p = v;
+        }
+        append_int(out, p);
+      }
+      out += '\n';
+    }
+    *text_out = t;
+    return SAI_OK;
+  });
+}
+
+int sai_format_doubles(const double* values_host, int64_t n, sai_text** text_out) {
+  return guarded_text("sai_format_doubles", [&]() -> int {
+    if (!text_out || (n > 0 && !values_host) || n < 0) return sai_set_error(SAI_ERR_ARG, "bad argument");
+    sai_text* t = new sai_text;
+    for (int64_t i = 0; i < n; ++i) {
+      append_double(t->s, values_host[i]);
+      t->s += '\n';
+    }
+    *text_out = t;
+    return SAI_OK;
+  });
+}
+
+const char* sai_text_data(const sai_text* text, int64_t* n_bytes) {
+  if (!text) {
+    if (n_bytes) *n_bytes = 0;
+    return "";
+  }
+  if (n_bytes) *n_bytes = static_cast<int64_t>(text->s.size());
+  return text->s.data();
+}
+
+int sai_text_free(sai_text* text) {
+  delete text;
+  return SAI_OK;
+}
+
+}  // extern "C"

@@ -91,3 +91,8 @@ class ChunkPreprocessor(DataPreprocessor):
 
     def process_items(self, items: list[dict[str, Any]]) -> None:
         self.feature_preprocessor.process_items(items)
+
+    def write_results(self, batches) -> None:
+        """Write the tasks' batches without going through item dictionaries (same files as
+        ``process_items(items_from_results(batches))``)."""
+        self.feature_preprocessor.write_batches(batches)

@@ -88,7 +88,9 @@ def score(vcf_file: str, chr_name: str, win_len: int, win_step: int, anc_allele_
     chunks = ChunkGenerator(vcf_file=vcf_file, chr_name=chr_name, window_size=win_len, step_size=win_step, num_chunks=1)
     driver = chunk_preprocessor_for(cfg, vcf_file, win_len, win_step, output_file, anc_allele_file)
     write_headers(output_file, cfg.statistics, cfg.ploidies)
-    driver.process_items([item for chunk in chunks.get() for item in driver.run(**chunk)])
+    # numeric batches -> text, natively; the item-dictionary route (driver.run + process_items)
+    # writes the same bytes and stays what plug-ins and the sharded executors use
+    driver.write_results([driver.run_compact(**chunk) for chunk in chunks.get()])
 
 
 def outlier(score_file: str, output_prefix: str, quantile: float) -> None:

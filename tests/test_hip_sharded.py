@@ -193,3 +193,4 @@ def test_bench_default_line_has_the_contract_fields():
     assert line["cpu_baseline"]["kind"] == "port" and line["cpu_baseline"]["cpu_model"] and line["cpu_baseline"]["cores"] >= 1
     sp = line["score_path"]
     assert sp["windows"] == line["config"]["windows_total"] and sp["value"] > 0
+    assert sp["item_protocol"]["same_bytes_as_native"] is True

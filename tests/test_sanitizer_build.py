@@ -18,6 +18,7 @@ from conftest import ROOT
 TARGETS = [
     "tests/test_ingest_native.py",
     "tests/test_ingest_stream.py",
+    "tests/test_text_out.py",
     "tests/test_host_logic.py::test_to_int8_dosage",
     "tests/test_sanitizer_build.py::test_host_generator_equals_numpy_statement",
 ]

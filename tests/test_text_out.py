@@ -1,0 +1,94 @@
+"""The native output formatter (libsaihip: sai_format_score_rows / sai_format_log_rows, host side):
+numbers print exactly as Python's str() prints them, and the rows equal what
+FeaturePreprocessor.process_items writes from item dictionaries (whose text is pinned to the
+reference's by the golden captures)."""
+
+import ctypes as C
+import struct
+
+import numpy as np
+import pytest
+
+
+def native_strs(values: np.ndarray) -> list[str]:
+    from sai_amd import _ffi
+
+    lib = _ffi.load_host()
+    v = np.ascontiguousarray(values, dtype=np.float64)
+    h = C.c_void_p()
+    _ffi.check(lib.sai_format_doubles(v.ctypes.data_as(C.c_void_p), v.size, C.byref(h)), lib)
+    n = C.c_int64()
+    ptr = lib.sai_text_data(h, C.byref(n))
+    text = C.string_at(ptr, n.value).decode()
+    lib.sai_text_free(h)
+    return text.split("\n")[:-1]
+
+
+def test_doubles_print_like_python_str():
+    rng = np.random.default_rng(1)
+    special = [0.0, -0.0, 1.0, -1.0, 0.1, 0.9, 0.5, 1e-4, 9.999e-5, 1e-5, 1e15, 9.999999999999998e15, 1e16, 1e17, 1e22, 1e23,
+               123456.0, 0.6179, 0.6142000000000001, 0.9666666666666667, 2 / 3, 1 / 3, 5e-324, 2.2250738585072014e-308,
+               1.7976931348623157e308, float("nan"), float("inf"), float("-inf"), 1e-4 * (1 - 2**-52), 4.35, 0.1 + 0.2]  # fmt: skip
+    bits = rng.integers(0, 2**64, size=200_000, dtype=np.uint64)  # every exponent, every kind of mantissa
+    rand = bits.view(np.float64)
+    ratios = rng.integers(0, 4001, size=100_000) / rng.integers(1, 4001, size=100_000)  # frequencies and the like
+    small = ratios * 10.0 ** rng.integers(-12, 20, size=ratios.size)
+    values = np.concatenate([np.array(special), rand, ratios, small, -small])
+    got = native_strs(values)
+    assert len(got) == values.size
+    bad = [(float(v).hex(), g, str(float(v))) for v, g in zip(values.tolist(), got) if g != str(float(v))]
+    assert not bad, bad[:5]
+    assert str(np.float64(0.6142000000000001)) == native_strs(np.array([0.6142000000000001]))[0]  # numpy scalars print the same
+
+
+def _random_batch(rng, n_w, n_src, with_extra, pos_dtype):
+    from sai_amd.engine import RECORD_DTYPE, WindowResults
+    from sai_amd.preprocessors.window_batch import ComboBatch, WindowBatch
+
+    rec = np.zeros((2, n_w), dtype=RECORD_DTYPE)
+    nsnps = rng.integers(0, 40, n_w).astype(np.int32)
+    nsnps[rng.random(n_w) < 0.15] = 0
+    rec["n_sites"] = nsnps
+    rec["u_count"][0] = np.where(nsnps > 0, rng.integers(0, 4, n_w), 0)
+    rec["n_cond"][1] = np.where(nsnps > 0, rng.integers(0, 3, n_w), 0)
+    rec["n_cdd_q"][1] = np.where(rec["n_cond"][1] > 0, rng.integers(1, 3, n_w), 0)
+    rec["q"] = rng.integers(0, 2001, (2, n_w)) / 2000.0
+    rec["q"][1][rec["n_cond"][1] == 0] = np.nan
+    off = np.zeros((2, n_w, 2), dtype=np.int64)
+    for k, name in enumerate(("u_count", "n_cdd_q")):
+        flat = rec[name].reshape(-1).astype(np.int64)
+        off[:, :, k] = (np.cumsum(flat) - flat).reshape(2, n_w)
+    uq = WindowResults(rec, off, rng.integers(1, 10**8, int(rec["u_count"].sum())).astype(np.int32),
+                       rng.integers(1, 10**8, int(rec["n_cdd_q"].sum())).astype(np.int32))  # fmt: skip
+    win = np.stack([np.arange(n_w) * 500 + 1, np.arange(n_w) * 500 + 1000], axis=1).astype(np.int64)
+    four = dd = None
+    if with_extra:
+        four = rng.standard_normal((n_w, n_src, 4)) * 10.0 ** rng.integers(-8, 8, (n_w, n_src, 4))
+        four[rng.random(four.shape) < 0.1] = np.nan
+        dd = rng.standard_normal((n_w, n_src))
+    cb = ComboBatch("refA", "tgtB", tuple(f"s{i}" for i in range(n_src)), "og" if with_extra else None, win, nsnps, ["U", "Q"], uq,
+                    four, dd, pos_dtype)  # fmt: skip
+    return WindowBatch("chr7", [cb])
+
+
+@pytest.mark.parametrize("n_src,with_extra,pos_dtype", [(1, False, "int32"), (2, True, "int32"), (1, True, "int64"), (3, False, "int64")])
+def test_native_rows_equal_process_items(tmp_path, n_src, with_extra, pos_dtype):
+    from sai_amd.configs import StatConfig
+    from sai_amd.preprocessors import FeaturePreprocessor
+
+    rng = np.random.default_rng(n_src * 7 + with_extra)
+    src = {f"s{i}": "=1" for i in range(n_src)}
+    stats = {"U": {"ref": {"refA": 0.1}, "tgt": {"tgtB": 0.5}, "src": dict(src)},
+             "Q": {"ref": {"refA": 0.1}, "tgt": {"tgtB": 0.9}, "src": dict(src)}}  # fmt: skip
+    if with_extra:
+        stats = {"fd": True, "U": stats["U"], "df": True, "Danc": False, "Q": stats["Q"], "Dplus": True, "DD": True}
+    batch = _random_batch(rng, 400, n_src, with_extra, pos_dtype)
+    a, b = tmp_path / "items.tsv", tmp_path / "native.tsv"
+    fa = FeaturePreprocessor(str(a), StatConfig(dict(stats)))
+    fa.process_items(fa.items_from_batch(batch))
+    fb = FeaturePreprocessor(str(b), StatConfig(dict(stats)))
+    fb.write_batches([batch])
+    assert b.read_text() == a.read_text() and len(a.read_text().splitlines()) == 400
+    for k in ("U", "Q"):
+        assert b.with_suffix(f".{k}.log").read_text() == a.with_suffix(f".{k}.log").read_text()
+    assert "NA\n" in a.with_suffix(".Q.log").read_text() and "\tnan" in a.read_text()
