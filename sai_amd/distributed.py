@@ -97,18 +97,25 @@ def _finish(data_processor, results: list) -> list:
     return [it for per_task in results for it in per_task]
 
 
-def run_sharded(data_processor, data_generator, group=None) -> Optional[list]:
+def run_sharded(data_processor, data_generator, group=None, as_items: bool = True) -> Optional[list]:
     """mp_pool's decomposition over ranks: every rank runs its share of ``data_generator.get()``
     (``run_compact`` when the processor has the numeric protocol, else ``run``), the per-task results
     come to rank 0 in generator order, and rank 0 calls ``process_items`` on the items -- written in
     the order a one-process run writes them, so the output files are byte-identical for any number
-    of ranks.  Returns the items on rank 0."""
+    of ranks.  Returns the items on rank 0.  ``as_items=False`` (``score_sharded``): a processor that
+    can write its numeric results directly (``write_results``) does so and the per-task results are
+    returned instead of items -- no Python object per window is ever built."""
     import torch.distributed as dist
 
     tasks = list(data_generator.get())
     compute = getattr(data_processor, "run_compact", None) or data_processor.run
+    direct = not as_items and hasattr(data_processor, "write_results") and hasattr(data_processor, "run_compact")
     if not (dist.is_available() and dist.is_initialized()):
-        items = _finish(data_processor, [compute(**params) for params in tasks])
+        results = [compute(**params) for params in tasks]
+        if direct:
+            data_processor.write_results(results)
+            return results
+        items = _finish(data_processor, results)
         data_processor.process_items(items)
         return items
     rank, world = dist.get_rank(group), dist.get_world_size(group)
@@ -118,6 +125,9 @@ def run_sharded(data_processor, data_generator, group=None) -> Optional[list]:
     results = _exchange_task_results(data_processor, mine, group)
     if rank != 0:
         return None
+    if direct:
+        data_processor.write_results(results)
+        return results
     items = _finish(data_processor, results)
     data_processor.process_items(items)
     return items
@@ -214,7 +224,8 @@ def score_sharded(vcf_file: str, chr_name: str, win_len: int, win_step: int, anc
                   config: str, chunks_per_rank: int = 1) -> Optional[list[dict[str, Any]]]:  # fmt: skip
     """``score`` over all ranks of the job: the chromosome's window list is cut into
     ``world * chunks_per_rank`` ChunkGenerator chunks, each rank loads and scores only its own
-    regions on its GPU, rank 0 writes the reference's TSV / log files."""
+    regions on its GPU, rank 0 writes the reference's TSV / log files (natively, from the gathered
+    numeric batches) and gets the batches back; the other ranks get None."""
     import torch.distributed as dist
 
     from .generators import ChunkGenerator
@@ -230,4 +241,4 @@ def score_sharded(vcf_file: str, chr_name: str, win_len: int, win_step: int, anc
         write_headers(output_file, cfg.statistics, cfg.ploidies)
     if world > 1:
         dist.barrier()
-    return run_sharded(preprocessor, generator)
+    return run_sharded(preprocessor, generator, as_items=False)
