@@ -221,7 +221,7 @@ class RowGather:
 
 
 def score_sharded(vcf_file: str, chr_name: str, win_len: int, win_step: int, anc_allele_file, output_file: str,
-                  config: str, chunks_per_rank: int = 1) -> Optional[list[dict[str, Any]]]:  # fmt: skip
+                  config: str, chunks_per_rank: int = 1) -> Optional[list]:  # fmt: skip
     """``score`` over all ranks of the job: the chromosome's window list is cut into
     ``world * chunks_per_rank`` ChunkGenerator chunks, each rank loads and scores only its own
     regions on its GPU, rank 0 writes the reference's TSV / log files (natively, from the gathered
