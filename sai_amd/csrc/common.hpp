@@ -64,7 +64,12 @@ inline int check_launch(const char* what) {
 int check_sets(int32_t n_sets, const sai_params* sets, int32_t n_src, int32_t max_sets = SAI_MAX_SETS);
 
 inline unsigned stream_grid(const sai_ctx* ctx, int64_t n_tiles) {
-  const int64_t max_grid = static_cast<int64_t>(ctx->n_cu) * kStreamWavesPerCu;  // grid-stride beyond this
+  static const int waves_per_cu = [] {  // SAI_STREAM_WAVES_PER_CU: tuning knob for sweeps
+    const char* e = std::getenv("SAI_STREAM_WAVES_PER_CU");
+    const int v = e ? std::atoi(e) : 0;
+    return v > 0 ? v : kStreamWavesPerCu;
+  }();
+  const int64_t max_grid = static_cast<int64_t>(ctx->n_cu) * waves_per_cu;  // grid-stride beyond this
   return static_cast<unsigned>(n_tiles < max_grid ? n_tiles : max_grid);
 }
 

@@ -257,8 +257,8 @@ __global__ __launch_bounds__(256) void window_stats_wave_kernel(WinArgs a) {
 // each.  The k-th smallest value is found by a radix select ON THE VALUE: all values lie in [0, 1],
 // so digit l of a value is floor(frac_l * 1024) with frac_0 = v, frac_{l+1} = frac_l * 1024 - digit_l
 // -- multiplications by a power of two and subtractions of the integer part, all exact in binary
-// floating point -- which makes the digits a monotone, lossless code of the value (six digits use
-// up the 53-bit mantissa).  One histogram pass per level narrows the candidates to one of 1025 bins
+// floating point -- which makes the digits a monotone, lossless code of the value (twelve digits
+// use up the mantissa of every frequency a block can produce).  One histogram pass per level narrows the candidates to one of 1025 bins
 // (bin 1024 holds exactly 1.0); frequencies k / (called * ploidy) separate within two or three
 // levels, then the few members of the bin are gathered and ranked directly.  The first version
 // selected on the f64 bit pattern, 8 bits per pass: 8 passes per order statistic, two statistics per
@@ -266,7 +266,10 @@ __global__ __launch_bounds__(256) void window_stats_wave_kernel(WinArgs a) {
 // of C5 against 0.2 ms now).
 
 constexpr int kBins = 1025;      // digits 0..1023, and 1024 for the value 1.0
-constexpr int kMaxLevels = 6;    // 6 x 10 bits cover the mantissa
+// 12 x 10 bits: a frequency is >= 1 / (n_called * ploidy) > 2^-55 (n_ind <= 2^24, ploidy < 2^31), so
+// its 53 mantissa bits end above 2^-108 -- 120 fractional bits tell any two distinct doubles apart,
+// and members that still share a bin after the last level are the same number
+constexpr int kMaxLevels = 12;
 constexpr int kSmallBin = 256;   // members ranked directly
 
 struct WinShared {
