@@ -437,9 +437,26 @@ __global__ __launch_bounds__(kWinThreads) void window_stats_heavy_kernel(WinArgs
   if (tid == 0) sh.n_stored = 0;
   __syncthreads();
   if (in_lds) {
-    for (int i = lo + tid; i < hi; i += kWinThreads) {
-      const uint8_t f = fl[i];
-      if (f & 1u) sh.vals[atomicAdd(&sh.n_stored, 1u)] = eff_freq(a.tgt_freq, f, i);
+    // 8 sites per thread and round: all flag bytes first, then all frequencies, so that a round costs
+    // two memory latencies instead of sixteen (under the next step's genotype stream a latency is
+    // several microseconds, and this kernel's time was mostly that chain)
+    constexpr int kRound = 8;
+    for (int base = lo; base < hi; base += kWinThreads * kRound) {
+      uint8_t f[kRound];
+      double val[kRound];
+#pragma unroll
+      for (int u = 0; u < kRound; ++u) {
+        const int i = base + u * kWinThreads + tid;
+        f[u] = i < hi ? fl[i] : uint8_t{0};
+      }
+#pragma unroll
+      for (int u = 0; u < kRound; ++u) {
+        const int i = base + u * kWinThreads + tid;
+        val[u] = (f[u] & 1u) ? a.tgt_freq[i] : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < kRound; ++u)
+        if (f[u] & 1u) sh.vals[atomicAdd(&sh.n_stored, 1u)] = (f[u] & 4u) ? 1.0 - val[u] : val[u];
     }
   }
   __syncthreads();
