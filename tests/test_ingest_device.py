@@ -154,3 +154,35 @@ def test_read_data_device_and_score_equal_the_host_path(eng, in_repo_root, tmp_p
               config=cfgfile, num_workers=1)  # fmt: skip
         outs[mode] = {p.suffixes[-2] if len(p.suffixes) > 1 else "": p.read_text() for p in tmp_path.glob(f"{mode}*")}
     assert outs["device"] == outs["host"] and len(outs["device"][""].splitlines()) > 1
+
+
+import os  # noqa: E402
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("SAI_INGEST_FUZZ", "6"))))
+def test_device_reader_fuzz(eng, tmp_path, seed, monkeypatch):
+    """Random files (size, samples, container, line ends), random selections, ploidies, regions,
+    staging-buffer and batch sizes: the GPU reader against the host reader.  SAI_INGEST_FUZZ=300 was
+    run once on the GPU box."""
+    from sai_amd.utils.device_vcf import load_dosage_device
+    from sai_amd.utils.native_vcf import load_dosage
+
+    rng = np.random.default_rng(1000 + seed)
+    gz = [False, True, "bgzf"][int(rng.integers(3))]
+    n_samples = int(rng.integers(1, 90))
+    path = tmp_path / ("f.vcf.gz" if gz else "f.vcf")
+    names = write_vcf(path, rng, int(rng.integers(1, 400)), n_samples, gz=gz, crlf=bool(rng.integers(2)))
+    if rng.random() < 0.5:
+        monkeypatch.setenv("SAI_VCF_BATCH_BYTES", str(int(rng.integers(3000, 200000))))
+    k = int(rng.integers(1, n_samples + 1))
+    pick = [names[i] for i in rng.permutation(n_samples)[:k]]
+    ploidies = [int(rng.integers(1, 5)) for _ in pick]
+    chrom = str(rng.choice(["7", "21", "22"]))
+    for _ in range(3):
+        start = None if rng.random() < 0.4 else int(rng.integers(1, 20000))
+        end = None if start is None or rng.random() < 0.3 else start + int(rng.integers(0, 20000))
+        cap = None if rng.random() < 0.5 else int(rng.integers(1 << 16, 1 << 18))
+        got = load_dosage_device(eng, str(path), chrom, pick, ploidies, start, end, None, int(rng.integers(1, 7)), cap)
+        want = load_dosage(str(path), chrom, pick, ploidies, start, end, None, 2)
+        assert got[0].tolist() == want[0].tolist() and got[2] == want[2]
+        assert np.array_equal(got[1].cpu().numpy(), want[1])
