@@ -482,9 +482,30 @@ def main() -> None:
         if rank == 0:
             per_rank = gather.decode(out["rows"])
             res = merge_rank_results(per_rank, plan_shards(win_counts, world), n_sets)
-            own = scorer.results()  # rank 0's own share must be what it sent
-            n0 = own.records.shape[1]
-            assert res.records[:, :n0].tobytes() == own.records.tobytes(), "gathered records differ from rank 0's own"
+        # every rank's own results against what rank 0 received from it: CRC of the records, sizes and
+        # sums of the candidate lists (outside the timed region)
+        import zlib
+
+        own = scorer.results() if scorer is not None else None
+        mine = [0, 0, 0, 0, 0, 0]
+        if own is not None:
+            mine = [own.records.shape[1], zlib.crc32(own.records.tobytes()), int(own.cdd_u.size), int(own.cdd_u.sum()),
+                    int(own.cdd_q.size), int(own.cdd_q.sum())]  # fmt: skip
+        digest = torch.tensor(mine, dtype=torch.int64, device=cdev)
+        digests = [torch.zeros_like(digest) for _ in range(world)]
+        dist.all_gather(digests, digest)
+        if rank == 0:
+            digests = [d.cpu().tolist() for d in digests]
+            off = 0
+            for r, d in enumerate(digests):
+                got = res.records[:, off : off + d[0]]
+                assert zlib.crc32(np.ascontiguousarray(got).tobytes()) == d[1], f"gathered records of rank {r} differ from its own"
+                off += d[0]
+            assert off == res.records.shape[1] == total_windows, (off, res.records.shape, total_windows)
+            sums = [sum(d[i] for d in digests) for i in (2, 3, 4, 5)]
+            have = [int(res.cdd_u.size), int(res.cdd_u.sum()), int(res.cdd_q.size), int(res.cdd_q.sum())]
+            assert sums == have, f"gathered candidate lists differ from the ranks' own: {sums} != {have}"
+            gather_check = f"records CRC + candidate-list sizes and sums of {world} rank(s) match what rank 0 received"
     else:
         res = scorer.results()  # also checks the candidate buffers were large enough
 
@@ -543,6 +564,7 @@ def main() -> None:
                 ),
                 "gather": args.gather if dist_on else None,
                 "gather_row_bytes": gather.sizes if dist_on else None,
+                "gather_check": gather_check if dist_on else None,
                 "setup_s": round(t_setup, 2),
                 "u_sum": int(res.records["u_count"].sum()),
                 "q_finite": int(np.isfinite(res.records["q"]).sum()),

@@ -173,6 +173,7 @@ def test_bench_two_ranks_on_one_gpu_equal_one_rank(gather):
     assert two["config"]["pieces_rank0"] == 3 and one["config"]["pieces_rank0"] == 5
     assert "configs[3]" in two["config"]["workload"] and "REDUCED" in two["config"]["workload"]
     assert two["roofline"]["frac"] > 0 and two["value"] > 0
+    assert "2 rank(s) match" in two["config"]["gather_check"] and one["config"]["gather_check"] is None
 
 
 def test_bench_one_rank_on_real_rccl():
@@ -183,6 +184,7 @@ def test_bench_one_rank_on_real_rccl():
     for k in ("windows_total", "u_sum", "q_finite", "cdd_u_entries", "cdd_q_entries"):
         assert rccl["config"][k] == one["config"][k], k
     assert rccl["config"]["gather"] == "step" and rccl["config"]["gather_row_bytes"][0] > 24 * one["config"]["windows_total"]
+    assert "1 rank(s) match" in rccl["config"]["gather_check"]
 
 
 def test_bench_default_line_has_the_contract_fields():
