@@ -126,17 +126,52 @@ class Engine:
         self._tile_cache = None  # {id(matrix): (matrix, TiledPop)} while an upload_scope is open
         self._scope_depth = 0
         self._staging = None  # pinned int8 buffer the host matrices are narrowed into
+        self._pinned_free: dict[int, list] = {}  # capacity -> [(pinned uint8 tensor, [events])]
 
     def close(self) -> None:
         if getattr(self, "ctx", None):
             self.lib.sai_ctx_destroy(self.ctx)
             self.ctx = None
+            self._pinned_free.clear()
             Engine._cache.pop(self.device_index, None)
 
     # -- helpers ---------------------------------------------------------------------------
 
     def _stream(self):
         return C.c_void_p(_torch().cuda.current_stream(self.device).cuda_stream)
+
+    # Page-locking host memory is slow and erratic (measured on the MI355X box: 5 ms for a first
+    # 400 KB buffer, 60-90 ms every third time torch's host allocator is asked again), so the pinned
+    # mirrors of the window-stage buffers are recycled here instead of being pinned per scorer.
+    _PINNED_KEEP = 8  # free buffers kept per capacity
+
+    def pinned_acquire(self, nbytes: int):
+        """A pinned uint8 host tensor of at least ``nbytes`` (capacity = next power of two >= 4 KiB).
+        A recycled buffer is handed out only after the work recorded at its release has finished."""
+        torch = _torch()
+        cap = 1 << max(int(nbytes) - 1, 4095).bit_length()
+        free = self._pinned_free.get(cap)
+        if free:
+            buf, events = free.pop()
+            for ev in events:
+                ev.synchronize()
+            return buf
+        return torch.empty((cap,), dtype=torch.uint8).pin_memory()
+
+    def pinned_release(self, buf, streams=()) -> None:
+        """Give a buffer of ``pinned_acquire`` back; copies still in flight on ``streams`` (and on the
+        current stream) are waited for when the buffer is handed out again."""
+        torch = _torch()
+        free = self._pinned_free.setdefault(int(buf.numel()), [])
+        if len(free) >= self._PINNED_KEEP:
+            return
+        events = []
+        for st in (torch.cuda.current_stream(self.device), *streams):
+            if st is not None:
+                ev = torch.cuda.Event()
+                ev.record(st)
+                events.append(ev)
+        free.append((buf, events))
 
     def _empty(self, shape, dtype):
         return _torch().empty(shape, dtype=dtype, device=self.device)

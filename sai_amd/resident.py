@@ -88,13 +88,21 @@ class _SetChunk:
         self.s0, self.s1 = s0, s1
         self.bufs = eng.alloc_window_bufs(s1 - s0, n_windows, cap_u, cap_q)
         # pinned mirror of the records | offsets | totals buffer: one copy per step
-        self.host_head = torch.empty((self.bufs[5].numel(),), dtype=torch.uint8).pin_memory()
+        self._eng, self._pinned = eng, eng.pinned_acquire(self.bufs[5].numel())
+        self.host_head = self._pinned[: self.bufs[5].numel()]
         rec_bytes = (s1 - s0) * n_windows * RECORD_DTYPE.itemsize
         self.rec_bytes = rec_bytes
         self.host_records = self.host_head[:rec_bytes]
         off_bytes = (s1 - s0) * n_windows * 16
         self.host_offsets = self.host_head[rec_bytes : rec_bytes + off_bytes].view(torch.int64)
         self.host_totals = self.host_head[rec_bytes + off_bytes : rec_bytes + off_bytes + 16].view(torch.int64)
+
+    def release(self, streams=()) -> None:
+        """Hand the pinned mirror back to the engine's pool (the chunk must not be used afterwards)."""
+        if self._pinned is not None:
+            buf, self._pinned = self._pinned, None
+            self.host_head = self.host_records = self.host_offsets = self.host_totals = None
+            self._eng.pinned_release(buf, streams)
 
 
 class ResidentScorer:
@@ -183,6 +191,7 @@ class ResidentScorer:
     def _alloc_chunks(self, cap_u: int, cap_q: int) -> None:
         m = _ffi.SAI_MAX_SETS
         self.cap_u, self.cap_q = int(cap_u), int(cap_q)
+        self._release_chunks()
         self.chunks = [
             _SetChunk(self.eng, s0, min(s0 + m, self.n_sets), self.n_windows, cap_u, cap_q)
             for s0 in range(0, self.n_sets, m)
@@ -190,6 +199,21 @@ class ResidentScorer:
         first = self.chunks[0]  # the whole scorer when n_sets <= SAI_MAX_SETS
         self.bufs, self.host_head = first.bufs, first.host_head
         self.host_records, self.host_offsets, self.host_totals = first.host_records, first.host_offsets, first.host_totals
+
+    def _release_chunks(self) -> None:
+        for ch in getattr(self, "chunks", None) or ():
+            ch.release((self.side,) if getattr(self, "side", None) is not None else ())
+        self.chunks = []
+
+    def close(self) -> None:
+        """Return the pinned host mirrors to the engine (also done when the scorer is collected)."""
+        self._release_chunks()
+
+    def __del__(self):
+        try:
+            self._release_chunks()
+        except Exception:  # interpreter shutdown: torch may be half gone
+            pass
 
     @property
     def tgt_freq(self):
