@@ -225,6 +225,7 @@ class FeaturePreprocessor(DataPreprocessor):
             return torch.stack([counts_rows[k] for k in keys])
 
         pos_dev_cache = {}
+        win_arrays = {}
         group_data = {"ref": wg.ref_data, "tgt": wg.tgt_data, "src": wg.src_data, "outgroup": wg.out_data}
         for ref_pop, tgt_pop, src_comb, out_pop in combos:
             al = wg.aligned(ref_pop, tgt_pop, src_comb, out_pop)
@@ -236,8 +237,10 @@ class FeaturePreprocessor(DataPreprocessor):
                 counts_rows = {}
             else:
                 tiled, counts_rows = shared_tiled, shared_counts
-            windows = wg.tgt_windows[tgt_pop]
-            win = np.asarray(windows, dtype=np.int64).reshape(-1, 2)
+            win = win_arrays.get(tgt_pop)
+            if win is None:  # one conversion per target population, not per combination
+                win = win_arrays[tgt_pop] = np.asarray(wg.tgt_windows[tgt_pop], dtype=np.int64).reshape(-1, 2)
+            windows = win
             src_ploidies = pc.get_ploidy("src")
             ploidy = [pc.get_ploidy("ref", ref_pop), pc.get_ploidy("tgt", tgt_pop)] + list(src_ploidies)
             n_eff = min(len(src_comb), len(src_ploidies))

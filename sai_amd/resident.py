@@ -137,12 +137,13 @@ class ResidentScorer:
         if len(sets) < 1:
             raise ValueError("at least one parameter set per scorer")
         self.eng, self.block, self.sets = eng, block, list(sets)
-        self.windows = list(windows)
-        n, n_w, n_s = block.n_sites, len(self.windows), len(self.sets)
+        # (start, end) pairs or an int64 array [n_windows][2] (no Python object per window)
+        self.windows = np.ascontiguousarray(np.asarray(windows, dtype=np.int64).reshape(-1, 2).T)  # [2][n_windows]
+        n, n_w, n_s = block.n_sites, int(self.windows.shape[1]), len(self.sets)
         self.n_windows, self.n_sets = n_w, n_s
         dev = eng.device
-        self.win_start = torch.as_tensor(np.array([w[0] for w in self.windows], dtype=np.int64)).to(dev)
-        self.win_end = torch.as_tensor(np.array([w[1] for w in self.windows], dtype=np.int64)).to(dev)
+        both = torch.as_tensor(self.windows).to(dev)
+        self.win_start, self.win_end = both[0], both[1]
         self.seg_lo = self.seg_hi = None
         if block.segments is not None:
             if window_segment is None:
