@@ -60,4 +60,11 @@ rows = sum(1 for _ in open(out)) - 1
 print(f"score: {dt:.3f} s for {n_sites} sites, {rows} windows -> {os.path.getsize(vcf) / dt / 1e6:.0f} MB/s of VCF")
 s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats("cumulative").print_stats(18); print(s.getvalue()[-3500:])
 print(open(out).read()[:400])
+# repeated calls in one process (a per-chromosome loop): any erratic host-side cost shows here
+reps = []
+for _ in range(12):
+    t0 = time.perf_counter()
+    score(vcf_file=vcf, chr_name="1", win_len=50000, win_step=25000, anc_allele_file=None, output_file=out, config=cfg, num_workers=1)
+    reps.append(time.perf_counter() - t0)
+print("12 more calls, ms each:", " ".join(f"{1e3 * t:.1f}" for t in reps))
 import shutil; shutil.rmtree(d)
