@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define SAI_ABI_VERSION 10
+#define SAI_ABI_VERSION 11
 #define SAI_TILE_SITES 64
 #define SAI_MAX_SRC 6   /* source populations per call */
 #define SAI_MAX_SETS 16 /* parameter sets per call */
@@ -357,6 +357,28 @@ int sai_tokenize_gt(sai_ctx* ctx, const char* text, int64_t n_text_bytes, int64_
                     const int32_t* line_len, const uint8_t* line_flip, const uint8_t* line_gi, int32_t n_cols,
                     const int32_t* slot_of_col, int32_t n_out, const int32_t* ploidy_of_slot, int8_t* out,
                     int32_t* status, void* stream);
+
+/* bgzip input inflated on the GPU.  A BGZF file (the container of every .vcf.gz that tabix can
+ * index) is a sequence of independent gzip members of at most 64 KiB of text; sai_inflate_bgzf
+ * inflates the members of a batch side by side, one wavefront per member (RFC 1951: stored, fixed
+ * and dynamic blocks), so the compressed bytes cross PCIe instead of the text and the host's
+ * inflate (vcf_ingest.cpp, libdeflate on the box's cores) is out of the way.  comp = the compressed
+ * bytes of the batch in HBM (4-byte aligned, n_comp_bytes a multiple of 4: pad the tail);
+ * members[m] = where member m's raw deflate stream lies in comp and where its text goes in `text`
+ * (device copy of the table sai_bgzf_stream_next hands out); status[m] = 0, or non-zero for a member
+ * that is not valid DEFLATE of exactly isize bytes (nothing outside [out_off, out_off + isize) is
+ * ever written).  The CRC-32 of the trailer is checked by the host on the text it receives
+ * (sai_vcf_index_text), as after the host's own inflate. */
+typedef struct sai_bgzf_member {
+  int64_t data_off;  /* first byte of the raw deflate stream inside the compressed batch */
+  int64_t out_off;   /* first byte of the member's text inside the batch text */
+  uint32_t data_len; /* compressed bytes */
+  uint32_t isize;    /* uncompressed bytes (<= 65536) */
+  uint32_t crc;      /* CRC-32 of the text (gzip trailer) */
+  uint32_t reserved;
+} sai_bgzf_member;
+int sai_inflate_bgzf(sai_ctx* ctx, const void* comp, int64_t n_comp_bytes, const sai_bgzf_member* members,
+                     int32_t n_members, void* text, int64_t n_text_bytes, int32_t* status, void* stream);
 
 /* ---- output text (host side) -------------------------------------------------------------- */
 

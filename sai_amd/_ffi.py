@@ -20,7 +20,7 @@ SAI_MAX_SETS = 16
 SAI_FUSED_SETS = 20
 SAI_ERR_UNSUPPORTED = -4  # enum sai_status
 FREQ_MODES = {"dense": 0, "candidates": 1}  # enum sai_freq_mode
-SAI_ABI_VERSION = 10
+SAI_ABI_VERSION = 11
 
 OPS = {"=": 0, "<": 1, ">": 2, "<=": 3, ">=": 4}
 
@@ -131,6 +131,7 @@ SIGNATURES = {
     ),
     "sai_vcf_stream_selection": (C.c_int, [_p, _p, _i32, C.POINTER(_i32), C.POINTER(_i64), C.POINTER(_i64)]),
     "sai_vcf_stream_close": (C.c_int, [_p]),
+    "sai_inflate_bgzf": (C.c_int, [_p, _p, _i64, _p, _i32, _p, _i64, _p, _p]),
     "sai_tokenize_gt": (C.c_int, [_p, _p, _i64, _i64, _p, _p, _p, _p, _i32, _p, _i32, _p, _p, _p, _p]),
     "sai_format_score_rows": (
         C.c_int,

@@ -1,0 +1,430 @@
+// sai_inflate_bgzf: the members of a bgzip (BGZF) file inflated on the GPU.
+//
+// A BGZF member is an independent raw DEFLATE stream (RFC 1951) of at most 64 KiB of text, so the
+// members of a batch are inflated side by side, ONE WAVEFRONT PER MEMBER.  DEFLATE is serial inside
+// a stream; what the 64 lanes share is everything around the symbol decode:
+//   * the compressed bytes are held 256 B at a time in one register per lane (one coalesced load,
+//     the next 256 B prefetched) and fed to a wave-uniform bit buffer with v_readlane;
+//   * the 32 KiB history window lives in LDS; a match of length L is copied by L lanes at once
+//     (overlapping matches read `src + k % dist`), a literal is one LDS byte store;
+//   * the Huffman tables (10-bit / 8-bit primary look-up + a canonical walk for longer codes) are
+//     built by all lanes: code counts with ballots, a symbol's rank inside its length with a prefix
+//     popcount, every lane fills the table entries of its own symbols;
+//   * finished text leaves the window for HBM 256 B at a time, one word per lane.
+// Every lane executes the same decode on the same values, so nothing is broadcast or synchronised.
+// Each access is bounded (window index masked, output against ISIZE, distance against what the
+// member has produced, input against the member's length): a corrupt member ends with a non-zero
+// status, never with a stray access.  The host checks the CRC-32 of the text it receives
+// (vcf_ingest.cpp), as it does after its own inflate.
+
+#include "common.hpp"
+
+namespace {
+
+constexpr int kWin = 32768;  // DEFLATE's window
+constexpr int kLitBits = 10;
+constexpr int kDistBits = 8;
+constexpr int kClBits = 7;
+constexpr int kMaxLit = 288;
+constexpr int kMaxDist = 32;
+
+enum : int32_t {
+  kOk = 0,
+  kBadBlockType = 1,
+  kBadCodeLengths = 2,
+  kOutputOverrun = 3,
+  kBadDistance = 4,
+  kInputOverrun = 5,
+  kSizeMismatch = 6,
+  kBadSymbol = 7,
+  kBadStored = 8,
+};
+
+struct HuffLds {
+  uint16_t tab[1 << kLitBits];  // (len << 9) | symbol for codes of up to `bits` bits, 0 otherwise
+  uint16_t sorted[kMaxLit];     // symbols in canonical order (for the longer codes)
+  uint16_t count[16];           // codes per length
+};
+
+struct WaveLds {
+  uint8_t win[kWin];
+  HuffLds lit;
+  HuffLds dist;  // only the first 2^kDistBits table entries and 32 symbols are used; also the code-length code
+  uint8_t lens[kMaxLit + kMaxDist];  // literal/length code lengths, the distance ones right behind them
+  uint8_t cl_lens[32];
+};
+
+struct InflateArgs {
+  const uint8_t* comp;
+  int64_t n_comp;  // bytes of `comp` that may be read
+  const sai_bgzf_member* members;
+  int32_t n_members;
+  uint8_t* text;
+  int64_t n_text;  // bytes of `text` that may be written
+  int32_t* status;
+};
+
+// ---- wave-uniform bit reader ---------------------------------------------------------------------
+struct BitIn {
+  const uint32_t* words;  // aligned base of the member's stream
+  int64_t n_words;        // words that may be loaded
+  uint32_t cur, nxt;      // lane l holds word 64 * chunk + l of the current / next chunk
+  int widx;               // next word to enter the bit buffer
+  uint64_t buf;
+  int cnt;
+  int lane;
+  int64_t origin_bits;  // position of the aligned base relative to the member's first byte, in bits
+
+  __device__ __forceinline__ uint32_t load_chunk(int chunk) const {
+    const int64_t i = static_cast<int64_t>(chunk) * 64 + lane;
+    return i < n_words ? words[i] : 0u;
+  }
+  __device__ __forceinline__ void start(const uint8_t* comp, int64_t n_comp, int64_t member_off, int64_t byte_off, int lane_) {
+    lane = lane_;
+    const int64_t aligned = byte_off & ~int64_t(3);
+    origin_bits = (aligned - member_off) * 8;
+    words = reinterpret_cast<const uint32_t*>(comp + aligned);
+    n_words = (n_comp - aligned) >> 2;  // the caller pads the buffer to a multiple of 4
+    cur = load_chunk(0);
+    nxt = load_chunk(1);
+    widx = 0;
+    buf = 0;
+    cnt = 0;
+    fill();
+    const int skip = static_cast<int>(byte_off - aligned) * 8;
+    buf >>= skip;
+    cnt -= skip;
+  }
+  // at least 32 bits in the buffer afterwards
+  __device__ __forceinline__ void fill() {
+    while (cnt <= 32) {
+      const int l = __builtin_amdgcn_readfirstlane(widx & 63);
+      const uint32_t w = __builtin_amdgcn_readlane(cur, l);
+      buf |= static_cast<uint64_t>(w) << cnt;
+      cnt += 32;
+      ++widx;
+      if ((widx & 63) == 0) {
+        cur = nxt;
+        nxt = load_chunk((widx >> 6) + 1);
+      }
+    }
+  }
+  __device__ __forceinline__ uint32_t peek(int n) const { return static_cast<uint32_t>(buf) & ((1u << n) - 1u); }
+  __device__ __forceinline__ void drop(int n) {
+    buf >>= n;
+    cnt -= n;
+  }
+  __device__ __forceinline__ uint32_t take(int n) {
+    const uint32_t v = peek(n);
+    drop(n);
+    return v;
+  }
+  // bits of the member consumed so far
+  __device__ __forceinline__ int64_t pos_bits() const { return origin_bits + static_cast<int64_t>(widx) * 32 - cnt; }
+};
+
+__device__ __forceinline__ uint32_t reverse_bits(uint32_t code, int len) { return __brev(code) >> (32 - len); }
+
+// Canonical Huffman tables of `n` code lengths (s.lens[base ...]), built by the whole wavefront.
+// Returns false for an over-subscribed set of lengths.
+template <int BITS, int MAXSYM>
+__device__ bool build_tables(const uint8_t* lens, int n, HuffLds& h, int lane) {
+  constexpr int kPer = (MAXSYM + 63) / 64;
+  int my_len[kPer];
+#pragma unroll
+  for (int k = 0; k < kPer; ++k) {
+    const int s = k * 64 + lane;
+    my_len[k] = s < n ? lens[s] : 0;
+  }
+  for (int i = lane; i < (1 << BITS); i += 64) h.tab[i] = 0;
+  // codes per length, first code and first slot of every length (uniform), rank of my symbols
+  uint32_t code = 0, slot = 0, left = 1;
+  bool over = false;
+  int my_code[kPer], my_slot[kPer];
+#pragma unroll
+  for (int k = 0; k < kPer; ++k) my_code[k] = my_slot[k] = 0;
+  for (int len = 1; len <= 15; ++len) {
+    uint32_t count = 0;
+    code <<= 1;
+    left <<= 1;
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) {
+      const bool mine = my_len[k] == len;
+      const uint64_t m = __ballot(mine);
+      if (mine) {
+        const uint32_t rank = count + __popcll(m & ((1ull << lane) - 1ull));
+        my_code[k] = static_cast<int>(code + rank);
+        my_slot[k] = static_cast<int>(slot + rank);
+      }
+      count += __popcll(m);
+    }
+    if (count > left) over = true;
+    left -= count > left ? left : count;
+    if (lane == 0) h.count[len] = static_cast<uint16_t>(count);
+    code += count;
+    slot += count;
+  }
+  if (over) return false;
+#pragma unroll
+  for (int k = 0; k < kPer; ++k) {
+    const int len = my_len[k];
+    if (len == 0) continue;
+    const int s = k * 64 + lane;
+    h.sorted[my_slot[k]] = static_cast<uint16_t>(s);
+    if (len <= BITS) {
+      const uint32_t rev = reverse_bits(static_cast<uint32_t>(my_code[k]), len);
+      const uint16_t e = static_cast<uint16_t>((len << 9) | s);
+      for (uint32_t i = rev; i < (1u << BITS); i += 1u << len) h.tab[i] = e;
+    }
+  }
+  __syncthreads();  // one wavefront per workgroup: orders the LDS writes before the look-ups
+  return true;
+}
+
+// One symbol; -1 for a bit pattern that is no code.  Needs >= 15 bits in the buffer.
+template <int BITS>
+__device__ __forceinline__ int decode_symbol(BitIn& in, const HuffLds& h) {
+  const uint16_t e = h.tab[in.peek(BITS)];
+  if (e) {
+    in.drop(e >> 9);
+    return e & 511;
+  }
+  // codes longer than BITS: walk the canonical code one bit at a time (rare symbols)
+  int code = 0, first = 0, index = 0;
+  uint32_t bits = static_cast<uint32_t>(in.buf);
+  for (int len = 1; len <= 15; ++len) {
+    code |= static_cast<int>(bits & 1u);
+    bits >>= 1;
+    const int count = h.count[len];
+    if (code - count < first) {
+      in.drop(len);
+      return h.sorted[index + (code - first)];
+    }
+    index += count;
+    first += count;
+    first <<= 1;
+    code <<= 1;
+  }
+  return -1;
+}
+
+__global__ __launch_bounds__(64) void inflate_bgzf_kernel(InflateArgs a) {
+  __shared__ WaveLds s;
+  const int lane = threadIdx.x;
+  const int m = blockIdx.x;
+  if (m >= a.n_members) return;
+  const sai_bgzf_member mem = a.members[m];
+  const int64_t isize = mem.isize;
+  int32_t err = kOk;
+  // the member's own bounds inside the two buffers (checked on the host as well)
+  if (mem.data_off < 0 || mem.data_off + static_cast<int64_t>(mem.data_len) > a.n_comp || mem.out_off < 0 ||
+      mem.out_off + isize > a.n_text || isize > 65536) {
+    if (lane == 0) a.status[m] = kSizeMismatch;
+    return;
+  }
+  uint8_t* dst = a.text + mem.out_off;
+  const bool dst_aligned = (reinterpret_cast<uintptr_t>(dst) & 3u) == 0;
+  BitIn in;
+  in.start(a.comp, a.n_comp, mem.data_off, mem.data_off, lane);
+  const int64_t bit_limit = static_cast<int64_t>(mem.data_len) * 8;
+  int64_t out_pos = 0, flushed = 0;
+  bool last = false;
+
+  auto flush_groups = [&]() {
+    while (out_pos - flushed >= 256) {
+      const uint32_t w = *reinterpret_cast<const uint32_t*>(&s.win[(flushed + 4 * lane) & (kWin - 1)]);
+      uint8_t* d = dst + flushed + 4 * lane;
+      if (dst_aligned) {
+        *reinterpret_cast<uint32_t*>(d) = w;
+      } else {
+        d[0] = static_cast<uint8_t>(w);
+        d[1] = static_cast<uint8_t>(w >> 8);
+        d[2] = static_cast<uint8_t>(w >> 16);
+        d[3] = static_cast<uint8_t>(w >> 24);
+      }
+      flushed += 256;
+    }
+  };
+
+  while (!last && err == kOk) {
+    in.fill();
+    if (in.pos_bits() > bit_limit) { err = kInputOverrun; break; }
+    last = in.take(1) != 0;
+    const uint32_t type = in.take(2);
+    if (type == 3) { err = kBadBlockType; break; }
+    if (type == 0) {
+      // stored: LEN / NLEN on the next byte boundary, then LEN raw bytes
+      in.drop(in.cnt & 7);
+      in.fill();
+      const uint32_t len = in.take(16);
+      in.fill();
+      const uint32_t nlen = in.take(16);
+      if ((len ^ nlen) != 0xFFFFu) { err = kBadStored; break; }
+      const int64_t byte0 = mem.data_off + (in.pos_bits() >> 3);  // absolute offset of the raw bytes
+      if (byte0 + len > mem.data_off + static_cast<int64_t>(mem.data_len)) { err = kInputOverrun; break; }
+      if (out_pos + len > isize) { err = kOutputOverrun; break; }
+      for (uint32_t done = 0; done < len;) {  // through the window in pieces that fit it
+        const uint32_t step = len - done < 16384u ? len - done : 16384u;
+        for (uint32_t k = lane; k < step; k += 64) s.win[(out_pos + k) & (kWin - 1)] = a.comp[byte0 + done + k];
+        __syncthreads();
+        out_pos += step;
+        done += step;
+        flush_groups();
+      }
+      in.start(a.comp, a.n_comp, mem.data_off, byte0 + len, lane);
+      continue;
+    }
+    int n_lit, n_dist;
+    if (type == 1) {
+      n_lit = 288;
+      n_dist = 32;
+      for (int i = lane; i < 288; i += 64) s.lens[i] = i < 144 ? 8 : (i < 256 ? 9 : (i < 280 ? 7 : 8));
+      if (lane < 32) s.lens[288 + lane] = 5;
+      __syncthreads();
+    } else {
+      n_lit = static_cast<int>(in.take(5)) + 257;
+      n_dist = static_cast<int>(in.take(5)) + 1;
+      const int n_cl = static_cast<int>(in.take(4)) + 4;
+      if (n_lit > 286 || n_dist > 30) { err = kBadCodeLengths; break; }
+      // the code-length code: 3 bits per length, in the permuted order of RFC 1951 3.2.7
+      if (lane < 32) s.cl_lens[lane] = 0;
+      __syncthreads();
+      for (int i = 0; i < n_cl; ++i) {
+        in.fill();
+        const uint32_t v = in.take(3);
+        // 16 17 18 0 8 7 9 6 10 5 11 4 12 3 13 2 14 1 15
+        const int pos = i < 3 ? 16 + i : (i == 3 ? 0 : ((i & 1) ? (19 - i) >> 1 : 6 + (i >> 1)));
+        if (lane == 0) s.cl_lens[pos] = static_cast<uint8_t>(v);
+      }
+      __syncthreads();
+      if (!build_tables<kClBits, 64>(s.cl_lens, 19, s.dist, lane)) { err = kBadCodeLengths; break; }
+      // the literal/length and distance code lengths, run-length coded with the code-length code
+      int i = 0, prev = 0;
+      const int total = n_lit + n_dist;
+      while (i < total) {
+        in.fill();
+        if (in.pos_bits() > bit_limit + 64) { err = kInputOverrun; break; }
+        const int sym = decode_symbol<kClBits>(in, s.dist);
+        if (sym < 0 || sym > 18) { err = kBadCodeLengths; break; }
+        if (sym < 16) {
+          if (lane == 0) s.lens[i] = static_cast<uint8_t>(sym);
+          prev = sym;
+          ++i;
+          continue;
+        }
+        int rep, val = 0;
+        if (sym == 16) {
+          if (i == 0) { err = kBadCodeLengths; break; }
+          val = prev;
+          rep = 3 + static_cast<int>(in.take(2));
+        } else if (sym == 17) {
+          rep = 3 + static_cast<int>(in.take(3));
+        } else {
+          rep = 11 + static_cast<int>(in.take(7));
+        }
+        if (i + rep > total) { err = kBadCodeLengths; break; }
+        for (int k = lane; k < rep; k += 64) s.lens[i + k] = static_cast<uint8_t>(val);
+        i += rep;
+        prev = val;
+      }
+      if (err != kOk) break;
+      __syncthreads();
+      if (s.lens[256] == 0) { err = kBadCodeLengths; break; }  // no end-of-block code
+    }
+    if (!build_tables<kLitBits, kMaxLit>(s.lens, n_lit, s.lit, lane)) { err = kBadCodeLengths; break; }
+    if (!build_tables<kDistBits, 64>(s.lens + n_lit, n_dist, s.dist, lane)) { err = kBadCodeLengths; break; }
+
+    // ---- the symbols of the block --------------------------------------------------------------
+    for (;;) {
+      in.fill();
+      if (in.pos_bits() > bit_limit + 64) { err = kInputOverrun; break; }
+      int sym = decode_symbol<kLitBits>(in, s.lit);
+      if (sym < 0) { err = kBadSymbol; break; }
+      if (sym < 256) {
+        if (out_pos >= isize) { err = kOutputOverrun; break; }
+        if (lane == 0) s.win[out_pos & (kWin - 1)] = static_cast<uint8_t>(sym);
+        ++out_pos;
+      } else if (sym == 256) {
+        break;
+      } else {
+        sym -= 257;
+        if (sym >= 29) { err = kBadSymbol; break; }
+        int len;
+        if (sym < 8) {
+          len = 3 + sym;
+        } else if (sym == 28) {
+          len = 258;
+        } else {
+          const int e = (sym - 4) >> 2;
+          len = 3 + ((4 + (sym & 3)) << e) + static_cast<int>(in.take(e));
+        }
+        in.fill();
+        const int dsym = decode_symbol<kDistBits>(in, s.dist);
+        if (dsym < 0 || dsym >= 30) { err = kBadSymbol; break; }
+        int dist;
+        if (dsym < 4) {
+          dist = 1 + dsym;
+        } else {
+          const int e = (dsym >> 1) - 1;
+          dist = 1 + ((2 + (dsym & 1)) << e) + static_cast<int>(in.take(e));
+        }
+        if (dist > out_pos) { err = kBadDistance; break; }
+        if (out_pos + len > isize) { err = kOutputOverrun; break; }
+        const int64_t src = out_pos - dist;
+        if (dist >= len) {
+          for (int k = lane; k < len; k += 64) s.win[(out_pos + k) & (kWin - 1)] = s.win[(src + k) & (kWin - 1)];
+        } else {
+          // the match overlaps its own output: the text repeats with period `dist`
+          uint8_t b[5];
+#pragma unroll
+          for (int j = 0; j < 5; ++j) {
+            const int k = j * 64 + lane;
+            b[j] = k < len ? s.win[(src + k % dist) & (kWin - 1)] : 0;
+          }
+#pragma unroll
+          for (int j = 0; j < 5; ++j) {
+            const int k = j * 64 + lane;
+            if (k < len) s.win[(out_pos + k) & (kWin - 1)] = b[j];
+          }
+        }
+        out_pos += len;
+      }
+      if (out_pos - flushed >= 256) {
+        __syncthreads();
+        flush_groups();
+      }
+    }
+  }
+  if (err == kOk) {
+    if (out_pos != isize) err = kSizeMismatch;
+    else if (in.pos_bits() > bit_limit) err = kInputOverrun;
+  }
+  if (err == kOk) {
+    __syncthreads();
+    flush_groups();
+    for (int64_t k = flushed + lane; k < out_pos; k += 64) dst[k] = s.win[k & (kWin - 1)];
+  }
+  if (lane == 0) a.status[m] = err;
+}
+
+}  // namespace
+
+extern "C" int sai_inflate_bgzf(sai_ctx* ctx, const void* comp, int64_t n_comp_bytes, const sai_bgzf_member* members,
+                                int32_t n_members, void* text, int64_t n_text_bytes, int32_t* status, void* stream) {
+  if (int rc = enter(ctx)) return rc;
+  if (n_members < 0 || n_comp_bytes < 0 || n_text_bytes < 0) return fail(SAI_ERR_ARG, "negative size");
+  if (n_members == 0) return SAI_OK;
+  if (!comp || !members || !text || !status) return fail(SAI_ERR_ARG, "NULL buffer");
+  if ((reinterpret_cast<uintptr_t>(comp) & 3u) || (n_comp_bytes & 3))
+    return fail(SAI_ERR_ARG, "the compressed buffer must be 4-byte aligned and padded to a multiple of 4 bytes");
+  InflateArgs a;
+  a.comp = static_cast<const uint8_t*>(comp);
+  a.n_comp = n_comp_bytes;
+  a.members = members;
+  a.n_members = n_members;
+  a.text = static_cast<uint8_t*>(text);
+  a.n_text = n_text_bytes;
+  a.status = status;
+  hipLaunchKernelGGL(inflate_bgzf_kernel, dim3(static_cast<unsigned>(n_members)), dim3(64), 0, static_cast<hipStream_t>(stream), a);
+  return check_launch("inflate_bgzf");
+}
