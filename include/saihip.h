@@ -380,6 +380,37 @@ typedef struct sai_bgzf_member {
 int sai_inflate_bgzf(sai_ctx* ctx, const void* comp, int64_t n_comp_bytes, const sai_bgzf_member* members,
                      int32_t n_members, void* text, int64_t n_text_bytes, int32_t* status, void* stream);
 
+/* The host side of that path.  sai_bgzf_stream_open starts a reader thread that hands the file's
+ * BGZF members over as they are -- whole members, padded to a multiple of 4 bytes -- in the caller's
+ * two pinned buffers alternately, at most text_batch_bytes of text per batch; SAI_ERR_UNSUPPORTED
+ * when the file is not bgzip, or when a region is asked of a file with a usable .tbi (that is a
+ * seek and a few blocks: sai_vcf_stream_open).  sai_bgzf_stream_next returns batch k (blocking) and
+ * releases the buffer of batch k-1 (its H2D copy must be over); members_host = the table for
+ * sai_inflate_bgzf, valid until the following call.  The caller inflates the batch on the GPU behind
+ * the n_carry bytes the previous batch left over (its last, incomplete line), copies carry + text to
+ * the host once, and calls sai_vcf_index_text(text_host, n_bytes = n_carry + text, n_carry, the
+ * batch's member table): the text of every member is checked against its CRC-32, the header is
+ * consumed, the complete record lines are indexed exactly as sai_vcf_stream_next reports them
+ * (offsets relative to text_host, i.e. to the same place in the device copy) and *n_usable = bytes up
+ * to the end of the last complete line (is_last: all of it).  *done = 1 once the region has been
+ * passed (stop reading).  After the last batch the caller indexes the left-over carry with
+ * n_members = 0, is_last = 1.  sai_bgzf_stream_selection as sai_vcf_stream_selection. */
+typedef struct sai_bgzf_stream sai_bgzf_stream;
+int sai_bgzf_stream_open(const char* path, const char* chrom, int64_t start, int64_t end, int32_t n_samples,
+                         const char* const* sample_names, const int32_t* ploidy, const char* anc_bed_path,
+                         int32_t n_threads, void* comp0_host, void* comp1_host, int64_t comp_buffer_bytes,
+                         int64_t text_batch_bytes, sai_bgzf_stream** stream_out);
+int sai_bgzf_stream_next(sai_bgzf_stream* stream, int32_t* buffer_index, int64_t* n_comp_bytes, int32_t* n_members,
+                         const sai_bgzf_member** members_host, int64_t* n_text_bytes, int32_t* done);
+int sai_vcf_index_text(sai_bgzf_stream* stream, const char* text_host, int64_t n_bytes, int64_t n_carry,
+                       const sai_bgzf_member* members_host, int32_t n_members, int32_t is_last, int64_t* n_usable,
+                       int64_t* n_lines, const int64_t** line_off_host, const int32_t** line_len_host,
+                       const int32_t** line_pos_host, const uint8_t** line_flip_host, const uint8_t** line_gi_host,
+                       int32_t* done);
+int sai_bgzf_stream_selection(sai_bgzf_stream* stream, int32_t* slot_of_col_host, int32_t capacity, int32_t* n_cols,
+                              int64_t* n_matched, int64_t* n_anc_entries);
+int sai_bgzf_stream_close(sai_bgzf_stream* stream);
+
 /* ---- output text (host side) -------------------------------------------------------------- */
 
 /* The rows FeaturePreprocessor.process_items writes (feature_preprocessor.py:193-258), formatted

@@ -186,3 +186,79 @@ def test_device_reader_fuzz(eng, tmp_path, seed, monkeypatch):
         want = load_dosage(str(path), chrom, pick, ploidies, start, end, None, 2)
         assert got[0].tolist() == want[0].tolist() and got[2] == want[2]
         assert np.array_equal(got[1].cpu().numpy(), want[1])
+
+
+def test_bgzip_is_inflated_on_the_gpu(eng, tmp_path, monkeypatch):
+    """A bgzip file read without a region seek takes the sai_inflate_bgzf route (compressed bytes
+    over PCIe, text indexed once on the host, tokenised in HBM): many small batches with a carried
+    line between them, a last line without a newline, the same answer as the host-inflating stream
+    and as the host reader; a damaged member is reported, not followed."""
+    import zlib
+
+    from sai_amd.utils import device_vcf
+    from sai_amd.utils.native_vcf import load_dosage
+
+    rng = np.random.default_rng(9)
+    path = tmp_path / "big.vcf.gz"
+    names = write_vcf(path, rng, 2500, 61, gz="bgzf")
+    calls = {"n": 0}
+    real = device_vcf._load_bgzf_device
+
+    def spy(*a, **k):
+        got = real(*a, **k)
+        calls["n"] += got is not None
+        return got
+
+    monkeypatch.setattr(device_vcf, "_load_bgzf_device", spy)
+    pick = [names[i] for i in rng.permutation(61)[:40]]
+    ploidies = [int(rng.choice([1, 2, 2, 4])) for _ in pick]
+    for chrom in ("7", "21", "22"):
+        for start, end in ((None, None), (300, 20000)):
+            want = load_dosage(str(path), chrom, pick, ploidies, start, end, None, 2)
+            for cap in (1 << 16, 1 << 18, None):
+                before = calls["n"]
+                got = device_vcf.load_dosage_device(eng, str(path), chrom, pick, ploidies, start, end, None, 4, cap)
+                assert calls["n"] == before + 1
+                assert got[0].tolist() == want[0].tolist() and got[2] == want[2]
+                assert np.array_equal(got[1].cpu().numpy(), want[1])
+            monkeypatch.setenv("SAI_AMD_GPU_INFLATE", "0")
+            before = calls["n"]
+            host = device_vcf.load_dosage_device(eng, str(path), chrom, pick, ploidies, start, end, None, 4, 1 << 18)
+            monkeypatch.delenv("SAI_AMD_GPU_INFLATE")
+            assert calls["n"] == before and host[0].tolist() == want[0].tolist() and np.array_equal(host[1].cpu().numpy(), want[1])
+    # the last record line without its newline (re-pack the text in members of odd sizes)
+    import gzip
+    import struct
+
+    text = gzip.open(path, "rb").read().rstrip(b"\n")
+
+    def member(chunk):
+        comp = zlib.compressobj(6, zlib.DEFLATED, -15)
+        raw = comp.compress(chunk) + comp.flush()
+        head = b"\x1f\x8b\x08\x04" + b"\x00" * 4 + b"\x00\xff" + struct.pack("<H", 6) + b"BC" + struct.pack("<HH", 2, 12 + 6 + len(raw) + 8 - 1)
+        return head + raw + struct.pack("<II", zlib.crc32(chunk) & 0xFFFFFFFF, len(chunk))
+
+    odd = tmp_path / "odd.vcf.gz"
+    with open(odd, "wb") as f:
+        o = 0
+        while o < len(text):
+            step = int(rng.integers(1, 65281))
+            f.write(member(text[o : o + step]))
+            o += step
+        f.write(member(b""))
+    want = load_dosage(str(odd), "22", pick, ploidies, None, None, None, 2)
+    for cap in (1 << 16, None):
+        before = calls["n"]
+        got = device_vcf.load_dosage_device(eng, str(odd), "22", pick, ploidies, None, None, None, 3, cap)
+        assert calls["n"] == before + 1 and got[0].tolist() == want[0].tolist() and np.array_equal(got[1].cpu().numpy(), want[1])
+    # damage in the middle of the file: the kernel's status or the host's CRC check stops the read
+    raw = bytearray(open(path, "rb").read())
+    raw[len(raw) // 2] ^= 0x55
+    bad = tmp_path / "bad.vcf.gz"
+    open(bad, "wb").write(raw)
+    with pytest.raises(ValueError, match="BGZF|corrupt"):
+        device_vcf.load_dosage_device(eng, str(bad), "22", pick, ploidies)
+    # and the buffers are in order for the next call
+    got = device_vcf.load_dosage_device(eng, str(path), "22", pick, ploidies)
+    want = load_dosage(str(path), "22", pick, ploidies, None, None, None, 2)
+    assert got[0].tolist() == want[0].tolist() and np.array_equal(got[1].cpu().numpy(), want[1])

@@ -145,3 +145,141 @@ def test_stream_errors_and_tabix_region(tmp_path, monkeypatch):
     assert lib.sai_vcf_stream_open(os.fsencode(str(path)), b"21", -1, -1, 1, c_names, (C.c_int32 * 1)(2), None, 2,
                                    bufs[0].ctypes.data_as(C.c_void_p), bufs[1].ctypes.data_as(C.c_void_p), 1 << 16, C.byref(h)) == 0  # fmt: skip
     assert lib.sai_vcf_stream_close(h) == 0
+
+
+# ---- the bgzip stream for the GPU inflate: the host half, with zlib standing in for the kernel ----
+
+BGZF_MEMBER = np.dtype([("data_off", "<i8"), ("out_off", "<i8"), ("data_len", "<u4"), ("isize", "<u4"), ("crc", "<u4"), ("reserved", "<u4")])
+
+
+def bgzf_stream_batches(path, chrom, names, ploidies, start=None, end=None, anc=None, threads=3, cap=1 << 17, text_cap=1 << 16,
+                        damage=None):  # fmt: skip
+    """Drive sai_bgzf_stream_* + sai_vcf_index_text the way device_vcf does, inflating the members
+    with zlib where the GPU kernel would.  Same return value as ``stream_batches``."""
+    import zlib
+
+    from sai_amd import _ffi
+
+    lib = _ffi.load_host()
+    bufs = [np.zeros(cap, dtype=np.uint8) for _ in range(2)]
+    n = len(names)
+    c_names = (C.c_char_p * n)(*[s.encode() for s in names])
+    c_pl = (C.c_int32 * n)(*ploidies)
+    h = C.c_void_p()
+    rc = lib.sai_bgzf_stream_open(os.fsencode(str(path)), chrom.encode(), -1 if start is None else start, -1 if end is None else end,
+                                  n, c_names, c_pl, os.fsencode(anc) if anc else None, threads, bufs[0].ctypes.data_as(C.c_void_p),
+                                  bufs[1].ctypes.data_as(C.c_void_p), cap, text_cap, C.byref(h))  # fmt: skip
+    if rc:
+        err = lib.sai_last_error().decode()
+        raise (NotImplementedError if rc == _ffi.SAI_ERR_UNSUPPORTED else ValueError)(err)
+    out, sel, carry = [], None, b""
+    try:
+        b, nc, nm, nt, done = C.c_int32(), C.c_int64(), C.c_int32(), C.c_int64(), C.c_int32()
+        table_p = C.c_void_p()
+        usable, nl, idone = C.c_int64(), C.c_int64(), C.c_int32()
+        ptrs = [C.c_void_p() for _ in range(5)]
+
+        def index(text, n_carry, table, n_members, last):
+            buf = np.frombuffer(text, dtype=np.uint8).copy() if text else np.zeros(1, dtype=np.uint8)
+            if lib.sai_vcf_index_text(h, buf.ctypes.data_as(C.c_void_p), len(text), n_carry, table, n_members, last, C.byref(usable),
+                                      C.byref(nl), *[C.byref(p) for p in ptrs], C.byref(idone)):  # fmt: skip
+                raise ValueError(lib.sai_last_error().decode())
+            k = int(nl.value)
+            get = lambda p, ct: np.ctypeslib.as_array(C.cast(p, C.POINTER(ct)), shape=(k,)).copy() if k else np.zeros(0, np.int64)  # noqa: E731
+            out.append((text, get(ptrs[0], C.c_int64), get(ptrs[1], C.c_int32), get(ptrs[2], C.c_int32), get(ptrs[3], C.c_uint8),
+                        get(ptrs[4], C.c_uint8)))  # fmt: skip
+            return text[usable.value :]
+
+        n_batches = 0
+        while not idone.value:
+            if lib.sai_bgzf_stream_next(h, C.byref(b), C.byref(nc), C.byref(nm), C.byref(table_p), C.byref(nt), C.byref(done)):
+                raise ValueError(lib.sai_last_error().decode())
+            if done.value:
+                if carry:
+                    carry = index(carry, len(carry), None, 0, 1)
+                break
+            n_batches += 1
+            assert nc.value % 4 == 0 and nc.value <= cap
+            table = np.ctypeslib.as_array(C.cast(table_p, C.POINTER(C.c_uint8)), shape=(nm.value * BGZF_MEMBER.itemsize,)).copy().view(BGZF_MEMBER)
+            comp = bufs[b.value][: nc.value].tobytes()
+            text = bytearray(nt.value)
+            for row in table:
+                raw = zlib.decompress(comp[row["data_off"] : row["data_off"] + row["data_len"]], -15)
+                assert len(raw) == row["isize"]
+                text[row["out_off"] : row["out_off"] + row["isize"]] = raw
+            if damage is not None and n_batches == damage and text:
+                text[len(text) // 2] ^= 0x20
+            carry = index(carry + bytes(text), len(carry), table.ctypes.data_as(C.c_void_p), nm.value, 0)
+        cols, n_match, n_anc = C.c_int32(), C.c_int64(), C.c_int64()
+        if lib.sai_bgzf_stream_selection(h, None, 0, C.byref(cols), C.byref(n_match), C.byref(n_anc)) == 0:
+            slots = np.empty(max(cols.value, 1), dtype=np.int32)
+            assert lib.sai_bgzf_stream_selection(h, slots.ctypes.data_as(C.c_void_p), cols.value, C.byref(cols), None, None) == 0
+            sel = (slots[: cols.value].tolist(), int(n_match.value), int(n_anc.value))
+    finally:
+        lib.sai_bgzf_stream_close(h)
+    return out, sel, n_batches
+
+
+@pytest.mark.parametrize("crlf", [False, True])
+def test_bgzf_stream_index_equals_host_reader(tmp_path, crlf):
+    from sai_amd.utils.native_vcf import load_dosage
+    from sai_amd.utils.vcf import read_region
+
+    rng = np.random.default_rng(77 + crlf)
+    path = tmp_path / "t.vcf.gz"
+    names = write_vcf(path, rng, 400, 13, gz="bgzf", crlf=crlf)
+    bed = tmp_path / "anc.bed"
+    reg = read_region(str(path), "21", names[:1])
+    with open(bed, "w") as f:
+        for p, r, a in zip(reg.pos, reg.ref, reg.alt):
+            u = rng.random()
+            if u >= 0.3:
+                f.write(f"21\t{p - 1}\t{p}\t{r if u < 0.6 else (a if u < 0.9 else '-')}\n")
+    pick = [names[i] for i in (4, 0, 12, 3)]
+    ploidies = [2, 1, 4, 3]
+    for chrom in ("21", "7", "22"):
+        for start, end in ((None, None), (500, 9000), (10**7, None)):
+            for anc in (None, str(bed)):
+                for text_cap in (1 << 16, 1 << 22):
+                    batches, sel, n_batches = bgzf_stream_batches(path, chrom, pick, ploidies, start, end, anc, text_cap=text_cap)
+                    want = load_dosage(str(path), chrom, pick, ploidies, start, end, anc, 2)
+                    pos, dos = python_tokenize(batches, sel[0], ploidies)
+                    assert pos.tolist() == want[0].tolist(), (chrom, start, end, anc, text_cap)
+                    assert np.array_equal(dos, want[1]) and sel[1] == want[2]
+                    if anc and want[2]:
+                        assert sel[2] == want[3]
+    # a text batch of one member: many batches, every carry-over path between them
+    _, _, n_batches = bgzf_stream_batches(path, "22", pick, ploidies, text_cap=1 << 16)
+    assert n_batches >= 3
+
+
+def test_bgzf_stream_refusals(tmp_path):
+    rng = np.random.default_rng(5)
+    plain = tmp_path / "p.vcf"
+    names = write_vcf(plain, rng, 50, 5)
+    with pytest.raises(NotImplementedError, match="not a bgzip file"):
+        bgzf_stream_batches(plain, "21", names[:2], [2, 2])
+    gz = tmp_path / "g.vcf.gz"
+    write_vcf(gz, rng, 50, 5, gz=True)  # gzip, but one plain member
+    with pytest.raises(NotImplementedError):
+        bgzf_stream_batches(gz, "21", names[:2], [2, 2])
+    bg = tmp_path / "b.vcf.gz"
+    names = write_vcf(bg, rng, 300, 5, gz="bgzf")
+    write_tbi(bg)
+    with pytest.raises(NotImplementedError, match="tabix"):  # a region of an indexed file: the seeking stream does that
+        bgzf_stream_batches(bg, "21", names[:2], [2, 2], start=100, end=200)
+    assert bgzf_stream_batches(bg, "21", names[:2], [2, 2])[1] is not None  # the whole file is fine
+    with pytest.raises(ValueError, match="CRC"):  # text that differs from what the trailer promises
+        bgzf_stream_batches(bg, "21", names[:2], [2, 2], damage=1)
+    with pytest.raises(ValueError, match="not found|sample"):
+        bgzf_stream_batches(bg, "21", ["nobody"], [2])
+    raw = bytearray(open(bg, "rb").read())
+    trunc = tmp_path / "t.vcf.gz"
+    open(trunc, "wb").write(raw[: len(raw) - 40])
+    with pytest.raises(ValueError, match="truncated|corrupt"):
+        bgzf_stream_batches(trunc, "22", names[:2], [2, 2])  # the last chromosome: the reader must reach the end
+    raw[len(raw) // 2] ^= 0xFF  # damage inside a member: zlib (standing in for the kernel) or the CRC objects
+    bad = tmp_path / "d.vcf.gz"
+    open(bad, "wb").write(raw)
+    with pytest.raises((ValueError, Exception)):
+        bgzf_stream_batches(bad, "22", names[:2], [2, 2])
