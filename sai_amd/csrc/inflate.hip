@@ -21,7 +21,6 @@
 
 namespace {
 
-constexpr int kWin = 32768;  // DEFLATE's window
 constexpr int kLitBits = 10;
 constexpr int kDistBits = 8;
 constexpr int kClBits = 7;
@@ -40,19 +39,28 @@ enum : int32_t {
   kBadStored = 8,
 };
 
+template <int BITS, int SYMS>
 struct HuffLds {
-  uint16_t tab[1 << kLitBits];  // (len << 9) | symbol for codes of up to `bits` bits, 0 otherwise
-  uint16_t sorted[kMaxLit];     // symbols in canonical order (for the longer codes)
-  uint16_t count[16];           // codes per length
+  uint16_t tab[1 << BITS];  // (len << 9) | symbol for codes of up to BITS bits, 0 otherwise
+  uint16_t sorted[SYMS];    // symbols in canonical order (for the longer codes)
+  uint16_t count[16];       // codes per length
 };
+using LitLds = HuffLds<kLitBits, kMaxLit>;
+using DistLds = HuffLds<kDistBits, kMaxDist>;  // also holds the code-length code (7-bit table, 19 symbols)
 
+// W = bytes of history kept in LDS.  W = 32768 is DEFLATE's whole window (4 wavefronts per CU by
+// LDS); W = 16384 doubles the wavefronts in flight -- the decode is a chain of dependent
+// instructions, so that doubles the rate -- and serves the rare match that reaches further back
+// from the text the wavefront has already written to HBM.
+template <int W>
 struct WaveLds {
-  uint8_t win[kWin];
-  HuffLds lit;
-  HuffLds dist;  // only the first 2^kDistBits table entries and 32 symbols are used; also the code-length code
+  uint8_t win[W];
+  LitLds lit;
+  DistLds dist;
   uint8_t lens[kMaxLit + kMaxDist];  // literal/length code lengths, the distance ones right behind them
   uint8_t cl_lens[32];
 };
+static_assert(sizeof(WaveLds<16384>) <= 20480, "eight wavefronts per CU need <= 20 KiB each");
 
 struct InflateArgs {
   const uint8_t* comp;
@@ -73,7 +81,7 @@ struct BitIn {
   uint64_t buf;
   int cnt;
   int lane;
-  int64_t origin_bits;  // position of the aligned base relative to the member's first byte, in bits
+  int origin_bits;  // position of the aligned base relative to the member's first byte, in bits (a member is < 2^20 bits)
 
   __device__ __forceinline__ uint32_t load_chunk(int chunk) const {
     const int64_t i = static_cast<int64_t>(chunk) * 64 + lane;
@@ -82,7 +90,7 @@ struct BitIn {
   __device__ __forceinline__ void start(const uint8_t* comp, int64_t n_comp, int64_t member_off, int64_t byte_off, int lane_) {
     lane = lane_;
     const int64_t aligned = byte_off & ~int64_t(3);
-    origin_bits = (aligned - member_off) * 8;
+    origin_bits = static_cast<int>(aligned - member_off) * 8;
     words = reinterpret_cast<const uint32_t*>(comp + aligned);
     n_words = (n_comp - aligned) >> 2;  // the caller pads the buffer to a multiple of 4
     cur = load_chunk(0);
@@ -120,15 +128,15 @@ struct BitIn {
     return v;
   }
   // bits of the member consumed so far
-  __device__ __forceinline__ int64_t pos_bits() const { return origin_bits + static_cast<int64_t>(widx) * 32 - cnt; }
+  __device__ __forceinline__ int pos_bits() const { return origin_bits + widx * 32 - cnt; }
 };
 
 __device__ __forceinline__ uint32_t reverse_bits(uint32_t code, int len) { return __brev(code) >> (32 - len); }
 
 // Canonical Huffman tables of `n` code lengths (s.lens[base ...]), built by the whole wavefront.
 // Returns false for an over-subscribed set of lengths.
-template <int BITS, int MAXSYM>
-__device__ bool build_tables(const uint8_t* lens, int n, HuffLds& h, int lane) {
+template <int BITS, int MAXSYM, typename H>
+__device__ bool build_tables(const uint8_t* lens, int n, H& h, int lane) {
   constexpr int kPer = (MAXSYM + 63) / 64;
   int my_len[kPer];
 #pragma unroll
@@ -181,24 +189,32 @@ __device__ bool build_tables(const uint8_t* lens, int n, HuffLds& h, int lane) {
   return true;
 }
 
-// One symbol; -1 for a bit pattern that is no code.  Needs >= 15 bits in the buffer.
-template <int BITS>
-__device__ __forceinline__ int decode_symbol(BitIn& in, const HuffLds& h) {
-  const uint16_t e = h.tab[in.peek(BITS)];
+// The primary-table entry of the code at the head of the bit buffer (0 = a longer code).  Every lane
+// reads the same entry: readfirstlane hands it to the scalar unit, so that the symbol arithmetic
+// and the branches of the decode loop run there.  Only peeks: the look-up can be issued early.
+template <int BITS, typename H>
+__device__ __forceinline__ uint32_t peek_entry(const BitIn& in, const H& h) {
+  return __builtin_amdgcn_readfirstlane(h.tab[in.peek(BITS)]);
+}
+
+// The symbol of entry `e` (consumes its bits); -1 for a bit pattern that is no code.  Needs >= 15
+// bits in the buffer.
+template <typename H>
+__device__ __forceinline__ int take_symbol(BitIn& in, const H& h, uint32_t e) {
   if (e) {
     in.drop(e >> 9);
     return e & 511;
   }
-  // codes longer than BITS: walk the canonical code one bit at a time (rare symbols)
+  // codes longer than the primary table: walk the canonical code one bit at a time (rare symbols)
   int code = 0, first = 0, index = 0;
   uint32_t bits = static_cast<uint32_t>(in.buf);
   for (int len = 1; len <= 15; ++len) {
     code |= static_cast<int>(bits & 1u);
     bits >>= 1;
-    const int count = h.count[len];
+    const int count = __builtin_amdgcn_readfirstlane(h.count[len]);
     if (code - count < first) {
       in.drop(len);
-      return h.sorted[index + (code - first)];
+      return __builtin_amdgcn_readfirstlane(h.sorted[index + (code - first)]);
     }
     index += count;
     first += count;
@@ -208,17 +224,24 @@ __device__ __forceinline__ int decode_symbol(BitIn& in, const HuffLds& h) {
   return -1;
 }
 
+template <int BITS, typename H>
+__device__ __forceinline__ int decode_symbol(BitIn& in, const H& h) {
+  return take_symbol(in, h, peek_entry<BITS>(in, h));
+}
+
+template <int W>
 __global__ __launch_bounds__(64) void inflate_bgzf_kernel(InflateArgs a) {
-  __shared__ WaveLds s;
+  constexpr int kWin = W;
+  __shared__ WaveLds<W> s;
   const int lane = threadIdx.x;
   const int m = blockIdx.x;
   if (m >= a.n_members) return;
   const sai_bgzf_member mem = a.members[m];
-  const int64_t isize = mem.isize;
+  const int isize = static_cast<int>(mem.isize);
   int32_t err = kOk;
   // the member's own bounds inside the two buffers (checked on the host as well)
   if (mem.data_off < 0 || mem.data_off + static_cast<int64_t>(mem.data_len) > a.n_comp || mem.out_off < 0 ||
-      mem.out_off + isize > a.n_text || isize > 65536) {
+      mem.isize > 65536u || mem.data_len > (1u << 17) || mem.out_off + static_cast<int64_t>(mem.isize) > a.n_text) {
     if (lane == 0) a.status[m] = kSizeMismatch;
     return;
   }
@@ -226,8 +249,8 @@ __global__ __launch_bounds__(64) void inflate_bgzf_kernel(InflateArgs a) {
   const bool dst_aligned = (reinterpret_cast<uintptr_t>(dst) & 3u) == 0;
   BitIn in;
   in.start(a.comp, a.n_comp, mem.data_off, mem.data_off, lane);
-  const int64_t bit_limit = static_cast<int64_t>(mem.data_len) * 8;
-  int64_t out_pos = 0, flushed = 0;
+  const int bit_limit = static_cast<int>(mem.data_len) * 8;
+  int out_pos = 0, flushed = 0, fenced = 0;  // text produced / stored to HBM / known to be visible there
   bool last = false;
 
   auto flush_groups = [&]() {
@@ -264,7 +287,7 @@ __global__ __launch_bounds__(64) void inflate_bgzf_kernel(InflateArgs a) {
       if (byte0 + len > mem.data_off + static_cast<int64_t>(mem.data_len)) { err = kInputOverrun; break; }
       if (out_pos + len > isize) { err = kOutputOverrun; break; }
       for (uint32_t done = 0; done < len;) {  // through the window in pieces that fit it
-        const uint32_t step = len - done < 16384u ? len - done : 16384u;
+        const uint32_t step = len - done < static_cast<uint32_t>(W / 2) ? len - done : static_cast<uint32_t>(W / 2);
         for (uint32_t k = lane; k < step; k += 64) s.win[(out_pos + k) & (kWin - 1)] = a.comp[byte0 + done + k];
         __syncthreads();
         out_pos += step;
@@ -335,15 +358,20 @@ __global__ __launch_bounds__(64) void inflate_bgzf_kernel(InflateArgs a) {
     if (!build_tables<kDistBits, 64>(s.lens + n_lit, n_dist, s.dist, lane)) { err = kBadCodeLengths; break; }
 
     // ---- the symbols of the block --------------------------------------------------------------
+    // `e` = the table entry of the NEXT symbol, looked up while the copy of the current match is
+    // still on its way through the LDS (the look-up only peeks at the bits)
+    in.fill();
+    uint32_t e = peek_entry<kLitBits>(in, s.lit);
     for (;;) {
-      in.fill();
       if (in.pos_bits() > bit_limit + 64) { err = kInputOverrun; break; }
-      int sym = decode_symbol<kLitBits>(in, s.lit);
+      int sym = take_symbol(in, s.lit, e);
       if (sym < 0) { err = kBadSymbol; break; }
       if (sym < 256) {
         if (out_pos >= isize) { err = kOutputOverrun; break; }
-        if (lane == 0) s.win[out_pos & (kWin - 1)] = static_cast<uint8_t>(sym);
+        s.win[out_pos & (kWin - 1)] = static_cast<uint8_t>(sym);  // all lanes, one address: no exec-mask juggling
         ++out_pos;
+        in.fill();
+        e = peek_entry<kLitBits>(in, s.lit);
       } else if (sym == 256) {
         break;
       } else {
@@ -355,8 +383,8 @@ __global__ __launch_bounds__(64) void inflate_bgzf_kernel(InflateArgs a) {
         } else if (sym == 28) {
           len = 258;
         } else {
-          const int e = (sym - 4) >> 2;
-          len = 3 + ((4 + (sym & 3)) << e) + static_cast<int>(in.take(e));
+          const int x = (sym - 4) >> 2;
+          len = 3 + ((4 + (sym & 3)) << x) + static_cast<int>(in.take(x));
         }
         in.fill();
         const int dsym = decode_symbol<kDistBits>(in, s.dist);
@@ -365,25 +393,59 @@ __global__ __launch_bounds__(64) void inflate_bgzf_kernel(InflateArgs a) {
         if (dsym < 4) {
           dist = 1 + dsym;
         } else {
-          const int e = (dsym >> 1) - 1;
-          dist = 1 + ((2 + (dsym & 1)) << e) + static_cast<int>(in.take(e));
+          const int x = (dsym >> 1) - 1;
+          dist = 1 + ((2 + (dsym & 1)) << x) + static_cast<int>(in.take(x));
         }
         if (dist > out_pos) { err = kBadDistance; break; }
         if (out_pos + len > isize) { err = kOutputOverrun; break; }
-        const int64_t src = out_pos - dist;
-        if (dist >= len) {
-          for (int k = lane; k < len; k += 64) s.win[(out_pos + k) & (kWin - 1)] = s.win[(src + k) & (kWin - 1)];
-        } else {
-          // the match overlaps its own output: the text repeats with period `dist`
+        const int src = out_pos - dist;
+        if (W < 32768 && dist > W) {
+          // further back than the LDS history: the text is in HBM already (everything but the last
+          // few hundred bytes is); one fence per 16 KiB of output makes this wavefront's own stores
+          // visible to all its lanes
+          if (src + len > fenced) {
+            __threadfence();
+            fenced = flushed;
+          }
           uint8_t b[5];
 #pragma unroll
           for (int j = 0; j < 5; ++j) {
             const int k = j * 64 + lane;
-            b[j] = k < len ? s.win[(src + k % dist) & (kWin - 1)] : 0;
+            b[j] = k < len ? __hip_atomic_load(dst + src + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : uint8_t(0);
           }
+          in.fill();
+          e = peek_entry<kLitBits>(in, s.lit);
 #pragma unroll
           for (int j = 0; j < 5; ++j) {
             const int k = j * 64 + lane;
+            if (k < len) s.win[(out_pos + k) & (kWin - 1)] = b[j];
+          }
+          out_pos += len;
+          if (out_pos - flushed >= 256) {
+            __syncthreads();
+            flush_groups();
+          }
+          continue;
+        }
+        // first 64 bytes of the match: loads, then the next symbol's look-up, then the stores
+        // (a match that overlaps its own output repeats with period `dist`)
+        int k0 = lane;
+        if (dist < len) k0 = dist == 1 ? 0 : lane % dist;  // uniform branch; the division only where the text repeats
+        uint8_t b0 = 0;
+        if (lane < len) b0 = s.win[(src + k0) & (kWin - 1)];
+        in.fill();
+        e = peek_entry<kLitBits>(in, s.lit);
+        if (lane < len) s.win[(out_pos + lane) & (kWin - 1)] = b0;
+        if (len > 64) {
+          uint8_t b[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int k = (j + 1) * 64 + lane;
+            b[j] = k < len ? s.win[(src + (dist >= len ? k : k % dist)) & (kWin - 1)] : 0;
+          }
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int k = (j + 1) * 64 + lane;
             if (k < len) s.win[(out_pos + k) & (kWin - 1)] = b[j];
           }
         }
@@ -402,7 +464,7 @@ __global__ __launch_bounds__(64) void inflate_bgzf_kernel(InflateArgs a) {
   if (err == kOk) {
     __syncthreads();
     flush_groups();
-    for (int64_t k = flushed + lane; k < out_pos; k += 64) dst[k] = s.win[k & (kWin - 1)];
+    for (int k = flushed + lane; k < out_pos; k += 64) dst[k] = s.win[k & (kWin - 1)];
   }
   if (lane == 0) a.status[m] = err;
 }
@@ -425,6 +487,12 @@ extern "C" int sai_inflate_bgzf(sai_ctx* ctx, const void* comp, int64_t n_comp_b
   a.text = static_cast<uint8_t*>(text);
   a.n_text = n_text_bytes;
   a.status = status;
-  hipLaunchKernelGGL(inflate_bgzf_kernel, dim3(static_cast<unsigned>(n_members)), dim3(64), 0, static_cast<hipStream_t>(stream), a);
+  static const int window = [] {  // SAI_INFLATE_WINDOW=32768: the whole DEFLATE window in LDS (for A/B runs)
+    const char* e = std::getenv("SAI_INFLATE_WINDOW");
+    return e && std::atoi(e) == 32768 ? 32768 : 16384;
+  }();
+  const dim3 grid(static_cast<unsigned>(n_members));
+  if (window == 32768) hipLaunchKernelGGL(inflate_bgzf_kernel<32768>, grid, dim3(64), 0, static_cast<hipStream_t>(stream), a);
+  else hipLaunchKernelGGL(inflate_bgzf_kernel<16384>, grid, dim3(64), 0, static_cast<hipStream_t>(stream), a);
   return check_launch("inflate_bgzf");
 }

@@ -213,6 +213,17 @@ def _load_bgzf_device(eng, vcf_file, chr_name, samples, ploidies, start, end, an
             outs.append(out)
             stats.append(status)
 
+    import time as _time
+
+    trace = {} if os.environ.get("SAI_AMD_INGEST_TRACE") else None
+    t_mark = [_time.perf_counter()]
+
+    def lap(name):
+        if trace is not None:
+            now = _time.perf_counter()
+            trace[name] = trace.get(name, 0.0) + now - t_mark[0]
+            t_mark[0] = now
+
     try:
         buf, n_comp, n_mem, n_text, done = C.c_int32(), C.c_int64(), C.c_int32(), C.c_int64(), C.c_int32()
         table_p = C.c_void_p()
@@ -221,11 +232,14 @@ def _load_bgzf_device(eng, vcf_file, chr_name, samples, ploidies, start, end, an
         while True:
             batch = None
             if not reader_done:
+                lap("other")
                 if h2d is not None:
                     h2d.synchronize()  # next() releases the pinned buffer of the batch before
+                lap("wait_h2d")
                 if lib.sai_bgzf_stream_next(handle, C.byref(buf), C.byref(n_comp), C.byref(n_mem), C.byref(table_p),
                                             C.byref(n_text), C.byref(done)):  # fmt: skip
                     raise _io_error(lib)
+                lap("wait_reader")
                 if done.value:
                     reader_done = True
                 else:
@@ -245,12 +259,15 @@ def _load_bgzf_device(eng, vcf_file, chr_name, samples, ploidies, start, end, an
                                                  C.c_void_p(side.cuda_stream))
                         )  # fmt: skip
                     batch = {"b": b, "n_text": nt, "table": table, "d_stat": d_stat, "d_tab": d_tab}
+            lap("enqueue_inflate")
             if prev is not None:
                 prev["d2h"].synchronize()
+                lap("wait_d2h")
                 if int(flag_host[prev["b"]][0]):
                     raise ValueError(f"{vcf_file}: BGZF block fails to inflate or its CRC")
                 base = room - prev["carry"]
                 index_and_tokenize(prev["b"], base, prev["carry"] + prev["n_text"], prev["carry"], prev["table"], False)
+                lap("index_and_tokenize")
                 carry = prev["carry"] + prev["n_text"] - int(usable.value)
                 carry_at = (prev["b"], base + int(usable.value))
                 if carry > room:
@@ -277,13 +294,18 @@ def _load_bgzf_device(eng, vcf_file, chr_name, samples, ploidies, start, end, an
         n_match, n_anc, cols = C.c_int64(), C.c_int64(), C.c_int32()
         have_header = lib.sai_bgzf_stream_selection(handle, None, 0, C.byref(cols), C.byref(n_match), C.byref(n_anc)) == 0
     finally:
+        lap("other")
         lib.sai_bgzf_stream_close(handle)
         side.synchronize()  # also on an error: the staging buffers are reused by the next call
         copy.synchronize()
+        lap("close_and_drain")
     if stats and bool(torch.cat(stats).any()):
         load_dosage(vcf_file, chr_name, samples, ploidies, start, end, anc_allele_file, n_threads)
         raise ValueError(f"{vcf_file}: the GPU tokenizer flagged a line the host reader accepts")
     torch.cuda.current_stream(eng.device).wait_stream(side)
     pos = np.concatenate(pos_parts) if pos_parts else np.zeros(0, dtype=np.int32)
     dos = torch.cat(outs) if len(outs) > 1 else (outs[0] if outs else torch.empty((0, n), dtype=torch.int8, device=eng.device))
+    lap("status_and_concat")
+    if trace is not None:
+        print("bgzf route, ms:", " ".join(f"{k}={1e3 * v:.1f}" for k, v in trace.items()), flush=True)
     return pos, dos, (int(n_match.value) if have_header else 0), (int(n_anc.value) if have_header else 0)

@@ -109,6 +109,14 @@ def test_every_block_type_and_shape(eng):
     add(bytes(rng.integers(0, 256, size=2000, dtype=np.uint8)) * 30)  # long matches at distance 2000
     period = bytes(rng.integers(0, 256, size=32768, dtype=np.uint8))
     add(period + period)  # matches at distance 32768, the far end of the window
+    add(period[:20000] * 3 + period[:5536])  # distances beyond the 16 KiB kept in LDS: served from the text in HBM
+    mix = bytearray(vcf_like(rng, 65536))
+    for _ in range(40):  # far and near matches interleaved
+        o = int(rng.integers(0, 30000))
+        n = int(rng.integers(3, 300))
+        t = int(rng.integers(o + 17000, 65536 - n))
+        mix[t : t + n] = mix[o : o + n]
+    add(bytes(mix), level=9)
     add(text[:60000], flush_every=7000)  # several blocks per member, empty stored blocks between them
     add(text[:60000], level=9, flush_every=100)
     # skewed symbol frequencies: Huffman codes longer than the 10-bit / 8-bit primary tables

@@ -62,6 +62,14 @@ def main() -> None:
         ms_copy, ms_inf = e[0].elapsed_time(e[1]), e[1].elapsed_time(e[2])
         print(f"H2D of the compressed bytes {ms_copy:.2f} ms, inflate {ms_inf:.2f} ms = {len(text) / ms_inf / 1e6:.1f} GB/s of text", flush=True)
     assert not bool(d_stat.any())
+    for n_sub in (1, 64, 256, 1024, 2048, 4096, len(chunks)):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        _ffi.check(eng.lib.sai_inflate_bgzf(eng.ctx, C.c_void_p(d_comp.data_ptr()), d_comp.numel(), C.c_void_p(d_tab.data_ptr()),
+                                            n_sub, C.c_void_p(d_text.data_ptr()), out + 8, C.c_void_p(d_stat.data_ptr()), None))  # fmt: skip
+        e1.record()
+        torch.cuda.synchronize()
+        print(f"  first {n_sub:5d} members: {e0.elapsed_time(e1):.3f} ms", flush=True)
     got = d_text[:out].cpu().numpy().tobytes()
     assert got == text
     print("text identical; zlib.crc32 ok:", zlib.crc32(got) == zlib.crc32(text))
