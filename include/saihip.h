@@ -366,9 +366,9 @@ int sai_tokenize_gt(sai_ctx* ctx, const char* text, int64_t n_text_bytes, int64_
  * bytes of the batch in HBM (4-byte aligned, n_comp_bytes a multiple of 4: pad the tail);
  * members[m] = where member m's raw deflate stream lies in comp and where its text goes in `text`
  * (device copy of the table sai_bgzf_stream_next hands out); status[m] = 0, or non-zero for a member
- * that is not valid DEFLATE of exactly isize bytes (nothing outside [out_off, out_off + isize) is
- * ever written).  The CRC-32 of the trailer is checked by the host on the text it receives
- * (sai_vcf_index_text), as after the host's own inflate. */
+ * that is not valid DEFLATE of exactly isize bytes, or whose text fails the CRC-32 of its trailer
+ * (checked on the GPU as well, by a second launch); nothing outside [out_off, out_off + isize) is
+ * ever written. */
 typedef struct sai_bgzf_member {
   int64_t data_off;  /* first byte of the raw deflate stream inside the compressed batch */
   int64_t out_off;   /* first byte of the member's text inside the batch text */
@@ -389,8 +389,8 @@ int sai_inflate_bgzf(sai_ctx* ctx, const void* comp, int64_t n_comp_bytes, const
  * sai_inflate_bgzf, valid until the following call.  The caller inflates the batch on the GPU behind
  * the n_carry bytes the previous batch left over (its last, incomplete line), copies carry + text to
  * the host once, and calls sai_vcf_index_text(text_host, n_bytes = n_carry + text, n_carry, the
- * batch's member table): the text of every member is checked against its CRC-32, the header is
- * consumed, the complete record lines are indexed exactly as sai_vcf_stream_next reports them
+ * batch's member table, or NULL / 0 when the CRCs have been checked on the GPU): the text of every
+ * member is checked against its CRC-32, the header is consumed, the complete record lines are indexed exactly as sai_vcf_stream_next reports them
  * (offsets relative to text_host, i.e. to the same place in the device copy) and *n_usable = bytes up
  * to the end of the last complete line (is_last: all of it).  *done = 1 once the region has been
  * passed (stop reading).  After the last batch the caller indexes the left-over carry with

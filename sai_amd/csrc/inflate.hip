@@ -14,8 +14,8 @@
 // Every lane executes the same decode on the same values, so nothing is broadcast or synchronised.
 // Each access is bounded (window index masked, output against ISIZE, distance against what the
 // member has produced, input against the member's length): a corrupt member ends with a non-zero
-// status, never with a stray access.  The host checks the CRC-32 of the text it receives
-// (vcf_ingest.cpp), as it does after its own inflate.
+// status, never with a stray access.  A second kernel checks the CRC-32 of every member's text against
+// its gzip trailer, as the host reader does after its own inflate.
 
 #include "common.hpp"
 
@@ -37,6 +37,7 @@ enum : int32_t {
   kSizeMismatch = 6,
   kBadSymbol = 7,
   kBadStored = 8,
+  kCrcMismatch = 9,
 };
 
 template <int BITS, int SYMS>
@@ -469,6 +470,93 @@ __global__ __launch_bounds__(64) void inflate_bgzf_kernel(InflateArgs a) {
   if (lane == 0) a.status[m] = err;
 }
 
+// ---- CRC-32 of every member's text ---------------------------------------------------------------
+// One wavefront per member again, but this part is parallel inside a member: every lane takes a
+// contiguous slice of the text (just written, so it comes from L2), runs the table-driven CRC over it
+// four bytes per step (slicing-by-4, tables in LDS), and the 64 slice CRCs are combined with the
+// GF(2) algebra of zlib's crc32_combine: crc(A || B) = crc(A) * x^(8 |B|) mod P  xor  crc(B).
+
+constexpr uint32_t kCrcPoly = 0xEDB88320u;
+
+// a(x) * b(x) mod P in the reflected representation (bit 31 = x^0)
+__host__ __device__ constexpr uint32_t gf2_multmod(uint32_t a, uint32_t b) {
+  uint32_t p = 0;
+  for (uint32_t m = 1u << 31; m; m >>= 1) {
+    if (a & m) p ^= b;
+    b = (b & 1u) ? (b >> 1) ^ kCrcPoly : b >> 1;
+  }
+  return p;
+}
+
+struct X2nTable {
+  uint32_t v[32];  // x^(2^k) mod P
+  constexpr X2nTable() : v() {
+    uint32_t p = 1u << 30;  // x^1
+    v[0] = p;
+    for (int k = 1; k < 32; ++k) v[k] = p = gf2_multmod(p, p);
+  }
+};
+__constant__ const X2nTable kX2n;
+
+// x^(8 n) mod P
+__device__ inline uint32_t gf2_shift_op(uint32_t n_bytes) {
+  uint32_t p = 1u << 31;  // x^0
+  for (int k = 3; n_bytes; n_bytes >>= 1, ++k)
+    if (n_bytes & 1u) p = gf2_multmod(kX2n.v[k & 31], p);
+  return p;
+}
+
+__global__ __launch_bounds__(64) void crc_members_kernel(InflateArgs a) {
+  __shared__ uint32_t tab[4][256];
+  const int lane = threadIdx.x;
+  const int m = blockIdx.x;
+  if (m >= a.n_members) return;
+  if (a.status[m] != kOk) return;  // uniform: nothing sensible to check
+  const sai_bgzf_member mem = a.members[m];
+  for (int i = lane; i < 256; i += 64) {
+    uint32_t c = static_cast<uint32_t>(i);
+    for (int k = 0; k < 8; ++k) c = (c & 1u) ? (c >> 1) ^ kCrcPoly : c >> 1;
+    tab[0][i] = c;
+  }
+  __syncthreads();
+  for (int t = 1; t < 4; ++t) {
+    for (int i = lane; i < 256; i += 64) {
+      const uint32_t c = tab[t - 1][i];
+      tab[t][i] = (c >> 8) ^ tab[0][c & 0xFFu];
+    }
+    __syncthreads();
+  }
+  const uint8_t* p0 = a.text + mem.out_off;
+  const uint8_t* p1 = p0 + mem.isize;
+  // slices on the 4-byte grid of the address space: only the first and the last one have ragged ends
+  const uintptr_t base = reinterpret_cast<uintptr_t>(p0) & ~uintptr_t(3);
+  const uint32_t span = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(p1) - base);
+  const uint32_t slice = ((span + 63u) / 64u + 3u) & ~3u;
+  const uint8_t* lo = reinterpret_cast<const uint8_t*>(base) + static_cast<size_t>(lane) * slice;
+  const uint8_t* hi = lo + slice;
+  if (lo < p0) lo = p0;
+  if (hi > p1) hi = p1;
+  uint32_t crc = 0;
+  uint32_t after = 0;
+  if (lo < hi) {
+    uint32_t c = 0xFFFFFFFFu;
+    const uint8_t* q = lo;
+    while (q < hi && (reinterpret_cast<uintptr_t>(q) & 3u)) c = tab[0][(c ^ *q++) & 0xFFu] ^ (c >> 8);
+    for (; q + 4 <= hi; q += 4) {
+      c ^= *reinterpret_cast<const uint32_t*>(q);
+      c = tab[3][c & 0xFFu] ^ tab[2][(c >> 8) & 0xFFu] ^ tab[1][(c >> 16) & 0xFFu] ^ tab[0][c >> 24];
+    }
+    while (q < hi) c = tab[0][(c ^ *q++) & 0xFFu] ^ (c >> 8);
+    crc = c ^ 0xFFFFFFFFu;
+    after = static_cast<uint32_t>(p1 - hi);
+  }
+  // shift every slice CRC by the bytes behind it and fold (an empty slice contributes nothing)
+  uint32_t part = (lo < hi) ? gf2_multmod(gf2_shift_op(after), crc) : 0u;
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) part ^= __shfl_xor(part, off);
+  if (lane == 0 && part != mem.crc) a.status[m] = kCrcMismatch;
+}
+
 }  // namespace
 
 extern "C" int sai_inflate_bgzf(sai_ctx* ctx, const void* comp, int64_t n_comp_bytes, const sai_bgzf_member* members,
@@ -494,5 +582,7 @@ extern "C" int sai_inflate_bgzf(sai_ctx* ctx, const void* comp, int64_t n_comp_b
   const dim3 grid(static_cast<unsigned>(n_members));
   if (window == 32768) hipLaunchKernelGGL(inflate_bgzf_kernel<32768>, grid, dim3(64), 0, static_cast<hipStream_t>(stream), a);
   else hipLaunchKernelGGL(inflate_bgzf_kernel<16384>, grid, dim3(64), 0, static_cast<hipStream_t>(stream), a);
-  return check_launch("inflate_bgzf");
+  if (int rc = check_launch("inflate_bgzf")) return rc;
+  hipLaunchKernelGGL(crc_members_kernel, grid, dim3(64), 0, static_cast<hipStream_t>(stream), a);
+  return check_launch("crc_members");
 }

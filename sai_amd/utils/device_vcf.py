@@ -20,6 +20,7 @@ from .. import _ffi
 from .native_vcf import default_threads, load_dosage
 
 BUFFER_BYTES = 32 << 20
+INFLATE_BATCH_BYTES = 128 << 20
 _MEMBER_BYTES = 32  # sizeof(sai_bgzf_member)
 
 
@@ -42,7 +43,9 @@ def load_dosage_device(eng, vcf_file: str, chr_name: str, samples: Sequence[str]
     cap = int(buffer_bytes or os.environ.get("SAI_AMD_INGEST_BUFFER", BUFFER_BYTES))
     if os.environ.get("SAI_AMD_GPU_INFLATE", "1") != "0":
         try:
-            got = _load_bgzf_device(eng, vcf_file, chr_name, samples, ploidies, start, end, anc_allele_file, n_threads, cap)
+            # 2 048 members are in flight on the chip at a time: a batch of 128 MiB of text fills it
+            icap = int(buffer_bytes or os.environ.get("SAI_AMD_INFLATE_BATCH", INFLATE_BATCH_BYTES))
+            got = _load_bgzf_device(eng, vcf_file, chr_name, samples, ploidies, start, end, anc_allele_file, n_threads, icap)
             if got is not None:
                 return got
         except _Fallback:
@@ -131,15 +134,16 @@ def load_dosage_device(eng, vcf_file: str, chr_name: str, samples: Sequence[str]
 
 def _load_bgzf_device(eng, vcf_file, chr_name, samples, ploidies, start, end, anc_allele_file, n_threads, cap):
     """``load_dosage_device`` for a bgzip file without a region seek: the compressed members cross
-    PCIe and are inflated by ``sai_inflate_bgzf`` (one wavefront per member); the text comes back to
-    the host ONCE, for ``sai_vcf_index_text`` (CRC of every member, header, record index -- the same
-    code the host stream runs), and is tokenised where it lies in HBM.  Batch k+1 is being inflated
+    PCIe and are inflated by ``sai_inflate_bgzf`` (one wavefront per member); a second
+    launch checks every member's CRC-32; the text comes back to the host ONCE, for
+    ``sai_vcf_index_text`` (header, record index -- the same code the host stream runs), and is
+    tokenised where it lies in HBM.  Batch k+1 is being inflated
     while the host indexes batch k.  Returns None when the file is not bgzip (or a tabix index
     serves the region): the caller falls back to the host-inflating stream."""
     import torch
 
     lib = eng.lib
-    room = max(1 << 20, cap // 4)  # the incomplete last line of a batch is carried in front of the next one
+    room = max(1 << 20, min(cap // 4, 8 << 20))  # the incomplete last line of a batch is carried in front of the next one
     comp_cap = cap // 4 + (1 << 20)
     st = eng.__dict__.setdefault("_inflate_state", {})
     if st.get("cap") != cap:
@@ -152,8 +156,9 @@ def _load_bgzf_device(eng, vcf_file, chr_name, samples, ploidies, start, end, an
         st["flag_host"] = [torch.zeros((1,), dtype=torch.int32).pin_memory() for _ in range(2)]
         st["side"] = torch.cuda.Stream(device=eng.device)
         st["copy"] = torch.cuda.Stream(device=eng.device)
+        st["d2h"] = torch.cuda.Stream(device=eng.device)
     comp_host, comp_dev, text_host, text_dev = st["comp_host"], st["comp_dev"], st["text_host"], st["text_dev"]
-    flag_host, side, copy = st["flag_host"], st["side"], st["copy"]
+    flag_host, side, copy, d2h = st["flag_host"], st["side"], st["copy"], st["d2h"]
     n = len(samples)
     names = (C.c_char_p * n)(*[s.encode() for s in samples])
     pl = (C.c_int32 * n)(*[int(p) for p in ploidies])
@@ -228,7 +233,10 @@ def _load_bgzf_device(eng, vcf_file, chr_name, samples, ploidies, start, end, an
         buf, n_comp, n_mem, n_text, done = C.c_int32(), C.c_int64(), C.c_int32(), C.c_int64(), C.c_int32()
         table_p = C.c_void_p()
         prev, h2d, reader_done = None, None, False
-        carry, carry_at = 0, (0, 0)  # bytes left over by the batch before, and where they lie (buffer, offset)
+        # Per batch: H2D of the compressed bytes (copy stream) -> inflate (side stream) -> D2H of the
+        # text (d2h stream), all enqueued as soon as the reader hands the batch over; the host then
+        # indexes the batch BEFORE it while those run.  The incomplete last line of batch k is copied
+        # in front of batch k+1 on both sides (host memcpy, D2D copy) once the index of k is known.
         while True:
             batch = None
             if not reader_done:
@@ -258,38 +266,43 @@ def _load_bgzf_device(eng, vcf_file, chr_name, samples, ploidies, start, end, an
                                                  C.c_void_p(text_dev[b].data_ptr() + room), nt, C.c_void_p(d_stat.data_ptr()),
                                                  C.c_void_p(side.cuda_stream))
                         )  # fmt: skip
-                    batch = {"b": b, "n_text": nt, "table": table, "d_stat": d_stat, "d_tab": d_tab}
+                        inflated = torch.cuda.Event()
+                        inflated.record(side)
+                    with torch.cuda.stream(d2h):
+                        d2h.wait_event(inflated)
+                        text_host[b][room : room + nt].copy_(text_dev[b][room : room + nt], non_blocking=True)
+                        flag_host[b].copy_((d_stat != 0).sum(dtype=torch.int32).reshape(1), non_blocking=True)
+                        back = torch.cuda.Event()
+                        back.record(d2h)
+                    batch = {"b": b, "n_text": nt, "table": table, "d_stat": d_stat, "d_tab": d_tab, "d2h": back, "carry": 0}
             lap("enqueue_inflate")
             if prev is not None:
                 prev["d2h"].synchronize()
                 lap("wait_d2h")
                 if int(flag_host[prev["b"]][0]):
                     raise ValueError(f"{vcf_file}: BGZF block fails to inflate or its CRC")
-                base = room - prev["carry"]
-                index_and_tokenize(prev["b"], base, prev["carry"] + prev["n_text"], prev["carry"], prev["table"], False)
+                pb, base = prev["b"], room - prev["carry"]
+                index_and_tokenize(pb, base, prev["carry"] + prev["n_text"], prev["carry"], None, False)  # CRCs: checked on the GPU
                 lap("index_and_tokenize")
-                carry = prev["carry"] + prev["n_text"] - int(usable.value)
-                carry_at = (prev["b"], base + int(usable.value))
-                if carry > room:
+                left = prev["carry"] + prev["n_text"] - int(usable.value)
+                at = base + int(usable.value)
+                if left > room:
                     raise _Fallback  # a record line longer than the carry room
                 if idone.value:
                     break
-            if batch is None:
-                if prev is not None and carry:  # the file ends without a newline
-                    index_and_tokenize(carry_at[0], carry_at[1], carry, carry, None, True)
-                elif prev is None:  # an empty file: let the indexer say what is missing
-                    index_and_tokenize(0, room, 0, 0, None, True)
+                if batch is None:
+                    if left:  # the file ends without a newline
+                        index_and_tokenize(pb, at, left, left, None, True)
+                    break
+                if left:
+                    nb = batch["b"]
+                    text_host[nb][room - left : room].copy_(text_host[pb][at : at + left])
+                    with torch.cuda.stream(side):
+                        text_dev[nb][room - left : room].copy_(text_dev[pb][at : at + left], non_blocking=True)
+                    batch["carry"] = left
+            elif batch is None:  # not a single batch: let the indexer say what is missing
+                index_and_tokenize(0, room, 0, 0, None, True)
                 break
-            b, nt = batch["b"], batch["n_text"]
-            with torch.cuda.stream(side):
-                lo = room - carry
-                if carry:
-                    text_dev[b][lo:room].copy_(text_dev[carry_at[0]][carry_at[1] : carry_at[1] + carry], non_blocking=True)
-                text_host[b][lo : room + nt].copy_(text_dev[b][lo : room + nt], non_blocking=True)
-                flag_host[b].copy_((batch["d_stat"] != 0).sum(dtype=torch.int32).reshape(1), non_blocking=True)
-                batch["d2h"] = torch.cuda.Event()
-                batch["d2h"].record(side)
-            batch["carry"] = carry
             prev = batch
         n_match, n_anc, cols = C.c_int64(), C.c_int64(), C.c_int32()
         have_header = lib.sai_bgzf_stream_selection(handle, None, 0, C.byref(cols), C.byref(n_match), C.byref(n_anc)) == 0
@@ -298,6 +311,7 @@ def _load_bgzf_device(eng, vcf_file, chr_name, samples, ploidies, start, end, an
         lib.sai_bgzf_stream_close(handle)
         side.synchronize()  # also on an error: the staging buffers are reused by the next call
         copy.synchronize()
+        d2h.synchronize()
         lap("close_and_drain")
     if stats and bool(torch.cat(stats).any()):
         load_dosage(vcf_file, chr_name, samples, ploidies, start, end, anc_allele_file, n_threads)

@@ -41,7 +41,7 @@ def main() -> None:
     table = np.zeros(len(chunks), dtype=MEMBER)
     comp, off, out = bytearray(), 0, 0
     for i, (s, t) in enumerate(zip(streams, chunks)):
-        table[i] = (len(comp), out, len(s), len(t), 0, 0)
+        table[i] = (len(comp), out, len(s), len(t), zlib.crc32(t), 0)
         comp += s
         out += len(t)
     comp += b"\0" * (-len(comp) % 4 + 4)
