@@ -392,7 +392,8 @@ int sai_inflate_bgzf(sai_ctx* ctx, const void* comp, int64_t n_comp_bytes, const
  * batch's member table, or NULL / 0 when the CRCs have been checked on the GPU): the text of every
  * member is checked against its CRC-32, the header is consumed, the complete record lines are indexed exactly as sai_vcf_stream_next reports them
  * (offsets relative to text_host, i.e. to the same place in the device copy) and *n_usable = bytes up
- * to the end of the last complete line (is_last: all of it).  *done = 1 once the region has been
+ * to the end of the last complete line (is_last: all of it); the header itself was read when the
+ * stream was opened, '#' lines are skipped.  *done = 1 once the region has been
  * passed (stop reading).  After the last batch the caller indexes the left-over carry with
  * n_members = 0, is_last = 1.  sai_bgzf_stream_selection as sai_vcf_stream_selection. */
 typedef struct sai_bgzf_stream sai_bgzf_stream;
@@ -402,14 +403,42 @@ int sai_bgzf_stream_open(const char* path, const char* chrom, int64_t start, int
                          int64_t text_batch_bytes, sai_bgzf_stream** stream_out);
 int sai_bgzf_stream_next(sai_bgzf_stream* stream, int32_t* buffer_index, int64_t* n_comp_bytes, int32_t* n_members,
                          const sai_bgzf_member** members_host, int64_t* n_text_bytes, int32_t* done);
+/* Early form of the release sai_bgzf_stream_next performs: the batch's compressed bytes have been
+ * copied (and the member table too: it is refilled with the buffer), the reader may go on. */
+int sai_bgzf_stream_release(sai_bgzf_stream* stream);
 int sai_vcf_index_text(sai_bgzf_stream* stream, const char* text_host, int64_t n_bytes, int64_t n_carry,
                        const sai_bgzf_member* members_host, int32_t n_members, int32_t is_last, int64_t* n_usable,
                        int64_t* n_lines, const int64_t** line_off_host, const int32_t** line_len_host,
                        const int32_t** line_pos_host, const uint8_t** line_flip_host, const uint8_t** line_gi_host,
                        int32_t* done);
+/* The same index from the line table of sai_text_line_starts / sai_text_line_heads (host copies):
+ * heads_host[i * head_bytes ...] = the first bytes of line i, line_start_host[0 .. n_lines], the
+ * line_info words; head_bytes must cover info[1] (the longest fixed-column part).  Record lines are
+ * reported exactly as by sai_vcf_index_text, with offsets relative to the text the table was made of. */
+int sai_vcf_index_heads(sai_bgzf_stream* stream, const char* heads_host, int32_t head_bytes, const int64_t* line_start_host,
+                        const int32_t* line_info_host, int64_t n_lines, int64_t* n_record_lines,
+                        const int64_t** line_off_host, const int32_t** line_len_host, const int32_t** line_pos_host,
+                        const uint8_t** line_flip_host, const uint8_t** line_gi_host, int32_t* done);
 int sai_bgzf_stream_selection(sai_bgzf_stream* stream, int32_t* slot_of_col_host, int32_t capacity, int32_t* n_cols,
                               int64_t* n_matched, int64_t* n_anc_entries);
 int sai_bgzf_stream_close(sai_bgzf_stream* stream);
+
+/* The line structure of a text batch in HBM (the text sai_inflate_bgzf produced), so that the host
+ * can index the records from a few MB instead of the whole text.  sai_text_line_starts: n = number
+ * of newlines (info[0]); line_start[i] = offset of line i for i = 0 .. n (line_start[0] = 0,
+ * line_start[n] = first byte behind the last complete line = the bytes usable in this batch);
+ * line_info[i] = bytes of line i up to and including its ninth tab -- the fixed columns CHROM ..
+ * FORMAT -- or 1 for a '#' line, or (bytes of the line + 1) when it has fewer than ten columns, or
+ * 4097 when the ninth tab is further than 4096 bytes away; bit 31 = the line ends with "\r\n";
+ * info[1] = the largest of them; info[2] = 1 when line_capacity was too small (nothing beyond it is
+ * written).  block_scratch: (n_bytes + 15) / 4096 + 2 int32.  The text buffer must be readable up to
+ * the next 16-byte boundary behind n_bytes (aligned 16-byte loads).  sai_text_line_heads then copies
+ * the first head_bytes (a multiple of 4) of lines 0 .. n_lines-1 into heads[line][head_bytes], padded
+ * with '\n' behind the line's own newline. */
+int sai_text_line_starts(sai_ctx* ctx, const char* text, int64_t n_bytes, int64_t line_capacity, int64_t* line_start,
+                         int32_t* line_info, int32_t* block_scratch, int32_t* info, void* stream);
+int sai_text_line_heads(sai_ctx* ctx, const char* text, int64_t n_bytes, const int64_t* line_start, int64_t n_lines,
+                        int32_t head_bytes, void* heads, void* stream);
 
 /* ---- output text (host side) -------------------------------------------------------------- */
 

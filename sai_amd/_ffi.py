@@ -132,6 +132,8 @@ SIGNATURES = {
     "sai_vcf_stream_selection": (C.c_int, [_p, _p, _i32, C.POINTER(_i32), C.POINTER(_i64), C.POINTER(_i64)]),
     "sai_vcf_stream_close": (C.c_int, [_p]),
     "sai_inflate_bgzf": (C.c_int, [_p, _p, _i64, _p, _i32, _p, _i64, _p, _p]),
+    "sai_text_line_starts": (C.c_int, [_p, _p, _i64, _i64, _p, _p, _p, _p, _p]),
+    "sai_text_line_heads": (C.c_int, [_p, _p, _i64, _p, _i64, _i32, _p, _p]),
     "sai_bgzf_stream_open": (
         C.c_int,
         [C.c_char_p, C.c_char_p, _i64, _i64, _i32, C.POINTER(C.c_char_p), C.POINTER(_i32), C.c_char_p, _i32, _p, _p, _i64,
@@ -144,6 +146,12 @@ SIGNATURES = {
         C.c_int,
         [_p, _p, _i64, _i64, _p, _i32, _i32, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_p), C.POINTER(_p), C.POINTER(_p),
          C.POINTER(_p), C.POINTER(_p), C.POINTER(_i32)],
+    ),
+    "sai_bgzf_stream_release": (C.c_int, [_p]),
+    "sai_vcf_index_heads": (
+        C.c_int,
+        [_p, _p, _i32, _p, _p, _i64, C.POINTER(_i64), C.POINTER(_p), C.POINTER(_p), C.POINTER(_p), C.POINTER(_p),
+         C.POINTER(_p), C.POINTER(_i32)],
     ),
     "sai_bgzf_stream_selection": (C.c_int, [_p, _p, _i32, C.POINTER(_i32), C.POINTER(_i64), C.POINTER(_i64)]),
     "sai_bgzf_stream_close": (C.c_int, [_p]),
@@ -166,7 +174,7 @@ HOST_SYMBOLS = (
     "sai_abi_version", "sai_build_arch", "sai_last_error", "sai_synth_fill_host", "sai_synth_gaps_host",
     "sai_narrow_to_int8", "sai_vcf_scan", "sai_vcf_load", "sai_vcf_block_info", "sai_vcf_block_copy", "sai_vcf_block_free",
     "sai_vcf_stream_open", "sai_vcf_stream_next", "sai_vcf_stream_selection", "sai_vcf_stream_close",
-    "sai_bgzf_stream_open", "sai_bgzf_stream_next", "sai_vcf_index_text", "sai_bgzf_stream_selection", "sai_bgzf_stream_close",
+    "sai_bgzf_stream_open", "sai_bgzf_stream_next", "sai_bgzf_stream_release", "sai_vcf_index_text", "sai_vcf_index_heads", "sai_bgzf_stream_selection", "sai_bgzf_stream_close",
     "sai_format_score_rows", "sai_format_log_rows", "sai_format_doubles", "sai_text_data", "sai_text_free",
 )  # fmt: skip
 

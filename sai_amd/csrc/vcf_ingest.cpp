@@ -1277,6 +1277,7 @@ int bgzf_reader_run(sai_bgzf_stream* st) {
   if (fstat(fd, &sb) != 0) return sai_set_error(SAI_ERR_ARG, "cannot stat %s", path);
   const size_t total = static_cast<size_t>(sb.st_size);
   size_t file_off = 0;
+  WorkerPool readers(std::max(1, std::min(st->n_threads, 8)));
   while (file_off < total) {
     int b;
     {
@@ -1287,13 +1288,23 @@ int bgzf_reader_run(sai_bgzf_stream* st) {
     }
     unsigned char* dst = st->bufs[b];
     const size_t want = std::min(st->cap - 8, total - file_off);  // 8 bytes of zero padding behind the data
-    size_t have = 0;
-    while (have < want) {
-      const ssize_t got = pread(fd, dst + have, want - have, static_cast<off_t>(file_off + have));
-      if (got < 0) return sai_set_error(SAI_ERR_ARG, "read error in %s", path);
-      if (got == 0) break;
-      have += static_cast<size_t>(got);
+    {
+      // one thread copies ~3 GB/s out of the page cache, i.e. ~35 GB/s of text: not enough
+      const int rt = static_cast<int>(std::min<size_t>(static_cast<size_t>(readers.size()), want / (size_t(1) << 20) + 1));
+      std::vector<char> bad(static_cast<size_t>(rt), 0);
+      auto piece = [&](int t) {
+        size_t lo = want * static_cast<size_t>(t) / static_cast<size_t>(rt), hi = want * static_cast<size_t>(t + 1) / static_cast<size_t>(rt);
+        while (lo < hi) {
+          const ssize_t got = pread(fd, dst + lo, hi - lo, static_cast<off_t>(file_off + lo));
+          if (got <= 0) { bad[static_cast<size_t>(t)] = 1; return; }
+          lo += static_cast<size_t>(got);
+        }
+      };
+      readers.run(rt, piece);
+      for (char x : bad)
+        if (x) return sai_set_error(SAI_ERR_ARG, "read error in %s", path);
     }
+    const size_t have = want;
     std::vector<sai_bgzf_member>& mem = st->members[b];
     mem.clear();
     size_t off = 0, out_total = 0;
@@ -1360,6 +1371,83 @@ void bgzf_reader_thread(sai_bgzf_stream* st) {
     st->finished = true;
   }
   st->cv.notify_all();
+}
+
+// index_lines on the line heads the GPU gathered (sai_text_line_starts / _heads): line i of the
+// batch starts at start[i], its first min(H, length) bytes are heads[i * H ...], info[i] says how long
+// its fixed columns are and whether it ends with "\r\n".  Same decisions, same outputs.
+void index_head_lines(const char* heads, int32_t H, const int64_t* start, const int32_t* info, int64_t i0, int64_t i1,
+                      const std::string& chrom, int64_t region_start, int64_t stop, const AncMap& anc, IndexOut& out) {
+  for (int64_t i = i0; i < i1; ++i) {
+    const char* line = heads + i * static_cast<int64_t>(H);
+    const int cr = static_cast<int>(static_cast<uint32_t>(info[i]) >> 31);
+    const int64_t line_len = start[i + 1] - 1 - cr - start[i];
+    if (line_len <= 0 || *line == '#') continue;
+    const int32_t fixed = info[i] & 0x7FFFFFFF;
+    const char* le = line + std::min<int64_t>(H, line_len);  // end of what is known of the line
+    const char* t1 = find_tab(line, le);
+    if (static_cast<size_t>(t1 - line) != chrom.size() || memcmp(line, chrom.data(), chrom.size()) != 0) {
+      out.last_line_other = true;
+      continue;
+    }
+    if (t1 >= le) continue;
+    out.last_line_other = false;
+    out.saw_chrom = true;
+    const char* f = t1 + 1;
+    int64_t pos = 0;
+    while (f < le && *f >= '0' && *f <= '9') pos = pos * 10 + (*f++ - '0');
+    if (stop >= 0 && pos > stop) out.beyond_stop = true;
+    if ((region_start >= 0 && pos < region_start) || (stop >= 0 && pos > stop)) continue;
+    ++out.matched;
+    if (fixed > H) { out.error = "line head shorter than the fixed columns at " + chrom + ":" + std::to_string(pos); return; }
+    const char* col[10];
+    col[0] = line;
+    col[1] = t1 + 1;
+    const char* q = find_tab(f, le);
+    bool ok = true;
+    for (int c = 2; c <= 9; ++c) {
+      if (q >= le) { ok = false; break; }
+      col[c] = q + 1;
+      q = find_tab(col[c], le);
+    }
+    if (!ok) { out.error = "record with fewer than 10 columns at " + chrom + ":" + std::to_string(pos); return; }
+    bool flip = false;
+    if (anc.active) {
+      auto it = anc.allele.find(pos);
+      if (it == anc.allele.end()) continue;
+      const char* ref = col[3];
+      const size_t ref_len = static_cast<size_t>(col[4] - 1 - col[3]);
+      const char* alt = col[4];
+      const char* alt_end = col[5] - 1;
+      const void* comma = memchr(alt, ',', static_cast<size_t>(alt_end - alt));
+      const size_t alt_len = static_cast<size_t>((comma ? static_cast<const char*>(comma) : alt_end) - alt);
+      const std::string& a = it->second;
+      if (a.size() == alt_len && memcmp(a.data(), alt, alt_len) == 0) flip = true;
+      else if (!(a.size() == ref_len && memcmp(a.data(), ref, ref_len) == 0)) continue;
+    }
+    int gi = -1;
+    {
+      const char* fs = col[8];
+      const char* fe = col[9] - 1;
+      int k = 0;
+      while (fs <= fe) {
+        const void* c = memchr(fs, ':', static_cast<size_t>(fe - fs));
+        const char* ce = c ? static_cast<const char*>(c) : fe;
+        if (ce - fs == 2 && fs[0] == 'G' && fs[1] == 'T') { gi = k; break; }
+        if (!c) break;
+        fs = ce + 1;
+        ++k;
+      }
+    }
+    if (gi < 0) { out.error = "record " + chrom + ":" + std::to_string(pos) + " has no GT field"; return; }
+    const int64_t samples_at = col[9] - line;
+    if (gi > 255 || line_len - samples_at > 0x7FFFFFFF) { out.error = "record " + chrom + ":" + std::to_string(pos) + " is outside the streaming limits"; return; }
+    out.off.push_back(start[i] + samples_at);
+    out.len.push_back(static_cast<int32_t>(line_len - samples_at));
+    out.pos.push_back(static_cast<int32_t>(pos));
+    out.flip.push_back(flip ? 1 : 0);
+    out.gi.push_back(static_cast<uint8_t>(gi));
+  }
 }
 
 uint32_t crc32_of(const void* p, size_t n) {
@@ -1934,6 +2022,28 @@ int sai_bgzf_stream_open(const char* path, const char* chrom, int64_t start, int
     }
     if (anc_bed_path)
       if (int rc = load_anc(anc_bed_path, st->chrom, st->start, st->end, st->anc, &st->n_anc)) return rc;
+    {  // the header, from the top of the file (a few blocks, inflated here): the record index --
+       // from the text or from the line heads the GPU extracts -- then only ever skips '#' lines
+      std::vector<const char*> names;
+      for (auto& n : st->names) names.push_back(n.c_str());
+      sai_bgzf_stream* raw = st.get();
+      const int hrc = for_each_block_from(path, 1, 0, size_t(1) << 16, [&](const char* p, const char* endp) -> int {
+        while (!raw->header_seen && p < endp) {
+          const char* eol = static_cast<const char*>(memchr(p, '\n', static_cast<size_t>(endp - p)));
+          if (!eol) eol = endp;
+          if (*p != '#') return sai_set_error(SAI_ERR_ARG, "%s: no #CHROM header line before the records", path);
+          if (eol - p > 6 && memcmp(p, "#CHROM", 6) == 0) {
+            if (int rc = parse_header(p, eol, path, static_cast<int32_t>(names.size()), names.data(), raw->ploidy.data(), raw->sel))
+              return rc;
+            raw->header_seen = true;
+          }
+          p = eol + 1;
+        }
+        return (raw->header_seen || p < endp) ? 1 : 0;
+      });
+      if (hrc) return hrc;
+      if (!st->header_seen) return sai_set_error(SAI_ERR_ARG, "%s: not a VCF (no #CHROM header)", path);
+    }
     st->bufs[0] = static_cast<unsigned char*>(comp0_host);
     st->bufs[1] = static_cast<unsigned char*>(comp1_host);
     st->cap = static_cast<size_t>(comp_buffer_bytes);
@@ -1977,6 +2087,17 @@ int sai_bgzf_stream_next(sai_bgzf_stream* st, int32_t* buffer_index, int64_t* n_
   *n_members = static_cast<int32_t>(st->members[b].size());
   *members_host = st->members[b].data();
   *n_text_bytes = static_cast<int64_t>(st->text_bytes[b]);
+  return SAI_OK;
+}
+
+int sai_bgzf_stream_release(sai_bgzf_stream* st) {
+  if (!st) return sai_set_error(SAI_ERR_ARG, "NULL argument");
+  std::lock_guard<std::mutex> lk(st->m);
+  if (st->held >= 0) {  // the compressed bytes have left the pinned buffer: the reader may refill it now
+    st->state[st->held] = 0;
+    st->held = -1;
+    st->cv.notify_all();
+  }
   return SAI_OK;
 }
 
@@ -2074,6 +2195,56 @@ int sai_vcf_index_text(sai_bgzf_stream* st, const char* text_host, int64_t n_byt
     }
     *n_usable = static_cast<int64_t>(cut - text_host);
     *n_lines = static_cast<int64_t>(st->out.off.size());
+    *line_off_host = st->out.off.data();
+    *line_len_host = st->out.len.data();
+    *line_pos_host = st->out.pos.data();
+    *line_flip_host = st->out.flip.data();
+    *line_gi_host = st->out.gi.data();
+    *done = st->done ? 1 : 0;
+    return SAI_OK;
+  });
+}
+
+int sai_vcf_index_heads(sai_bgzf_stream* st, const char* heads_host, int32_t head_bytes, const int64_t* line_start_host,
+                        const int32_t* line_info_host, int64_t n_lines, int64_t* n_lines_out,
+                        const int64_t** line_off_host, const int32_t** line_len_host, const int32_t** line_pos_host,
+                        const uint8_t** line_flip_host, const uint8_t** line_gi_host, int32_t* done) {
+  return guarded("sai_vcf_index_heads", [&]() -> int {
+    if (!st || !n_lines_out || !line_off_host || !line_len_host || !line_pos_host || !line_flip_host || !line_gi_host || !done)
+      return sai_set_error(SAI_ERR_ARG, "NULL argument");
+    if (n_lines < 0 || head_bytes < 4 || (n_lines > 0 && (!heads_host || !line_start_host || !line_info_host)))
+      return sai_set_error(SAI_ERR_ARG, "bad line table");
+    const char* path = st->path.c_str();
+    if (!st->header_seen) return sai_set_error(SAI_ERR_ARG, "%s: not a VCF (no #CHROM header)", path);
+    const int nt = std::max(1, st->n_threads);
+    st->out.clear();
+    if (n_lines > 0 && !st->done) {
+      for (auto& o : st->outs) o.clear();
+      auto piece = [&](int t) {
+        IndexOut& o = st->outs[static_cast<size_t>(t)];
+        const int64_t i0 = n_lines * t / nt, i1 = n_lines * (t + 1) / nt;
+        if (i0 >= i1) return;
+        try {
+          index_head_lines(heads_host, head_bytes, line_start_host, line_info_host, i0, i1, st->chrom, st->start, st->end, st->anc, o);
+        } catch (...) {
+          o.failed = true;
+        }
+      };
+      st->pool->run(nt, piece);
+      for (auto& o : st->outs) {
+        if (o.failed) return sai_set_error(SAI_ERR_HIP, "%s: indexing failed (out of memory)", path);
+        if (!o.error.empty()) return sai_set_error(SAI_ERR_ARG, "%s: %s", path, o.error.c_str());
+        st->n_matched += o.matched;
+        st->out.off.insert(st->out.off.end(), o.off.begin(), o.off.end());
+        st->out.len.insert(st->out.len.end(), o.len.begin(), o.len.end());
+        st->out.pos.insert(st->out.pos.end(), o.pos.begin(), o.pos.end());
+        st->out.flip.insert(st->out.flip.end(), o.flip.begin(), o.flip.end());
+        st->out.gi.insert(st->out.gi.end(), o.gi.begin(), o.gi.end());
+        st->seen_chrom = st->seen_chrom || o.saw_chrom;
+        if (o.beyond_stop || (st->seen_chrom && o.last_line_other)) st->done = true;
+      }
+    }
+    *n_lines_out = static_cast<int64_t>(st->out.off.size());
     *line_off_host = st->out.off.data();
     *line_len_host = st->out.len.data();
     *line_pos_host = st->out.pos.data();

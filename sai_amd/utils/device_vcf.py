@@ -20,12 +20,17 @@ from .. import _ffi
 from .native_vcf import default_threads, load_dosage
 
 BUFFER_BYTES = 32 << 20
-INFLATE_BATCH_BYTES = 128 << 20
+INFLATE_BATCH_BYTES = 1984 << 16  # 124 MiB: at most 1 984 full members, under the 2 048 the chip holds at a time
 _MEMBER_BYTES = 32  # sizeof(sai_bgzf_member)
 
 
 class _Fallback(Exception):
     """The bgzip-on-the-GPU route cannot serve this read; the host-inflating stream takes it."""
+
+
+class _TextIndex(Exception):
+    """The line heads would be most of the text (short lines) or do not reach the ninth tab: index
+    this file from the whole text instead."""
 
 
 def _io_error(lib) -> ValueError:
@@ -43,9 +48,13 @@ def load_dosage_device(eng, vcf_file: str, chr_name: str, samples: Sequence[str]
     cap = int(buffer_bytes or os.environ.get("SAI_AMD_INGEST_BUFFER", BUFFER_BYTES))
     if os.environ.get("SAI_AMD_GPU_INFLATE", "1") != "0":
         try:
-            # 2 048 members are in flight on the chip at a time: a batch of 128 MiB of text fills it
+            # 2 048 members are in flight on the chip at a time: a batch of 124 MiB of text fills it in one round
             icap = int(buffer_bytes or os.environ.get("SAI_AMD_INFLATE_BATCH", INFLATE_BATCH_BYTES))
-            got = _load_bgzf_device(eng, vcf_file, chr_name, samples, ploidies, start, end, anc_allele_file, n_threads, icap)
+            try:
+                got = _load_bgzf_device(eng, vcf_file, chr_name, samples, ploidies, start, end, anc_allele_file, n_threads, icap)
+            except _TextIndex:
+                got = _load_bgzf_device(eng, vcf_file, chr_name, samples, ploidies, start, end, anc_allele_file, n_threads, icap,
+                                        index_from="text")  # fmt: skip
             if got is not None:
                 return got
         except _Fallback:
@@ -132,33 +141,50 @@ def load_dosage_device(eng, vcf_file: str, chr_name: str, samples: Sequence[str]
     return pos, dos, (int(n_match.value) if have_header else 0), (int(n_anc.value) if have_header else 0)
 
 
-def _load_bgzf_device(eng, vcf_file, chr_name, samples, ploidies, start, end, anc_allele_file, n_threads, cap):
-    """``load_dosage_device`` for a bgzip file without a region seek: the compressed members cross
-    PCIe and are inflated by ``sai_inflate_bgzf`` (one wavefront per member); a second
-    launch checks every member's CRC-32; the text comes back to the host ONCE, for
-    ``sai_vcf_index_text`` (header, record index -- the same code the host stream runs), and is
-    tokenised where it lies in HBM.  Batch k+1 is being inflated
-    while the host indexes batch k.  Returns None when the file is not bgzip (or a tabix index
-    serves the region): the caller falls back to the host-inflating stream."""
+def _load_bgzf_device(eng, vcf_file, chr_name, samples, ploidies, start, end, anc_allele_file, n_threads, cap, index_from=None):
+    """``load_dosage_device`` for a bgzip file without a region seek.  The compressed members cross
+    PCIe and are inflated by ``sai_inflate_bgzf`` (one wavefront per member; a second launch checks
+    every member's CRC-32).  The record index -- chromosome / region filter, POS, the ancestral-allele
+    decision, where the sample columns start: the host's ``index_lines`` rules -- is made from the
+    line table the GPU extracts (``sai_text_line_starts`` / ``_heads``: line offsets + the fixed
+    columns of every line, a few MB) or, ``index_from="text"``, from the whole text copied back once;
+    the text is tokenised where it lies in HBM either way.  Batch k+1 is inflated and scanned while
+    the host indexes batch k.  Returns None when the file is not bgzip (or a tabix index serves the
+    region): the caller falls back to the host-inflating stream."""
     import torch
 
     lib = eng.lib
+    index_from = index_from or os.environ.get("SAI_AMD_BGZF_INDEX", "heads")
     room = max(1 << 20, min(cap // 4, 8 << 20))  # the incomplete last line of a batch is carried in front of the next one
     comp_cap = cap // 4 + (1 << 20)
+    line_cap = (room + cap) // 48 + 16
+    heads_cap = (room + cap) // 4
     st = eng.__dict__.setdefault("_inflate_state", {})
     if st.get("cap") != cap:
         st.clear()
         st["cap"] = cap
         st["comp_host"] = [torch.empty((comp_cap,), dtype=torch.uint8).pin_memory() for _ in range(2)]
         st["comp_dev"] = [torch.empty((comp_cap,), dtype=torch.uint8, device=eng.device) for _ in range(2)]
-        st["text_host"] = [torch.empty((room + cap + 16,), dtype=torch.uint8).pin_memory() for _ in range(2)]
-        st["text_dev"] = [torch.empty((room + cap + 16,), dtype=torch.uint8, device=eng.device) for _ in range(2)]
-        st["flag_host"] = [torch.zeros((1,), dtype=torch.int32).pin_memory() for _ in range(2)]
+        st["text_dev"] = [torch.empty((room + cap + 32,), dtype=torch.uint8, device=eng.device) for _ in range(2)]
+        st["flag_host"] = [torch.zeros((4,), dtype=torch.int32).pin_memory() for _ in range(2)]
         st["side"] = torch.cuda.Stream(device=eng.device)
         st["copy"] = torch.cuda.Stream(device=eng.device)
         st["d2h"] = torch.cuda.Stream(device=eng.device)
-    comp_host, comp_dev, text_host, text_dev = st["comp_host"], st["comp_dev"], st["text_host"], st["text_dev"]
+    if index_from == "text" and "text_host" not in st:
+        st["text_host"] = [torch.empty((room + cap + 32,), dtype=torch.uint8).pin_memory() for _ in range(2)]
+    if index_from != "text" and "starts_dev" not in st:
+        st["starts_dev"] = [torch.empty((line_cap + 1,), dtype=torch.int64, device=eng.device) for _ in range(2)]
+        st["info_dev"] = [torch.empty((line_cap,), dtype=torch.int32, device=eng.device) for _ in range(2)]
+        st["heads_dev"] = [torch.empty((heads_cap,), dtype=torch.uint8, device=eng.device) for _ in range(2)]
+        st["scratch_dev"] = torch.empty(((room + cap + 32) // 4096 + 4,), dtype=torch.int32, device=eng.device)
+        st["info4_dev"] = [torch.zeros((4,), dtype=torch.int32, device=eng.device) for _ in range(2)]
+        st["starts_host"] = [torch.empty((line_cap + 1,), dtype=torch.int64).pin_memory() for _ in range(2)]
+        st["info_host"] = [torch.empty((line_cap,), dtype=torch.int32).pin_memory() for _ in range(2)]
+        st["heads_host"] = [torch.empty((heads_cap,), dtype=torch.uint8).pin_memory() for _ in range(2)]
+        st["tail_host"] = torch.empty((room,), dtype=torch.uint8).pin_memory()
+    comp_host, comp_dev, text_dev = st["comp_host"], st["comp_dev"], st["text_dev"]
     flag_host, side, copy, d2h = st["flag_host"], st["side"], st["copy"], st["d2h"]
+    text_host = st.get("text_host")
     n = len(samples)
     names = (C.c_char_p * n)(*[s.encode() for s in samples])
     pl = (C.c_int32 * n)(*[int(p) for p in ploidies])
@@ -177,15 +203,10 @@ def _load_bgzf_device(eng, vcf_file, chr_name, samples, ploidies, start, end, an
     outs, stats, pos_parts = [], [], []
     usable, n_lines, idone = C.c_int64(), C.c_int64(), C.c_int32()
     p_off, p_len, p_pos, p_flip, p_gi = (C.c_void_p() for _ in range(5))
+    index_out = (C.byref(n_lines), C.byref(p_off), C.byref(p_len), C.byref(p_pos), C.byref(p_flip), C.byref(p_gi), C.byref(idone))
 
-    def index_and_tokenize(b, base, n_bytes, n_carry, table, is_last):
-        """Index text_host[b][base : base + n_bytes] and tokenise its record lines from text_dev[b]."""
-        tab_ptr = C.c_void_p(table.ctypes.data) if table is not None else None
-        if lib.sai_vcf_index_text(handle, C.c_void_p(text_host[b].data_ptr() + base), n_bytes, n_carry, tab_ptr,
-                                  0 if table is None else len(table) // _MEMBER_BYTES, 1 if is_last else 0, C.byref(usable),
-                                  C.byref(n_lines), C.byref(p_off), C.byref(p_len), C.byref(p_pos), C.byref(p_flip), C.byref(p_gi),
-                                  C.byref(idone)):  # fmt: skip
-            raise _io_error(lib)
+    def tokenize(b, base, n_bytes):
+        """The record lines the index call just reported (offsets relative to text_dev[b][base])."""
         nl = int(n_lines.value)
         if nl == 0:
             return
@@ -218,6 +239,12 @@ def _load_bgzf_device(eng, vcf_file, chr_name, samples, ploidies, start, end, an
             outs.append(out)
             stats.append(status)
 
+    def index_text_and_tokenize(host_ptr, b, base, n_bytes, n_carry, is_last):
+        if lib.sai_vcf_index_text(handle, C.c_void_p(host_ptr), n_bytes, n_carry, None, 0, 1 if is_last else 0, C.byref(usable),
+                                  *index_out):  # fmt: skip
+            raise _io_error(lib)
+        tokenize(b, base, n_bytes)
+
     import time as _time
 
     trace = {} if os.environ.get("SAI_AMD_INGEST_TRACE") else None
@@ -229,81 +256,198 @@ def _load_bgzf_device(eng, vcf_file, chr_name, samples, ploidies, start, end, an
             trace[name] = trace.get(name, 0.0) + now - t_mark[0]
             t_mark[0] = now
 
-    try:
+    last_inflate = [None, None]  # per ring slot: the event behind the inflate that read comp_dev[slot] last
+
+    def fetch():
+        """The next batch of members from the reader; its compressed bytes start for HBM (copy stream)."""
         buf, n_comp, n_mem, n_text, done = C.c_int32(), C.c_int64(), C.c_int32(), C.c_int64(), C.c_int32()
         table_p = C.c_void_p()
-        prev, h2d, reader_done = None, None, False
-        # Per batch: H2D of the compressed bytes (copy stream) -> inflate (side stream) -> D2H of the
-        # text (d2h stream), all enqueued as soon as the reader hands the batch over; the host then
-        # indexes the batch BEFORE it while those run.  The incomplete last line of batch k is copied
-        # in front of batch k+1 on both sides (host memcpy, D2D copy) once the index of k is known.
-        while True:
-            batch = None
-            if not reader_done:
-                lap("other")
-                if h2d is not None:
-                    h2d.synchronize()  # next() releases the pinned buffer of the batch before
-                lap("wait_h2d")
-                if lib.sai_bgzf_stream_next(handle, C.byref(buf), C.byref(n_comp), C.byref(n_mem), C.byref(table_p),
-                                            C.byref(n_text), C.byref(done)):  # fmt: skip
-                    raise _io_error(lib)
-                lap("wait_reader")
-                if done.value:
-                    reader_done = True
-                else:
-                    b, nc, nm, nt = int(buf.value), int(n_comp.value), int(n_mem.value), int(n_text.value)
-                    table = np.ctypeslib.as_array(C.cast(table_p, C.POINTER(C.c_uint8)), shape=(nm * _MEMBER_BYTES,)).copy()
-                    with torch.cuda.stream(copy):
-                        comp_dev[b][:nc].copy_(comp_host[b][:nc], non_blocking=True)
-                        h2d = torch.cuda.Event()
-                        h2d.record(copy)
-                    with torch.cuda.stream(side):
-                        side.wait_event(h2d)
-                        d_tab = torch.from_numpy(table).to(eng.device, non_blocking=True)
-                        d_stat = torch.empty((nm,), dtype=torch.int32, device=eng.device)
-                        _ffi.check(
-                            lib.sai_inflate_bgzf(eng.ctx, C.c_void_p(comp_dev[b].data_ptr()), nc, C.c_void_p(d_tab.data_ptr()), nm,
-                                                 C.c_void_p(text_dev[b].data_ptr() + room), nt, C.c_void_p(d_stat.data_ptr()),
-                                                 C.c_void_p(side.cuda_stream))
-                        )  # fmt: skip
-                        inflated = torch.cuda.Event()
-                        inflated.record(side)
+        if lib.sai_bgzf_stream_next(handle, C.byref(buf), C.byref(n_comp), C.byref(n_mem), C.byref(table_p), C.byref(n_text),
+                                    C.byref(done)):  # fmt: skip
+            raise _io_error(lib)
+        lap("wait_reader")
+        if done.value:
+            return None
+        b, nc, nm, nt = int(buf.value), int(n_comp.value), int(n_mem.value), int(n_text.value)
+        table = np.ctypeslib.as_array(C.cast(table_p, C.POINTER(C.c_uint8)), shape=(nm * _MEMBER_BYTES,)).copy()
+        with torch.cuda.stream(copy):
+            if last_inflate[b] is not None:
+                copy.wait_event(last_inflate[b])  # the inflate two batches back may still be reading comp_dev[b]
+            comp_dev[b][:nc].copy_(comp_host[b][:nc], non_blocking=True)
+            h2d = torch.cuda.Event()
+            h2d.record(copy)
+        lap("copy_table")
+        return {"b": b, "n_comp": nc, "n_members": nm, "n_text": nt, "table": table, "h2d": h2d, "carry": 0}
+
+    def launch(batch):
+        """Inflate + CRC of a fetched batch.  Its H2D copy was started one batch earlier -- a copy issued
+        while the inflate kernel holds the chip waits for it (measured: 2 ms instead of 0.2) -- so the
+        wait here is short, and the reader gets its pinned buffer back."""
+        b, nc, nm, nt = batch["b"], batch["n_comp"], batch["n_members"], batch["n_text"]
+        batch["h2d"].synchronize()
+        lib.sai_bgzf_stream_release(handle)
+        lap("h2d_sync")
+        with torch.cuda.stream(side):
+            d_tab = torch.from_numpy(batch["table"]).to(eng.device, non_blocking=True)
+            d_stat = torch.empty((nm,), dtype=torch.int32, device=eng.device)
+            _ffi.check(
+                lib.sai_inflate_bgzf(eng.ctx, C.c_void_p(comp_dev[b].data_ptr()), nc, C.c_void_p(d_tab.data_ptr()), nm,
+                                     C.c_void_p(text_dev[b].data_ptr() + room), nt, C.c_void_p(d_stat.data_ptr()),
+                                     C.c_void_p(side.cuda_stream))
+            )  # fmt: skip
+            batch["bad"] = (d_stat != 0).sum(dtype=torch.int32).reshape(1)
+            batch["inflated"] = torch.cuda.Event()
+            batch["inflated"].record(side)
+            last_inflate[b] = batch["inflated"]
+            batch["keep"] = (d_tab, d_stat)
+        lap("enqueue_inflate")
+
+    upcoming = [None, False]  # the batch fetched ahead, whether the reader has said "done"
+
+    def next_batch():
+        if not upcoming[1] and upcoming[0] is None:
+            upcoming[0] = fetch()
+            upcoming[1] = upcoming[0] is None
+        batch = upcoming[0]
+        if batch is None:
+            return None
+        launch(batch)
+        upcoming[0] = None
+        if not upcoming[1]:
+            upcoming[0] = fetch()  # its H2D runs under the inflate just launched
+            upcoming[1] = upcoming[0] is None
+        return batch
+
+    def move_carry(prev_b, at, left, batch):
+        """The incomplete last line of the batch before, in front of `batch` on the device."""
+        if left > room:
+            raise _Fallback  # a record line longer than the carry room
+        if left and batch is not None:
+            with torch.cuda.stream(side):
+                text_dev[batch["b"]][room - left : room].copy_(text_dev[prev_b][at : at + left], non_blocking=True)
+            batch["carry"] = left
+
+    try:
+        if index_from == "text":
+            # the whole text comes back once (d2h stream) and sai_vcf_index_text reads it
+            prev = None
+            while True:
+                batch = next_batch()
+                if batch is not None:
+                    b, nt = batch["b"], batch["n_text"]
                     with torch.cuda.stream(d2h):
-                        d2h.wait_event(inflated)
+                        d2h.wait_event(batch["inflated"])
                         text_host[b][room : room + nt].copy_(text_dev[b][room : room + nt], non_blocking=True)
-                        flag_host[b].copy_((d_stat != 0).sum(dtype=torch.int32).reshape(1), non_blocking=True)
-                        back = torch.cuda.Event()
-                        back.record(d2h)
-                    batch = {"b": b, "n_text": nt, "table": table, "d_stat": d_stat, "d_tab": d_tab, "d2h": back, "carry": 0}
-            lap("enqueue_inflate")
-            if prev is not None:
-                prev["d2h"].synchronize()
-                lap("wait_d2h")
-                if int(flag_host[prev["b"]][0]):
+                        flag_host[b][:1].copy_(batch["bad"], non_blocking=True)
+                        batch["back"] = torch.cuda.Event()
+                        batch["back"].record(d2h)
+                if prev is not None:
+                    prev["back"].synchronize()
+                    lap("wait_d2h")
+                    if int(flag_host[prev["b"]][0]):
+                        raise ValueError(f"{vcf_file}: BGZF block fails to inflate or its CRC")
+                    pb, base, total = prev["b"], room - prev["carry"], prev["carry"] + prev["n_text"]
+                    index_text_and_tokenize(text_host[pb].data_ptr() + base, pb, base, total, prev["carry"], False)
+                    lap("index_and_tokenize")
+                    left, at = total - int(usable.value), base + int(usable.value)
+                    if idone.value:
+                        break
+                    if batch is None:
+                        if left:  # the file ends without a newline
+                            index_text_and_tokenize(text_host[pb].data_ptr() + at, pb, at, left, left, True)
+                        break
+                    if left:
+                        text_host[batch["b"]][room - left : room].copy_(text_host[pb][at : at + left])
+                    move_carry(pb, at, left, batch)
+                elif batch is None:
+                    break
+                prev = batch
+        else:
+            # the GPU finds the lines; the host indexes from their heads
+            starts_dev, info_dev, heads_dev, scratch = st["starts_dev"], st["info_dev"], st["heads_dev"], st["scratch_dev"]
+            info4_dev, starts_host, info_host, heads_host = st["info4_dev"], st["starts_host"], st["info_host"], st["heads_host"]
+            tail_host = st["tail_host"]
+
+            def scan_lines(batch):
+                b, base, total = batch["b"], room - batch["carry"], batch["carry"] + batch["n_text"]
+                with torch.cuda.stream(side):
+                    _ffi.check(
+                        lib.sai_text_line_starts(eng.ctx, C.c_void_p(text_dev[b].data_ptr() + base), total, line_cap,
+                                                 C.c_void_p(starts_dev[b].data_ptr()), C.c_void_p(info_dev[b].data_ptr()),
+                                                 C.c_void_p(scratch.data_ptr()), C.c_void_p(info4_dev[b].data_ptr()),
+                                                 C.c_void_p(side.cuda_stream))
+                    )  # fmt: skip
+                    flag_host[b][:3].copy_(info4_dev[b][:3], non_blocking=True)
+                    flag_host[b][3:].copy_(batch["bad"], non_blocking=True)
+                    batch["scanned"] = torch.cuda.Event()
+                    batch["scanned"].record(side)
+
+            def fetch_table(batch):
+                """Wait for the scan, gather the heads and start their copy to the host."""
+                b, base, total = batch["b"], room - batch["carry"], batch["carry"] + batch["n_text"]
+                batch["scanned"].synchronize()
+                lap("wait_scan")
+                n_l, fixed, overflow, bad = (int(v) for v in flag_host[b].tolist())
+                if bad:
                     raise ValueError(f"{vcf_file}: BGZF block fails to inflate or its CRC")
-                pb, base = prev["b"], room - prev["carry"]
-                index_and_tokenize(pb, base, prev["carry"] + prev["n_text"], prev["carry"], None, False)  # CRCs: checked on the GPU
+                hb = max(16, (fixed + 3) & ~3)
+                if overflow or fixed > 4096 or n_l * hb > heads_cap:
+                    raise _TextIndex  # short lines / far fixed columns: the whole-text index serves this file
+                batch["n_lines"], batch["hb"] = n_l, hb
+                with torch.cuda.stream(d2h):  # its own stream: the next batch's inflate is already queued on `side`
+                    _ffi.check(
+                        lib.sai_text_line_heads(eng.ctx, C.c_void_p(text_dev[b].data_ptr() + base), total,
+                                                C.c_void_p(starts_dev[b].data_ptr()), n_l, hb, C.c_void_p(heads_dev[b].data_ptr()),
+                                                C.c_void_p(d2h.cuda_stream))
+                    )  # fmt: skip
+                    starts_host[b][: n_l + 1].copy_(starts_dev[b][: n_l + 1], non_blocking=True)
+                    info_host[b][: max(n_l, 1)].copy_(info_dev[b][: max(n_l, 1)], non_blocking=True)
+                    heads_host[b][: max(n_l * hb, 1)].copy_(heads_dev[b][: max(n_l * hb, 1)], non_blocking=True)
+                    batch["tabled"] = torch.cuda.Event()
+                    batch["tabled"].record(d2h)
+
+            def index_batch(batch):
+                b, base, total = batch["b"], room - batch["carry"], batch["carry"] + batch["n_text"]
+                batch["tabled"].synchronize()
+                lap("wait_table")
+                n_l = batch["n_lines"]
+                if lib.sai_vcf_index_heads(handle, C.c_void_p(heads_host[b].data_ptr()), batch["hb"], C.c_void_p(starts_host[b].data_ptr()),
+                                           C.c_void_p(info_host[b].data_ptr()), n_l, *index_out):  # fmt: skip
+                    raise _io_error(lib)
+                tokenize(b, base, total)
                 lap("index_and_tokenize")
-                left = prev["carry"] + prev["n_text"] - int(usable.value)
-                at = base + int(usable.value)
-                if left > room:
-                    raise _Fallback  # a record line longer than the carry room
-                if idone.value:
+                used = int(starts_host[b][n_l]) if n_l else 0
+                return base + used, total - used  # where the incomplete last line lies, and its length
+
+            prev = None
+            while True:
+                batch = next_batch()
+                at = left = 0
+                if prev is not None:
+                    # the line table of `prev` is on its way; its last offset says what is carried over
+                    prev["scanned"].synchronize()
+                    fetch_table(prev)
+                    prev["tabled"].synchronize()
+                    n_l = prev["n_lines"]
+                    used = int(starts_host[prev["b"]][n_l]) if n_l else 0
+                    at, left = room - prev["carry"] + used, prev["carry"] + prev["n_text"] - used
+                    move_carry(prev["b"], at, left, batch)
+                if batch is not None:
+                    scan_lines(batch)  # runs behind the inflate of `batch`, while the host indexes `prev`
+                if prev is not None:
+                    index_batch(prev)
+                    if idone.value:
+                        break
+                    if batch is None:
+                        if left:  # the file ends without a newline: those few bytes come to the host as text
+                            with torch.cuda.stream(side):
+                                tail_host[:left].copy_(text_dev[prev["b"]][at : at + left], non_blocking=True)
+                            side.synchronize()
+                            index_text_and_tokenize(tail_host.data_ptr(), prev["b"], at, left, left, True)
+                        break
+                elif batch is None:
                     break
-                if batch is None:
-                    if left:  # the file ends without a newline
-                        index_and_tokenize(pb, at, left, left, None, True)
-                    break
-                if left:
-                    nb = batch["b"]
-                    text_host[nb][room - left : room].copy_(text_host[pb][at : at + left])
-                    with torch.cuda.stream(side):
-                        text_dev[nb][room - left : room].copy_(text_dev[pb][at : at + left], non_blocking=True)
-                    batch["carry"] = left
-            elif batch is None:  # not a single batch: let the indexer say what is missing
-                index_and_tokenize(0, room, 0, 0, None, True)
-                break
-            prev = batch
+                prev = batch
         n_match, n_anc, cols = C.c_int64(), C.c_int64(), C.c_int32()
         have_header = lib.sai_bgzf_stream_selection(handle, None, 0, C.byref(cols), C.byref(n_match), C.byref(n_anc)) == 0
     finally:
@@ -321,5 +465,5 @@ def _load_bgzf_device(eng, vcf_file, chr_name, samples, ploidies, start, end, an
     dos = torch.cat(outs) if len(outs) > 1 else (outs[0] if outs else torch.empty((0, n), dtype=torch.int8, device=eng.device))
     lap("status_and_concat")
     if trace is not None:
-        print("bgzf route, ms:", " ".join(f"{k}={1e3 * v:.1f}" for k, v in trace.items()), flush=True)
+        print(f"bgzf route ({index_from}), ms:", " ".join(f"{k}={1e3 * v:.1f}" for k, v in trace.items()), flush=True)
     return pos, dos, (int(n_match.value) if have_header else 0), (int(n_anc.value) if have_header else 0)

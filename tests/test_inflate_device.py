@@ -211,3 +211,76 @@ def test_argument_checks(eng):
     assert eng.lib.sai_inflate_bgzf(eng.ctx, p(buf), 64, p(tab), 1, p(buf), 64, p(st), None) == 0
     torch.cuda.synchronize()
     assert int(st.cpu()[0]) != 0
+
+
+def test_line_table_kernels(eng):
+    """sai_text_line_starts / sai_text_line_heads against their numpy statement: every base
+    alignment, CRLF lines, '#' lines, lines with fewer than ten columns, a ninth tab out of reach,
+    a batch that ends inside a line, an empty batch, a line capacity that is too small."""
+    import torch
+
+    from sai_amd import _ffi
+
+    rng = np.random.default_rng(2)
+    body = bytearray(b"##meta\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\ts1\ts2\n")
+    for i in range(700):
+        info = b"X" * int(rng.integers(1, 5000 if i % 97 == 0 else 60))
+        line = b"21\t%d\t.\tA\tC\t.\tPASS\t%s\tGT\t" % (i + 1, info) + b"\t".join([b"0|1"] * int(rng.integers(1, 400)))
+        if i % 50 == 3:
+            line = b"21\t5\tshort"
+        if i % 60 == 7:
+            line = b""
+        body += line + (b"\r\n" if i % 3 == 0 else b"\n")
+    body += b"21\t999\tpartial line without its end"
+    body = bytes(body)
+    for mis in (0, 1, 7, 15, 16, 33):
+        for n in (len(body), 0, 1, 4095, 4096, 4097, 20000):
+            text = body[:n]
+            raw = np.frombuffer(text, dtype=np.uint8)
+            ends = np.flatnonzero(raw == 10)
+            starts = np.concatenate([[0], ends + 1]).astype(np.int64)
+            n_l = len(ends)
+            want_info = np.zeros(n_l, dtype=np.int64)
+            for i in range(n_l):
+                line = text[starts[i] : starts[i + 1] - 1]
+                cr = line.endswith(b"\r")
+                line = line[:-1] if cr else line
+                fixed = 1
+                if line and not line.startswith(b"#"):
+                    tabs = [k for k, ch in enumerate(line[:4096]) if ch == 9]
+                    fixed = tabs[8] + 1 if len(tabs) >= 9 else (len(line) + 1 if len(line) <= 4096 else 4097)
+                want_info[i] = fixed | ((1 << 31) if cr else 0)
+            cap = n_l + 5
+            d_text = torch.zeros((mis + n + 48,), dtype=torch.uint8, device=eng.device)
+            d_text[:mis] = 10  # newlines in front of the text must not count
+            d_text[mis + n :] = 10  # nor behind it
+            if n:
+                d_text[mis : mis + n] = torch.from_numpy(raw.copy()).to(eng.device)
+            d_starts = torch.full((cap + 1,), -7, dtype=torch.int64, device=eng.device)
+            d_info = torch.full((cap,), -7, dtype=torch.int32, device=eng.device)
+            d_scr = torch.zeros(((n + 15) // 4096 + 2,), dtype=torch.int32, device=eng.device)
+            d_i4 = torch.zeros((4,), dtype=torch.int32, device=eng.device)
+            p = lambda t, o=0: C.c_void_p(t.data_ptr() + o)  # noqa: E731
+            _ffi.check(eng.lib.sai_text_line_starts(eng.ctx, p(d_text, mis), n, cap, p(d_starts), p(d_info), p(d_scr), p(d_i4), None))
+            i4 = d_i4.cpu().tolist()
+            assert i4[0] == n_l and i4[2] == 0, (mis, n, i4)
+            assert d_starts[: n_l + 1].cpu().tolist() == starts.tolist()
+            assert (d_starts[n_l + 1 :] == -7).all()
+            got_info = d_info[:n_l].cpu().numpy().astype(np.int64) & 0xFFFFFFFF
+            assert got_info.tolist() == want_info.tolist(), (mis, n)
+            assert i4[1] == (int((want_info & 0x7FFFFFFF).max()) if n_l else 0)
+            for hb in (16, 64):
+                d_heads = torch.full((max(n_l, 1) * hb + 4,), 0x55, dtype=torch.uint8, device=eng.device)
+                _ffi.check(eng.lib.sai_text_line_heads(eng.ctx, p(d_text, mis), n, p(d_starts), n_l, hb, p(d_heads), None))
+                heads = d_heads.cpu().numpy()
+                assert (heads[n_l * hb :] == 0x55).all()
+                for i in range(n_l):
+                    chunk = raw[starts[i] : min(starts[i] + hb, starts[i + 1])]
+                    want = np.full(hb, 10, dtype=np.uint8)
+                    want[: len(chunk)] = chunk
+                    assert heads[i * hb : (i + 1) * hb].tolist() == want.tolist(), (mis, n, i)
+    # a capacity that is too small is reported and respected
+    d_starts = torch.full((4,), -7, dtype=torch.int64, device=eng.device)
+    d_info = torch.full((3,), -7, dtype=torch.int32, device=eng.device)
+    _ffi.check(eng.lib.sai_text_line_starts(eng.ctx, p(d_text, mis), n, 3, p(d_starts), p(d_info), p(d_scr), p(d_i4), None))
+    assert d_i4.cpu().tolist()[2] == 1 and d_starts.cpu().tolist() == starts[:4].tolist()

@@ -251,6 +251,37 @@ def test_bgzip_is_inflated_on_the_gpu(eng, tmp_path, monkeypatch):
         before = calls["n"]
         got = device_vcf.load_dosage_device(eng, str(odd), "22", pick, ploidies, None, None, None, 3, cap)
         assert calls["n"] == before + 1 and got[0].tolist() == want[0].tolist() and np.array_equal(got[1].cpu().numpy(), want[1])
+    # both ways of indexing (line heads extracted on the GPU / the whole text copied back) agree
+    for mode in ("heads", "text"):
+        monkeypatch.setenv("SAI_AMD_BGZF_INDEX", mode)
+        for cap in (1 << 16, None):
+            got = device_vcf.load_dosage_device(eng, str(odd), "22", pick, ploidies, None, None, None, 3, cap)
+            assert got[0].tolist() == want[0].tolist() and np.array_equal(got[1].cpu().numpy(), want[1])
+    monkeypatch.delenv("SAI_AMD_BGZF_INDEX")
+    # a record whose INFO column pushes FORMAT beyond the reach of the line heads: the file is indexed from the text
+    lines = text.split(b"\n")
+    k = next(i for i, ln in enumerate(lines) if ln.startswith(b"22\t"))
+    f = lines[k].split(b"\t")
+    f[7] = b"NOTE=" + b"x" * 6000
+    lines[k] = b"\t".join(f)
+    far = tmp_path / "far.vcf.gz"
+    with open(far, "wb") as fh:
+        blob = b"\n".join(lines) + b"\n"
+        for o in range(0, len(blob), 60000):
+            fh.write(member(blob[o : o + 60000]))
+        fh.write(member(b""))
+    seen = []
+    real_inner = real
+
+    def spy_modes(*a, **k):
+        seen.append(k.get("index_from"))
+        return real_inner(*a, **k)
+
+    monkeypatch.setattr(device_vcf, "_load_bgzf_device", spy_modes)
+    want_far = load_dosage(str(far), "22", pick, ploidies, None, None, None, 2)
+    got = device_vcf.load_dosage_device(eng, str(far), "22", pick, ploidies)
+    assert seen == [None, "text"] and got[0].tolist() == want_far[0].tolist() and np.array_equal(got[1].cpu().numpy(), want_far[1])
+    monkeypatch.setattr(device_vcf, "_load_bgzf_device", spy)
     # damage in the middle of the file: the kernel's status or the host's CRC check stops the read
     raw = bytearray(open(path, "rb").read())
     raw[len(raw) // 2] ^= 0x55

@@ -153,7 +153,7 @@ BGZF_MEMBER = np.dtype([("data_off", "<i8"), ("out_off", "<i8"), ("data_len", "<
 
 
 def bgzf_stream_batches(path, chrom, names, ploidies, start=None, end=None, anc=None, threads=3, cap=1 << 17, text_cap=1 << 16,
-                        damage=None):  # fmt: skip
+                        damage=None, heads=False):  # fmt: skip
     """Drive sai_bgzf_stream_* + sai_vcf_index_text the way device_vcf does, inflating the members
     with zlib where the GPU kernel would.  Same return value as ``stream_batches``."""
     import zlib
@@ -179,7 +179,47 @@ def bgzf_stream_batches(path, chrom, names, ploidies, start=None, end=None, anc=
         usable, nl, idone = C.c_int64(), C.c_int64(), C.c_int32()
         ptrs = [C.c_void_p() for _ in range(5)]
 
+        def index_from_heads(text, last):
+            """What sai_text_line_starts / _heads produce (restated with numpy), then sai_vcf_index_heads."""
+            body = text if not last or text.endswith(b"\n") or not text else text + b"\n"
+            raw = np.frombuffer(body, dtype=np.uint8)
+            ends = np.flatnonzero(raw == 10)
+            starts = np.concatenate([[0], ends + 1]).astype(np.int64)
+            n_l = len(ends)
+            info = np.zeros(max(n_l, 1), dtype=np.int32)
+            for i in range(n_l):
+                line = body[starts[i] : starts[i + 1] - 1]
+                cr = line.endswith(b"\r")
+                if cr:
+                    line = line[:-1]
+                fixed = 1
+                if line and not line.startswith(b"#"):
+                    scan, tabs, at = line[:4096], 0, -1
+                    for k, ch in enumerate(scan):
+                        if ch == 9:
+                            tabs += 1
+                            if tabs == 9:
+                                at = k
+                                break
+                    fixed = at + 1 if at >= 0 else (len(line) + 1 if len(line) <= 4096 else 4097)
+                info[i] = fixed | (-(1 << 31) if cr else 0)
+            H = max(4, (int((info[:n_l] & 0x7FFFFFFF).max()) + 3) // 4 * 4) if n_l else 4
+            heads = np.full((max(n_l, 1), H), 10, dtype=np.uint8)
+            for i in range(n_l):
+                chunk = raw[starts[i] : min(starts[i] + H, starts[i + 1])]
+                heads[i, : len(chunk)] = chunk
+            if lib.sai_vcf_index_heads(h, heads.ctypes.data_as(C.c_void_p), H, starts.ctypes.data_as(C.c_void_p),
+                                       info.ctypes.data_as(C.c_void_p), n_l, C.byref(nl), *[C.byref(p) for p in ptrs], C.byref(idone)):  # fmt: skip
+                raise ValueError(lib.sai_last_error().decode())
+            k = int(nl.value)
+            get = lambda p, ct: np.ctypeslib.as_array(C.cast(p, C.POINTER(ct)), shape=(k,)).copy() if k else np.zeros(0, np.int64)  # noqa: E731
+            out.append((body, get(ptrs[0], C.c_int64), get(ptrs[1], C.c_int32), get(ptrs[2], C.c_int32), get(ptrs[3], C.c_uint8),
+                        get(ptrs[4], C.c_uint8)))  # fmt: skip
+            return text[int(starts[-1]) :] if not last else b""
+
         def index(text, n_carry, table, n_members, last):
+            if heads:
+                return index_from_heads(text, last)
             buf = np.frombuffer(text, dtype=np.uint8).copy() if text else np.zeros(1, dtype=np.uint8)
             if lib.sai_vcf_index_text(h, buf.ctypes.data_as(C.c_void_p), len(text), n_carry, table, n_members, last, C.byref(usable),
                                       C.byref(nl), *[C.byref(p) for p in ptrs], C.byref(idone)):  # fmt: skip
@@ -240,8 +280,9 @@ def test_bgzf_stream_index_equals_host_reader(tmp_path, crlf):
     for chrom in ("21", "7", "22"):
         for start, end in ((None, None), (500, 9000), (10**7, None)):
             for anc in (None, str(bed)):
-                for text_cap in (1 << 16, 1 << 22):
-                    batches, sel, n_batches = bgzf_stream_batches(path, chrom, pick, ploidies, start, end, anc, text_cap=text_cap)
+                for text_cap, heads in ((1 << 16, False), (1 << 22, False), (1 << 16, True), (1 << 22, True)):
+                    batches, sel, n_batches = bgzf_stream_batches(path, chrom, pick, ploidies, start, end, anc, text_cap=text_cap,
+                                                                  heads=heads)  # fmt: skip
                     want = load_dosage(str(path), chrom, pick, ploidies, start, end, anc, 2)
                     pos, dos = python_tokenize(batches, sel[0], ploidies)
                     assert pos.tolist() == want[0].tolist(), (chrom, start, end, anc, text_cap)

@@ -57,7 +57,7 @@ def main() -> None:
     want = None
     for label, env in (("host inflate", "0"), ("GPU inflate", "1")):
         os.environ["SAI_AMD_GPU_INFLATE"] = env
-        for cap_mb in ((32, 128) if env == "1" and os.environ.get("SAI_AMD_INGEST_TRACE") else (32, 64, 128, 256)):
+        for cap_mb in ((32, 124) if env == "1" and os.environ.get("SAI_AMD_INGEST_TRACE") else (32, 64, 124, 248)):
             device_vcf.load_dosage_device(eng, path, "1", names, [2] * n_samples, buffer_bytes=cap_mb << 20)
             best = 1e9
             for _ in range(3):
