@@ -384,7 +384,8 @@ int sai_inflate_bgzf(sai_ctx* ctx, const void* comp, int64_t n_comp_bytes, const
  * BGZF members over as they are -- whole members, padded to a multiple of 4 bytes -- in the caller's
  * two pinned buffers alternately, at most text_batch_bytes of text per batch; SAI_ERR_UNSUPPORTED
  * when the file is not bgzip, or when a region is asked of a file with a usable .tbi (that is a
- * seek and a few blocks: sai_vcf_stream_open).  sai_bgzf_stream_next returns batch k (blocking) and
+ * seek and a few blocks: sai_vcf_stream_open); n_samples = 0 asks for the record index only (the
+ * positions of a chromosome).  sai_bgzf_stream_next returns batch k (blocking) and
  * releases the buffer of batch k-1 (its H2D copy must be over); members_host = the table for
  * sai_inflate_bgzf, valid until the following call.  The caller inflates the batch on the GPU behind
  * the n_carry bytes the previous batch left over (its last, incomplete line), copies carry + text to

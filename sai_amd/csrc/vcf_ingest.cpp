@@ -1995,7 +1995,8 @@ int sai_bgzf_stream_open(const char* path, const char* chrom, int64_t start, int
   return guarded("sai_bgzf_stream_open", [&]() -> int {
     if (!path || !chrom || !stream_out) return sai_set_error(SAI_ERR_ARG, "NULL argument");
     *stream_out = nullptr;
-    if (n_samples < 1 || !sample_names || !ploidy) return sai_set_error(SAI_ERR_ARG, "empty sample selection");
+    // n_samples == 0: only the record index is wanted (positions of a chromosome: ChunkGenerator's scan)
+    if (n_samples < 0 || (n_samples > 0 && (!sample_names || !ploidy))) return sai_set_error(SAI_ERR_ARG, "bad sample selection");
     if (!comp0_host || !comp1_host || comp_buffer_bytes < (1 << 17) || text_batch_bytes < (1 << 16))
       return sai_set_error(SAI_ERR_ARG, "two staging buffers of at least 128 KiB and a text batch of at least 64 KiB are needed");
     for (int32_t s = 0; s < n_samples; ++s)

@@ -141,7 +141,8 @@ def load_dosage_device(eng, vcf_file: str, chr_name: str, samples: Sequence[str]
     return pos, dos, (int(n_match.value) if have_header else 0), (int(n_anc.value) if have_header else 0)
 
 
-def _load_bgzf_device(eng, vcf_file, chr_name, samples, ploidies, start, end, anc_allele_file, n_threads, cap, index_from=None):
+def _load_bgzf_device(eng, vcf_file, chr_name, samples, ploidies, start, end, anc_allele_file, n_threads, cap, index_from=None,
+                      positions_only=False):  # fmt: skip
     """``load_dosage_device`` for a bgzip file without a region seek.  The compressed members cross
     PCIe and are inflated by ``sai_inflate_bgzf`` (one wavefront per member; a second launch checks
     every member's CRC-32).  The record index -- chromosome / region filter, POS, the ancestral-allele
@@ -150,7 +151,8 @@ def _load_bgzf_device(eng, vcf_file, chr_name, samples, ploidies, start, end, an
     columns of every line, a few MB) or, ``index_from="text"``, from the whole text copied back once;
     the text is tokenised where it lies in HBM either way.  Batch k+1 is inflated and scanned while
     the host indexes batch k.  Returns None when the file is not bgzip (or a tabix index serves the
-    region): the caller falls back to the host-inflating stream."""
+    region): the caller falls back to the host-inflating stream.  ``positions_only`` (no samples):
+    the record index alone, nothing is tokenised."""
     import torch
 
     lib = eng.lib
@@ -210,7 +212,7 @@ def _load_bgzf_device(eng, vcf_file, chr_name, samples, ploidies, start, end, an
         nl = int(n_lines.value)
         if nl == 0:
             return
-        if state["slot_dev"] is None:
+        if state["slot_dev"] is None and not positions_only:
             cols = C.c_int32()
             if lib.sai_bgzf_stream_selection(handle, None, 0, C.byref(cols), None, None):
                 raise _io_error(lib)
@@ -224,6 +226,8 @@ def _load_bgzf_device(eng, vcf_file, chr_name, samples, ploidies, start, end, an
             return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(ctype)), shape=(nl,)).astype(dtype, copy=True)
 
         pos_parts.append(arr(p_pos, C.c_int32, np.int32))
+        if positions_only:
+            return
         with torch.cuda.stream(side):
             d_off = torch.from_numpy(arr(p_off, C.c_int64, np.int64) + base).to(eng.device, non_blocking=True)
             d_len = torch.from_numpy(arr(p_len, C.c_int32, np.int32)).to(eng.device, non_blocking=True)
@@ -467,3 +471,21 @@ def _load_bgzf_device(eng, vcf_file, chr_name, samples, ploidies, start, end, an
     if trace is not None:
         print(f"bgzf route ({index_from}), ms:", " ".join(f"{k}={1e3 * v:.1f}" for k, v in trace.items()), flush=True)
     return pos, dos, (int(n_match.value) if have_header else 0), (int(n_anc.value) if have_header else 0)
+
+
+def scan_first_last_device(eng, vcf_file: str, chr_name: str):
+    """First and last POS of the first contiguous run of ``chr_name`` in a bgzip file, found with the
+    GPU-inflate pass (no sample column is tokenised): what ``ChunkGenerator`` needs before the windows
+    can be laid out.  None when this route does not serve the file (not bgzip, lines it cannot index
+    from their heads and would have to copy back whole, ...): the host scan does it then."""
+    if os.environ.get("SAI_AMD_GPU_INFLATE", "1") == "0":
+        return None
+    cap = int(os.environ.get("SAI_AMD_INFLATE_BATCH", INFLATE_BATCH_BYTES))
+    try:
+        got = _load_bgzf_device(eng, vcf_file, chr_name, [], [], None, None, None, None, cap, positions_only=True)
+    except (_Fallback, _TextIndex):
+        return None
+    if got is None:
+        return None
+    pos = got[0]
+    return (None, None) if pos.size == 0 else (int(pos[0]), int(pos[-1]))

@@ -1,5 +1,6 @@
 """ctypes front end of the native VCF tokenizer in libsaihip (sai_vcf_scan / sai_vcf_load,
-sai_amd/csrc/vcf_ingest.cpp).  Host-side only; no GPU is involved."""
+sai_amd/csrc/vcf_ingest.cpp).  Host-side, except that the scan of a bgzip file is handed to the
+GPU-inflate pass when a GPU is present."""
 
 from __future__ import annotations
 
@@ -21,13 +22,34 @@ def default_threads() -> int:
 
 
 def scan_first_last(vcf_file: str, chr_name: str) -> tuple[Optional[int], Optional[int]]:
-    """First and last POS of the first contiguous run of ``chr_name`` (None, None if absent)."""
+    """First and last POS of the first contiguous run of ``chr_name`` (None, None if absent).  A bgzip
+    file is scanned with the GPU-inflate pass when a GPU is there (the host would inflate the whole
+    file for it: 53 ms against 12 for 480 MB of text); everything else, and every machine without a
+    GPU, takes the host scan."""
+    if str(vcf_file).endswith((".gz", ".bgz")) and os.environ.get("SAI_AMD_INGEST") != "host":
+        got = _scan_on_device(vcf_file, chr_name)
+        if got is not None:
+            return got
     lib = _ffi.load_host()
     first, last = C.c_int64(-1), C.c_int64(-1)
     _check_io(lib.sai_vcf_scan(os.fsencode(vcf_file), str(chr_name).encode(), C.byref(first), C.byref(last)))
     if first.value < 0:
         return None, None
     return int(first.value), int(last.value)
+
+
+def _scan_on_device(vcf_file: str, chr_name: str):
+    try:
+        import torch
+
+        if not torch.cuda.is_available():
+            return None
+        from ..engine import Engine
+        from .device_vcf import scan_first_last_device
+
+        return scan_first_last_device(Engine.get(), str(vcf_file), chr_name)
+    except (ImportError, ValueError):  # a file the indexer refuses: the host scan (and later the load) says why
+        return None
 
 
 def _check_io(status: int) -> None:

@@ -293,3 +293,37 @@ def test_bgzip_is_inflated_on_the_gpu(eng, tmp_path, monkeypatch):
     got = device_vcf.load_dosage_device(eng, str(path), "22", pick, ploidies)
     want = load_dosage(str(path), "22", pick, ploidies, None, None, None, 2)
     assert got[0].tolist() == want[0].tolist() and np.array_equal(got[1].cpu().numpy(), want[1])
+
+
+def test_chromosome_scan_of_a_bgzip_file_runs_on_the_gpu(eng, tmp_path, monkeypatch):
+    """ChunkGenerator's first / last position of a chromosome: the GPU-inflate pass without a
+    tokenizer gives what the host scan gives (file order, first contiguous run, absent chromosome),
+    plain and gzip files stay with the host."""
+    from sai_amd.utils import device_vcf, native_vcf
+
+    rng = np.random.default_rng(21)
+    path = tmp_path / "s.vcf.gz"
+    write_vcf(path, rng, 1500, 30, gz="bgzf")
+    calls = {"n": 0}
+    real = device_vcf.scan_first_last_device
+
+    def spy(*a, **k):
+        got = real(*a, **k)
+        calls["n"] += got is not None
+        return got
+
+    monkeypatch.setattr(device_vcf, "scan_first_last_device", spy)
+    for chrom in ("7", "21", "22", "X"):
+        got = native_vcf.scan_first_last(str(path), chrom)
+        monkeypatch.setenv("SAI_AMD_INGEST", "host")
+        want = native_vcf.scan_first_last(str(path), chrom)
+        monkeypatch.delenv("SAI_AMD_INGEST")
+        assert got == want, chrom
+    assert calls["n"] == 4
+    plain = tmp_path / "p.vcf"
+    write_vcf(plain, rng, 200, 5)
+    gz = tmp_path / "g.vcf.gz"
+    write_vcf(gz, rng, 200, 5, gz=True)
+    before = calls["n"]
+    assert native_vcf.scan_first_last(str(plain), "21")[0] is not None and native_vcf.scan_first_last(str(gz), "21")[0] is not None
+    assert calls["n"] == before
