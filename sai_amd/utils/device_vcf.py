@@ -172,6 +172,7 @@ def _load_bgzf_device(eng, vcf_file, chr_name, samples, ploidies, start, end, an
         st["side"] = torch.cuda.Stream(device=eng.device)
         st["copy"] = torch.cuda.Stream(device=eng.device)
         st["d2h"] = torch.cuda.Stream(device=eng.device)
+        st["tok"] = torch.cuda.Stream(device=eng.device)
     if index_from == "text" and "text_host" not in st:
         st["text_host"] = [torch.empty((room + cap + 32,), dtype=torch.uint8).pin_memory() for _ in range(2)]
     if index_from != "text" and "starts_dev" not in st:
@@ -185,7 +186,8 @@ def _load_bgzf_device(eng, vcf_file, chr_name, samples, ploidies, start, end, an
         st["heads_host"] = [torch.empty((heads_cap,), dtype=torch.uint8).pin_memory() for _ in range(2)]
         st["tail_host"] = torch.empty((room,), dtype=torch.uint8).pin_memory()
     comp_host, comp_dev, text_dev = st["comp_host"], st["comp_dev"], st["text_dev"]
-    flag_host, side, copy, d2h = st["flag_host"], st["side"], st["copy"], st["d2h"]
+    flag_host, side, copy, d2h, tok = st["flag_host"], st["side"], st["copy"], st["d2h"], st["tok"]
+    tok_done = [None, None]  # per ring slot: the tokenizer that read text_dev[slot] last
     text_host = st.get("text_host")
     n = len(samples)
     names = (C.c_char_p * n)(*[s.encode() for s in samples])
@@ -207,8 +209,10 @@ def _load_bgzf_device(eng, vcf_file, chr_name, samples, ploidies, start, end, an
     p_off, p_len, p_pos, p_flip, p_gi = (C.c_void_p() for _ in range(5))
     index_out = (C.byref(n_lines), C.byref(p_off), C.byref(p_len), C.byref(p_pos), C.byref(p_flip), C.byref(p_gi), C.byref(idone))
 
-    def tokenize(b, base, n_bytes):
-        """The record lines the index call just reported (offsets relative to text_dev[b][base])."""
+    def tokenize(b, base, n_bytes, ready=None):
+        """The record lines the index call just reported (offsets relative to text_dev[b][base]).  With
+        ``ready`` (the event behind the batch's text) the kernel runs on its own stream, beside the
+        inflate of the next batch -- that one occupies a fifth of the wavefront slots."""
         nl = int(n_lines.value)
         if nl == 0:
             return
@@ -228,7 +232,10 @@ def _load_bgzf_device(eng, vcf_file, chr_name, samples, ploidies, start, end, an
         pos_parts.append(arr(p_pos, C.c_int32, np.int32))
         if positions_only:
             return
-        with torch.cuda.stream(side):
+        stream = side if ready is None else tok
+        with torch.cuda.stream(stream):
+            if ready is not None:
+                tok.wait_event(ready)
             d_off = torch.from_numpy(arr(p_off, C.c_int64, np.int64) + base).to(eng.device, non_blocking=True)
             d_len = torch.from_numpy(arr(p_len, C.c_int32, np.int32)).to(eng.device, non_blocking=True)
             d_flip = torch.from_numpy(arr(p_flip, C.c_uint8, np.uint8)).to(eng.device, non_blocking=True)
@@ -238,10 +245,13 @@ def _load_bgzf_device(eng, vcf_file, chr_name, samples, ploidies, start, end, an
             _ffi.check(
                 lib.sai_tokenize_gt(eng.ctx, C.c_void_p(text_dev[b].data_ptr()), (base + n_bytes + 3) & ~3, nl, eng._ptr(d_off),
                                     eng._ptr(d_len), eng._ptr(d_flip), eng._ptr(d_gi), state["n_cols"], eng._ptr(state["slot_dev"]), n,
-                                    eng._ptr(ploidy_dev), eng._ptr(out), eng._ptr(status), C.c_void_p(side.cuda_stream))
+                                    eng._ptr(ploidy_dev), eng._ptr(out), eng._ptr(status), C.c_void_p(stream.cuda_stream))
             )  # fmt: skip
             outs.append(out)
             stats.append(status)
+            if ready is not None:
+                tok_done[b] = torch.cuda.Event()
+                tok_done[b].record(tok)
 
     def index_text_and_tokenize(host_ptr, b, base, n_bytes, n_carry, is_last):
         if lib.sai_vcf_index_text(handle, C.c_void_p(host_ptr), n_bytes, n_carry, None, 0, 1 if is_last else 0, C.byref(usable),
@@ -292,6 +302,8 @@ def _load_bgzf_device(eng, vcf_file, chr_name, samples, ploidies, start, end, an
         lib.sai_bgzf_stream_release(handle)
         lap("h2d_sync")
         with torch.cuda.stream(side):
+            if tok_done[b] is not None:
+                side.wait_event(tok_done[b])  # the tokenizer two batches back read text_dev[b]
             d_tab = torch.from_numpy(batch["table"]).to(eng.device, non_blocking=True)
             d_stat = torch.empty((nm,), dtype=torch.int32, device=eng.device)
             _ffi.check(
@@ -418,7 +430,7 @@ def _load_bgzf_device(eng, vcf_file, chr_name, samples, ploidies, start, end, an
                 if lib.sai_vcf_index_heads(handle, C.c_void_p(heads_host[b].data_ptr()), batch["hb"], C.c_void_p(starts_host[b].data_ptr()),
                                            C.c_void_p(info_host[b].data_ptr()), n_l, *index_out):  # fmt: skip
                     raise _io_error(lib)
-                tokenize(b, base, total)
+                tokenize(b, base, total, ready=batch["scanned"])
                 lap("index_and_tokenize")
                 used = int(starts_host[b][n_l]) if n_l else 0
                 return base + used, total - used  # where the incomplete last line lies, and its length
@@ -460,11 +472,13 @@ def _load_bgzf_device(eng, vcf_file, chr_name, samples, ploidies, start, end, an
         side.synchronize()  # also on an error: the staging buffers are reused by the next call
         copy.synchronize()
         d2h.synchronize()
+        tok.synchronize()
         lap("close_and_drain")
     if stats and bool(torch.cat(stats).any()):
         load_dosage(vcf_file, chr_name, samples, ploidies, start, end, anc_allele_file, n_threads)
         raise ValueError(f"{vcf_file}: the GPU tokenizer flagged a line the host reader accepts")
     torch.cuda.current_stream(eng.device).wait_stream(side)
+    torch.cuda.current_stream(eng.device).wait_stream(tok)
     pos = np.concatenate(pos_parts) if pos_parts else np.zeros(0, dtype=np.int32)
     dos = torch.cat(outs) if len(outs) > 1 else (outs[0] if outs else torch.empty((0, n), dtype=torch.int8, device=eng.device))
     lap("status_and_concat")
