@@ -327,7 +327,6 @@ __global__ __launch_bounds__(64) void inflate_bgzf_kernel(InflateArgs a) {
       const int total = n_lit + n_dist;
       while (i < total) {
         in.fill();
-        if (in.pos_bits() > bit_limit + 64) { err = kInputOverrun; break; }
         const int sym = decode_symbol<kClBits>(in, s.dist);
         if (sym < 0 || sym > 18) { err = kBadCodeLengths; break; }
         if (sym < 16) {
@@ -359,12 +358,14 @@ __global__ __launch_bounds__(64) void inflate_bgzf_kernel(InflateArgs a) {
     if (!build_tables<kDistBits, 64>(s.lens + n_lit, n_dist, s.dist, lane)) { err = kBadCodeLengths; break; }
 
     // ---- the symbols of the block --------------------------------------------------------------
+    // No input check per symbol: every symbol either produces text (bounded by ISIZE) or ends the
+    // block, and the next block header is checked against the member's length -- a stream that runs
+    // off its end into the bytes of the next member stops there at the latest.
     // `e` = the table entry of the NEXT symbol, looked up while the copy of the current match is
     // still on its way through the LDS (the look-up only peeks at the bits)
     in.fill();
     uint32_t e = peek_entry<kLitBits>(in, s.lit);
     for (;;) {
-      if (in.pos_bits() > bit_limit + 64) { err = kInputOverrun; break; }
       int sym = take_symbol(in, s.lit, e);
       if (sym < 0) { err = kBadSymbol; break; }
       if (sym < 256) {
