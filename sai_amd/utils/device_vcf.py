@@ -24,6 +24,20 @@ INFLATE_BATCH_BYTES = 1984 << 16  # 124 MiB: at most 1 984 full members, under t
 _MEMBER_BYTES = 32  # sizeof(sai_bgzf_member)
 
 
+def _inflate_batch_for(vcf_file) -> int:
+    """Text bytes per GPU-inflate batch: the full 124 MiB for files that can fill it, a quarter-step
+    size class for small ones (the staging buffers are pinned and kept per size: a 100 kB file should
+    not page-lock 200 MB).  Only a ceiling: a file that inflates to more simply takes more batches."""
+    try:
+        guess = os.path.getsize(vcf_file) * 16  # genotype text compresses 10-20x
+    except OSError:
+        return INFLATE_BATCH_BYTES
+    cap = 1 << 20
+    while cap < guess and cap < INFLATE_BATCH_BYTES:
+        cap <<= 2
+    return min(cap, INFLATE_BATCH_BYTES)
+
+
 class _Fallback(Exception):
     """The bgzip-on-the-GPU route cannot serve this read; the host-inflating stream takes it."""
 
@@ -49,7 +63,7 @@ def load_dosage_device(eng, vcf_file: str, chr_name: str, samples: Sequence[str]
     if os.environ.get("SAI_AMD_GPU_INFLATE", "1") != "0":
         try:
             # 2 048 members are in flight on the chip at a time: a batch of 124 MiB of text fills it in one round
-            icap = int(buffer_bytes or os.environ.get("SAI_AMD_INFLATE_BATCH", INFLATE_BATCH_BYTES))
+            icap = int(buffer_bytes or os.environ.get("SAI_AMD_INFLATE_BATCH", 0)) or _inflate_batch_for(vcf_file)
             try:
                 got = _load_bgzf_device(eng, vcf_file, chr_name, samples, ploidies, start, end, anc_allele_file, n_threads, icap)
             except _TextIndex:
@@ -494,7 +508,7 @@ def scan_first_last_device(eng, vcf_file: str, chr_name: str):
     from their heads and would have to copy back whole, ...): the host scan does it then."""
     if os.environ.get("SAI_AMD_GPU_INFLATE", "1") == "0":
         return None
-    cap = int(os.environ.get("SAI_AMD_INFLATE_BATCH", INFLATE_BATCH_BYTES))
+    cap = int(os.environ.get("SAI_AMD_INFLATE_BATCH", 0)) or _inflate_batch_for(vcf_file)
     try:
         got = _load_bgzf_device(eng, vcf_file, chr_name, [], [], None, None, None, None, cap, positions_only=True)
     except (_Fallback, _TextIndex):
