@@ -12,6 +12,8 @@
 //     popcount, every lane fills the table entries of its own symbols;
 //   * finished text leaves the window for HBM 256 B at a time, one word per lane.
 // Every lane executes the same decode on the same values, so nothing is broadcast or synchronised.
+// (Whether the compiler keeps those values in scalar or in vector registers makes no difference to
+// the rate -- measured both ways: a lone wavefront issues an instruction every few cycles either way.)
 // Each access is bounded (window index masked, output against ISIZE, distance against what the
 // member has produced, input against the member's length): a corrupt member ends with a non-zero
 // status, never with a stray access.  A second kernel checks the CRC-32 of every member's text against
