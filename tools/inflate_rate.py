@@ -21,13 +21,22 @@ from test_inflate_device import MEMBER, deflate  # noqa: E402
 
 def main() -> None:
     mb = int(sys.argv[1]) if len(sys.argv) > 1 else 256
-    n_samples = 2002
+    n_samples = int(sys.argv[2]) if len(sys.argv) > 2 else 2002
     rng = np.random.default_rng(1)
     calls = np.array([b"0|0", b"0|1", b"1|0", b"1|1", b".|."])
     lines, pos = [], 0
-    while sum(map(len, lines)) < (8 << 20):
+    linked = len(sys.argv) > 3 and sys.argv[3] == "linked"  # every line a copy of the one before with 2 % of the calls redrawn
+    row = calls[rng.choice(5, size=n_samples, p=[0.7, 0.1, 0.1, 0.095, 0.005])]
+    size = 0
+    while size < (8 << 20):
         pos += int(rng.integers(1, 50))
-        row = calls[rng.choice(5, size=n_samples, p=[0.7, 0.1, 0.1, 0.095, 0.005])]
+        if linked:
+            row = row.copy()
+            hit = rng.random(n_samples) < 0.02
+            row[hit] = calls[rng.choice(5, size=int(hit.sum()), p=[0.7, 0.1, 0.1, 0.095, 0.005])]
+        else:
+            row = calls[rng.choice(5, size=n_samples, p=[0.7, 0.1, 0.1, 0.095, 0.005])]
+        size += 4 * n_samples + 30
         lines.append(b"1\t%d\t.\tA\tT\t100\tPASS\t.\tGT\t" % pos + b"\t".join(row) + b"\n")
     unit = b"".join(lines)
     text = (unit * (mb * (1 << 20) // len(unit) + 1))[: mb << 20]
@@ -35,7 +44,7 @@ def main() -> None:
     t0 = time.perf_counter()
     with ThreadPoolExecutor(16) as ex:
         streams = list(ex.map(deflate, chunks))
-    print(f"{len(text) / 1e6:.0f} MB of text, {len(chunks)} members, {sum(map(len, streams)) / 1e6:.1f} MB compressed "
+    print(f"{n_samples} samples per line; {len(text) / 1e6:.0f} MB of text, {len(chunks)} members, {sum(map(len, streams)) / 1e6:.1f} MB compressed "
           f"(deflated in {time.perf_counter() - t0:.1f} s)", flush=True)  # fmt: skip
     eng = Engine.get(0)
     table = np.zeros(len(chunks), dtype=MEMBER)
