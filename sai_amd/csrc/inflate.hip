@@ -5,7 +5,8 @@
 // a stream; what the 64 lanes share is everything around the symbol decode:
 //   * the compressed bytes are held 256 B at a time in one register per lane (one coalesced load,
 //     the next 256 B prefetched) and fed to a wave-uniform bit buffer with v_readlane;
-//   * the 32 KiB history window lives in LDS; a match of length L is copied by L lanes at once
+//   * the last 4 KiB of history live in LDS (older text is read back from HBM); a match of length L
+//     is copied by L lanes at once
 //     (overlapping matches read `src + k % dist`), a literal is one LDS byte store;
 //   * the Huffman tables (10-bit / 8-bit primary look-up + a canonical walk for longer codes) are
 //     built by all lanes: code counts with ballots, a symbol's rank inside its length with a prefix
@@ -51,10 +52,13 @@ struct HuffLds {
 using LitLds = HuffLds<kLitBits, kMaxLit>;
 using DistLds = HuffLds<kDistBits, kMaxDist>;  // also holds the code-length code (7-bit table, 19 symbols)
 
-// W = bytes of history kept in LDS.  W = 32768 is DEFLATE's whole window (4 wavefronts per CU by
-// LDS); W = 16384 doubles the wavefronts in flight -- the decode is a chain of dependent
-// instructions, so that doubles the rate -- and serves the rare match that reaches further back
-// from the text the wavefront has already written to HBM.
+// W = bytes of history kept in LDS.  The decode is a chain of dependent instructions, so its rate
+// is the number of wavefronts in flight, and LDS decides that number: W = 32768 (DEFLATE's whole
+// window) allows 4 per CU, 16384 allows 8, 4096 allows 16 (the register file allows no more).  A match
+// that reaches further back than W is served from the text the wavefront has already written to HBM
+// (one global load; a fence whenever the source is younger than the last fence).  Measured on 503 MB
+// of VCF text: 36 / 65 / 77 / 91 GB/s for W = 32768 / 16384 / 8192 / 4096, and the same order on
+// lines that copy their predecessor 8, 14 or 20 KB back (106 / 98 / 98 GB/s at W = 4096).
 template <int W>
 struct WaveLds {
   uint8_t win[W];
@@ -64,6 +68,7 @@ struct WaveLds {
   uint8_t cl_lens[32];
 };
 static_assert(sizeof(WaveLds<16384>) <= 20480, "eight wavefronts per CU need <= 20 KiB each");
+static_assert(sizeof(WaveLds<4096>) <= 8192, "twenty wavefronts per CU need <= 8 KiB each");
 
 struct InflateArgs {
   const uint8_t* comp;
@@ -580,12 +585,15 @@ extern "C" int sai_inflate_bgzf(sai_ctx* ctx, const void* comp, int64_t n_comp_b
   a.text = static_cast<uint8_t*>(text);
   a.n_text = n_text_bytes;
   a.status = status;
-  static const int window = [] {  // SAI_INFLATE_WINDOW=32768: the whole DEFLATE window in LDS (for A/B runs)
+  static const int window = [] {  // SAI_INFLATE_WINDOW = 8192 / 16384 / 32768: more history in LDS (for A/B runs)
     const char* e = std::getenv("SAI_INFLATE_WINDOW");
-    return e && std::atoi(e) == 32768 ? 32768 : 16384;
+    const int v = e ? std::atoi(e) : 0;
+    return v == 32768 || v == 16384 || v == 8192 ? v : 4096;
   }();
   const dim3 grid(static_cast<unsigned>(n_members));
-  if (window == 32768) hipLaunchKernelGGL(inflate_bgzf_kernel<32768>, grid, dim3(64), 0, static_cast<hipStream_t>(stream), a);
+  if (window == 4096) hipLaunchKernelGGL(inflate_bgzf_kernel<4096>, grid, dim3(64), 0, static_cast<hipStream_t>(stream), a);
+  else if (window == 8192) hipLaunchKernelGGL(inflate_bgzf_kernel<8192>, grid, dim3(64), 0, static_cast<hipStream_t>(stream), a);
+  else if (window == 32768) hipLaunchKernelGGL(inflate_bgzf_kernel<32768>, grid, dim3(64), 0, static_cast<hipStream_t>(stream), a);
   else hipLaunchKernelGGL(inflate_bgzf_kernel<16384>, grid, dim3(64), 0, static_cast<hipStream_t>(stream), a);
   if (int rc = check_launch("inflate_bgzf")) return rc;
   hipLaunchKernelGGL(crc_members_kernel, grid, dim3(64), 0, static_cast<hipStream_t>(stream), a);

@@ -20,14 +20,14 @@ from .. import _ffi
 from .native_vcf import default_threads, load_dosage
 
 BUFFER_BYTES = 32 << 20
-INFLATE_BATCH_BYTES = 1984 << 16  # 124 MiB: at most 1 984 full members, under the 2 048 the chip holds at a time
+INFLATE_BATCH_BYTES = 3968 << 16  # 248 MiB: at most 3 968 full members, under the 4 096 the chip holds at a time
 _MEMBER_BYTES = 32  # sizeof(sai_bgzf_member)
 
 
 def _inflate_batch_for(vcf_file) -> int:
-    """Text bytes per GPU-inflate batch: the full 124 MiB for files that can fill it, a quarter-step
+    """Text bytes per GPU-inflate batch: the full 248 MiB for files that can fill it, a quarter-step
     size class for small ones (the staging buffers are pinned and kept per size: a 100 kB file should
-    not page-lock 200 MB).  Only a ceiling: a file that inflates to more simply takes more batches."""
+    not page-lock 400 MB).  Only a ceiling: a file that inflates to more simply takes more batches."""
     try:
         guess = os.path.getsize(vcf_file) * 16  # genotype text compresses 10-20x
     except OSError:
@@ -62,7 +62,7 @@ def load_dosage_device(eng, vcf_file: str, chr_name: str, samples: Sequence[str]
     cap = int(buffer_bytes or os.environ.get("SAI_AMD_INGEST_BUFFER", BUFFER_BYTES))
     if os.environ.get("SAI_AMD_GPU_INFLATE", "1") != "0":
         try:
-            # 2 048 members are in flight on the chip at a time: a batch of 124 MiB of text fills it in one round
+            # 4 096 members are in flight on the chip at a time: a batch of 248 MiB of text fills it in one round
             icap = int(buffer_bytes or os.environ.get("SAI_AMD_INFLATE_BATCH", 0)) or _inflate_batch_for(vcf_file)
             try:
                 got = _load_bgzf_device(eng, vcf_file, chr_name, samples, ploidies, start, end, anc_allele_file, n_threads, icap)
