@@ -410,7 +410,7 @@ __global__ __launch_bounds__(64) void inflate_bgzf_kernel(InflateArgs a) {
         const int src = out_pos - dist;
         if (W < 32768 && dist > W) {
           // further back than the LDS history: the text is in HBM already (everything but the last
-          // few hundred bytes is); one fence per 16 KiB of output makes this wavefront's own stores
+          // few hundred bytes is); a fence whenever the source is younger than the last one makes this wavefront's own stores
           // visible to all its lanes
           if (src + len > fenced) {
             __threadfence();
