@@ -149,9 +149,44 @@ struct Selection {
   int32_t max_col = -1;
 };
 
+// Ancestral alleles of one chromosome / region: position -> allele, as sorted arrays (a BED of a whole
+// chromosome has millions of lines; a hash map of std::string took seconds to fill).  `allele` keeps
+// the few map operations the readers use: find(pos), end(), size().
+struct AncAllele {
+  const char* p = nullptr;
+  size_t n = 0;
+  size_t size() const { return n; }
+  const char* data() const { return p; }
+};
+struct AncTable {
+  std::vector<int64_t> pos;   // ascending, unique
+  std::vector<uint32_t> off;  // allele of entry i = text[off[i] .. off[i] + len[i])
+  std::vector<uint32_t> len;
+  std::string text;
+  struct Hit {
+    bool ok = false;
+    AncAllele second;
+    const Hit* operator->() const { return this; }
+    bool operator==(const Hit& o) const { return ok == o.ok; }
+    bool operator!=(const Hit& o) const { return ok != o.ok; }
+  };
+  Hit find(int64_t p) const {
+    const auto it = std::lower_bound(pos.begin(), pos.end(), p);
+    Hit h;
+    if (it != pos.end() && *it == p) {
+      const size_t i = static_cast<size_t>(it - pos.begin());
+      h.ok = true;
+      h.second.p = text.data() + off[i];
+      h.second.n = len[i];
+    }
+    return h;
+  }
+  Hit end() const { return Hit(); }
+  size_t size() const { return pos.size(); }
+};
 struct AncMap {
   bool active = false;
-  std::unordered_map<int64_t, std::string> allele;
+  AncTable allele;
 };
 
 struct ThreadOut {
@@ -235,7 +270,7 @@ void parse_lines(const char* begin, const char* end, const std::string& chrom, i
       const char* alt_end = col[5] - 1;
       const void* comma = memchr(alt, ',', static_cast<size_t>(alt_end - alt));
       const size_t alt_len = static_cast<size_t>((comma ? static_cast<const char*>(comma) : alt_end) - alt);
-      const std::string& a = it->second;
+      const AncAllele& a = it->second;
       if (a.size() == alt_len && memcmp(a.data(), alt, alt_len) == 0) flip = true;
       else if (!(a.size() == ref_len && memcmp(a.data(), ref, ref_len) == 0)) continue;
     }
@@ -325,26 +360,136 @@ void parse_lines(const char* begin, const char* end, const std::string& chrom, i
   }
 }
 
+bool read_all_gz(const std::string& path, std::vector<unsigned char>& out);
+
+// The BED of ancestral alleles: whitespace-separated chrom, start, pos, allele (+ anything); lines of
+// other chromosomes or outside the region are skipped, a later line of a position replaces an earlier
+// one, a line with one to three columns is an error (as before).  The file is read whole and parsed
+// by up to 8 threads over line-aligned pieces; the entries are sorted only when the file is not.
 int load_anc(const char* path, const std::string& chrom, int64_t start, int64_t stop, AncMap& anc, int64_t* n_entries) {
-  GzReader r(path);
-  if (!r.f) return sai_set_error(SAI_ERR_ARG, "cannot open ancestral-allele file %s", path);
-  std::vector<char> line(1 << 16);
-  while (gzgets(r.f, line.data(), static_cast<int>(line.size()))) {
-    // columns: chrom, start, pos, allele (whitespace separated)
-    char* save = nullptr;
-    const char* c0 = strtok_r(line.data(), " \t\r\n", &save);
-    const char* c1 = c0 ? strtok_r(nullptr, " \t\r\n", &save) : nullptr;
-    const char* c2 = c1 ? strtok_r(nullptr, " \t\r\n", &save) : nullptr;
-    const char* c3 = c2 ? strtok_r(nullptr, " \t\r\n", &save) : nullptr;
-    if (!c0) continue;
-    if (!c3) return sai_set_error(SAI_ERR_ARG, "%s: line with fewer than 4 columns", path);
-    if (chrom != c0) continue;
-    const int64_t p = strtoll(c2, nullptr, 10);
-    if ((start >= 0 && p < start) || (stop >= 0 && p > stop)) continue;
-    anc.allele[p] = c3;
+  std::vector<unsigned char> raw;
+  {
+    FILE* f = fopen(path, "rb");
+    if (!f) return sai_set_error(SAI_ERR_ARG, "cannot open ancestral-allele file %s", path);
+    fclose(f);
+  }
+  if (!read_all_gz(path, raw)) return sai_set_error(SAI_ERR_ARG, "cannot read ancestral-allele file %s", path);  // gzread passes plain text through
+  const char* base = reinterpret_cast<const char*>(raw.data());
+  const size_t total = raw.size();
+  struct Piece {
+    std::vector<int64_t> pos;
+    std::vector<uint32_t> off, len;
+    std::string text;
+    bool short_line = false;
+  };
+  unsigned hw = std::thread::hardware_concurrency();
+  const int nt = static_cast<int>(std::max<size_t>(1, std::min<size_t>({size_t(8), hw ? hw : 1, total / (size_t(1) << 20) + 1})));
+  std::vector<Piece> pieces(static_cast<size_t>(nt));
+  std::vector<size_t> edge(static_cast<size_t>(nt) + 1, total);
+  edge[0] = 0;
+  for (int t = 1; t < nt; ++t) {
+    size_t guess = std::max(edge[static_cast<size_t>(t) - 1], total * static_cast<size_t>(t) / static_cast<size_t>(nt));
+    const void* nl = guess < total ? memchr(base + guess, '\n', total - guess) : nullptr;
+    edge[static_cast<size_t>(t)] = nl ? static_cast<size_t>(static_cast<const char*>(nl) - base) + 1 : total;
+  }
+  auto is_ws = [](char c) { return c == ' ' || c == '\t' || c == '\r' || c == '\n'; };
+  auto work = [&](int t) {
+    Piece& pc = pieces[static_cast<size_t>(t)];
+    const char* p = base + edge[static_cast<size_t>(t)];
+    const char* endp = base + edge[static_cast<size_t>(t) + 1];
+    while (p < endp) {
+      const char* eol = static_cast<const char*>(memchr(p, '\n', static_cast<size_t>(endp - p)));
+      if (!eol) eol = endp;
+      const char* tok[4];
+      size_t tlen[4];
+      int found = 0;
+      const char* q = p;
+      while (found < 4) {
+        while (q < eol && is_ws(*q)) ++q;
+        if (q >= eol) break;
+        const char* s0 = q;
+        while (q < eol && !is_ws(*q)) ++q;
+        tok[found] = s0;
+        tlen[found] = static_cast<size_t>(q - s0);
+        ++found;
+      }
+      p = eol + 1;
+      if (found == 0) continue;
+      if (found < 4) { pc.short_line = true; return; }
+      if (tlen[0] != chrom.size() || memcmp(tok[0], chrom.data(), chrom.size()) != 0) continue;
+      // strtoll's reading of the third column: optional sign, leading digits
+      const char* d = tok[2];
+      const char* de = tok[2] + tlen[2];
+      bool neg = false;
+      if (d < de && (*d == '+' || *d == '-')) neg = *d++ == '-';
+      int64_t v = 0;
+      while (d < de && *d >= '0' && *d <= '9') v = v * 10 + (*d++ - '0');
+      if (neg) v = -v;
+      if ((start >= 0 && v < start) || (stop >= 0 && v > stop)) continue;
+      pc.pos.push_back(v);
+      pc.off.push_back(static_cast<uint32_t>(pc.text.size()));
+      pc.len.push_back(static_cast<uint32_t>(tlen[3]));
+      pc.text.append(tok[3], tlen[3]);
+    }
+  };
+  {
+    ThreadGroup tg;
+    for (int t = 1; t < nt; ++t) tg.spawn([&work, t] { work(t); });
+    work(0);
+    tg.join();
+  }
+  AncTable& tab = anc.allele;
+  tab = AncTable();
+  size_t n = 0, bytes = 0;
+  for (const Piece& pc : pieces) {
+    if (pc.short_line) return sai_set_error(SAI_ERR_ARG, "%s: line with fewer than 4 columns", path);
+    n += pc.pos.size();
+    bytes += pc.text.size();
+  }
+  if (bytes >= (size_t(1) << 32)) return sai_set_error(SAI_ERR_UNSUPPORTED, "%s: more than 4 GiB of alleles", path);
+  tab.pos.reserve(n);
+  tab.off.reserve(n);
+  tab.len.reserve(n);
+  tab.text.reserve(bytes);
+  bool sorted = true;
+  for (const Piece& pc : pieces) {
+    const uint32_t shift = static_cast<uint32_t>(tab.text.size());
+    for (size_t i = 0; i < pc.pos.size(); ++i) {
+      if (!tab.pos.empty() && pc.pos[i] <= tab.pos.back()) {
+        if (sorted && pc.pos[i] == tab.pos.back()) {  // the later line of a position wins
+          tab.off.back() = pc.off[i] + shift;
+          tab.len.back() = pc.len[i];
+          continue;
+        }
+        sorted = false;
+      }
+      tab.pos.push_back(pc.pos[i]);
+      tab.off.push_back(pc.off[i] + shift);
+      tab.len.push_back(pc.len[i]);
+    }
+    tab.text += pc.text;
+  }
+  if (!sorted) {  // order by position, the LAST line of a position kept (what a map filled in file order holds)
+    std::vector<uint32_t> order(tab.pos.size());
+    for (size_t i = 0; i < order.size(); ++i) order[i] = static_cast<uint32_t>(i);
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return tab.pos[x] < tab.pos[y]; });
+    AncTable out;
+    out.text = std::move(tab.text);
+    for (size_t k = 0; k < order.size(); ++k) {
+      const uint32_t i = order[k];
+      if (!out.pos.empty() && out.pos.back() == tab.pos[i]) {
+        out.off.back() = tab.off[i];
+        out.len.back() = tab.len[i];
+        continue;
+      }
+      out.pos.push_back(tab.pos[i]);
+      out.off.push_back(tab.off[i]);
+      out.len.push_back(tab.len[i]);
+    }
+    tab = std::move(out);
   }
   anc.active = true;
-  if (n_entries) *n_entries = static_cast<int64_t>(anc.allele.size());
+  if (n_entries) *n_entries = static_cast<int64_t>(tab.size());
   return SAI_OK;
 }
 
@@ -889,7 +1034,7 @@ void index_lines(const char* begin, const char* end, const char* text0, const st
       const char* alt_end = col[5] - 1;
       const void* comma = memchr(alt, ',', static_cast<size_t>(alt_end - alt));
       const size_t alt_len = static_cast<size_t>((comma ? static_cast<const char*>(comma) : alt_end) - alt);
-      const std::string& a = it->second;
+      const AncAllele& a = it->second;
       if (a.size() == alt_len && memcmp(a.data(), alt, alt_len) == 0) flip = true;
       else if (!(a.size() == ref_len && memcmp(a.data(), ref, ref_len) == 0)) continue;
     }
@@ -1421,7 +1566,7 @@ void index_head_lines(const char* heads, int32_t H, const int64_t* start, const 
       const char* alt_end = col[5] - 1;
       const void* comma = memchr(alt, ',', static_cast<size_t>(alt_end - alt));
       const size_t alt_len = static_cast<size_t>((comma ? static_cast<const char*>(comma) : alt_end) - alt);
-      const std::string& a = it->second;
+      const AncAllele& a = it->second;
       if (a.size() == alt_len && memcmp(a.data(), alt, alt_len) == 0) flip = true;
       else if (!(a.size() == ref_len && memcmp(a.data(), ref, ref_len) == 0)) continue;
     }

@@ -372,3 +372,56 @@ def test_bgzf_through_zlib_when_libdeflate_is_switched_off(tmp_path):
     res = subprocess.run([sys.executable, "-c", code], env={**os.environ, "SAI_NO_LIBDEFLATE": "1"}, capture_output=True, text=True)
     assert res.returncode == 0, res.stderr
     assert int(res.stdout.strip()) == len(want[0]) and np.array_equal(np.load(tmp_path / "z.npy"), want[1])
+
+
+def test_ancestral_allele_table_semantics(tmp_path):
+    """The BED loader (sorted arrays, parsed by several threads): unsorted files, a position listed
+    twice (the later line wins), alleles of several characters, runs of blanks and tabs, CRLF, extra
+    columns, other chromosomes, plain and gzip -- the native reader against the Python statement of
+    the rules; a line with one to three columns is an error."""
+    import gzip
+
+    from sai_amd.utils.native_vcf import load_dosage
+
+    rng = np.random.default_rng(12)
+    path = tmp_path / "a.vcf"
+    names = write_vcf(path, rng, 600, 7)
+    reg_pos, reg_ref, reg_alt = [], [], []
+    for line in open(path):
+        if line.startswith("21\t"):
+            f = line.split("\t")
+            reg_pos.append(int(f[1])), reg_ref.append(f[3]), reg_alt.append(f[4].split(",")[0])
+    lines = []
+    for p, r, a in zip(reg_pos, reg_ref, reg_alt):
+        u = rng.random()
+        allele = r if u < 0.4 else (a if u < 0.7 else ("N" if u < 0.8 else r + a))
+        sep = ["\t", " ", "  \t ", "\t\t"][int(rng.integers(4))]
+        extra = "" if rng.random() < 0.7 else sep + "extra" + sep + "columns"
+        lines.append(f"21{sep}{p - 1}{sep}{p}{sep}{allele}{extra}" + ("\r\n" if rng.random() < 0.2 else "\n"))
+        if rng.random() < 0.15:  # listed again with another allele: the later line counts
+            lines.append(f"21\t{p - 1}\t{p}\t{a if allele != a else r}\n")
+        if rng.random() < 0.1:
+            lines.append(f"22\t{p - 1}\t{p}\t{a}\n")
+        if rng.random() < 0.05:
+            lines.append("\n")
+    # padding so that the parse is cut into several pieces, then shuffled: an unsorted file
+    lines += [f"7\t{i}\t{i + 1}\tA\n" for i in range(60000)]
+    order = rng.permutation(len(lines))
+    dup_safe = [lines[i] for i in order]
+    for name, body in (("sorted", lines), ("shuffled", dup_safe)):
+        bed = tmp_path / f"{name}.bed"
+        with open(bed, "w", newline="") as f:
+            f.write("".join(body))
+        bed_gz = tmp_path / f"{name}.bed.gz"
+        with gzip.open(bed_gz, "wt", newline="") as f:
+            f.write("".join(body))
+        for start, end in ((None, None), (reg_pos[50], reg_pos[400])):
+            want = python_reader(path, "21", names[:3], 2, start, end, str(bed))
+            for b in (bed, bed_gz):
+                got = load_dosage(str(path), "21", names[:3], [2, 2, 2], start, end, str(b), 3)
+                assert got[0].tolist() == want[0].tolist(), (name, start)
+                assert np.array_equal(got[1], want[1]) and got[2] == want[2] and got[3] == want[3]
+    bad = tmp_path / "bad.bed"
+    open(bad, "w").write("21\t5\t6\tA\n21\t7\t8\n")
+    with pytest.raises(ValueError, match="fewer than 4 columns"):
+        load_dosage(str(path), "21", names[:3], [2, 2, 2], None, None, str(bad), 2)
