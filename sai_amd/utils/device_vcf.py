@@ -195,10 +195,12 @@ def _load_bgzf_device(eng, vcf_file, chr_name, samples, ploidies, start, end, an
         st["heads_dev"] = [torch.empty((heads_cap,), dtype=torch.uint8, device=eng.device) for _ in range(2)]
         st["scratch_dev"] = torch.empty(((room + cap + 32) // 4096 + 4,), dtype=torch.int32, device=eng.device)
         st["info4_dev"] = [torch.zeros((4,), dtype=torch.int32, device=eng.device) for _ in range(2)]
-        st["starts_host"] = [torch.empty((line_cap + 1,), dtype=torch.int64).pin_memory() for _ in range(2)]
-        st["info_host"] = [torch.empty((line_cap,), dtype=torch.int32).pin_memory() for _ in range(2)]
-        st["heads_host"] = [torch.empty((heads_cap,), dtype=torch.uint8).pin_memory() for _ in range(2)]
-        st["tail_host"] = torch.empty((room,), dtype=torch.uint8).pin_memory()
+        # the pinned mirrors grow with the line counts actually seen (a 2 002-sample file has 31 000 lines
+        # in a 248 MiB batch: 2 MB of table; page-locking for the worst case would cost 270 MB and 0.2 s)
+        st["starts_host"] = [torch.empty((1,), dtype=torch.int64).pin_memory() for _ in range(2)]
+        st["info_host"] = [torch.empty((1,), dtype=torch.int32).pin_memory() for _ in range(2)]
+        st["heads_host"] = [torch.empty((1,), dtype=torch.uint8).pin_memory() for _ in range(2)]
+        st["tail_host"] = torch.empty((1,), dtype=torch.uint8).pin_memory()
     comp_host, comp_dev, text_dev = st["comp_host"], st["comp_dev"], st["text_dev"]
     flag_host, side, copy, d2h, tok = st["flag_host"], st["side"], st["copy"], st["d2h"], st["tok"]
     tok_done = [None, None]  # per ring slot: the tokenizer that read text_dev[slot] last
@@ -424,6 +426,10 @@ def _load_bgzf_device(eng, vcf_file, chr_name, samples, ploidies, start, end, an
                 if overflow or fixed > 4096 or n_l * hb > heads_cap:
                     raise _TextIndex  # short lines / far fixed columns: the whole-text index serves this file
                 batch["n_lines"], batch["hb"] = n_l, hb
+                for buf, need, dt in ((starts_host, n_l + 1, torch.int64), (info_host, max(n_l, 1), torch.int32),
+                                      (heads_host, max(n_l * hb, 1), torch.uint8)):
+                    if buf[b].numel() < need:
+                        buf[b] = torch.empty((1 << (need - 1).bit_length(),), dtype=dt).pin_memory()
                 with torch.cuda.stream(d2h):  # its own stream: the next batch's inflate is already queued on `side`
                     _ffi.check(
                         lib.sai_text_line_heads(eng.ctx, C.c_void_p(text_dev[b].data_ptr() + base), total,
@@ -470,6 +476,8 @@ def _load_bgzf_device(eng, vcf_file, chr_name, samples, ploidies, start, end, an
                         break
                     if batch is None:
                         if left:  # the file ends without a newline: those few bytes come to the host as text
+                            if tail_host.numel() < left:
+                                tail_host = st["tail_host"] = torch.empty((1 << (left - 1).bit_length(),), dtype=torch.uint8).pin_memory()
                             with torch.cuda.stream(side):
                                 tail_host[:left].copy_(text_dev[prev["b"]][at : at + left], non_blocking=True)
                             side.synchronize()
