@@ -67,6 +67,60 @@ for _ in range(12):
     score(vcf_file=vcf, chr_name="1", win_len=50000, win_step=25000, anc_allele_file=None, output_file=out, config=cfg, num_workers=1)
     reps.append(time.perf_counter() - t0)
 print("12 more calls, ms each:", " ".join(f"{1e3 * t:.1f}" for t in reps))
+# every statistic the path offers, polarised: an ancestral-allele BED for every site and an outgroup
+# (ten of the reference samples), fd / df / Danc / Dplus / DD next to U and Q
+bed = os.path.join(d, "anc.bed")
+with open(vcf) as f, open(bed, "w") as g:
+    for line in f:
+        if line[0] != "#":
+            p1 = int(line.split("\t", 2)[1])
+            g.write(f"1\t{p1 - 1}\t{p1}\tA\n")
+with open(os.path.join(d, "out.list"), "w") as f:
+    f.write("".join(f"OUT\t{n}\n" for n in names[:10]))
+with open(os.path.join(d, "ref2.list"), "w") as f:
+    f.write("".join(f"REF\t{n}\n" for n in names[10:n_ref]))
+cfg_all = os.path.join(d, "cfg_all.yaml")
+with open(cfg_all, "w") as f:
+    f.write(f"""statistics:
+  U:
+    ref: {{REF: 0.01}}
+    tgt: {{TGT: 0.5}}
+    src: {{SRC: "=1"}}
+  Q:
+    ref: {{REF: 0.01}}
+    tgt: {{TGT: 0.95}}
+    src: {{SRC: "=1"}}
+  fd: true
+  df: true
+  Danc: true
+  Dplus: true
+  DD: true
+ploidies:
+  ref: {{REF: 2}}
+  tgt: {{TGT: 2}}
+  src: {{SRC: 2}}
+  outgroup: {{OUT: 2}}
+populations:
+  ref: {d}/ref2.list
+  tgt: {d}/tgt.list
+  src: {d}/src.list
+  outgroup: {d}/out.list
+""")
+out_all = os.path.join(d, "out_all.tsv")
+score(vcf_file=vcf, chr_name="1", win_len=50000, win_step=25000, anc_allele_file=bed, output_file=out_all, config=cfg_all, num_workers=1)
+pr = cProfile.Profile()
+reps = []
+for k in range(5):
+    t0 = time.perf_counter()
+    if k == 4:
+        pr.enable()
+    score(vcf_file=vcf, chr_name="1", win_len=50000, win_step=25000, anc_allele_file=bed, output_file=out_all, config=cfg_all, num_workers=1)
+    if k == 4:
+        pr.disable()
+    reps.append(time.perf_counter() - t0)
+print("all seven statistics, polarised, with an outgroup: ms each", " ".join(f"{1e3 * t:.1f}" for t in reps))
+s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats("cumulative").print_stats(22); print(s.getvalue()[-4200:])
+print(open(out_all).read()[:300])
 # the same file as bgzip (what real VCFs are): members inflated on the GPU
 import struct, zlib
 from concurrent.futures import ThreadPoolExecutor
