@@ -339,10 +339,50 @@ def score_path_rate(eng, wl, block, lay, repeats: int = 3) -> dict:
     }
 
 
+def one_gpu_base(wl, args) -> dict:
+    """What an N > 1 line is to be divided by: the SAME job on one GPU.  `--gpus 1` runs C3, the
+    configuration the metric is quoted on, `--gpus N` the whole-genome job C4 cut into N window ranges,
+    so the strong-scaling denominator is C4 on one GPU (`python bench.py --workload c4`: 220 GB
+    resident) as measured and kept under profiles/ -- per window the two jobs move the same bytes."""
+    rec = {"workload_id": wl.name, "command": f"python bench.py --workload {wl.name}", "value": None, "unit": "windows/s"}
+    f = ROOT / "profiles" / "one_gpu_base.json"
+    reduced = bool(args.sites or args.chroms or args.scaling != "strong" or args.layout != "int8")
+    if f.exists() and not reduced:
+        rec.update(json.loads(f.read_text()).get(wl.name, {}))
+    elif reduced:
+        rec["note"] = "reduced / non-default job: run the same arguments with --gpus 1 for the base"
+    return rec
+
+
 def _trim(pop, n_sites):
     from sai_amd.engine import TiledPop
 
     return TiledPop(pop.tiles, n_sites, pop.n_ind)
+
+
+def self_launch(n_ranks: int, argv: list, result_out, script: str = "") -> int:
+    """`python bench.py --gpus N` without a launcher around it: build the library once, then run the N
+    ranks as ONE child process tree (`python -m torch.distributed.run ... bench.py <same arguments>`,
+    one rank per GPU, rendezvous on 127.0.0.1) whose stdout is this process's stdout, and return the
+    child's exit code.  Nothing here touches the GPU -- no torch.cuda call, no library context -- and
+    the child is started with subprocess, never exec'd over this process.  The reference starts its
+    workers the same way from the parent that owns the task list (mp_pool.py:45-73)."""
+    import socket
+    import subprocess
+
+    import __graft_entry__ as entry
+
+    entry.build()  # once, before N ranks would all find the tree stale
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_ranks}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), script or str(Path(__file__).resolve()), *argv]  # fmt: skip
+    result_out.flush()
+    child = subprocess.run(cmd, stdout=result_out.fileno(), cwd=str(ROOT))
+    if child.returncode != 0:
+        print(f"bench.py: the {n_ranks}-rank child job exited with {child.returncode}", file=sys.stderr)
+    return child.returncode
 
 
 def main() -> None:
@@ -378,13 +418,13 @@ def main() -> None:
                     "(auto = on for one GPU and a one-chromosome workload)")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # plain `python bench.py --gpus N`: this process only builds and starts the ranks
+        sys.exit(self_launch(args.gpus, sys.argv[1:], result_out))
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
-        args.gpus = world
+    args.gpus = world
 
     # build first, before anything touches the GPU or joins a process group: hipcc children are
     # forked from a process that has not initialised HIP; concurrent ranks serialise on a file lock
@@ -565,6 +605,7 @@ def main() -> None:
                 "gather": args.gather if dist_on else None,
                 "gather_row_bytes": gather.sizes if dist_on else None,
                 "gather_check": gather_check if dist_on else None,
+                "one_gpu_base": one_gpu_base(wl, args) if world > 1 else None,
                 "setup_s": round(t_setup, 2),
                 "u_sum": int(res.records["u_count"].sum()),
                 "q_finite": int(np.isfinite(res.records["q"]).sum()),

@@ -1,0 +1,73 @@
+"""`python bench.py --gpus N` without a launcher around it: the parent builds once,
+starts the ranks as one child job (torch.distributed.run, rendezvous on 127.0.0.1), hands the child
+its own stdout and returns the child's exit code.  Checked here on CPU with a stand-in script for
+the ranks (a gloo group that reduces over the ranks and prints one JSON line from rank 0), and with
+bench.py itself, whose ranks cannot run without a GPU: the failure must come back as a non-zero
+exit code, not as a hang or a zero.  The GPU counterpart is tests/test_hip_sharded.py."""
+
+import json
+import os
+import subprocess
+import sys
+import textwrap
+
+from conftest import ROOT
+
+RANK_SCRIPT = textwrap.dedent(
+    """
+    import json, os, sys
+    import torch, torch.distributed as dist
+    dist.init_process_group("gloo")
+    t = torch.tensor([dist.get_rank() + 1.0])
+    dist.all_reduce(t)
+    if os.environ.get("FAIL_RANK") == os.environ["RANK"]:
+        sys.exit(7)
+    if dist.get_rank() == 0:
+        print(json.dumps({"sum": t.item(), "world": dist.get_world_size(), "argv": sys.argv[1:],
+                          "master": os.environ["MASTER_ADDR"]}), flush=True)
+    dist.destroy_process_group()
+    """
+)
+
+
+def _launch(tmp_path, n, extra_env=None):
+    script = tmp_path / "ranks.py"
+    script.write_text(RANK_SCRIPT)
+    code = (
+        "import os, sys; sys.path.insert(0, %r); import bench; "
+        "out = os.fdopen(os.dup(1), 'w'); os.dup2(2, 1); "
+        "sys.exit(bench.self_launch(%d, ['--gpus', '%d', '--steps', '2'], out, script=%r))" % (str(ROOT), n, n, str(script))
+    )
+    env = {**os.environ, **(extra_env or {})}
+    env.pop("WORLD_SIZE", None)
+    return subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env)
+
+
+def test_self_launch_starts_the_ranks_and_relays_one_line(tmp_path):
+    res = _launch(tmp_path, 3)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout
+    rec = json.loads(lines[0])
+    assert rec == {"sum": 6.0, "world": 3, "argv": ["--gpus", "3", "--steps", "2"], "master": "127.0.0.1"}
+
+
+def test_self_launch_returns_the_childs_exit_code(tmp_path):
+    res = _launch(tmp_path, 2, {"FAIL_RANK": "1"})
+    assert res.returncode != 0  # rank 1 left with 7: torchrun fails the job, the launcher passes that on
+    assert "child job exited with" in res.stderr
+
+
+def test_plain_bench_gpus_2_without_a_gpu_fails_loudly():
+    """No GPU here: the ranks die in torch.cuda.set_device / Engine(); `python bench.py --gpus 2` must
+    come back non-zero with no JSON line (it used to exit with a usage message before starting anything)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    res = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "1", "--warmup", "0", "--sites", "5000",
+                          "--chroms", "2", "--cpu-sites", "0"], cwd=str(ROOT), capture_output=True, text=True, timeout=600, env=env)  # fmt: skip
+    import torch
+
+    if torch.cuda.is_available():  # on a GPU box this is simply a run (RCCL needs one device per rank: may fail too)
+        return
+    assert res.returncode != 0
+    assert not [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert "launch with torch.distributed.run" not in res.stderr

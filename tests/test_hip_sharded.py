@@ -176,6 +176,28 @@ def test_bench_two_ranks_on_one_gpu_equal_one_rank(gather):
     assert "2 rank(s) match" in two["config"]["gather_check"] and one["config"]["gather_check"] is None
 
 
+def test_plain_bench_gpus_2_launches_its_own_ranks():
+    """`python bench.py --gpus 2 ...` with no launcher on the command line (how the driver starts the
+    N = 1 run): bench.py starts its ranks itself as a child job and relays rank 0's line; same totals
+    as the one-process run, and the line names the one-GPU job it is to be divided by."""
+    one = _bench(REDUCED)
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(SAI_BENCH_DEVICE="0", SAI_BENCH_BACKEND="gloo")
+    res = subprocess.run([sys.executable, "bench.py", "--gpus", "2", *REDUCED], cwd=str(ROOT), env=env, capture_output=True,
+                         text=True, timeout=900)  # fmt: skip
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    two = json.loads(lines[0])
+    assert two["n_gpus"] == 2 and two["scaling"] == "strong"
+    for k in ("windows_total", "u_sum", "q_finite", "cdd_u_entries", "cdd_q_entries", "chromosomes", "parameter_sets"):
+        assert two["config"][k] == one["config"][k], k
+    assert "2 rank(s) match" in two["config"]["gather_check"]
+    base = two["config"]["one_gpu_base"]
+    assert base["workload_id"] == "c4" and "note" in base  # a reduced job has no stored base
+    assert one["config"]["one_gpu_base"] is None
+
+
 def test_bench_one_rank_on_real_rccl():
     """The same branches -- process group with device_id, header all_gather, the per-pass gather on
     the window stream, the MAX reduction -- with one rank on real RCCL."""
