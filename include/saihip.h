@@ -28,6 +28,17 @@
  *   so one wavefront instruction (64 lanes x 16 B) reads 16 individuals x 64 sites = 1 KiB of
  *   contiguous memory and a tile is one contiguous n_ind * 64 byte run.  The last tile is padded
  *   with zero bytes.  sai_tiled_bytes() gives the allocation size.
+ *
+ * Flag planes (what the per-site decision hands to the windows stage)
+ *   Per tile of 64 sites and parameter set three 64-bit words, bit b = site tile * 64 + b:
+ *       planes[tile * plane_stride + 3 * set + 0]   condition of compute_matching_loci (stat_utils.py:166)
+ *       planes[tile * plane_stride + 3 * set + 1]   condition && tgt_freq > x           (u_statistic.py:92)
+ *       planes[tile * plane_stride + 3 * set + 2]   site inverted: its effective target frequency is
+ *                                                   1 - tgt_freq[site]                  (stat_utils.py:156-160)
+ *   plane_stride = words per tile row (>= 3 * n_sets of the call; a caller that evaluates more than
+ *   SAI_MAX_SETS sets in several calls hands each call the row offset of its first set).  Bits of
+ *   sites >= n_sites are 0.  A tile's row is written by one store instruction of the wavefront that
+ *   evaluated the tile, and a window of 2 000 sites is 32 words per plane for the windows stage.
  */
 #ifndef SAIHIP_H
 #define SAIHIP_H
@@ -39,11 +50,12 @@
 extern "C" {
 #endif
 
-#define SAI_ABI_VERSION 11
+#define SAI_ABI_VERSION 12
 #define SAI_TILE_SITES 64
 #define SAI_MAX_SRC 6   /* source populations per call */
-#define SAI_MAX_SETS 16 /* parameter sets per call */
-#define SAI_FUSED_SETS 20 /* parameter sets the fused site pass carries (C5's 18-set sweep fits) */
+#define SAI_MAX_SETS 20 /* parameter sets per call: 3 * 20 plane words of a tile = one wave store (C5's 18 sets fit) */
+#define SAI_FUSED_SETS SAI_MAX_SETS /* parameter sets the fused site pass carries */
+#define SAI_PLANES_PER_SET 3
 
 enum sai_status {
   SAI_OK = 0,
@@ -120,30 +132,34 @@ int sai_tile_from_site_major(sai_ctx* ctx, const int8_t* src, int64_t n_sites, i
 int sai_site_counts(sai_ctx* ctx, int64_t n_sites, int32_t n_pops, const sai_pop* pops,
                     uint32_t* counts, void* stream);
 
+/* Words of a flag-plane buffer with rows of exactly 3 * n_sets words: ceil(n_sites / 64) * 3 * n_sets
+ * (-1 on bad arguments). */
+int64_t sai_plane_words(int64_t n_sites, int32_t n_sets);
+
 /* Kernels 1+2 fused (the fast path when there are at most SAI_FUSED_SETS parameter sets): one pass over the
  * genotypes that also evaluates sai_site_flags' per-site decision for each set at the end of every
  * tile, while the counts are still on chip.  `counts` may be NULL (then the 8 bytes per site and
  * population are neither written nor re-read); pops[p].ploidy is used.  Results are identical to
  * sai_site_counts followed by sai_site_flags.
  * freq_mode = SAI_FREQ_DENSE writes tgt_freq[site] for every site; SAI_FREQ_CANDIDATES writes it
- * only where some set's flags bit 0 is set -- the only entries sai_window_stats reads -- and
+ * only where some set's condition bit is set -- the only entries sai_window_stats reads -- and
  * leaves the rest of the buffer untouched (dense 8-byte stores interleaved with the genotype
  * stream cost about 10 % of the pass on MI355X). */
 int sai_site_pass(sai_ctx* ctx, int64_t n_sites, int32_t n_pops, const sai_pop* pops,
                   uint32_t* counts, int32_t n_sets, const sai_params* sets_host, int32_t freq_mode,
-                  double* tgt_freq, uint8_t* flags, void* stream);
+                  double* tgt_freq, uint64_t* planes, int64_t plane_stride, void* stream);
 
 /* Kernel 2: calc_freq's f64 division (stat_utils.py:51-52) and compute_matching_loci
  * (stat_utils.py:114-166) for every site and parameter set, plus U's final test
  * (u_statistic.py:92).  tgt_freq[site] is the UNinverted target frequency (NaN when nothing is
- * called); flags[set * n_sites + site] has bit0 = condition, bit1 = condition && tgt_freq > x,
- * bit2 = site inverted (its effective target frequency is 1 - tgt_freq[site]).
+ * called); the decisions go to the flag planes described at the top of this header (condition,
+ * condition && tgt_freq > x, site inverted).
  * ploidy[p] pairs with population p of sai_site_counts.  adj_freq may be NULL; otherwise it
  * receives compute_matching_loci's returned (possibly inverted) frequencies:
  * adj_freq[(set * 2 + 0) * n_sites + site] = ref_freq, [(set * 2 + 1) * n_sites + site] = tgt_freq. */
 int sai_site_flags(sai_ctx* ctx, int64_t n_sites, int32_t n_pops, const int32_t* ploidy_host,
                    const uint32_t* counts, int32_t n_sets, const sai_params* sets_host,
-                   double* tgt_freq, uint8_t* flags, double* adj_freq, void* stream);
+                   double* tgt_freq, uint64_t* planes, int64_t plane_stride, double* adj_freq, void* stream);
 
 /* Kernel 3: window -> site-index range.  Replaces the per-window position masks of
  * WindowGenerator._window_generator (window_generator.py:173-183) for a resident block with
@@ -175,13 +191,12 @@ int sai_window_bounds_seg(sai_ctx* ctx, const int32_t* pos, int64_t n_sites, int
  *   cdd_total[0..1] = entries needed for all U / Q lists: when a total exceeds its capacity,
  *     re-run with larger buffers.  cdd_total must hold sai_window_total_words(n_sets, n_windows)
  *     int64 words: the two totals, then scratch of the parallel prefix sum (one pair per 1024 records).
- * `quantile` is taken from sets_host[set].quantile.  `flags` is read as aligned 32-bit words, so up
- * to 3 bytes on either side of the n_sets * n_sites bytes are loaded (never used): inside the
- * same aligned word as a valid byte, hence always inside the same page.  tgt_freq is read only
- * at sites whose flags bit 0 is set (see SAI_FREQ_CANDIDATES). */
+ * `quantile` is taken from sets_host[set].quantile.  `planes` / `plane_stride`: the flag planes of
+ * these n_sets sets (rows of plane_stride words per tile, this call's first set at word 0 of the
+ * pointer).  tgt_freq is read only at sites whose condition bit is set (see SAI_FREQ_CANDIDATES). */
 int64_t sai_window_total_words(int32_t n_sets, int32_t n_windows); /* -1 on bad arguments */
-int sai_window_stats(sai_ctx* ctx, int64_t n_sites, const double* tgt_freq, const uint8_t* flags,
-                     int32_t n_sets, const sai_params* sets_host, int32_t n_windows,
+int sai_window_stats(sai_ctx* ctx, int64_t n_sites, const double* tgt_freq, const uint64_t* planes,
+                     int64_t plane_stride, int32_t n_sets, const sai_params* sets_host, int32_t n_windows,
                      const int32_t* lo, const int32_t* hi, const int32_t* pos,
                      sai_window_record* records, int64_t* cdd_off, int32_t* cdd_u, int64_t cap_u,
                      int32_t* cdd_q, int64_t cap_q, int64_t* cdd_total, void* stream);
@@ -269,7 +284,8 @@ int sai_pack2_from_tiles(sai_ctx* ctx, const int8_t* tiles, int64_t n_sites, int
  * obtain only the counts.  Results are identical to the int8 entry points. */
 int sai_site_pass_packed2(sai_ctx* ctx, int64_t n_sites, int32_t n_pops, const sai_pop* pops,
                           uint32_t* counts, int32_t n_sets, const sai_params* sets_host,
-                          int32_t freq_mode, double* tgt_freq, uint8_t* flags, void* stream);
+                          int32_t freq_mode, double* tgt_freq, uint64_t* planes, int64_t plane_stride,
+                          void* stream);
 
 /* ---- synthetic data ("synth-v1") ---------------------------------- */
 

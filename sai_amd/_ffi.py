@@ -16,11 +16,12 @@ LIB_PATH = Path(__file__).resolve().parent / "lib" / LIB_NAME
 
 SAI_TILE_SITES = 64
 SAI_MAX_SRC = 6
-SAI_MAX_SETS = 16
-SAI_FUSED_SETS = 20
+SAI_MAX_SETS = 20
+SAI_FUSED_SETS = SAI_MAX_SETS
+SAI_PLANES_PER_SET = 3
 SAI_ERR_UNSUPPORTED = -4  # enum sai_status
 FREQ_MODES = {"dense": 0, "candidates": 1}  # enum sai_freq_mode
-SAI_ABI_VERSION = 11
+SAI_ABI_VERSION = 12
 
 OPS = {"=": 0, "<": 1, ">": 2, "<=": 3, ">=": 4}
 
@@ -78,20 +79,21 @@ SIGNATURES = {
     "sai_tiled_bytes": (_i64, [_i64, _i32]),
     "sai_tile_from_site_major": (C.c_int, [_p, _p, _i64, _i32, _i64, _p, _p]),
     "sai_site_counts": (C.c_int, [_p, _i64, _i32, C.POINTER(SaiPop), _p, _p]),
+    "sai_plane_words": (_i64, [_i64, _i32]),
     "sai_site_pass": (
         C.c_int,
-        [_p, _i64, _i32, C.POINTER(SaiPop), _p, _i32, C.POINTER(SaiParams), _i32, _p, _p, _p],
+        [_p, _i64, _i32, C.POINTER(SaiPop), _p, _i32, C.POINTER(SaiParams), _i32, _p, _p, _i64, _p],
     ),
     "sai_site_flags": (
         C.c_int,
-        [_p, _i64, _i32, C.POINTER(_i32), _p, _i32, C.POINTER(SaiParams), _p, _p, _p, _p],
+        [_p, _i64, _i32, C.POINTER(_i32), _p, _i32, C.POINTER(SaiParams), _p, _p, _i64, _p, _p],
     ),
     "sai_window_bounds": (C.c_int, [_p, _p, _i64, _i32, _p, _p, _p, _p, _p]),
     "sai_window_bounds_seg": (C.c_int, [_p, _p, _i64, _i32, _p, _p, _p, _p, _p, _p, _p]),
     "sai_window_total_words": (_i64, [_i32, _i32]),
     "sai_window_stats": (
         C.c_int,
-        [_p, _i64, _p, _p, _i32, C.POINTER(SaiParams), _i32, _p, _p, _p, _p, _p, _p, _i64, _p, _i64, _p, _p],
+        [_p, _i64, _p, _p, _i64, _i32, C.POINTER(SaiParams), _i32, _p, _p, _p, _p, _p, _p, _i64, _p, _i64, _p, _p],
     ),
     "sai_single_window": (
         C.c_int,
@@ -106,7 +108,7 @@ SIGNATURES = {
     "sai_pack2_from_tiles": (C.c_int, [_p, _p, _i64, _i32, _p, _p, _p]),
     "sai_site_pass_packed2": (
         C.c_int,
-        [_p, _i64, _i32, C.POINTER(SaiPop), _p, _i32, C.POINTER(SaiParams), _i32, _p, _p, _p],
+        [_p, _i64, _i32, C.POINTER(SaiPop), _p, _i32, C.POINTER(SaiParams), _i32, _p, _p, _i64, _p],
     ),
     "sai_synth_fill": (C.c_int, [_p, _u64, _i32, _i64, _i64, _i32, _i32, _i32, _i32, _p, _p]),
     "sai_synth_fill_host": (C.c_int, [_u64, _i32, _i64, _i64, _i32, _i32, _i32, _i32, _p]),

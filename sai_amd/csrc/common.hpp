@@ -62,6 +62,8 @@ inline int check_launch(const char* what) {
 
 // site_pass.hip: argument checks of a parameter-set array (n_src < 0: any number of sources)
 int check_sets(int32_t n_sets, const sai_params* sets, int32_t n_src, int32_t max_sets = SAI_MAX_SETS);
+// site_pass.hip: a flag-plane row of plane_stride words holds n_sets sets
+int check_plane_stride(int64_t plane_stride, int32_t n_sets);
 
 inline unsigned stream_grid(const sai_ctx* ctx, int64_t n_tiles) {
   static const int waves_per_cu = [] {  // SAI_STREAM_WAVES_PER_CU: tuning knob for sweeps

@@ -145,10 +145,10 @@ __global__ __launch_bounds__(64) void site_counts_packed2_kernel(PackedArgs a, F
       if (a.counts && site < a.n_sites) store_counts_nt(a.counts + static_cast<int64_t>(p) * a.n_sites + site, cnt);
       if (FUSED) stash[p][lane] = cnt;
     }
-    if (FUSED && site < a.n_sites)
+    if (FUSED)  // lane = site inside the tile already: the ballots of eval_site are the tile's flag planes
       eval_site(
-          a.n_pops, fa.ploidy, [&](int p) { return stash[p][lane]; }, fa.n_sets, fa.sets, site, a.n_sites, fa.tgt_freq,
-          fa.flags, nullptr, fa.sparse_freq != 0);
+          a.n_pops, fa.ploidy, [&](int p) { return stash[p][lane]; }, fa.n_sets, fa.sets, tile, lane, site < a.n_sites,
+          a.n_sites, fa.tgt_freq, fa.planes, fa.plane_stride, nullptr, fa.sparse_freq != 0);
   }
 }
 
@@ -185,7 +185,7 @@ int sai_pack2_from_tiles(sai_ctx* ctx, const int8_t* tiles, int64_t n_sites, int
 
 int sai_site_pass_packed2(sai_ctx* ctx, int64_t n_sites, int32_t n_pops, const sai_pop* pops, uint32_t* counts,
                           int32_t n_sets, const sai_params* sets_host, int32_t freq_mode, double* tgt_freq,
-                          uint8_t* flags, void* stream) {
+                          uint64_t* planes, int64_t plane_stride, void* stream) {
   if (int rc = enter(ctx)) return rc;
   if (freq_mode != SAI_FREQ_DENSE && freq_mode != SAI_FREQ_CANDIDATES) return fail(SAI_ERR_ARG, "bad freq_mode %d", freq_mode);
   if (n_sites < 0 || n_sites >= 0x7FFFFFFFll) return fail(SAI_ERR_ARG, "n_sites out of range");
@@ -195,7 +195,8 @@ int sai_site_pass_packed2(sai_ctx* ctx, int64_t n_sites, int32_t n_pops, const s
   if (n_sets > 0) {
     if (n_pops < 2) return fail(SAI_ERR_ARG, "n_pops must be >= 2 (ref, tgt, sources)");
     if (int rc = check_sets(n_sets, sets_host, n_pops - 2, kFusedSets)) return rc;
-    if (n_sites > 0 && (!tgt_freq || !flags)) return fail(SAI_ERR_ARG, "NULL buffer");
+    if (n_sites > 0 && (!tgt_freq || !planes)) return fail(SAI_ERR_ARG, "NULL buffer");
+    if (int rc = check_plane_stride(plane_stride, n_sets)) return rc;
   } else if (!counts && n_sites > 0) {
     return fail(SAI_ERR_ARG, "nothing to compute: no parameter sets and counts is NULL");
   }
@@ -223,7 +224,8 @@ int sai_site_pass_packed2(sai_ctx* ctx, int64_t n_sites, int32_t n_pops, const s
   fa.n_sets = n_sets;
   fa.sparse_freq = freq_mode == SAI_FREQ_CANDIDATES;
   fa.tgt_freq = tgt_freq;
-  fa.flags = flags;
+  fa.planes = planes;
+  fa.plane_stride = plane_stride;
   for (int s = 0; s < n_sets; ++s) fa.sets[s] = sets_host[s];
   const dim3 grid(stream_grid(ctx, a.n_tiles));
   hipStream_t st = static_cast<hipStream_t>(stream);

@@ -44,10 +44,10 @@ extern "C" int sai_single_window(sai_ctx* ctx, int64_t n_sites, int32_t n_pops, 
     return SAI_OK;
   }
   const size_t n = static_cast<size_t>(n_sites);
-  // device scratch: tgt_freq | flags | lo,hi | record | offsets | totals | cdd_u | cdd_q
+  // device scratch: tgt_freq | flag planes | lo,hi | record | offsets | totals | cdd_u | cdd_q
   size_t o = 0;
   const size_t o_freq = o;   o = align_up(o + n * sizeof(double), 256);
-  const size_t o_flags = o;  o = align_up(o + n + 8, 256);
+  const size_t o_flags = o;  o = align_up(o + static_cast<size_t>(sai_plane_words(n_sites, 1)) * sizeof(uint64_t), 256);
   const size_t o_lohi = o;   o = align_up(o + 2 * sizeof(int32_t), 256);
   const size_t o_head = o;   // record (24) | offsets (16) | totals (16 + scratch): one copy brings them back
   // record | offsets (2) | totals (2) + the prefix sum's scratch pair for the one record
@@ -59,7 +59,7 @@ extern "C" int sai_single_window(sai_ctx* ctx, int64_t n_sites, int32_t n_pops, 
   char* d = static_cast<char*>(ctx->sw_dev);
   char* h = static_cast<char*>(ctx->sw_host);
   double* tgt_freq = reinterpret_cast<double*>(d + o_freq);
-  uint8_t* flags = reinterpret_cast<uint8_t*>(d + o_flags);
+  uint64_t* planes = reinterpret_cast<uint64_t*>(d + o_flags);
   int32_t* lohi = reinterpret_cast<int32_t*>(d + o_lohi);
   sai_window_record* rec = reinterpret_cast<sai_window_record*>(d + o_head);
   int64_t* off = reinterpret_cast<int64_t*>(d + o_head + sizeof(sai_window_record));
@@ -69,9 +69,10 @@ extern "C" int sai_single_window(sai_ctx* ctx, int64_t n_sites, int32_t n_pops, 
 
   const int32_t bounds[2] = {0, static_cast<int32_t>(n_sites)};
   SAI_HIP(hipMemcpyAsync(lohi, bounds, sizeof(bounds), hipMemcpyHostToDevice, st));
-  if (int rc = sai_site_pass(ctx, n_sites, n_pops, pops, nullptr, 1, set_host, SAI_FREQ_CANDIDATES, tgt_freq, flags, st))
+  if (int rc = sai_site_pass(ctx, n_sites, n_pops, pops, nullptr, 1, set_host, SAI_FREQ_CANDIDATES, tgt_freq, planes,
+                             SAI_PLANES_PER_SET, st))
     return rc;
-  if (int rc = sai_window_stats(ctx, n_sites, tgt_freq, flags, 1, set_host, 1, lohi, lohi + 1, nullptr, rec, off, cdd_u,
+  if (int rc = sai_window_stats(ctx, n_sites, tgt_freq, planes, SAI_PLANES_PER_SET, 1, set_host, 1, lohi, lohi + 1, nullptr, rec, off, cdd_u,
                                 n_sites, cdd_q, n_sites, totals, st))
     return rc;
   // results through the pinned mirror: head first (its counts size the two list copies)

@@ -20,13 +20,28 @@ __device__ __forceinline__ bool cmp_op(int op, double f, double y) {
   }
 }
 
-// get(p) -> uint2 {alt_sum, n_called} of population p at this site.
+// Flag planes: what the per-site decision leaves behind for the windows stage.  Per tile of 64
+// sites and parameter set three 64-bit words -- bit b of a word = site tile * 64 + b --
+//   planes[tile * stride + 3 * set + 0]  condition (compute_matching_loci's, stat_utils.py:166)
+//   planes[tile * stride + 3 * set + 1]  condition && tgt_freq > x (u_statistic.py:92)
+//   planes[tile * stride + 3 * set + 2]  site inverted (stat_utils.py:156)
+// The decisions of a tile are taken by the 64 lanes of one wavefront (lane = site), three
+// ballots per set collect them, and ONE store instruction per tile writes the tile's row (lane k
+// holds word k).  Round 2 kept a byte per site and set, stored by every lane in the middle of the
+// genotype stream: 18 B per site for the 18 sets of C5, which cost 8 % of the pass; a row of
+// planes is 6.75 B per site there and 0.375 B for one set.
+constexpr int kPlanesPerSet = SAI_PLANES_PER_SET;
+
+// get(p) -> uint2 {alt_sum, n_called} of population p at this lane's site (site = tile * 64 + lane;
+// `live` = the site exists).  Must be called by the whole wavefront.
 template <typename GetCounts>
 __device__ __forceinline__ void eval_site(int n_pops, const int32_t* ploidy, GetCounts get, int n_sets,
-                                          const sai_params* sets, int64_t site, int64_t n_sites, double* tgt_freq,
-                                          uint8_t* flags, double* adj_freq, bool sparse_freq = false) {
+                                          const sai_params* sets, int64_t tile, int lane, bool live, int64_t n_sites,
+                                          double* tgt_freq, uint64_t* planes, int64_t plane_stride, double* adj_freq,
+                                          bool sparse_freq = false) {
+  const int64_t site = tile * kTile + lane;
   double f[kMaxPops];
-  bool valid = true;
+  bool valid = live;
 #pragma unroll
   for (int p = 0; p < kMaxPops; ++p) {
     if (p < n_pops) {
@@ -42,6 +57,7 @@ __device__ __forceinline__ void eval_site(int n_pops, const int32_t* ploidy, Get
   }
   bool any_cond = false;
   const int n_src = n_pops - 2;
+  uint64_t row_word = 0;  // lane k ends up with word k of the tile's row
   for (int s = 0; s < n_sets; ++s) {
     const sai_params& ps = sets[s];
     bool hit_y = true, hit_m = true;
@@ -60,19 +76,29 @@ __device__ __forceinline__ void eval_site(int n_pops, const int32_t* ploidy, Get
     const bool cond = valid && hit && (rf < ps.w);
     const bool ucand = cond && (tf > ps.x);
     any_cond = any_cond || cond;
-    // non-temporal stores: measured on MI355X, plain stores in the middle of the genotype stream cost
-    // twice as much of the pass as streaming ones
-    __builtin_nontemporal_store(static_cast<uint8_t>((cond ? 1 : 0) | (ucand ? 2 : 0) | (inverted ? 4 : 0)),
-                                flags + static_cast<int64_t>(s) * n_sites + site);
-    if (adj_freq) {
+    const uint64_t bc = __ballot(cond), bu = __ballot(ucand), bi = __ballot(inverted);
+    const int k = lane - kPlanesPerSet * s;
+    row_word = k == 0 ? bc : k == 1 ? bu : k == 2 ? bi : row_word;
+    if (adj_freq && live) {
       adj_freq[(static_cast<int64_t>(s) * 2 + 0) * n_sites + site] = rf;
       adj_freq[(static_cast<int64_t>(s) * 2 + 1) * n_sites + site] = tf;
     }
   }
-  // The windows stage reads tgt_freq only where a set's bit 0 is up (about 1 site in 1000), and
-  // dense f64 stores in the middle of the genotype stream cost ~10 % of the pass (HBM read/write
+  // non-temporal stores: measured on MI355X, plain stores in the middle of the genotype stream cost
+  // twice as much of the pass as streaming ones
+  if (lane < kPlanesPerSet * n_sets) __builtin_nontemporal_store(row_word, planes + tile * plane_stride + lane);
+  // The windows stage reads tgt_freq only where a set's condition bit is up (about 1 site in 1000),
+  // and dense f64 stores in the middle of the genotype stream cost ~10 % of the pass (HBM read/write
   // turnarounds): SAI_FREQ_CANDIDATES leaves every other entry untouched.
-  if (!sparse_freq || any_cond) __builtin_nontemporal_store(f[1], tgt_freq + site);
+  if (live && (!sparse_freq || any_cond)) __builtin_nontemporal_store(f[1], tgt_freq + site);
+}
+
+// LDS operations of one wavefront execute in order; this only stops the compiler from moving
+// accesses across a point where lanes start reading what other lanes of the wave wrote.
+__device__ __forceinline__ void wave_lds_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
 // parameter sets the fused tail of site_counts carries in its kernel arguments (20 x 152 B + the
@@ -84,6 +110,7 @@ struct FusedArgs {
   int32_t sparse_freq;
   int32_t ploidy[kMaxPops];
   double* tgt_freq;
-  uint8_t* flags;
+  uint64_t* planes;
+  int64_t plane_stride;  // words per tile row
   sai_params sets[kFusedSets];
 };

@@ -12,17 +12,23 @@ struct FlagArgs {
   int32_t ploidy[kMaxPops];
   const uint2* counts;
   double* tgt_freq;
-  uint8_t* flags;
+  uint64_t* planes;
+  int64_t plane_stride;
   double* adj_freq;
   sai_params sets[SAI_MAX_SETS];
 };
+static_assert(sizeof(FlagArgs) <= 4096, "kernel arguments exceed the kernarg segment");
 
+// one wavefront per tile (four per workgroup): lane = site inside the tile
 __global__ __launch_bounds__(256) void site_flags_kernel(FlagArgs a) {
   const int64_t site = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-  if (site >= a.n_sites) return;
+  if ((site & ~int64_t{63}) >= a.n_sites) return;  // whole wavefronts beyond the last tile: there is no row for them
+  const bool live = site < a.n_sites;              // the last tile's spare lanes vote 0
   eval_site(
-      a.n_pops, a.ploidy, [&](int p) { return a.counts[static_cast<int64_t>(p) * a.n_sites + site]; }, a.n_sets, a.sets,
-      site, a.n_sites, a.tgt_freq, a.flags, a.adj_freq);
+      a.n_pops, a.ploidy,
+      [&](int p) { return live ? a.counts[static_cast<int64_t>(p) * a.n_sites + site] : make_uint2(0u, 0u); }, a.n_sets,
+      a.sets, site >> 6, static_cast<int>(threadIdx.x & 63), live, a.n_sites, a.tgt_freq, a.planes, a.plane_stride,
+      a.adj_freq);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -58,9 +64,10 @@ static_assert(sizeof(CountsArgs) + sizeof(FusedArgs) <= 4096, "kernel arguments 
 // FUSED: evaluate the parameter sets at the end of each tile (site_flags folded in).
 template <bool MULTI, bool FUSED>
 __global__ __launch_bounds__(64) void site_counts_kernel(CountsArgs a, FusedArgs fa) {
-  // FUSED: each lane parks its site's {alt_sum, n_called} per population here and evaluates the
-  // parameter sets itself once all populations of the tile are done (only the lane that wrote a
-  // slot reads it back, so no synchronisation is involved)
+  // FUSED: the butterfly leaves lane l with site (l%4)*16 + l/4 of the tile; each lane parks those
+  // {alt_sum, n_called} per population in LDS AT ITS SITE'S INDEX, and once all populations of the
+  // tile are done lane l takes site l back and evaluates the parameter sets for it -- lanes in site
+  // order, so three ballots per set are the tile's flag planes and tgt_freq is stored coalesced
   __shared__ uint2 stash[FUSED ? kMaxPops : 1][FUSED ? 64 : 1];
   const int lane = threadIdx.x;
   const int r = lane >> 2;
@@ -99,19 +106,31 @@ __global__ __launch_bounds__(64) void site_counts_kernel(CountsArgs a, FusedArgs
       const int64_t site = tile * kTile + (lane & 3) * 16 + r;
       const uint2 cnt = make_uint2(sum32[0], static_cast<uint32_t>(n_ind) - miss32[0]);
       if (a.counts && site < a.n_sites) store_counts_nt(a.counts + static_cast<int64_t>(p) * a.n_sites + site, cnt);
-      if (FUSED) stash[p][lane] = cnt;
+      if (FUSED) stash[p][(lane & 3) * 16 + r] = cnt;
     }
     if (FUSED) {
-      const int64_t site = tile * kTile + (lane & 3) * 16 + r;
-      if (site < a.n_sites)
-        eval_site(
-            a.n_pops, fa.ploidy, [&](int p) { return stash[p][lane]; }, fa.n_sets, fa.sets, site,
-            a.n_sites, fa.tgt_freq, fa.flags, nullptr, fa.sparse_freq != 0);
+      wave_lds_fence();
+      eval_site(
+          a.n_pops, fa.ploidy, [&](int p) { return stash[p][lane]; }, fa.n_sets, fa.sets, tile, lane,
+          tile * kTile + lane < a.n_sites, a.n_sites, fa.tgt_freq, fa.planes, fa.plane_stride, nullptr,
+          fa.sparse_freq != 0);
+      wave_lds_fence();  // the next tile's counts must not overtake these reads
     }
   }
 }
 
 }  // namespace
+
+int check_plane_stride(int64_t plane_stride, int32_t n_sets) {
+  if (plane_stride < static_cast<int64_t>(kPlanesPerSet) * n_sets || plane_stride > (int64_t{1} << 20))
+    return fail(SAI_ERR_ARG, "plane_stride %lld does not hold %d sets", static_cast<long long>(plane_stride), n_sets);
+  return SAI_OK;
+}
+
+extern "C" int64_t sai_plane_words(int64_t n_sites, int32_t n_sets) {
+  if (n_sites < 0 || n_sets < 0 || n_sites >= 0x7FFFFFFFll) return -1;
+  return (n_sites + kTile - 1) / kTile * kPlanesPerSet * n_sets;
+}
 
 int check_sets(int32_t n_sets, const sai_params* sets, int32_t n_src, int32_t max_sets) {
   if (n_sets < 1 || n_sets > max_sets) return fail(SAI_ERR_ARG, "n_sets must be 1..%d", max_sets);
@@ -129,7 +148,7 @@ int check_sets(int32_t n_sets, const sai_params* sets, int32_t n_src, int32_t ma
 // shared by sai_site_counts (n_sets == 0) and sai_site_pass
 static int launch_site_counts(sai_ctx* ctx, int64_t n_sites, int32_t n_pops, const sai_pop* pops, uint32_t* counts,
                               int32_t n_sets, const sai_params* sets_host, int32_t freq_mode, double* tgt_freq,
-                              uint8_t* flags, void* stream) {
+                              uint64_t* planes, int64_t plane_stride, void* stream) {
   if (n_sites < 0 || n_sites >= 0x7FFFFFFFll) return fail(SAI_ERR_ARG, "n_sites out of range");
   if (n_pops < 1 || n_pops > kMaxPops) return fail(SAI_ERR_ARG, "n_pops must be 1..%d", kMaxPops);
   if (!pops) return fail(SAI_ERR_ARG, "pops is NULL");
@@ -157,7 +176,8 @@ static int launch_site_counts(sai_ctx* ctx, int64_t n_sites, int32_t n_pops, con
   fa.n_sets = n_sets;
   fa.sparse_freq = freq_mode == SAI_FREQ_CANDIDATES;
   fa.tgt_freq = tgt_freq;
-  fa.flags = flags;
+  fa.planes = planes;
+  fa.plane_stride = plane_stride;
   for (int s = 0; s < n_sets; ++s) fa.sets[s] = sets_host[s];
   const dim3 grid(stream_grid(ctx, a.n_tiles));
   hipStream_t st = static_cast<hipStream_t>(stream);
@@ -181,12 +201,12 @@ int sai_site_counts(sai_ctx* ctx, int64_t n_sites, int32_t n_pops, const sai_pop
                     void* stream) {
   if (int rc = enter(ctx)) return rc;
   if (!counts && n_sites > 0) return fail(SAI_ERR_ARG, "counts is NULL");
-  return launch_site_counts(ctx, n_sites, n_pops, pops, counts, 0, nullptr, SAI_FREQ_DENSE, nullptr, nullptr, stream);
+  return launch_site_counts(ctx, n_sites, n_pops, pops, counts, 0, nullptr, SAI_FREQ_DENSE, nullptr, nullptr, 0, stream);
 }
 
 int sai_site_pass(sai_ctx* ctx, int64_t n_sites, int32_t n_pops, const sai_pop* pops, uint32_t* counts,
-                  int32_t n_sets, const sai_params* sets_host, int32_t freq_mode, double* tgt_freq, uint8_t* flags,
-                  void* stream) {
+                  int32_t n_sets, const sai_params* sets_host, int32_t freq_mode, double* tgt_freq, uint64_t* planes,
+                  int64_t plane_stride, void* stream) {
   if (int rc = enter(ctx)) return rc;
   if (freq_mode != SAI_FREQ_DENSE && freq_mode != SAI_FREQ_CANDIDATES) return fail(SAI_ERR_ARG, "bad freq_mode %d", freq_mode);
   if (n_pops < 2) return fail(SAI_ERR_ARG, "n_pops must be >= 2 (ref, tgt, sources)");
@@ -197,20 +217,23 @@ int sai_site_pass(sai_ctx* ctx, int64_t n_sites, int32_t n_pops, const sai_pop* 
   if (pops)
     for (int p = 0; p < n_pops && p < kMaxPops; ++p)
       if (pops[p].ploidy <= 0) return fail(SAI_ERR_ARG, "ploidy[%d] must be positive", p);
-  if (n_sites > 0 && (!tgt_freq || !flags)) return fail(SAI_ERR_ARG, "NULL buffer");
-  return launch_site_counts(ctx, n_sites, n_pops, pops, counts, n_sets, sets_host, freq_mode, tgt_freq, flags, stream);
+  if (n_sites > 0 && (!tgt_freq || !planes)) return fail(SAI_ERR_ARG, "NULL buffer");
+  if (int rc = check_plane_stride(plane_stride, n_sets)) return rc;
+  return launch_site_counts(ctx, n_sites, n_pops, pops, counts, n_sets, sets_host, freq_mode, tgt_freq, planes,
+                            plane_stride, stream);
 }
 
 int sai_site_flags(sai_ctx* ctx, int64_t n_sites, int32_t n_pops, const int32_t* ploidy_host,
                    const uint32_t* counts, int32_t n_sets, const sai_params* sets_host, double* tgt_freq,
-                   uint8_t* flags, double* adj_freq, void* stream) {
+                   uint64_t* planes, int64_t plane_stride, double* adj_freq, void* stream) {
   if (int rc = enter(ctx)) return rc;
   if (n_sites < 0 || n_sites >= 0x7FFFFFFFll) return fail(SAI_ERR_ARG, "n_sites out of range");
   if (n_pops < 2 || n_pops > kMaxPops) return fail(SAI_ERR_ARG, "n_pops must be 2..%d (ref, tgt, sources)", kMaxPops);
   if (!ploidy_host) return fail(SAI_ERR_ARG, "ploidy_host is NULL");
   if (int rc = check_sets(n_sets, sets_host, n_pops - 2)) return rc;
   if (n_sites == 0) return SAI_OK;
-  if (!counts || !tgt_freq || !flags) return fail(SAI_ERR_ARG, "NULL buffer");
+  if (!counts || !tgt_freq || !planes) return fail(SAI_ERR_ARG, "NULL buffer");
+  if (int rc = check_plane_stride(plane_stride, n_sets)) return rc;
   FlagArgs a;
   std::memset(&a, 0, sizeof(a));
   a.n_sites = n_sites;
@@ -222,7 +245,8 @@ int sai_site_flags(sai_ctx* ctx, int64_t n_sites, int32_t n_pops, const int32_t*
   }
   a.counts = reinterpret_cast<const uint2*>(counts);
   a.tgt_freq = tgt_freq;
-  a.flags = flags;
+  a.planes = planes;
+  a.plane_stride = plane_stride;
   a.adj_freq = adj_freq;
   for (int s = 0; s < n_sets; ++s) a.sets[s] = sets_host[s];
   const unsigned grid = static_cast<unsigned>((n_sites + 255) / 256);

@@ -85,7 +85,8 @@ __global__ __launch_bounds__(256) void window_bounds_kernel(const int32_t* __res
 struct WinArgs {
   int64_t n_sites;
   const double* tgt_freq;
-  const uint8_t* flags;
+  const uint64_t* planes;  // flag planes of this call's sets (saihip.h): rows of `stride` words per tile
+  int64_t stride;
   int32_t n_sets;
   int32_t n_windows;
   const int32_t* lo;
@@ -105,10 +106,12 @@ constexpr int kWinThreads = 256;
 constexpr int kWaveCap = 256;       // qualifying sites a wave keeps in LDS; more -> heavy kernel
 constexpr int kSelCap = 4096;       // values the heavy kernel keeps in LDS (32 KiB); beyond: re-read
 constexpr int32_t kHeavyMark = -1;  // records[].n_cdd_q value that hands a window to the fallback
+constexpr int kPlanes = SAI_PLANES_PER_SET;
+enum { kCond = 0, kUcand = 1, kInv = 2 };
 
-__device__ __forceinline__ double eff_freq(const double* tgt_freq, uint8_t f, int64_t i) {
+__device__ __forceinline__ double eff_freq(const double* tgt_freq, bool inverted, int64_t i) {
   const double v = tgt_freq[i];
-  return (f & 4) ? 1.0 - v : v;
+  return inverted ? 1.0 - v : v;
 }
 
 // numpy 'linear' quantile from the two neighbouring order statistics (numpy _quantile/_lerp):
@@ -127,35 +130,36 @@ __device__ __forceinline__ void wave_lds_fence() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// Walk flags[lo, hi) of one parameter set with one wave, 4 bytes per lane and kFlagBatch wave loads
-// in flight: word k of the walk (lane k % 64 of chunk k / 64) holds sites s0 + 4k .. 4k+3, where s0 <=
-// lo makes the address 4-byte aligned; bytes outside [lo, hi) arrive as 0.  An aligned word that
-// contains one valid byte cannot cross a page, so the up to 3 bytes read past either end of the
-// caller's buffer never fault.  on_chunk(word, first_site) is called by the whole wave, chunks in
-// site order.  (One byte per lane per iteration, as in the first version, costs one L2 round trip
-// per 64 sites: 31 dependent trips for a C3 window; this form needs two.)
-constexpr int kFlagBatch = 4;
+// bits of tile t that lie inside the site range [lo, hi)
+__device__ __forceinline__ uint64_t range_mask(int t, int lo, int hi) {
+  const int64_t base = static_cast<int64_t>(t) * kTile;
+  const int64_t a = lo > base ? lo - base : 0, b = hi - base < kTile ? hi - base : kTile;
+  if (b <= a) return 0ull;
+  const uint64_t below_b = b >= kTile ? ~0ull : (1ull << b) - 1ull;
+  return below_b & (~0ull << a);
+}
 
+// inclusive prefix sum of v over the lanes of a wavefront
+__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v, int lane) {
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t t = __shfl_up(v, o, 64);
+    if (lane >= o) v += t;
+  }
+  return v;
+}
+
+// A window's sites are tiles [lo / 64, ceil(hi / 64)) of the planes, one word per tile and plane:
+// a C3 window (2 000 sites) is 32 words of a plane, so ONE load instruction of the wave (lane =
+// tile) fetches a plane of the whole window -- the byte flags of round 2 took eight rounds of
+// four loads for it.  on_chunk(t, live, mask) is called by the whole wave for every 64 tiles.
 template <typename F>
-__device__ __forceinline__ void walk_flags(const uint8_t* fl, int lo, int hi, int lane, F&& on_chunk) {
+__device__ __forceinline__ void walk_tiles(int lo, int hi, int lane, F&& on_chunk) {
   if (hi <= lo) return;
-  const int s0 = lo - static_cast<int>(reinterpret_cast<uintptr_t>(fl + lo) & 3u);
-  const uint32_t* words = reinterpret_cast<const uint32_t*>(fl + s0);
-  const int n_words = (hi - s0 + 3) >> 2;
-  for (int c0 = 0; c0 < n_words; c0 += 64 * kFlagBatch) {
-    uint32_t w[kFlagBatch];
-#pragma unroll
-    for (int u = 0; u < kFlagBatch; ++u) w[u] = words[min(c0 + u * 64 + lane, n_words - 1)];
-#pragma unroll
-    for (int u = 0; u < kFlagBatch; ++u) {
-      if (c0 + u * 64 >= n_words) break;  // uniform
-      const int k = c0 + u * 64 + lane;
-      const int site = s0 + 4 * k;
-      uint32_t keep = k < n_words ? 0xFFFFFFFFu : 0u;
-      if (site < lo) keep &= 0xFFFFFFFFu << (8 * (lo - site));          // 1..3 leading bytes before lo
-      if (site + 4 > hi && site < hi) keep &= 0xFFFFFFFFu >> (8 * (site + 4 - hi));  // 1..3 trailing bytes
-      on_chunk(w[u] & keep, site);
-    }
+  const int t0 = lo >> 6, t1 = (hi + kTile - 1) >> 6;
+  for (int tb = t0; tb < t1; tb += 64) {
+    const int t = tb + lane;
+    on_chunk(t, t < t1, t < t1 ? range_mask(t, lo, hi) : 0ull);
   }
 }
 
@@ -167,45 +171,35 @@ __global__ __launch_bounds__(256) void window_stats_wave_kernel(WinArgs a) {
   if (w >= a.n_windows) return;  // whole wave
   const int set = blockIdx.y;
   const int lo = a.lo[w], hi = a.hi[w];
-  const uint8_t* fl = a.flags + static_cast<int64_t>(set) * a.n_sites;
+  const uint64_t* pl = a.planes + kPlanes * set;
   const int64_t ridx = static_cast<int64_t>(set) * a.n_windows + w;
   double* vals = sh_vals[wv];
-  const unsigned long long lt_mask = (1ull << lane) - 1ull;
 
   // pass 1: counts + order-preserving compaction of the qualifying effective frequencies into LDS
-  uint32_t n_c = 0, n_u_lane = 0, n_c_lane = 0;
-  walk_flags(fl, lo, hi, lane, [&](uint32_t v, int site) {
-    n_u_lane += __popc(v & 0x02020202u);
-    const uint32_t cm = v & 0x01010101u;
-    if (n_c >= kWaveCap) {  // uniform: this window goes to the workgroup kernel, only the count matters
-      n_c_lane += __popc(cm);
-      return;
-    }
-    if (__ballot(cm != 0u) == 0ull) return;  // no condition site among these 256: the usual case
-    uint32_t below = 0, total = 0;
-#pragma unroll
-    for (int b = 0; b < 4; ++b) {
-      const unsigned long long bc = __ballot(((cm >> (8 * b)) & 1u) != 0u);
-      below += __popcll(bc & lt_mask);
-      total += __popcll(bc);
-    }
-    uint32_t slot = n_c + below;  // lanes hold consecutive sites: lower lanes first, then byte order
-#pragma unroll
-    for (int b = 0; b < 4; ++b) {
-      if ((cm >> (8 * b)) & 1u) {
-        if (slot < kWaveCap) vals[slot] = eff_freq(a.tgt_freq, static_cast<uint8_t>(v >> (8 * b)), site + b);
+  uint32_t n_c = 0, n_u_lane = 0;
+  walk_tiles(lo, hi, lane, [&](int t, bool live, uint64_t mask) {
+    const uint64_t* row = pl + static_cast<int64_t>(t) * a.stride;
+    uint64_t c = live ? row[kCond] & mask : 0ull;
+    const uint64_t u = live ? row[kUcand] & mask : 0ull;
+    n_u_lane += __popcll(u);
+    const uint32_t mine = __popcll(c);
+    if (__ballot(mine != 0u) == 0ull) return;  // no condition site among these 4 096: the usual case
+    const uint32_t incl = wave_inclusive_scan(mine, lane);
+    if (n_c < kWaveCap) {  // uniform; beyond it the window goes to the workgroup kernel and only the count matters
+      const uint64_t iv = c ? row[kInv] : 0ull;
+      uint32_t slot = n_c + incl - mine;  // lanes hold consecutive tiles: lower lanes first, then bit order
+      while (c) {
+        const int b = __ffsll(static_cast<long long>(c)) - 1;
+        c &= c - 1ull;
+        if (slot < kWaveCap) vals[slot] = eff_freq(a.tgt_freq, (iv >> b) & 1ull, static_cast<int64_t>(t) * kTile + b);
         ++slot;
       }
     }
-    n_c += total;
+    n_c += __shfl(incl, 63, 64);
   });
   uint32_t n_u = n_u_lane;
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    n_u += __shfl_xor(n_u, o, 64);
-    n_c_lane += __shfl_xor(n_c_lane, o, 64);
-  }
-  n_c += n_c_lane;
+  for (int o = 32; o > 0; o >>= 1) n_u += __shfl_xor(n_u, o, 64);
   double q = std::numeric_limits<double>::quiet_NaN();
   uint32_t n_q = 0;
   if (n_c > kWaveCap) {
@@ -323,24 +317,49 @@ __device__ __forceinline__ int digit_on_path(double v, int level, const int (&pa
   }
 }
 
+// One set's planes as the workgroup kernel walks them: eight threads per tile, each owning eight
+// sites (one byte of the tile's condition word), so a 2 000-site window keeps all 256 threads busy.
+struct SetPlanes {
+  const uint64_t* pl;  // word 0 of this set in row 0
+  int64_t stride;
+};
+constexpr int kSubs = 8;  // threads per tile
+
+// on_byte(first_site, cond_bits, inv_bits) for every byte of the window that holds a condition site
+template <typename F>
+__device__ __forceinline__ void for_each_cond_byte(const SetPlanes& sp, int lo, int hi, int tid, F&& on_byte) {
+  if (hi <= lo) return;
+  const int t0 = lo >> 6, t1 = (hi + kTile - 1) >> 6;
+  const int sub = tid % kSubs;
+  for (int t = t0 + tid / kSubs; t < t1; t += kWinThreads / kSubs) {
+    const uint64_t* row = sp.pl + static_cast<int64_t>(t) * sp.stride;
+    const uint32_t c = static_cast<uint32_t>((row[kCond] & range_mask(t, lo, hi)) >> (8 * sub)) & 0xFFu;
+    if (c == 0u) continue;
+    on_byte(static_cast<int64_t>(t) * kTile + 8 * sub, c, static_cast<uint32_t>(row[kInv] >> (8 * sub)) & 0xFFu);
+  }
+}
+
 // calls use(v) for every selected value of the window: from LDS, or from the per-site arrays when
 // the window holds more than kSelCap of them
 template <bool IN_LDS, typename F>
-__device__ __forceinline__ void for_each_selected(const WinShared& sh, const double* tgt_freq, const uint8_t* fl, int lo,
+__device__ __forceinline__ void for_each_selected(const WinShared& sh, const double* tgt_freq, const SetPlanes& sp, int lo,
                                                   int hi, uint32_t n_sel, int tid, F&& use) {
   if (IN_LDS) {
     for (uint32_t i = tid; i < n_sel; i += kWinThreads) use(sh.vals[i]);
   } else {
-    for (int i = lo + tid; i < hi; i += kWinThreads) {
-      const uint8_t f = fl[i];
-      if (f & 1) use(eff_freq(tgt_freq, f, i));
-    }
+    for_each_cond_byte(sp, lo, hi, tid, [&](int64_t site0, uint32_t c, uint32_t iv) {
+      while (c) {
+        const int b = __ffs(static_cast<int>(c)) - 1;
+        c &= c - 1u;
+        use(eff_freq(tgt_freq, (iv >> b) & 1u, site0 + b));
+      }
+    });
   }
 }
 
 // k-th smallest (0-based) of the selected values
 template <bool IN_LDS>
-__device__ double select_kth(WinShared& sh, const double* tgt_freq, const uint8_t* fl, int lo, int hi,
+__device__ double select_kth(WinShared& sh, const double* tgt_freq, const SetPlanes& fl, int lo, int hi,
                              uint32_t n_sel, uint32_t k, int tid) {
   int path[kMaxLevels];
 #pragma unroll
@@ -431,33 +450,24 @@ __global__ __launch_bounds__(kWinThreads) void window_stats_heavy_kernel(WinArgs
   const int64_t ridx = static_cast<int64_t>(set) * a.n_windows + w;
   if (a.records[ridx].n_cdd_q != kHeavyMark) return;  // uniform over the workgroup
   const int lo = a.lo[w], hi = a.hi[w];
-  const uint8_t* fl = a.flags + static_cast<int64_t>(set) * a.n_sites;
+  const SetPlanes fl{a.planes + kPlanes * set, a.stride};
   const uint32_t n_c = static_cast<uint32_t>(a.records[ridx].n_cond);
   const bool in_lds = n_c <= kSelCap;
   if (tid == 0) sh.n_stored = 0;
   __syncthreads();
   if (in_lds) {
-    // 8 sites per thread and round: all flag bytes first, then all frequencies, so that a round costs
-    // two memory latencies instead of sixteen (under the next step's genotype stream a latency is
-    // several microseconds, and this kernel's time was mostly that chain)
-    constexpr int kRound = 8;
-    for (int base = lo; base < hi; base += kWinThreads * kRound) {
-      uint8_t f[kRound];
-      double val[kRound];
+    // a thread's eight sites: all frequencies first (independent loads), then one reservation in LDS --
+    // a byte costs two memory latencies, not one per site (under the next step's genotype stream a
+    // latency is several microseconds, and this kernel's time was mostly that chain)
+    for_each_cond_byte(fl, lo, hi, tid, [&](int64_t site0, uint32_t c, uint32_t iv) {
+      double val[8];
 #pragma unroll
-      for (int u = 0; u < kRound; ++u) {
-        const int i = base + u * kWinThreads + tid;
-        f[u] = i < hi ? fl[i] : uint8_t{0};
-      }
+      for (int b = 0; b < 8; ++b) val[b] = ((c >> b) & 1u) ? a.tgt_freq[site0 + b] : 0.0;
+      uint32_t slot = atomicAdd(&sh.n_stored, static_cast<uint32_t>(__popc(c)));
 #pragma unroll
-      for (int u = 0; u < kRound; ++u) {
-        const int i = base + u * kWinThreads + tid;
-        val[u] = (f[u] & 1u) ? a.tgt_freq[i] : 0.0;
-      }
-#pragma unroll
-      for (int u = 0; u < kRound; ++u)
-        if (f[u] & 1u) sh.vals[atomicAdd(&sh.n_stored, 1u)] = (f[u] & 4u) ? 1.0 - val[u] : val[u];
-    }
+      for (int b = 0; b < 8; ++b)
+        if ((c >> b) & 1u) sh.vals[slot++] = ((iv >> b) & 1u) ? 1.0 - val[b] : val[b];
+    });
   }
   __syncthreads();
   const double v = static_cast<double>(n_c - 1) * a.quantile[set];
@@ -487,10 +497,7 @@ __global__ __launch_bounds__(kWinThreads) void window_stats_heavy_kernel(WinArgs
   if (in_lds) {
     for (uint32_t i = tid; i < n_c; i += kWinThreads) c_q += sh.vals[i] >= q ? 1u : 0u;
   } else {
-    for (int i = lo + tid; i < hi; i += kWinThreads) {
-      const uint8_t f = fl[i];
-      if ((f & 1u) && eff_freq(a.tgt_freq, f, i) >= q) ++c_q;
-    }
+    for_each_selected<false>(sh, a.tgt_freq, fl, lo, hi, n_c, tid, [&](double u) { c_q += u >= q ? 1u : 0u; });
   }
   const uint32_t n_q = block_sum(c_q, sh.red, tid);
   if (tid == 0) {
@@ -614,43 +621,39 @@ __global__ __launch_bounds__(256) void window_lists_kernel(WinArgs a) {
   const bool write_q = rec.n_cdd_q > 0 && off_q >= 0 && a.cdd_q != nullptr;
   if (!write_u && !write_q) return;
   const int lo = a.lo[w], hi = a.hi[w];
-  const uint8_t* fl = a.flags + static_cast<int64_t>(set) * a.n_sites;
-  const unsigned long long lt_mask = (1ull << lane) - 1ull;
+  const uint64_t* pl = a.planes + kPlanes * set;
   const double q = rec.q;
   uint32_t done_u = 0, done_q = 0;
-  walk_flags(fl, lo, hi, lane, [&](uint32_t v, int site) {
-    const uint32_t um = (v >> 1) & 0x01010101u;
-    uint32_t qm = 0;
-    if (write_q) {
-#pragma unroll
-      for (int b = 0; b < 4; ++b)
-        if (((v >> (8 * b)) & 1u) && eff_freq(a.tgt_freq, static_cast<uint8_t>(v >> (8 * b)), site + b) >= q) qm |= 1u << (8 * b);
+  // lane = tile: the lane's U sites are the bits of one word, its Q sites the condition bits whose
+  // effective frequency reaches q; a prefix sum over the lanes' counts places both in site order
+  walk_tiles(lo, hi, lane, [&](int t, bool live, uint64_t mask) {
+    const uint64_t* row = pl + static_cast<int64_t>(t) * a.stride;
+    uint64_t um = (live && write_u) ? row[kUcand] & mask : 0ull;
+    uint64_t c = (live && write_q) ? row[kCond] & mask : 0ull;
+    if (__ballot((um | c) != 0ull) == 0ull) return;
+    const uint64_t iv = c ? row[kInv] : 0ull;
+    const int64_t site0 = static_cast<int64_t>(t) * kTile;
+    uint64_t qm = 0ull;
+    while (c) {
+      const int b = __ffsll(static_cast<long long>(c)) - 1;
+      c &= c - 1ull;
+      if (eff_freq(a.tgt_freq, (iv >> b) & 1ull, site0 + b) >= q) qm |= 1ull << b;
     }
-    if (__ballot((um | qm) != 0u) == 0ull) return;
-    uint32_t below_u = 0, below_q = 0, total_u = 0, total_q = 0;
-#pragma unroll
-    for (int b = 0; b < 4; ++b) {
-      const unsigned long long mu = __ballot(((um >> (8 * b)) & 1u) != 0u);
-      const unsigned long long mq = __ballot(((qm >> (8 * b)) & 1u) != 0u);
-      below_u += __popcll(mu & lt_mask);
-      below_q += __popcll(mq & lt_mask);
-      total_u += __popcll(mu);
-      total_q += __popcll(mq);
+    const uint32_t mine_u = __popcll(um), mine_q = __popcll(qm);
+    const uint32_t incl_u = wave_inclusive_scan(mine_u, lane), incl_q = wave_inclusive_scan(mine_q, lane);
+    uint32_t slot_u = done_u + incl_u - mine_u, slot_q = done_q + incl_q - mine_q;
+    while (um) {
+      const int b = __ffsll(static_cast<long long>(um)) - 1;
+      um &= um - 1ull;
+      a.cdd_u[off_u + slot_u++] = a.pos ? a.pos[site0 + b] : static_cast<int32_t>(site0 + b);
     }
-    uint32_t slot_u = done_u + below_u, slot_q = done_q + below_q;
-#pragma unroll
-    for (int b = 0; b < 4; ++b) {
-      const bool pu = (um >> (8 * b)) & 1u, pq = (qm >> (8 * b)) & 1u;
-      if (pu || pq) {
-        const int32_t out = a.pos ? a.pos[site + b] : site + b;
-        if (pu && write_u) a.cdd_u[off_u + slot_u] = out;
-        if (pq) a.cdd_q[off_q + slot_q] = out;
-        slot_u += pu;
-        slot_q += pq;
-      }
+    while (qm) {
+      const int b = __ffsll(static_cast<long long>(qm)) - 1;
+      qm &= qm - 1ull;
+      a.cdd_q[off_q + slot_q++] = a.pos ? a.pos[site0 + b] : static_cast<int32_t>(site0 + b);
     }
-    done_u += total_u;
-    done_q += total_q;
+    done_u += __shfl(incl_u, 63, 64);
+    done_q += __shfl(incl_q, 63, 64);
   });
 }
 
@@ -693,8 +696,8 @@ int sai_window_bounds_seg(sai_ctx* ctx, const int32_t* pos, int64_t n_sites, int
   return launch_window_bounds(ctx, pos, n_sites, n_windows, win_start, win_end, seg_lo, seg_hi, lo, hi, stream);
 }
 
-int sai_window_stats(sai_ctx* ctx, int64_t n_sites, const double* tgt_freq, const uint8_t* flags, int32_t n_sets,
-                     const sai_params* sets_host, int32_t n_windows, const int32_t* lo, const int32_t* hi,
+int sai_window_stats(sai_ctx* ctx, int64_t n_sites, const double* tgt_freq, const uint64_t* planes,
+                     int64_t plane_stride, int32_t n_sets, const sai_params* sets_host, int32_t n_windows, const int32_t* lo, const int32_t* hi,
                      const int32_t* pos, sai_window_record* records, int64_t* cdd_off, int32_t* cdd_u, int64_t cap_u,
                      int32_t* cdd_q, int64_t cap_q, int64_t* cdd_total, void* stream) {
   if (int rc = enter(ctx)) return rc;
@@ -708,13 +711,15 @@ int sai_window_stats(sai_ctx* ctx, int64_t n_sites, const double* tgt_freq, cons
     SAI_HIP(hipMemsetAsync(cdd_total, 0, 2 * sizeof(int64_t), st));
     return SAI_OK;
   }
-  if ((n_sites > 0 && (!tgt_freq || !flags)) || !lo || !hi || !records || !cdd_off)
+  if ((n_sites > 0 && (!tgt_freq || !planes)) || !lo || !hi || !records || !cdd_off)
     return fail(SAI_ERR_ARG, "NULL buffer");
+  if (int rc = check_plane_stride(plane_stride, n_sets)) return rc;
   WinArgs a;
   std::memset(&a, 0, sizeof(a));
   a.n_sites = n_sites;
   a.tgt_freq = tgt_freq;
-  a.flags = flags;
+  a.planes = planes;
+  a.stride = plane_stride;
   a.n_sets = n_sets;
   a.n_windows = n_windows;
   a.lo = lo;

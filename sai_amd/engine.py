@@ -21,7 +21,8 @@ RECORD_DTYPE = np.dtype(
 )
 assert RECORD_DTYPE.itemsize == C.sizeof(_ffi.SaiWindowRecord) == 24
 
-FLAG_COND, FLAG_UCAND, FLAG_INVERTED = 1, 2, 4
+FLAG_COND, FLAG_UCAND, FLAG_INVERTED = 1, 2, 4  # bits of flag_bytes()' bytes = plane 0, 1, 2 of a set
+PLANES = _ffi.SAI_PLANES_PER_SET
 
 
 def _torch():
@@ -343,20 +344,53 @@ class Engine:
         _ffi.check(self.lib.sai_site_counts(self.ctx, n_sites, len(pops), arr, self._ptr(out), self._stream()))
         return out
 
+    def alloc_planes(self, n_sites: int, n_sets: int):
+        """Flag planes of ``n_sets`` parameter sets (saihip.h): int64 tensor [tiles][3 * n_sets], bit b
+        of planes[t, 3 * s + k] = site 64 t + b; k = 0 condition, 1 condition and tgt_freq > x, 2 site
+        inverted.  A column slice ``planes[:, 3 * s0 : 3 * s1]`` is the planes of sets s0..s1-1."""
+        torch = _torch()
+        n_tiles = (int(n_sites) + _ffi.SAI_TILE_SITES - 1) // _ffi.SAI_TILE_SITES
+        return self._empty((n_tiles, PLANES * int(n_sets)), torch.int64)
+
+    @staticmethod
+    def _planes_arg(planes, n_sets: int, n_sites: int):
+        """(pointer, row stride in words) of a planes tensor or column slice of one."""
+        n_tiles = (int(n_sites) + _ffi.SAI_TILE_SITES - 1) // _ffi.SAI_TILE_SITES
+        if planes.dim() != 2 or planes.element_size() != 8 or planes.shape[0] != n_tiles or planes.shape[1] != PLANES * n_sets:
+            raise ValueError(f"flag planes must be int64 [{n_tiles}][{PLANES * n_sets}], got {tuple(planes.shape)}")
+        if n_tiles > 1 and planes.shape[1] and (planes.stride(1) != 1 or planes.stride(0) < planes.shape[1]):
+            raise ValueError("flag planes must be rows of consecutive words")
+        stride = int(planes.stride(0)) if n_tiles > 1 else max(int(planes.stride(0)), PLANES * n_sets)
+        return C.c_void_p(planes.data_ptr() if planes.numel() else 0), stride
+
+    def flag_bytes(self, planes, n_sites: int):
+        """The planes as one byte per set and site (uint8 tensor [n_sets][n_sites]; FLAG_COND |
+        FLAG_UCAND | FLAG_INVERTED) -- for tests and for the single-window helpers, not on the hot path."""
+        torch = _torch()
+        n_tiles, n_words = int(planes.shape[0]), int(planes.shape[1])
+        n_sets = n_words // PLANES
+        shifts = torch.arange(_ffi.SAI_TILE_SITES, dtype=torch.int64, device=planes.device)
+        out = torch.zeros((n_sets, n_tiles * _ffi.SAI_TILE_SITES), dtype=torch.uint8, device=planes.device)
+        for s in range(n_sets):
+            for k in range(PLANES):
+                bits = (planes[:, PLANES * s + k].unsqueeze(1) >> shifts) & 1
+                out[s] |= (bits.reshape(-1) << k).to(torch.uint8)
+        return out[:, : int(n_sites)].contiguous()
+
     def _pass_out(self, n_sites: int, n_sets: int, freq_mode: str):
         torch = _torch()
         if freq_mode == "candidates":  # entries the pass does not write read as NaN, never as garbage
             freq = torch.full((n_sites,), float("nan"), dtype=torch.float64, device=self.device)
         else:
             freq = self._empty((n_sites,), torch.float64)
-        return freq, self._empty((n_sets, n_sites), torch.uint8)
+        return freq, self.alloc_planes(n_sites, n_sets)
 
     def site_pass(self, pops: Sequence[TiledPop], ploidies: Sequence[int], sets: Sequence[_ffi.SaiParams], out=None,
                   counts=None, freq_mode: str = "dense"):
         """Fused site_counts + site_flags (at most SAI_FUSED_SETS parameter sets): one launch,
         the per-population counts stay on chip unless a ``counts`` tensor is passed.  Returns
-        (tgt_freq, flags) exactly as ``site_flags(site_counts(pops), ...)`` would; with
-        ``freq_mode="candidates"`` tgt_freq is written only where some set's flags bit 0 is up
+        (tgt_freq, flag planes) exactly as ``site_flags(site_counts(pops), ...)`` would; with
+        ``freq_mode="candidates"`` tgt_freq is written only where some set's condition bit is up
         (all that ``window_stats`` reads) and every other entry of ``out[0]`` is left as it was."""
         torch = _torch()
         n_sites = pops[0].n_sites
@@ -371,10 +405,11 @@ class Engine:
             arr[i].ploidy = int(ploidies[i])
         if out is None:
             out = self._pass_out(n_sites, len(sets), freq_mode)
+        pl_ptr, pl_stride = self._planes_arg(out[1], len(sets), n_sites)
         _ffi.check(
             self.lib.sai_site_pass(
                 self.ctx, n_sites, len(pops), arr, self._ptr(counts) if counts is not None else None, len(sets),
-                self._params_array(sets), _ffi.FREQ_MODES[freq_mode], self._ptr(out[0]), self._ptr(out[1]),
+                self._params_array(sets), _ffi.FREQ_MODES[freq_mode], self._ptr(out[0]), pl_ptr, pl_stride,
                 self._stream(),
             )
         )  # fmt: skip
@@ -412,37 +447,39 @@ class Engine:
             arr[i].ploidy = int(ploidies[i])
         if out is None and sets:
             out = self._pass_out(n_sites, len(sets), freq_mode)
+        pl_ptr, pl_stride = self._planes_arg(out[1], len(sets), n_sites) if out else (None, PLANES * len(sets))
         _ffi.check(
             self.lib.sai_site_pass_packed2(
                 self.ctx, n_sites, len(pops), arr, self._ptr(counts) if counts is not None else None, len(sets),
                 self._params_array(sets) if sets else None, _ffi.FREQ_MODES[freq_mode],
-                self._ptr(out[0]) if out else None, self._ptr(out[1]) if out else None, self._stream(),
+                self._ptr(out[0]) if out else None, pl_ptr, pl_stride, self._stream(),
             )
         )  # fmt: skip
         return out
 
     def site_flags(self, counts, ploidies: Sequence[int], sets: Sequence[_ffi.SaiParams], want_adj=False, out=None):
-        """(tgt_freq f64 [n], flags u8 [S][n], adj f64 [S][2][n] or None)."""
+        """(tgt_freq f64 [n], flag planes i64 [tiles][3 S] (``alloc_planes``), adj f64 [S][2][n] or None)."""
         torch = _torch()
         n_pops, n_sites = int(counts.shape[0]), int(counts.shape[1])
         pl = (C.c_int32 * n_pops)(*[int(p) for p in ploidies])
         n_sets = len(sets)
         if out is None:
             tgt_freq = self._empty((n_sites,), torch.float64)
-            flags = self._empty((n_sets, n_sites), torch.uint8)
+            planes = self.alloc_planes(n_sites, n_sets)
         else:
-            tgt_freq, flags = out
+            tgt_freq, planes = out
         adj = self._empty((n_sets, 2, n_sites), torch.float64) if want_adj else None
         for s0 in range(0, n_sets, _ffi.SAI_MAX_SETS):
             chunk = sets[s0 : s0 + _ffi.SAI_MAX_SETS]
+            pl_ptr, pl_stride = self._planes_arg(planes[:, PLANES * s0 : PLANES * (s0 + len(chunk))], len(chunk), n_sites)
             _ffi.check(
                 self.lib.sai_site_flags(
                     self.ctx, n_sites, n_pops, pl, self._ptr(counts), len(chunk), self._params_array(chunk),
-                    self._ptr(tgt_freq), self._ptr(flags[s0:]), self._ptr(adj[s0:]) if want_adj else None,
+                    self._ptr(tgt_freq), pl_ptr, pl_stride, self._ptr(adj[s0:]) if want_adj else None,
                     self._stream(),
                 )
             )  # fmt: skip
-        return tgt_freq, flags, adj
+        return tgt_freq, planes, adj
 
     def site_freqs(self, counts, ploidies: Sequence[int]):
         """f64 frequency per population and site ([P][n_sites], NaN where nothing is called)."""
@@ -530,16 +567,18 @@ class Engine:
         )  # fmt: skip
         return lo, hi
 
-    def window_stats_async(self, tgt_freq, flags, sets, lo, hi, pos, bufs):
-        """Enqueue the window kernel into caller-held buffers (no sync).  ``bufs`` =
+    def window_stats_async(self, tgt_freq, planes, sets, lo, hi, pos, bufs):
+        """Enqueue the window kernel into caller-held buffers (no sync).  ``planes`` = the flag planes
+        of exactly these sets (a column slice of a larger planes tensor is fine); ``bufs`` =
         (records u8 [S*W*24], offsets i64 [S*W*2], cdd_u i32, cdd_q i32, totals i64 [2], ...)."""
-        n_sets, n_sites = int(flags.shape[0]), int(flags.shape[1])
+        n_sets, n_sites = len(sets), int(tgt_freq.numel())
         if n_sets > _ffi.SAI_MAX_SETS:
             raise ValueError("window_stats_async handles at most SAI_MAX_SETS sets per call")
         records, offsets, cdd_u, cdd_q, totals = bufs[:5]
+        pl_ptr, pl_stride = self._planes_arg(planes, n_sets, n_sites)
         _ffi.check(
             self.lib.sai_window_stats(
-                self.ctx, n_sites, self._ptr(tgt_freq), self._ptr(flags), n_sets, self._params_array(sets),
+                self.ctx, n_sites, self._ptr(tgt_freq), pl_ptr, pl_stride, n_sets, self._params_array(sets),
                 int(lo.numel()), self._ptr(lo), self._ptr(hi), self._ptr(pos) if pos is not None else None,
                 self._ptr(records), self._ptr(offsets), self._ptr(cdd_u), int(cdd_u.numel()), self._ptr(cdd_q),
                 int(cdd_q.numel()), self._ptr(totals), self._stream(),
@@ -563,14 +602,14 @@ class Engine:
             head,
         )
 
-    def window_stats(self, tgt_freq, flags, sets, lo, hi, pos=None, cap_hint=1 << 16) -> WindowResults:
+    def window_stats(self, tgt_freq, planes, sets, lo, hi, pos=None, cap_hint=1 << 16) -> WindowResults:
         """Records and candidate lists of every (set, window), copied to the host."""
-        n_sets, n_w = int(flags.shape[0]), int(lo.numel())
+        n_sets, n_w = len(sets), int(lo.numel())
         rec_parts, off_parts, u_parts, q_parts = [], [], [], []
         base_u = base_q = 0
         for s0 in range(0, n_sets, _ffi.SAI_MAX_SETS):
             chunk = sets[s0 : s0 + _ffi.SAI_MAX_SETS]
-            fl = flags[s0 : s0 + len(chunk)]
+            fl = planes[:, PLANES * s0 : PLANES * (s0 + len(chunk))]
             cap_u = cap_q = cap_hint
             while True:
                 bufs = self.alloc_window_bufs(len(chunk), n_w, cap_u, cap_q)

@@ -17,7 +17,7 @@ from typing import Optional, Sequence
 import numpy as np
 
 from . import _ffi
-from .engine import RECORD_DTYPE, Engine, WindowResults
+from .engine import PLANES, RECORD_DTYPE, Engine, WindowResults
 from .utils.windows import split_genome
 
 # A step is milliseconds, but in a multi-GPU job a windows stage ends with a gather, and the first
@@ -176,7 +176,7 @@ class ResidentScorer:
         n_buf = 2 if self.overlap else 1
         # the fused pass writes tgt_freq only at candidate sites (all the windows stage reads)
         self._tgt_freq = [torch.full((n,), float("nan"), dtype=torch.float64, device=dev) for _ in range(n_buf)]
-        self._flags = [torch.empty((n_s, n), dtype=torch.uint8, device=dev) for _ in range(n_buf)]
+        self._flags = [eng.alloc_planes(n, n_s) for _ in range(n_buf)]  # flag planes [tiles][3 * sets]
         self.side = torch.cuda.Stream(device=dev, priority=-1) if self.overlap else None  # small kernels first
         self._site_done = [torch.cuda.Event() for _ in range(n_buf)]
         self._win_done = [torch.cuda.Event() for _ in range(n_buf)]  # after the windows stage that last read buffer b
@@ -223,7 +223,12 @@ class ResidentScorer:
 
     @property
     def flags(self):
+        """Flag planes of the most recent step (Engine.alloc_planes' layout)."""
         return self._flags[(self._k - 1) % len(self._flags)]
+
+    def flag_bytes(self):
+        """The most recent step's decisions as one byte per set and site (Engine.flag_bytes)."""
+        return self.eng.flag_bytes(self.flags, self.block.n_sites)
 
     def window_stream(self):
         """Context manager selecting the stream on which window records are produced (for follow-up
@@ -341,8 +346,8 @@ class ResidentScorer:
                 )
             )  # fmt: skip
         for ch in self.chunks:
-            eng.window_stats_async(tgt_freq, flags[ch.s0 : ch.s1], self.sets[ch.s0 : ch.s1], self.lo, self.hi,
-                                   self.list_pos, ch.bufs)  # fmt: skip
+            eng.window_stats_async(tgt_freq, flags[:, PLANES * ch.s0 : PLANES * ch.s1], self.sets[ch.s0 : ch.s1], self.lo,
+                                   self.hi, self.list_pos, ch.bufs)  # fmt: skip
             ch.host_head.copy_(ch.bufs[5], non_blocking=True)
 
     # -- results ---------------------------------------------------------------------------

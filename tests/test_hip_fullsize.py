@@ -86,8 +86,9 @@ def check_identities(eng, block, scorer, res):
         assert int(counts[p, :, 1].sum()) == called - pad
         assert int(counts[p, :, 1].max()) <= pop.n_ind
     lo, hi = scorer.lo.to(torch.int64), scorer.hi.to(torch.int64)
+    flag_bytes = scorer.flag_bytes()  # one byte per set and site from the flag planes
     for si in range(scorer.n_sets):
-        fl = scorer.flags[si]
+        fl = flag_bytes[si]
         zero = torch.zeros(1, dtype=torch.int64, device=fl.device)
         cu = torch.cat([zero, torch.cumsum(((fl >> 1) & 1).to(torch.int64), 0)])
         cc = torch.cat([zero, torch.cumsum((fl & 1).to(torch.int64), 0)])
@@ -145,7 +146,7 @@ def test_c2_full_size(eng):
     # their U counts must add up to the count over the union (checked through the flags)
     import torch
 
-    fl = scorer.flags[0]
+    fl = scorer.flag_bytes()[0]
     lo, hi = scorer.lo.cpu().numpy(), scorer.hi.cpu().numpy()
     for k in (3, 500, 2000):
         chain = list(range(k, min(k + 50, len(windows)), 5))
@@ -204,8 +205,9 @@ def test_c5_two_sources_sweep(eng):
     assert res.records.shape == (18, len(windows))
     lo64, hi64 = lo.to(torch.int64), hi.to(torch.int64)
     zero = torch.zeros(1, dtype=torch.int64, device=flags.device)
+    flag_bytes = eng.flag_bytes(flags, block.n_sites)
     for si in range(18):
-        cu = torch.cat([zero, torch.cumsum(((flags[si] >> 1) & 1).to(torch.int64), 0)])
+        cu = torch.cat([zero, torch.cumsum(((flag_bytes[si] >> 1) & 1).to(torch.int64), 0)])
         assert (cu[hi64] - cu[lo64]).cpu().numpy().tolist() == res.records[si]["u_count"].tolist()
     # ">= 0" on both sources accepts every valid site; "= 1, = 1" is the strictest
     assert res.records[9]["n_cond"].sum() >= res.records[8]["n_cond"].sum()

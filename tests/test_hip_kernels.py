@@ -273,7 +273,7 @@ def test_fused_site_pass_equals_two_kernels(eng):
             sentinel = -7.25
             out = (torch.full_like(tf, sentinel), torch.zeros_like(fl))
             eng.site_pass(pops, pl, sets, out=out, freq_mode="candidates")
-            cand = ((fl & 1) != 0).any(dim=0)
+            cand = ((eng.flag_bytes(fl, n_sites) & 1) != 0).any(dim=0)
             assert torch.equal(out[1], fl) and (int(cand.sum()) < n_sites or n_sets == 18)
             n_cand_seen += int(cand.sum())
             assert out[0][cand].cpu().numpy().tobytes() == tf[cand].cpu().numpy().tobytes()
@@ -283,6 +283,44 @@ def test_fused_site_pass_equals_two_kernels(eng):
     assert n_cand_seen > 0
     with pytest.raises(ValueError, match="at most"):
         eng.site_pass(pops, pl, sets * 2)
+
+
+@pytest.mark.parametrize("n_sites", [1, 63, 64, 65, 1000])
+def test_flag_planes_are_the_oracle_decisions_bit_for_bit(eng, n_sites):
+    """The documented plane layout (saihip.h): bit b of planes[t, 3 s + k] = site 64 t + b of set s;
+    k = 0 compute_matching_loci's condition, 1 condition and tgt_freq > x, 2 site inverted -- from the
+    stand-alone kernel, the fused pass and the packed2 pass alike, spare bits of the last tile 0."""
+    from oracle import sai_oracle as O
+    from sai_amd import _ffi
+
+    rng = np.random.default_rng(n_sites)
+    mats = [rng.integers(-1, 3, size=(n_sites, n)).astype(np.int8) for n in (9, 7, 1, 2)]
+    pl = [2, 2, 2, 2]
+    specs = [(0.6, 0.3, [("=", 1.0), (">=", 0.5)], True), (0.9, 0.5, [("<=", 0.5), ("=", 0.0)], False),
+             (1.0, 0.0, [(">=", 0.0), (">=", 0.0)], False)]  # fmt: skip
+    sets = [_ffi.make_params(w, x, 0.9, y, anc) for w, x, y, anc in specs]
+    pops = [eng.tile(m) for m in mats]
+    _, planes, _ = eng.site_flags(eng.site_counts(pops), pl, sets)
+    assert tuple(planes.shape) == ((n_sites + 63) // 64, 9)
+    _, fused = eng.site_pass(pops, pl, sets)
+    _, packed = eng.site_pass_packed2([eng.pack2(p) for p in pops], pl, sets)
+    words = planes.cpu().numpy().view(np.uint64)
+    assert np.array_equal(words, fused.cpu().numpy().view(np.uint64)) and np.array_equal(words, packed.cpu().numpy().view(np.uint64))
+    site = np.arange(n_sites)
+    for s, (w, x, y, anc) in enumerate(specs):
+        m64 = [m.astype(np.int64) for m in mats]
+        _, tf, cond = O.matching_loci(m64[0], m64[1], m64[2:], w, y, pl, anc)
+        plain = [O.allele_freq(g, 2) for g in m64]
+        ok = np.all([np.isfinite(f) & (f >= 0) & (f <= 1) for f in plain], axis=0)
+        mirror = np.all([O._COMPARE[op](f, 1 - yy) for f, (op, yy) in zip(plain[2:], y)], axis=0)
+        want = [cond, cond & (tf > x), np.zeros(n_sites, bool) if anc else (mirror & ok)]
+        for k in range(3):
+            got = (words[site // 64, 3 * s + k] >> (site % 64).astype(np.uint64)) & np.uint64(1)
+            assert np.array_equal(got.astype(bool), want[k]), (s, k)
+            if n_sites % 64:  # spare bits of the last tile
+                assert int(words[-1, 3 * s + k]) >> (n_sites % 64) == 0
+    assert np.array_equal(eng.flag_bytes(planes, n_sites).cpu().numpy()[1] & 1, O.matching_loci(
+        mats[0].astype(np.int64), mats[1].astype(np.int64), [m.astype(np.int64) for m in mats[2:]], 0.9, specs[1][2], pl, False)[2])
 
 
 def test_randomized_windows_against_oracle(eng):
@@ -399,7 +437,7 @@ def test_packed2_layout_equals_int8_path(eng, sizes):
     eng.site_pass_packed2(packed, pl, [], counts=c3)
     assert torch.equal(counts, c3)
     tf4, fl4 = eng.site_pass_packed2(packed, pl, sets, freq_mode="candidates")
-    cand = ((fl & 1) != 0).any(dim=0)
+    cand = ((eng.flag_bytes(fl, n_sites) & 1) != 0).any(dim=0)
     assert torch.equal(fl4, fl) and tf4[cand].cpu().numpy().tobytes() == tf[cand].cpu().numpy().tobytes()
     assert bool(torch.isnan(tf4[~cand]).all())
     bad = mats[0].copy()
