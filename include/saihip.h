@@ -214,6 +214,44 @@ int sai_single_window(sai_ctx* ctx, int64_t n_sites, int32_t n_pops, const sai_p
                       const sai_params* set_host, sai_window_record* record_host, int32_t* cdd_u_host,
                       int32_t* cdd_q_host, void* stream);
 
+/* ---- prepared launch sequences ------------------------------------------------------------ */
+
+/* The arguments of a resident block's site pass and windows stage do not change from step to step
+ * (ChunkPreprocessor.run over a resident region, chunk_preprocessor.py:105-147; one statistic pass per
+ * parameter sweep).  A plan stores copies of the arguments of the entry points above -- parameter
+ * sets and population descriptors included; device and pinned-host pointers are the caller's and
+ * must stay valid -- and sai_plan_run replays them in the order they were added, on `stream`, with
+ * the same validation and the same kernels as the direct calls.  One call from the host language
+ * per sequence instead of one per kernel: a step of a small block costs the host less than the GPU.
+ * A plan belongs to its ctx; it is not thread-safe. */
+typedef struct sai_plan sai_plan;
+int sai_plan_create(sai_ctx* ctx, sai_plan** plan_out);
+int sai_plan_destroy(sai_plan* plan);
+int sai_plan_run(sai_plan* plan, void* stream);
+/* sai_site_counts */
+int sai_plan_add_site_counts(sai_plan* plan, int64_t n_sites, int32_t n_pops, const sai_pop* pops, uint32_t* counts);
+/* sai_site_pass (packed2 == 0) or sai_site_pass_packed2 (packed2 != 0) */
+int sai_plan_add_site_pass(sai_plan* plan, int64_t n_sites, int32_t n_pops, const sai_pop* pops,
+                           uint32_t* counts, int32_t n_sets, const sai_params* sets_host,
+                           int32_t freq_mode, double* tgt_freq, uint64_t* planes, int64_t plane_stride,
+                           int32_t packed2);
+/* sai_site_flags without adj_freq */
+int sai_plan_add_site_flags(sai_plan* plan, int64_t n_sites, int32_t n_pops, const int32_t* ploidy_host,
+                            const uint32_t* counts, int32_t n_sets, const sai_params* sets_host,
+                            double* tgt_freq, uint64_t* planes, int64_t plane_stride);
+/* sai_window_bounds (seg_lo == NULL) or sai_window_bounds_seg */
+int sai_plan_add_window_bounds(sai_plan* plan, const int32_t* pos, int64_t n_sites, int32_t n_windows,
+                               const int64_t* win_start, const int64_t* win_end, const int32_t* seg_lo,
+                               const int32_t* seg_hi, int32_t* lo, int32_t* hi);
+/* sai_window_stats */
+int sai_plan_add_window_stats(sai_plan* plan, int64_t n_sites, const double* tgt_freq, const uint64_t* planes,
+                              int64_t plane_stride, int32_t n_sets, const sai_params* sets_host,
+                              int32_t n_windows, const int32_t* lo, const int32_t* hi, const int32_t* pos,
+                              sai_window_record* records, int64_t* cdd_off, int32_t* cdd_u, int64_t cap_u,
+                              int32_t* cdd_q, int64_t cap_q, int64_t* cdd_total);
+/* hipMemcpyAsync of n_bytes from device memory to (pinned) host memory: the records of a step */
+int sai_plan_add_copy_to_host(sai_plan* plan, void* dst_host, const void* src, int64_t n_bytes);
+
 /* ---- ABBA-BABA family: fd, df, Danc, Dplus --------------------- */
 
 /* calc_freq's f64 division for every population of a counts tensor (stat_utils.py:48-52;

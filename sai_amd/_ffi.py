@@ -95,6 +95,21 @@ SIGNATURES = {
         C.c_int,
         [_p, _i64, _p, _p, _i64, _i32, C.POINTER(SaiParams), _i32, _p, _p, _p, _p, _p, _p, _i64, _p, _i64, _p, _p],
     ),
+    "sai_plan_create": (C.c_int, [_p, C.POINTER(_p)]),
+    "sai_plan_destroy": (C.c_int, [_p]),
+    "sai_plan_run": (C.c_int, [_p, _p]),
+    "sai_plan_add_site_counts": (C.c_int, [_p, _i64, _i32, C.POINTER(SaiPop), _p]),
+    "sai_plan_add_site_pass": (
+        C.c_int,
+        [_p, _i64, _i32, C.POINTER(SaiPop), _p, _i32, C.POINTER(SaiParams), _i32, _p, _p, _i64, _i32],
+    ),
+    "sai_plan_add_site_flags": (C.c_int, [_p, _i64, _i32, C.POINTER(_i32), _p, _i32, C.POINTER(SaiParams), _p, _p, _i64]),
+    "sai_plan_add_window_bounds": (C.c_int, [_p, _p, _i64, _i32, _p, _p, _p, _p, _p, _p]),
+    "sai_plan_add_window_stats": (
+        C.c_int,
+        [_p, _i64, _p, _p, _i64, _i32, C.POINTER(SaiParams), _i32, _p, _p, _p, _p, _p, _p, _i64, _p, _i64, _p],
+    ),
+    "sai_plan_add_copy_to_host": (C.c_int, [_p, _p, _p, _i64]),
     "sai_single_window": (
         C.c_int,
         [_p, _i64, _i32, C.POINTER(SaiPop), C.POINTER(SaiParams), C.POINTER(SaiWindowRecord), _p, _p, _p],

@@ -139,14 +139,37 @@ __device__ __forceinline__ uint64_t range_mask(int t, int lo, int hi) {
   return below_b & (~0ull << a);
 }
 
-// inclusive prefix sum of v over the lanes of a wavefront
-__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v, int lane) {
+// word `v` of lane `src` (wave-uniform index) for every lane
+__device__ __forceinline__ uint64_t read_lane64(uint64_t v, int src) {
+  const uint32_t lo = __builtin_amdgcn_readlane(static_cast<uint32_t>(v), src);
+  const uint32_t hi = __builtin_amdgcn_readlane(static_cast<uint32_t>(v >> 32), src);
+  return (static_cast<uint64_t>(hi) << 32) | lo;
+}
+
+constexpr int kTileBatch = 4;  // tiles whose per-site loads are in flight together
+
+// The per-site side of a chunk of 64 tiles.  Lane = tile while the plane words are fetched; the
+// tiles that hold a marked site (bit of `nonempty`, wave-uniform) are then visited one by one with
+// lane = SITE: on_tiles(n, tile_lane[], ...) gets up to kTileBatch of them at a time so that the
+// per-site loads of a batch (target frequency, position: 512 B coalesced per tile) are issued before
+// any is consumed.  A sparse window (C3: two condition sites in 2 000) visits one or two tiles, a
+// dense one (C5's loose sets: 600 in 2 000) all 32 with four loads in flight -- the first form of
+// this kernel walked the bits of its own word lane by lane, one dependent load per site.
+template <typename F>
+__device__ __forceinline__ void for_nonempty_tiles(unsigned long long nonempty, F&& on_batch) {
+  while (nonempty) {  // wave-uniform
+    int tl[kTileBatch];
+    int n = 0;
 #pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const uint32_t t = __shfl_up(v, o, 64);
-    if (lane >= o) v += t;
+    for (int u = 0; u < kTileBatch; ++u) {
+      tl[u] = nonempty ? __ffsll(static_cast<long long>(nonempty)) - 1 : 0;
+      if (nonempty) {
+        ++n;
+        nonempty &= nonempty - 1ull;
+      }
+    }
+    on_batch(n, tl);
   }
-  return v;
 }
 
 // A window's sites are tiles [lo / 64, ceil(hi / 64)) of the planes, one word per tile and plane:
@@ -174,28 +197,45 @@ __global__ __launch_bounds__(256) void window_stats_wave_kernel(WinArgs a) {
   const uint64_t* pl = a.planes + kPlanes * set;
   const int64_t ridx = static_cast<int64_t>(set) * a.n_windows + w;
   double* vals = sh_vals[wv];
+  const unsigned long long lt_mask = (1ull << lane) - 1ull;
 
   // pass 1: counts + order-preserving compaction of the qualifying effective frequencies into LDS
   uint32_t n_c = 0, n_u_lane = 0;
   walk_tiles(lo, hi, lane, [&](int t, bool live, uint64_t mask) {
     const uint64_t* row = pl + static_cast<int64_t>(t) * a.stride;
-    uint64_t c = live ? row[kCond] & mask : 0ull;
+    const uint64_t c = live ? row[kCond] & mask : 0ull;
     const uint64_t u = live ? row[kUcand] & mask : 0ull;
     n_u_lane += __popcll(u);
     const uint32_t mine = __popcll(c);
-    if (__ballot(mine != 0u) == 0ull) return;  // no condition site among these 4 096: the usual case
-    const uint32_t incl = wave_inclusive_scan(mine, lane);
-    if (n_c < kWaveCap) {  // uniform; beyond it the window goes to the workgroup kernel and only the count matters
-      const uint64_t iv = c ? row[kInv] : 0ull;
-      uint32_t slot = n_c + incl - mine;  // lanes hold consecutive tiles: lower lanes first, then bit order
-      while (c) {
-        const int b = __ffsll(static_cast<long long>(c)) - 1;
-        c &= c - 1ull;
-        if (slot < kWaveCap) vals[slot] = eff_freq(a.tgt_freq, (iv >> b) & 1ull, static_cast<int64_t>(t) * kTile + b);
-        ++slot;
-      }
+    const unsigned long long nonempty = __ballot(mine != 0u);
+    if (nonempty == 0ull) return;  // no condition site among these 4 096: the usual case
+    if (n_c >= kWaveCap) {  // uniform: the window goes to the workgroup kernel and only the count matters
+      uint32_t tot = mine;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o, 64);
+      n_c += tot;
+      return;
     }
-    n_c += __shfl(incl, 63, 64);
+    const uint64_t iv = c ? row[kInv] : 0ull;
+    const int tb = t - lane;  // first tile of the chunk
+    for_nonempty_tiles(nonempty, [&](int n, const int (&tl)[kTileBatch]) {
+      uint64_t cw[kTileBatch], iw[kTileBatch];
+      double v[kTileBatch];
+#pragma unroll
+      for (int u = 0; u < kTileBatch; ++u) {
+        cw[u] = u < n ? read_lane64(c, tl[u]) : 0ull;
+        iw[u] = u < n ? read_lane64(iv, tl[u]) : 0ull;
+      }
+#pragma unroll
+      for (int u = 0; u < kTileBatch; ++u)
+        v[u] = ((cw[u] >> lane) & 1ull) ? a.tgt_freq[static_cast<int64_t>(tb + tl[u]) * kTile + lane] : 0.0;
+#pragma unroll
+      for (int u = 0; u < kTileBatch; ++u) {
+        const uint32_t slot = n_c + __popcll(cw[u] & lt_mask);  // tiles ascend, sites ascend inside a tile
+        if (((cw[u] >> lane) & 1ull) && slot < kWaveCap) vals[slot] = ((iw[u] >> lane) & 1ull) ? 1.0 - v[u] : v[u];
+        n_c += __popcll(cw[u]);
+      }
+    });
   });
   uint32_t n_u = n_u_lane;
 #pragma unroll
@@ -623,37 +663,44 @@ __global__ __launch_bounds__(256) void window_lists_kernel(WinArgs a) {
   const int lo = a.lo[w], hi = a.hi[w];
   const uint64_t* pl = a.planes + kPlanes * set;
   const double q = rec.q;
+  const unsigned long long lt_mask = (1ull << lane) - 1ull;
   uint32_t done_u = 0, done_q = 0;
-  // lane = tile: the lane's U sites are the bits of one word, its Q sites the condition bits whose
-  // effective frequency reaches q; a prefix sum over the lanes' counts places both in site order
   walk_tiles(lo, hi, lane, [&](int t, bool live, uint64_t mask) {
     const uint64_t* row = pl + static_cast<int64_t>(t) * a.stride;
-    uint64_t um = (live && write_u) ? row[kUcand] & mask : 0ull;
-    uint64_t c = (live && write_q) ? row[kCond] & mask : 0ull;
-    if (__ballot((um | c) != 0ull) == 0ull) return;
+    const uint64_t um = (live && write_u) ? row[kUcand] & mask : 0ull;
+    const uint64_t c = (live && write_q) ? row[kCond] & mask : 0ull;
+    const unsigned long long nonempty = __ballot((um | c) != 0ull);
+    if (nonempty == 0ull) return;
     const uint64_t iv = c ? row[kInv] : 0ull;
-    const int64_t site0 = static_cast<int64_t>(t) * kTile;
-    uint64_t qm = 0ull;
-    while (c) {
-      const int b = __ffsll(static_cast<long long>(c)) - 1;
-      c &= c - 1ull;
-      if (eff_freq(a.tgt_freq, (iv >> b) & 1ull, site0 + b) >= q) qm |= 1ull << b;
-    }
-    const uint32_t mine_u = __popcll(um), mine_q = __popcll(qm);
-    const uint32_t incl_u = wave_inclusive_scan(mine_u, lane), incl_q = wave_inclusive_scan(mine_q, lane);
-    uint32_t slot_u = done_u + incl_u - mine_u, slot_q = done_q + incl_q - mine_q;
-    while (um) {
-      const int b = __ffsll(static_cast<long long>(um)) - 1;
-      um &= um - 1ull;
-      a.cdd_u[off_u + slot_u++] = a.pos ? a.pos[site0 + b] : static_cast<int32_t>(site0 + b);
-    }
-    while (qm) {
-      const int b = __ffsll(static_cast<long long>(qm)) - 1;
-      qm &= qm - 1ull;
-      a.cdd_q[off_q + slot_q++] = a.pos ? a.pos[site0 + b] : static_cast<int32_t>(site0 + b);
-    }
-    done_u += __shfl(incl_u, 63, 64);
-    done_q += __shfl(incl_q, 63, 64);
+    const int tb = t - lane;
+    // lane = site: a tile's marked sites leave in site order, placed by the popcount of the lanes below
+    for_nonempty_tiles(nonempty, [&](int n, const int (&tl)[kTileBatch]) {
+      uint64_t uw[kTileBatch], cw[kTileBatch], iw[kTileBatch];
+      double v[kTileBatch];
+      int32_t p[kTileBatch];
+#pragma unroll
+      for (int u = 0; u < kTileBatch; ++u) {
+        uw[u] = u < n ? read_lane64(um, tl[u]) : 0ull;
+        cw[u] = u < n ? read_lane64(c, tl[u]) : 0ull;
+        iw[u] = u < n ? read_lane64(iv, tl[u]) : 0ull;
+      }
+#pragma unroll
+      for (int u = 0; u < kTileBatch; ++u) {
+        const int64_t site = static_cast<int64_t>(tb + tl[u]) * kTile + lane;
+        v[u] = ((cw[u] >> lane) & 1ull) ? a.tgt_freq[site] : 0.0;
+        p[u] = (((uw[u] | cw[u]) >> lane) & 1ull) ? (a.pos ? a.pos[site] : static_cast<int32_t>(site)) : 0;
+      }
+#pragma unroll
+      for (int u = 0; u < kTileBatch; ++u) {
+        const double e = ((iw[u] >> lane) & 1ull) ? 1.0 - v[u] : v[u];
+        const bool mine_q = ((cw[u] >> lane) & 1ull) && e >= q;
+        const unsigned long long qw = __ballot(mine_q);
+        if ((uw[u] >> lane) & 1ull) a.cdd_u[off_u + done_u + __popcll(uw[u] & lt_mask)] = p[u];
+        if (mine_q) a.cdd_q[off_q + done_q + __popcll(qw & lt_mask)] = p[u];
+        done_u += __popcll(uw[u]);
+        done_q += __popcll(qw);
+      }
+    });
   });
 }
 

@@ -100,6 +100,114 @@ class WindowResults:
         return self.cdd_q[o : o + int(self.records[s, w]["n_cdd_q"])]
 
 
+class Plan:
+    """A prepared launch sequence (saihip.h, sai_plan_*): the engine calls of a step recorded once
+    with all their arguments, replayed by ONE C call on the current stream.  The tensors whose
+    pointers the plan holds are kept alive here."""
+
+    def __init__(self, eng: "Engine"):
+        self.eng = eng
+        self._keep: list = []
+        h = C.c_void_p()
+        _ffi.check(eng.lib.sai_plan_create(eng.ctx, C.byref(h)))
+        self._h = h
+        self._run = eng.lib.sai_plan_run
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            self.eng.lib.sai_plan_destroy(self._h)
+            self._h = None
+            self._keep.clear()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # interpreter shutdown
+            pass
+
+    def run(self) -> None:
+        rc = self._run(self._h, self.eng._stream())
+        if rc:
+            _ffi.check(rc)
+
+    def _pops(self, pops, ploidies, packed: bool):
+        arr = (_ffi.SaiPop * len(pops))()
+        for i, p in enumerate(pops):
+            t = p.data if packed else p.tiles
+            arr[i].tiles = t.data_ptr() if t.numel() else 0
+            arr[i].n_ind = p.n_ind
+            arr[i].ploidy = int(ploidies[i]) if ploidies is not None else 1
+            self._keep.append(t)
+        return arr
+
+    def add_site_counts(self, pops, counts) -> None:
+        e = self.eng
+        self._keep.append(counts)
+        _ffi.check(e.lib.sai_plan_add_site_counts(self._h, pops[0].n_sites, len(pops), self._pops(pops, None, False), e._ptr(counts)))
+
+    def add_site_pass(self, pops, ploidies, sets, out, counts=None, freq_mode="dense", packed2=False) -> None:
+        """``Engine.site_pass`` / ``site_pass_packed2`` (``packed2=True``; ``sets == []`` = counts only)."""
+        e = self.eng
+        n_sites = pops[0].n_sites
+        pl_ptr, pl_stride = e._planes_arg(out[1], len(sets), n_sites) if sets else (None, PLANES * len(sets))
+        self._keep.extend([t for t in (out or ()) if t is not None] + ([counts] if counts is not None else []))
+        _ffi.check(
+            e.lib.sai_plan_add_site_pass(
+                self._h, n_sites, len(pops), self._pops(pops, ploidies, packed2), e._ptr(counts) if counts is not None else None,
+                len(sets), e._params_array(sets) if sets else None, _ffi.FREQ_MODES[freq_mode],
+                e._ptr(out[0]) if sets else None, pl_ptr, pl_stride, int(bool(packed2)),
+            )
+        )  # fmt: skip
+
+    def add_site_flags(self, counts, ploidies, sets, out) -> None:
+        e = self.eng
+        n_pops, n_sites = int(counts.shape[0]), int(counts.shape[1])
+        pl = (C.c_int32 * n_pops)(*[int(p) for p in ploidies])
+        self._keep.extend([counts, out[0], out[1]])
+        for s0 in range(0, len(sets), _ffi.SAI_MAX_SETS):
+            chunk = sets[s0 : s0 + _ffi.SAI_MAX_SETS]
+            pl_ptr, pl_stride = e._planes_arg(out[1][:, PLANES * s0 : PLANES * (s0 + len(chunk))], len(chunk), n_sites)
+            _ffi.check(
+                e.lib.sai_plan_add_site_flags(self._h, n_sites, n_pops, pl, e._ptr(counts), len(chunk), e._params_array(chunk),
+                                              e._ptr(out[0]), pl_ptr, pl_stride)
+            )  # fmt: skip
+
+    def add_window_bounds(self, pos, win_start, win_end, seg_lo, seg_hi, lo, hi) -> None:
+        e = self.eng
+        self._keep.extend([t for t in (pos, win_start, win_end, seg_lo, seg_hi, lo, hi) if t is not None])
+        _ffi.check(
+            e.lib.sai_plan_add_window_bounds(
+                self._h, e._ptr(pos), int(pos.numel()), int(lo.numel()), e._ptr(win_start), e._ptr(win_end),
+                e._ptr(seg_lo) if seg_lo is not None else None, e._ptr(seg_hi) if seg_hi is not None else None, e._ptr(lo),
+                e._ptr(hi),
+            )
+        )  # fmt: skip
+
+    def add_window_stats(self, tgt_freq, planes, sets, lo, hi, pos, bufs) -> None:
+        """``Engine.window_stats_async``."""
+        e = self.eng
+        n_sets, n_sites = len(sets), int(tgt_freq.numel())
+        records, offsets, cdd_u, cdd_q, totals = bufs[:5]
+        pl_ptr, pl_stride = e._planes_arg(planes, n_sets, n_sites)
+        self._keep.extend([tgt_freq, planes, lo, hi, *bufs] + ([pos] if pos is not None else []))
+        _ffi.check(
+            e.lib.sai_plan_add_window_stats(
+                self._h, n_sites, e._ptr(tgt_freq), pl_ptr, pl_stride, n_sets, e._params_array(sets), int(lo.numel()),
+                e._ptr(lo), e._ptr(hi), e._ptr(pos) if pos is not None else None, e._ptr(records), e._ptr(offsets),
+                e._ptr(cdd_u), int(cdd_u.numel()), e._ptr(cdd_q), int(cdd_q.numel()), e._ptr(totals),
+            )
+        )  # fmt: skip
+
+    def add_copy_to_host(self, dst_pinned, src) -> None:
+        if not dst_pinned.is_pinned():
+            raise ValueError("the host side of a planned copy must be pinned memory")
+        n = int(src.numel() * src.element_size())
+        if int(dst_pinned.numel() * dst_pinned.element_size()) < n:
+            raise ValueError("host buffer smaller than the device buffer")
+        self._keep.extend([dst_pinned, src])
+        _ffi.check(self.eng.lib.sai_plan_add_copy_to_host(self._h, C.c_void_p(dst_pinned.data_ptr()), self.eng._ptr(src), n))
+
+
 class Engine:
     """One libsaihip context on one GPU of this process."""
 
@@ -186,6 +294,9 @@ class Engine:
         for i, s in enumerate(sets):
             arr[i] = s
         return arr
+
+    def plan(self) -> Plan:
+        return Plan(self)
 
     # -- layout ----------------------------------------------------------------------------
 

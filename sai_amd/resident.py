@@ -171,9 +171,10 @@ class ResidentScorer:
             self.counts = torch.empty((len(block.pops), n, 2), dtype=torch.int32, device=dev)
         self.list_pos = None if lists_as_indices else block.pos
         self.overlap = bool(overlap)
-        # two sets: the windows stage of step k runs under site pass k+1 and is over long before the
-        # host may enqueue site pass k+2 into the same buffers
-        n_buf = 2 if self.overlap else 1
+        # three sets: the windows stage of step k runs under site pass k+1, and the host may enqueue site
+        # pass k+2 without waiting for it (with two sets a short pass -- C2: 75 us -- left the main
+        # stream idle whenever the stage under it ran longer than the pass)
+        n_buf = 3 if self.overlap else 1
         # the fused pass writes tgt_freq only at candidate sites (all the windows stage reads)
         self._tgt_freq = [torch.full((n,), float("nan"), dtype=torch.float64, device=dev) for _ in range(n_buf)]
         self._flags = [eng.alloc_planes(n, n_s) for _ in range(n_buf)]  # flag planes [tiles][3 * sets]
@@ -187,6 +188,7 @@ class ResidentScorer:
         self.lo = torch.empty((n_w,), dtype=torch.int32, device=dev)
         self.hi = torch.empty((n_w,), dtype=torch.int32, device=dev)
         self._alloc_chunks(cap_u, cap_q)
+        self._build_pass_plans()
         self.count_events: list = []  # (start, end) torch events around site_counts, when requested
 
     def _alloc_chunks(self, cap_u: int, cap_q: int) -> None:
@@ -200,6 +202,46 @@ class ResidentScorer:
         first = self.chunks[0]  # the whole scorer when n_sets <= SAI_MAX_SETS
         self.bufs, self.host_head = first.bufs, first.host_head
         self.host_records, self.host_offsets, self.host_totals = first.host_records, first.host_offsets, first.host_totals
+        self._build_stage_plans()
+
+    # A step's launches are recorded once per buffer set as prepared sequences (Engine.plan): the
+    # host then pays for two C calls per step instead of nine with freshly marshalled arguments.
+    def _build_pass_plans(self) -> None:
+        eng, blk = self.eng, self.block
+        self._count_plans, self._flag_plans = [], []
+        for tgt_freq, planes in zip(self._tgt_freq, self._flags):
+            out = (tgt_freq, planes)
+            cp = fp = None
+            if self.packed is not None:
+                cp = eng.plan()
+                if self.fused:
+                    cp.add_site_pass(self.packed, blk.ploidies, self.sets, out, counts=self.counts_out, freq_mode="candidates",
+                                     packed2=True)  # fmt: skip
+                else:
+                    cp.add_site_pass(self.packed, blk.ploidies, [], None, counts=self.counts, packed2=True)
+            elif self.fused:
+                cp = eng.plan()
+                cp.add_site_pass(blk.pops, blk.ploidies, self.sets, out, counts=self.counts_out, freq_mode="candidates")
+            elif not self.have_counts:
+                cp = eng.plan()
+                cp.add_site_counts(blk.pops, self.counts)
+            if not self.fused:
+                fp = eng.plan()
+                fp.add_site_flags(self.counts, blk.ploidies, self.sets, out)
+            self._count_plans.append(cp)
+            self._flag_plans.append(fp)
+
+    def _build_stage_plans(self) -> None:
+        eng, blk = self.eng, self.block
+        self._stage_plans = []
+        for tgt_freq, planes in zip(self._tgt_freq, self._flags):
+            sp = eng.plan()
+            sp.add_window_bounds(blk.pos, self.win_start, self.win_end, self.seg_lo, self.seg_hi, self.lo, self.hi)
+            for ch in self.chunks:
+                sp.add_window_stats(tgt_freq, planes[:, PLANES * ch.s0 : PLANES * ch.s1], self.sets[ch.s0 : ch.s1], self.lo,
+                                    self.hi, self.list_pos, ch.bufs)  # fmt: skip
+                sp.add_copy_to_host(ch.host_head, ch.bufs[5])
+            self._stage_plans.append(sp)
 
     def _release_chunks(self) -> None:
         for ch in getattr(self, "chunks", None) or ():
@@ -276,7 +318,7 @@ class ResidentScorer:
         self._pending = None
         self._wait(self._site_done[b], "site pass")
         with torch.cuda.stream(self.side):
-            self._window_stage(self._tgt_freq[b], self._flags[b])
+            self._stage_plans[b].run()
             if self.after_stage is not None:
                 self.after_stage(index)
             self._win_done[b].record(self.side)
@@ -291,35 +333,25 @@ class ResidentScorer:
     def step(self, time_counts: bool = False) -> None:
         import torch
 
-        eng, blk = self.eng, self.block
+        eng = self.eng
         b = self._k % len(self._flags)
-        tgt_freq, flags = self._tgt_freq[b], self._flags[b]
         main = torch.cuda.current_stream(eng.device)
         if self.overlap and self._win_used[b]:
             self._wait(self._win_done[b], "windows stage")  # the stage that last read buffer set b (2 steps ago)
         if time_counts:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        if self.packed is not None:
-            if self.fused:
-                eng.site_pass_packed2(self.packed, blk.ploidies, self.sets, out=(tgt_freq, flags), counts=self.counts_out,
-                                      freq_mode="candidates")  # fmt: skip
-            else:
-                eng.site_pass_packed2(self.packed, blk.ploidies, [], counts=self.counts)
-        elif self.fused:
-            eng.site_pass(blk.pops, blk.ploidies, self.sets, out=(tgt_freq, flags), counts=self.counts_out,
-                          freq_mode="candidates")  # fmt: skip
-        elif not self.have_counts:
-            eng.site_counts(blk.pops, out=self.counts)
+        if self._count_plans[b] is not None:
+            self._count_plans[b].run()  # the genotype stream: site_counts, fused with the per-site decision when it can be
         if time_counts:
             e1.record()
             self.count_events.append((e0, e1))
-        if not self.fused:
-            eng.site_flags(self.counts, blk.ploidies, self.sets, out=(tgt_freq, flags))
+        if self._flag_plans[b] is not None:
+            self._flag_plans[b].run()
         index = self._k
         self._k += 1
         if not self.overlap:
-            self._window_stage(tgt_freq, flags)
+            self._stage_plans[b].run()
             if self.after_stage is not None:
                 self.after_stage(index)
             return
@@ -327,28 +359,6 @@ class ResidentScorer:
         main.query()                 # submit the site pass before the host starts waiting
         self._launch_pending()       # the previous step's stage runs under this site pass
         self._pending = (b, index)
-
-    def _window_stage(self, tgt_freq, flags) -> None:
-        eng, blk = self.eng, self.block
-        if self.seg_lo is None:
-            _ffi.check(
-                eng.lib.sai_window_bounds(
-                    eng.ctx, eng._ptr(blk.pos), blk.n_sites, self.n_windows, eng._ptr(self.win_start),
-                    eng._ptr(self.win_end), eng._ptr(self.lo), eng._ptr(self.hi), eng._stream(),
-                )
-            )  # fmt: skip
-        else:
-            _ffi.check(
-                eng.lib.sai_window_bounds_seg(
-                    eng.ctx, eng._ptr(blk.pos), blk.n_sites, self.n_windows, eng._ptr(self.win_start),
-                    eng._ptr(self.win_end), eng._ptr(self.seg_lo), eng._ptr(self.seg_hi), eng._ptr(self.lo),
-                    eng._ptr(self.hi), eng._stream(),
-                )
-            )  # fmt: skip
-        for ch in self.chunks:
-            eng.window_stats_async(tgt_freq, flags[:, PLANES * ch.s0 : PLANES * ch.s1], self.sets[ch.s0 : ch.s1], self.lo,
-                                   self.hi, self.list_pos, ch.bufs)  # fmt: skip
-            ch.host_head.copy_(ch.bufs[5], non_blocking=True)
 
     # -- results ---------------------------------------------------------------------------
 
@@ -378,7 +388,7 @@ class ResidentScorer:
                 )
             self._alloc_chunks(max(need_u, self.cap_u), max(need_q, self.cap_q))
             with self.window_stream():
-                self._window_stage(self.tgt_freq, self.flags)
+                self._stage_plans[(self._k - 1) % len(self._flags)].run()
             totals = self.list_totals()
         recs, offs, us, qs = [], [], [], []
         base_u = base_q = 0
