@@ -238,3 +238,101 @@ def test_c3_packed2_equals_int8(eng):
     assert ra.records.tobytes() == rb.records.tobytes()
     assert np.array_equal(ra.offsets, rb.offsets) and np.array_equal(ra.cdd_u, rb.cdd_u) and np.array_equal(ra.cdd_q, rb.cdd_q)
     assert sum(p.data.numel() for p in b.packed) * 3.5 < sum(p.tiles.numel() for p in block.pops)
+
+
+# ------------------------------------------------------------------------------------------
+# exactly what bench.py times ("GPU tests on exactly what the bench runs")
+# ------------------------------------------------------------------------------------------
+
+
+def _bench_scorer(eng, wl, steps=3):
+    """The scorer bench.py builds for a workload on one GPU: build_synth_shard(world=1) -> one block
+    of the job's chromosome pieces -> ResidentScorer(overlap=True), `steps` pipelined steps."""
+    from sai_amd.resident import ResidentScorer
+    from sai_amd.sharding import build_synth_shard
+
+    block, lay, win_counts = build_synth_shard(eng, wl, 0, 1)
+    scorer = ResidentScorer(eng, block, [(s, e) for _, s, e in lay.windows], wl.params(), cap_u=1 << 22, cap_q=1 << 22,
+                            overlap=True, window_segment=lay.window_segment)  # fmt: skip
+    for _ in range(steps):
+        scorer.step()
+    return block, lay, scorer, scorer.results()
+
+
+def check_piece_windows_against_oracle(block, lay, scorer, res, specs, sample):
+    """check_sampled_windows_against_oracle for a block of several pieces: the window's site range is
+    searched inside its own piece (positions ascend per piece only)."""
+    from oracle import sai_oracle as O
+
+    lo, hi = scorer.lo.cpu().numpy(), scorer.hi.cpu().numpy()
+    pos = block.pos.cpu().numpy()
+    for wi in sample:
+        _, start, end = lay.windows[wi]
+        s0, s1 = lay.segments[int(lay.window_segment[wi])]
+        a, b = int(lo[wi]), int(hi[wi])
+        assert (a, b) == (s0 + np.searchsorted(pos[s0:s1], start), s0 + np.searchsorted(pos[s0:s1], end, side="right")), wi
+        mats = [untile(p, a, b) for p in block.pops]
+        for si, s in enumerate(specs):
+            kw = dict(ref_gts=mats[0], tgt_gts=mats[1], src_gts_list=mats[2:], ref_ploidy=2, tgt_ploidy=2,
+                      src_ploidy_list=[2] * (len(mats) - 2), pos=pos[a:b], w=s["w"], y_list=s["y_list"],
+                      anc_allele_available=s["anc"])  # fmt: skip
+            eu, eq = O.u_stat(x=s["x"], **kw), O.q_stat(quantile=s["quantile"], **kw)
+            rec = res.records[si, wi]
+            assert rec["n_sites"] == b - a and rec["u_count"] == eu["value"], (wi, si)
+            assert res.u_list(si, wi).tolist() == eu["cdd_pos"].tolist()
+            assert same_f64(rec["q"], eq["value"]), (wi, si, rec["q"], eq["value"])
+            assert res.q_list(si, wi).tolist() == np.asarray(eq["cdd_pos"]).astype(np.int64).tolist()
+
+
+def test_c5_fused_sweep_pipelined_full_size(eng):
+    """configs[4] as bench.py --workload c5 runs it: 1e7 sites, the 18 sets riding in ONE fused site
+    pass, steps pipelined on two streams -- identities over the whole block and the oracle on sampled
+    windows, among them heavy ones (sets 0 and 9 select ~620 sites per window: the workgroup select)."""
+    import bench
+
+    wl = bench.make_workload("c5")
+    block, lay, scorer, res = _bench_scorer(eng, wl)
+    assert scorer.fused and scorer.overlap and len(scorer.chunks) == 1 and res.records.shape == (18, len(lay.windows))
+    assert len(lay.windows) in range(9900, 10100)
+    check_identities(eng, block, scorer, res)
+    heavy = [si for si in range(18) if int(np.median(res.records[si]["n_cond"])) > 256]
+    assert 0 in heavy and 9 in heavy  # ("=0", "=0") and (">=0", ">=0")
+    rng = np.random.default_rng(5)
+    sample = sorted({int(np.argmax(res.records[0]["n_cond"])), int(np.argmax(res.records[9]["n_cond"])),
+                     int(np.argmax(res.records[8]["u_count"])), 0, len(lay.windows) - 1, *rng.integers(0, len(lay.windows), 3).tolist()})  # fmt: skip
+    assert len(sample) >= 6
+    check_piece_windows_against_oracle(block, lay, scorer, res, wl.specs, sample)
+    # the pipelined steps repeat themselves: the un-pipelined scorer on the same block gives the same bytes
+    from sai_amd.resident import ResidentScorer
+
+    plain = ResidentScorer(eng, block, [(s, e) for _, s, e in lay.windows], wl.params(), cap_u=1 << 22, cap_q=1 << 22,
+                           window_segment=lay.window_segment)  # fmt: skip
+    plain.step()
+    want = plain.results()
+    assert want.records.tobytes() == res.records.tobytes()
+    assert np.array_equal(want.cdd_u, res.cdd_u) and np.array_equal(want.cdd_q, res.cdd_q)
+
+
+def test_c4_multi_piece_block_full_size(eng):
+    """configs[3]'s block as bench.py --workload c4 lays it out on one GPU, with three full-size
+    chromosomes (3 x 5e6 sites, 30 GB): pieces back to back at tile boundaries, one site pass and one
+    windows stage for all of them.  Windows next to every piece boundary against the oracle, and the
+    identities over the whole block."""
+    import bench
+
+    wl = bench.make_workload("c4", chroms=3)
+    block, lay, scorer, res = _bench_scorer(eng, wl)
+    assert len(lay.pieces) == 3 and block.segments is not None and res.records.shape == (1, len(lay.windows))
+    assert len(lay.windows) in range(14900, 15100) and block.n_real_sites == 3 * 5_000_000
+    check_identities(eng, block, scorer, res)
+    seg = np.asarray(lay.window_segment)
+    edges = np.flatnonzero(np.diff(seg)) + 1  # first window of pieces 1 and 2
+    assert len(edges) == 2
+    sample = sorted({0, len(lay.windows) - 1, *[int(e) + d for e in edges for d in (-2, -1, 0, 1)],
+                     *np.argsort(-res.records[0]["u_count"])[:3].tolist()})  # fmt: skip
+    check_piece_windows_against_oracle(block, lay, scorer, res, wl.specs, sample)
+    # the last window of a piece ends inside its piece; the first of the next starts at that piece's first site
+    lo, hi = scorer.lo.cpu().numpy(), scorer.hi.cpu().numpy()
+    for e in edges:
+        assert hi[e - 1] <= lay.segments[seg[e - 1]][1] and lo[e] == lay.segments[seg[e]][0]
+    assert res.records[0]["u_count"].sum() > 1000
