@@ -138,11 +138,11 @@ def _cpu_chunk(bounds):
     d = _CPU
     return len(
         O.run_chunk("1", {"ref": d["ref"]}, {"tgt": d["tgt"]}, d["src"], d["win_len"], d["win_step"], d["stats"],
-                    d["ploidies"], True, start=bounds[0], end=bounds[1])  # fmt: skip
+                    d["ploidies"], d["anc"], start=bounds[0], end=bounds[1])  # fmt: skip
     )
 
 
-def cpu_baseline(wl, n_sites: int, workers: int) -> dict:
+def cpu_baseline(wl, n_sites: int, workers: int, runs: int = 3, min_run_s: float = 5.0) -> dict:
     """windows/s of the numpy oracle on a site prefix of the job's first chromosome (same seed and
     generator as the GPU run).  Runs before any HIP call so that forking the pool is safe."""
     import multiprocessing as mp
@@ -179,7 +179,7 @@ def cpu_baseline(wl, n_sites: int, workers: int) -> dict:
         ref=O.Chrom(pos, host_block(0, wl.n_ref)),
         tgt=O.Chrom(pos, host_block(1, wl.n_tgt)),
         src={n: O.Chrom(pos, host_block(2 + i, k)) for i, (n, k) in enumerate(zip(src_names, wl.src_sizes))},
-        win_len=wl.win_len, win_step=wl.win_step,
+        win_len=wl.win_len, win_step=wl.win_step, anc=bool(s0["anc"]),
         stats={
             "U": {"ref": {"ref": s0["w"]}, "tgt": {"tgt": s0["x"]}, "src": dict(y)},
             "Q": {"ref": {"ref": s0["w"]}, "tgt": {"tgt": s0["quantile"]}, "src": dict(y)},
@@ -189,23 +189,39 @@ def cpu_baseline(wl, n_sites: int, workers: int) -> dict:
     windows = O.split_windows([int(pos[0]), int(pos[-1])], wl.win_len, wl.win_step)
     windows = [w for w in windows if w[1] <= int(pos[-1])]  # only windows fully inside the prefix
     chunks = O.split_window_ranges(windows, workers * 8)  # 8 chunks per worker (sai.py:91)
-    t0 = time.perf_counter()
+    # three runs of whole passes over the chunk list, each at least `min_run_s` long: one pass of the
+    # prefix takes 1.5-2 s, and single passes scattered by +-30 % from call to call
+    rates, walls, passes = [], [], []
     with mp.get_context("fork").Pool(workers) as pool:
-        done = sum(pool.map(_cpu_chunk, chunks, chunksize=1))
-    dt = time.perf_counter() - t0
+        for _ in range(runs):
+            t0, n_pass = time.perf_counter(), 0
+            while True:
+                done = sum(pool.map(_cpu_chunk, chunks, chunksize=1))
+                assert done == len(windows), (done, len(windows))
+                n_pass += 1
+                dt = time.perf_counter() - t0
+                if dt >= min_run_s:
+                    break
+            rates.append(n_pass * len(windows) / dt)
+            walls.append(dt)
+            passes.append(n_pass)
     _CPU.clear()
-    assert done == len(windows), (done, len(windows))
+    order = sorted(rates)
     return {
-        "value": round(len(windows) / dt, 2),
+        "value": round(order[len(order) // 2], 2),  # median of the runs
         "unit": "windows/s",
         "cores": workers,
         "kind": "port",
         "cpu_model": cpu_model(),
-        "wall_s": round(dt, 2),
-        "cpu_s": round(dt * workers, 1),
+        "runs": len(rates),
+        "min": round(order[0], 2),
+        "max": round(order[-1], 2),
+        "wall_s": [round(w, 2) for w in walls],
+        "cpu_s": round(sum(walls) * workers, 1),
         "sample": f"first {n_sites} sites of chromosome {chrom} of {wl.name} ({len(windows)} windows, "
         f"{wl.n_ref}/{wl.n_tgt}/{'+'.join(map(str, wl.src_sizes))} diploids, int64 matrices, U+Q95), "
-        f"multiprocessing.Pool({workers}) over {len(chunks)} chunks, {dt:.1f} s wall",
+        f"multiprocessing.Pool({workers}) over {len(chunks)} chunks; median of {len(rates)} runs of "
+        f"{'/'.join(map(str, passes))} whole passes (>= {min_run_s:g} s each)",
     }
 
 
@@ -411,6 +427,11 @@ def main() -> None:
     ap.add_argument("--gather", choices=["step", "end"], default="step",
                     help="N>1: 'step' gathers records + candidate lists to rank 0 after every pass, as a real run "
                     "does (default); 'end' keeps the K passes' rows in HBM and gathers them once before the closing fence")
+    ap.add_argument("--anc", choices=["true", "false"], default="true",
+                    help="anc_allele_available of every parameter set: true = the headline; false = SURVEY 8(d)'s "
+                    "second row (sources also matched against 1 - y, matching sites inverted; stat_utils.py:146-160)")
+    ap.add_argument("--cpu-runs", type=int, default=3, help="timed runs of the CPU baseline (the median is reported)")
+    ap.add_argument("--cpu-run-seconds", type=float, default=5.0, help="minimum length of one CPU run (whole passes)")
     ap.add_argument("--cpu-sites", type=float, default=1e6, help="site prefix timed on the CPU (0 = skip)")
     ap.add_argument("--cpu-workers", type=int, default=0, help="0 = usable cores (affinity mask capped by the cgroup quota)")
     ap.add_argument("--score-path", choices=["auto", "on", "off"], default="auto",
@@ -434,12 +455,16 @@ def main() -> None:
 
     name = args.workload if args.workload != "auto" else ("c3" if world == 1 else "c4")
     wl = make_workload(name, args.sites, args.chroms, args.scaling, world)
+    if args.anc == "false":
+        for spec in wl.specs:
+            spec["anc"] = False
+        wl.description += "; anc_allele_available=False (mirror match + inversion)"
 
     cpu = None
     if rank == 0 and world == 1 and args.cpu_sites > 0:
         # a one-GPU box grants a 16-CPU share of the host whatever nproc says
         workers = args.cpu_workers or min(usable_cores(), 16)
-        cpu = cpu_baseline(wl, min(int(args.cpu_sites), wl.n_sites), workers)
+        cpu = cpu_baseline(wl, min(int(args.cpu_sites), wl.n_sites), workers, args.cpu_runs, args.cpu_run_seconds)
 
     import torch
     import torch.distributed as dist
@@ -563,7 +588,7 @@ def main() -> None:
         tfile = ROOT / "profiles" / "traffic.json"
         if tfile.exists() and world == 1 and not args.sites and not args.chroms:
             rec = json.loads(tfile.read_text())
-            key = wl.name + ("" if args.layout == "int8" else f":{args.layout}")
+            key = wl.name + ("" if args.layout == "int8" else f":{args.layout}") + ("" if args.anc == "true" else ":noanc")
             if key in rec:
                 traffic = rec[key].get("site_counts_hbm_bytes_per_launch")
                 traffic_source = f"profiles/traffic.json[{key}] ({rec[key].get('source', 'rocprofv3 --pmc passes of this command')}); not measured in this run"
@@ -592,6 +617,7 @@ def main() -> None:
                 "chromosomes": len(wl.chroms),
                 "n_sites_per_chromosome": wl.n_sites,
                 "parameter_sets": n_sets,
+                "anc_allele_available": args.anc == "true",
                 "windows_total": total_windows,
                 "windows_rank0": scorer.n_windows,
                 "sites_rank0": n_sites_rank0,

@@ -33,96 +33,12 @@
 #include <unordered_map>
 #include <vector>
 
+#include "host_threads.hpp"
 #include "saihip.h"
 
 extern "C" int sai_set_error(int code, const char* fmt, ...);  // defined in host_core.cpp
 
 namespace {
-
-// Worker threads that are always joined, also when an exception unwinds the spawning scope (a
-// joinable std::thread that is destroyed calls std::terminate).
-struct ThreadGroup {
-  std::vector<std::thread> th;
-  template <typename F>
-  void spawn(F&& f) { th.emplace_back(std::forward<F>(f)); }
-  void join() {
-    for (auto& t : th)
-      if (t.joinable()) t.join();
-    th.clear();
-  }
-  ~ThreadGroup() { join(); }
-};
-
-
-// Persistent workers for loops that fan the same job out batch after batch (a thread costs tens of
-// microseconds to create; a 160 MB bgzip file is ~20 batches x 2 phases x 15 threads).  run(nt, fn)
-// executes fn(0) .. fn(nt-1), fn(0) on the calling thread, and returns when all are done.  fn must
-// not throw (the callers' jobs catch inside).
-class WorkerPool {
- public:
-  explicit WorkerPool(int n) : n_(n < 1 ? 1 : n) {
-    for (int t = 1; t < n_; ++t) threads_.emplace_back([this, t] { loop(t); });
-  }
-  ~WorkerPool() {
-    {
-      std::lock_guard<std::mutex> lk(m_);
-      stop_ = true;
-    }
-    cv_.notify_all();
-    for (auto& t : threads_)
-      if (t.joinable()) t.join();
-  }
-  int size() const { return n_; }
-  template <typename F>
-  void run(int nt, F&& fn) {
-    if (nt > n_) nt = n_;
-    if (nt <= 1) {
-      fn(0);
-      return;
-    }
-    std::function<void(int)> job = [&fn](int t) { fn(t); };
-    {
-      std::lock_guard<std::mutex> lk(m_);
-      job_ = &job;
-      active_ = nt;
-      pending_ = nt - 1;
-      ++gen_;
-    }
-    cv_.notify_all();
-    fn(0);
-    std::unique_lock<std::mutex> lk(m_);
-    done_.wait(lk, [this] { return pending_ == 0; });
-    job_ = nullptr;
-  }
-
- private:
-  void loop(int t) {
-    uint64_t seen = 0;
-    for (;;) {
-      std::function<void(int)>* job = nullptr;
-      {
-        std::unique_lock<std::mutex> lk(m_);
-        cv_.wait(lk, [&] { return stop_ || gen_ != seen; });
-        if (stop_) return;
-        seen = gen_;
-        if (t < active_) job = job_;
-      }
-      if (job) {
-        (*job)(t);
-        std::lock_guard<std::mutex> lk(m_);
-        if (--pending_ == 0) done_.notify_one();
-      }
-    }
-  }
-  int n_;
-  std::vector<std::thread> threads_;
-  std::mutex m_;
-  std::condition_variable cv_, done_;
-  std::function<void(int)>* job_ = nullptr;
-  int active_ = 0, pending_ = 0;
-  uint64_t gen_ = 0;
-  bool stop_ = false;
-};
 
 constexpr int kScanThreads = 16;  // inflate threads of sai_vcf_scan (it has no thread argument)
 
@@ -938,24 +854,6 @@ int parse_header(const char* p, const char* eol, const char* path, int32_t n_sam
 }  // namespace
 
 namespace {
-
-template <typename T>
-bool narrow_rows(const char* src, int64_t row_stride, int64_t r0, int64_t r1, int64_t n_cols, int8_t* dst) {
-  bool too_big = false;
-  for (int64_t r = r0; r < r1; ++r) {
-    const T* row = reinterpret_cast<const T*>(src + r * row_stride);
-    int8_t* out = dst + r * n_cols;
-    T hi = 0;  // running maximum: one compare per element instead of a branch
-    for (int64_t c = 0; c < n_cols; ++c) {
-      const T v = row[c];
-      hi = v > hi ? v : hi;
-      if constexpr (std::is_signed<T>::value) out[c] = static_cast<int8_t>(v < static_cast<T>(-128) ? static_cast<T>(-128) : v);
-      else out[c] = static_cast<int8_t>(v);
-    }
-    too_big = too_big || hi > static_cast<T>(127);
-  }
-  return !too_big;
-}
 
 }  // namespace
 
@@ -1961,40 +1859,6 @@ static int vcf_load_impl(const char* path, const char* chrom, int64_t start, int
   return SAI_OK;
 }
 
-static int narrow_impl(const void* src, int32_t itemsize, int32_t is_signed, int64_t n_rows, int64_t n_cols,
-                       int64_t row_stride_bytes, int8_t* dst, int32_t n_threads) {
-  if (n_rows < 0 || n_cols < 0) return sai_set_error(SAI_ERR_ARG, "negative shape");
-  if (n_rows == 0 || n_cols == 0) return SAI_OK;
-  if (!src || !dst) return sai_set_error(SAI_ERR_ARG, "NULL buffer");
-  if (itemsize != 1 && itemsize != 2 && itemsize != 4 && itemsize != 8) return sai_set_error(SAI_ERR_ARG, "itemsize must be 1, 2, 4 or 8");
-  const int64_t total = n_rows * n_cols;
-  int nt = std::max(1, std::min<int>(n_threads, static_cast<int>(std::min<int64_t>(n_rows, 1 + total / (1 << 20)))));
-  std::vector<char> ok(static_cast<size_t>(nt), 1);
-  const char* base = static_cast<const char*>(src);
-  auto work = [&](int t) {
-    const int64_t r0 = n_rows * t / nt, r1 = n_rows * (t + 1) / nt;
-    bool good = true;
-    switch (itemsize * 2 + (is_signed ? 1 : 0)) {
-      case 3: good = narrow_rows<int8_t>(base, row_stride_bytes, r0, r1, n_cols, dst); break;
-      case 2: good = narrow_rows<uint8_t>(base, row_stride_bytes, r0, r1, n_cols, dst); break;
-      case 5: good = narrow_rows<int16_t>(base, row_stride_bytes, r0, r1, n_cols, dst); break;
-      case 4: good = narrow_rows<uint16_t>(base, row_stride_bytes, r0, r1, n_cols, dst); break;
-      case 9: good = narrow_rows<int32_t>(base, row_stride_bytes, r0, r1, n_cols, dst); break;
-      case 8: good = narrow_rows<uint32_t>(base, row_stride_bytes, r0, r1, n_cols, dst); break;
-      case 17: good = narrow_rows<int64_t>(base, row_stride_bytes, r0, r1, n_cols, dst); break;
-      default: good = narrow_rows<uint64_t>(base, row_stride_bytes, r0, r1, n_cols, dst); break;
-    }
-    ok[static_cast<size_t>(t)] = good ? 1 : 0;
-  };
-  ThreadGroup th;  // narrow_rows touches only the caller's buffers: no throw inside the workers
-  for (int t = 1; t < nt; ++t) th.spawn([&work, t] { work(t); });
-  work(0);
-  th.join();
-  for (char g : ok)
-    if (!g) return sai_set_error(SAI_ERR_UNSUPPORTED, "dosage above 127 is not representable in the int8 device layout");
-  return SAI_OK;
-}
-
 int sai_vcf_scan(const char* path, const char* chrom, int64_t* first_pos, int64_t* last_pos) {
   return guarded("sai_vcf_scan", [&] { return vcf_scan_impl(path, chrom, first_pos, last_pos); });
 }
@@ -2004,13 +1868,6 @@ int sai_vcf_load(const char* path, const char* chrom, int64_t start, int64_t end
                  sai_vcf_block** block_out) {
   return guarded("sai_vcf_load", [&] {
     return vcf_load_impl(path, chrom, start, end, n_samples, sample_names, ploidy, anc_bed_path, n_threads, block_out);
-  });
-}
-
-int sai_narrow_to_int8(const void* src, int32_t itemsize, int32_t is_signed, int64_t n_rows, int64_t n_cols,
-                       int64_t row_stride_bytes, int8_t* dst, int32_t n_threads) {
-  return guarded("sai_narrow_to_int8", [&] {
-    return narrow_impl(src, itemsize, is_signed, n_rows, n_cols, row_stride_bytes, dst, n_threads);
   });
 }
 

@@ -225,7 +225,8 @@ class FeaturePreprocessor(DataPreprocessor):
             return torch.stack([counts_rows[k] for k in keys])
 
         pos_dev_cache = {}
-        win_arrays = {}
+        win_arrays = wg.__dict__.setdefault("_win_arrays", {})  # the grid as int64 [n][2], once per generator (0.7 ms for 10^4 tuples)
+        scorers = wg.__dict__.setdefault("_scorers", {})
         group_data = {"ref": wg.ref_data, "tgt": wg.tgt_data, "src": wg.src_data, "outgroup": wg.out_data}
         for ref_pop, tgt_pop, src_comb, out_pop in combos:
             al = wg.aligned(ref_pop, tgt_pop, src_comb, out_pop)
@@ -268,9 +269,16 @@ class FeaturePreprocessor(DataPreprocessor):
             lo = hi = None
             if uq_names:
                 block = ResidentBlock([tiled[k] for k in uq_keys], ploidy[: 2 + n_eff], pos_dev)
-                scorer = ResidentScorer(eng, block, windows, sets, cap_u=1 << 16, cap_q=1 << 16,
-                                        counts_in=counts_of(uq_keys) if shared else None,
-                                        lists_as_indices=al.uniq is not None)  # fmt: skip
+                # one scorer per (window grid, block length, number of sets) serves every combination of the
+                # region -- and the next call on the same generator: only its launch sequences are re-recorded
+                key = (tgt_pop, n_sites, len(sets))
+                scorer = scorers.get(key)
+                if scorer is None:
+                    scorer = scorers[key] = ResidentScorer(eng, block, windows, sets, cap_u=1 << 16, cap_q=1 << 16,
+                                                           counts_in=counts_of(uq_keys) if shared else None,
+                                                           lists_as_indices=al.uniq is not None)  # fmt: skip
+                else:
+                    scorer.rebind(block, sets, counts_of(uq_keys) if shared else None, lists_as_indices=al.uniq is not None)
                 scorer.step()
                 cb.uq = scorer.results(grow=True)
                 lo, hi = scorer.lo, scorer.hi

@@ -204,6 +204,33 @@ class ResidentScorer:
         self.host_records, self.host_offsets, self.host_totals = first.host_records, first.host_offsets, first.host_totals
         self._build_stage_plans()
 
+    def rebind(self, block: ResidentBlock, sets: Sequence[_ffi.SaiParams], counts_in=None,
+               lists_as_indices: bool = False) -> None:
+        """Point this scorer at another block over the SAME sites and windows -- the next population
+        combination of a region, or the same one again -- and other parameter sets of the same number:
+        the per-site arrays, the window arrays on the device, the candidate buffers and their pinned
+        mirrors stay; only the prepared launch sequences are recorded again.  (A scorer per combination
+        cost about a millisecond to build for a pass of three: the NaN fill of 80 MB of tgt_freq, the
+        upload of the windows, the allocations.)"""
+        if self.layout != "int8" or self.counts_out is not None:
+            raise ValueError("rebind serves the plain int8 scorer")
+        if block.n_sites != self.block.n_sites or len(block.pops) < 2 or len(sets) != self.n_sets:
+            raise ValueError("rebind needs a block of the same number of sites and as many parameter sets")
+        if (block.segments is None) != (self.block.segments is None) or (block.segments is not None and block.segments != self.block.segments):
+            raise ValueError("rebind needs the same chromosome pieces")
+        self._sync()  # nothing of the old block may still be in flight
+        self.block, self.sets = block, list(sets)
+        self.have_counts = counts_in is not None
+        self.fused = self.n_sets <= _ffi.SAI_FUSED_SETS and not self.have_counts
+        self.counts = counts_in
+        if self.counts is None and not self.fused:
+            import torch
+
+            self.counts = torch.empty((len(block.pops), block.n_sites, 2), dtype=torch.int32, device=self.eng.device)
+        self.list_pos = None if lists_as_indices else block.pos
+        self._build_pass_plans()
+        self._build_stage_plans()
+
     # A step's launches are recorded once per buffer set as prepared sequences (Engine.plan): the
     # host then pays for two C calls per step instead of nine with freshly marshalled arguments.
     def _build_pass_plans(self) -> None:

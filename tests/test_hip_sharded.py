@@ -198,6 +198,20 @@ def test_plain_bench_gpus_2_launches_its_own_ranks():
     assert one["config"]["one_gpu_base"] is None
 
 
+def test_bench_without_ancestral_alleles_is_a_different_job():
+    """--anc false (SURVEY 8d's second row): every set matches the sources against 1 - y as well and
+    inverts those sites; same windows, other counts, and the line says so."""
+    args = ["--workload", "c3", "--sites", "400000", "--steps", "2", "--warmup", "1", "--cpu-sites", "0", "--score-path", "off"]
+    yes, no = _bench(args), _bench([*args, "--anc", "false"])
+    assert no["config"]["anc_allele_available"] is False and "anc_allele_available=False" in no["config"]["workload"]
+    assert no["config"]["windows_total"] == yes["config"]["windows_total"]
+    # y = 1: the mirror 1 - y = 0 also matches the many sites where the source carries no derived allele; they
+    # are inverted (ref' = 1 - ref) and pass `ref' < w` only where the reference is nearly fixed, so the synthetic
+    # job gains few windows, never loses one
+    assert no["config"]["q_finite"] >= yes["config"]["q_finite"] and no["config"]["u_sum"] >= yes["config"]["u_sum"] > 0
+    assert no["roofline"]["traffic"] is None  # a reduced job has no stored counter figure
+
+
 def test_bench_one_rank_on_real_rccl():
     """The same branches -- process group with device_id, header all_gather, the per-pass gather on
     the window stream, the MAX reduction -- with one rank on real RCCL."""
@@ -210,11 +224,14 @@ def test_bench_one_rank_on_real_rccl():
 
 
 def test_bench_default_line_has_the_contract_fields():
-    line = _bench(["--workload", "c2", "--steps", "5", "--warmup", "1", "--cpu-sites", "20000"])
+    line = _bench(["--workload", "c2", "--steps", "5", "--warmup", "1", "--cpu-sites", "20000", "--cpu-run-seconds", "0.3"])
     assert line["metric"].startswith("windows/sec") and line["unit"] == "windows/s" and line["n_gpus"] == 1
     assert line["dtype"] == "u8" and line["vs_baseline"] is None and line["higher_is_better"] is True
     assert set(line["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source"}
     assert line["cpu_baseline"]["kind"] == "port" and line["cpu_baseline"]["cpu_model"] and line["cpu_baseline"]["cores"] >= 1
+    cb = line["cpu_baseline"]
+    assert cb["runs"] == 3 and cb["min"] <= cb["value"] <= cb["max"] and len(cb["wall_s"]) == 3 and min(cb["wall_s"]) >= 0.3
+    assert line["config"]["anc_allele_available"] is True
     sp = line["score_path"]
     assert sp["windows"] == line["config"]["windows_total"] and sp["value"] > 0
     assert sp["item_protocol"]["same_bytes_as_native"] is True
