@@ -437,9 +437,15 @@ int sai_inflate_bgzf(sai_ctx* ctx, const void* comp, int64_t n_comp_bytes, const
 /* The host side of that path.  sai_bgzf_stream_open starts a reader thread that hands the file's
  * BGZF members over as they are -- whole members, padded to a multiple of 4 bytes -- in the caller's
  * two pinned buffers alternately, at most text_batch_bytes of text per batch; SAI_ERR_UNSUPPORTED
- * when the file is not bgzip, or when a region is asked of a file with a usable .tbi (that is a
- * seek and a few blocks: sai_vcf_stream_open); n_samples = 0 asks for the record index only (the
- * positions of a chromosome).  sai_bgzf_stream_next returns batch k (blocking) and
+ * when the file is not bgzip; n_samples = 0 asks for the record index only (the positions of a
+ * chromosome).  A region (start >= 0) of a file with a usable <vcf>.tbi is a seek: the reader hands
+ * over only the members from the region's first record (the tabix linear index) to the member that
+ * holds the first record of a later 16 kb window, as each worker of the reference reads only its own
+ * region (utils.py:117-138, chunk_generator.py:130-142).  sai_bgzf_stream_region says what was
+ * decided: *file_begin / *file_stop = compressed offsets of the first and last member read (-1 / -1:
+ * the index holds no record for the region, nothing is read; file_stop -1: to the end of the file)
+ * and *first_text_skip = bytes of the first member's text that precede the region's first record --
+ * the caller starts its line table behind them.  sai_bgzf_stream_next returns batch k (blocking) and
  * releases the buffer of batch k-1 (its H2D copy must be over); members_host = the table for
  * sai_inflate_bgzf, valid until the following call.  The caller inflates the batch on the GPU behind
  * the n_carry bytes the previous batch left over (its last, incomplete line), copies carry + text to
@@ -458,6 +464,7 @@ int sai_bgzf_stream_open(const char* path, const char* chrom, int64_t start, int
                          int64_t text_batch_bytes, sai_bgzf_stream** stream_out);
 int sai_bgzf_stream_next(sai_bgzf_stream* stream, int32_t* buffer_index, int64_t* n_comp_bytes, int32_t* n_members,
                          const sai_bgzf_member** members_host, int64_t* n_text_bytes, int32_t* done);
+int sai_bgzf_stream_region(sai_bgzf_stream* stream, int64_t* file_begin, int64_t* file_stop, int64_t* first_text_skip);
 /* Early form of the release sai_bgzf_stream_next performs: the batch's compressed bytes have been
  * copied (and the member table too: it is refilled with the buffer), the reader may go on. */
 int sai_bgzf_stream_release(sai_bgzf_stream* stream);

@@ -170,6 +170,7 @@ SIGNATURES = {
         [_p, _p, _i32, _p, _p, _i64, C.POINTER(_i64), C.POINTER(_p), C.POINTER(_p), C.POINTER(_p), C.POINTER(_p),
          C.POINTER(_p), C.POINTER(_i32)],
     ),
+    "sai_bgzf_stream_region": (C.c_int, [_p, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)]),
     "sai_bgzf_stream_selection": (C.c_int, [_p, _p, _i32, C.POINTER(_i32), C.POINTER(_i64), C.POINTER(_i64)]),
     "sai_bgzf_stream_close": (C.c_int, [_p]),
     "sai_tokenize_gt": (C.c_int, [_p, _p, _i64, _i64, _p, _p, _p, _p, _i32, _p, _i32, _p, _p, _p, _p]),
@@ -191,7 +192,7 @@ HOST_SYMBOLS = (
     "sai_abi_version", "sai_build_arch", "sai_last_error", "sai_synth_fill_host", "sai_synth_gaps_host",
     "sai_narrow_to_int8", "sai_vcf_scan", "sai_vcf_load", "sai_vcf_block_info", "sai_vcf_block_copy", "sai_vcf_block_free",
     "sai_vcf_stream_open", "sai_vcf_stream_next", "sai_vcf_stream_selection", "sai_vcf_stream_close",
-    "sai_bgzf_stream_open", "sai_bgzf_stream_next", "sai_bgzf_stream_release", "sai_vcf_index_text", "sai_vcf_index_heads", "sai_bgzf_stream_selection", "sai_bgzf_stream_close",
+    "sai_bgzf_stream_open", "sai_bgzf_stream_next", "sai_bgzf_stream_release", "sai_bgzf_stream_region", "sai_vcf_index_text", "sai_vcf_index_heads", "sai_bgzf_stream_selection", "sai_bgzf_stream_close",
     "sai_format_score_rows", "sai_format_log_rows", "sai_format_doubles", "sai_text_data", "sai_text_free",
 )  # fmt: skip
 

@@ -1299,6 +1299,11 @@ struct sai_bgzf_stream {
   int rc = 0;
   std::string err;
   std::thread reader;
+  // region seek through <vcf>.tbi: the reader starts at the member of the region's first record and
+  // ends with the member that holds the first record beyond it (-1: to the end of the file)
+  int64_t file_begin = 0, file_stop = -1;
+  int64_t first_text_skip = 0;  // text of the first member that precedes the region's first record
+  bool nothing_to_read = false; // the index says the region holds no record
   // indexer (the consumer's thread)
   Selection sel;
   AncMap anc;
@@ -1319,9 +1324,11 @@ int bgzf_reader_run(sai_bgzf_stream* st) {
   struct stat sb;
   if (fstat(fd, &sb) != 0) return sai_set_error(SAI_ERR_ARG, "cannot stat %s", path);
   const size_t total = static_cast<size_t>(sb.st_size);
-  size_t file_off = 0;
+  size_t file_off = static_cast<size_t>(st->file_begin);
+  if (st->nothing_to_read || file_off >= total) return SAI_OK;
+  bool region_end = false;
   WorkerPool readers(std::max(1, std::min(st->n_threads, 8)));
-  while (file_off < total) {
+  while (file_off < total && !region_end) {
     int b;
     {
       std::unique_lock<std::mutex> lk(st->m);
@@ -1330,7 +1337,11 @@ int bgzf_reader_run(sai_bgzf_stream* st) {
       if (st->cancel) return SAI_OK;
     }
     unsigned char* dst = st->bufs[b];
-    const size_t want = std::min(st->cap - 8, total - file_off);  // 8 bytes of zero padding behind the data
+    size_t want = std::min(st->cap - 8, total - file_off);  // 8 bytes of zero padding behind the data
+    if (st->file_stop >= 0)  // a region: up to its last member (a member is < 64 KiB + header), not the whole buffer
+      want = std::min(want, static_cast<size_t>(st->file_stop) + (size_t(1) << 17) > file_off
+                                ? static_cast<size_t>(st->file_stop) + (size_t(1) << 17) - file_off : size_t(0));
+    if (want == 0) break;
     {
       // one thread copies ~3 GB/s out of the page cache, i.e. ~35 GB/s of text: not enough
       const int rt = static_cast<int>(std::min<size_t>(static_cast<size_t>(readers.size()), want / (size_t(1) << 20) + 1));
@@ -1373,7 +1384,12 @@ int bgzf_reader_run(sai_bgzf_stream* st) {
       r.reserved = 0;
       mem.push_back(r);
       out_total += isize;
+      const bool last_of_region = st->file_stop >= 0 && file_off + off >= static_cast<size_t>(st->file_stop);
       off += static_cast<size_t>(bsize);
+      if (last_of_region) {
+        region_end = true;
+        break;
+      }
     }
     if (mem.empty()) {
       if (file_off + have >= total) return sai_set_error(SAI_ERR_ARG, "%s: truncated BGZF file", path);
@@ -2009,11 +2025,34 @@ int sai_bgzf_stream_open(const char* path, const char* chrom, int64_t start, int
       fclose(f);
     }
     if (!file_is_bgzf(path)) return sai_set_error(SAI_ERR_UNSUPPORTED, "%s is not a bgzip file", path);
-    if (start >= 0) {  // a region of an indexed file is a seek and a few blocks: the host stream does that
-      TbiRef idx;
-      if (load_tbi(path, chrom, idx)) return sai_set_error(SAI_ERR_UNSUPPORTED, "%s has a tabix index: use sai_vcf_stream_open for a region", path);
-    }
     std::unique_ptr<sai_bgzf_stream> st(new sai_bgzf_stream);
+    if (start >= 0) {
+      // A region of a file with a usable index: only the members from the region's first record (the
+      // linear index, one entry per 16 kb window; utils.py:117-138 gets the same from scikit-allel) to the
+      // member of the first record of a LATER window take the trip -- each worker of a sharded run reads
+      // its own region (chunk_generator.py:130-142), not the file.  The record index filters by POS as
+      // always, so a coarse or stale bound costs bytes, never records: an entry equal to the window's
+      // own (an index that fills empty windows from the previous one) is not taken as the end.
+      TbiRef idx;
+      if (load_tbi(path, chrom, idx)) {
+        const uint64_t w0 = static_cast<uint64_t>(start > 0 ? start - 1 : 0) >> 14;
+        if (!idx.present || w0 >= idx.ioff.size()) {
+          st->nothing_to_read = true;
+        } else {
+          st->file_begin = static_cast<int64_t>(idx.ioff[w0] >> 16);
+          st->first_text_skip = static_cast<int64_t>(idx.ioff[w0] & 0xFFFFu);
+          if (end >= 0) {
+            const uint64_t w1 = std::min<uint64_t>(static_cast<uint64_t>(end > 0 ? end - 1 : 0) >> 14, idx.ioff.size() - 1);
+            for (uint64_t k = w1 + 1; k < idx.ioff.size(); ++k)
+              if (idx.ioff[k] > idx.ioff[w1]) {
+                st->file_stop = static_cast<int64_t>(idx.ioff[k] >> 16);
+                break;
+              }
+            if (st->file_stop >= 0 && st->file_stop < st->file_begin) st->file_stop = -1;  // not a sorted index: no end bound
+          }
+        }
+      }
+    }
     st->path = path;
     st->chrom = chrom;
     st->start = start;
@@ -2090,6 +2129,14 @@ int sai_bgzf_stream_next(sai_bgzf_stream* st, int32_t* buffer_index, int64_t* n_
   *n_members = static_cast<int32_t>(st->members[b].size());
   *members_host = st->members[b].data();
   *n_text_bytes = static_cast<int64_t>(st->text_bytes[b]);
+  return SAI_OK;
+}
+
+int sai_bgzf_stream_region(sai_bgzf_stream* st, int64_t* file_begin, int64_t* file_stop, int64_t* first_text_skip) {
+  if (!st || !file_begin || !file_stop || !first_text_skip) return sai_set_error(SAI_ERR_ARG, "NULL argument");
+  *file_begin = st->nothing_to_read ? -1 : st->file_begin;
+  *file_stop = st->file_stop;
+  *first_text_skip = st->first_text_skip;
   return SAI_OK;
 }
 

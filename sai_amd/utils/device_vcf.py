@@ -157,15 +157,17 @@ def load_dosage_device(eng, vcf_file: str, chr_name: str, samples: Sequence[str]
 
 def _load_bgzf_device(eng, vcf_file, chr_name, samples, ploidies, start, end, anc_allele_file, n_threads, cap, index_from=None,
                       positions_only=False):  # fmt: skip
-    """``load_dosage_device`` for a bgzip file without a region seek.  The compressed members cross
+    """``load_dosage_device`` for a bgzip file.  A region of a file with a usable ``.tbi`` is a seek: the
+    reader hands over only the members that hold the region (``sai_bgzf_stream_region``), and the line
+    table of the first batch starts behind the text that precedes the region's first record.  The compressed members cross
     PCIe and are inflated by ``sai_inflate_bgzf`` (one wavefront per member; a second launch checks
     every member's CRC-32).  The record index -- chromosome / region filter, POS, the ancestral-allele
     decision, where the sample columns start: the host's ``index_lines`` rules -- is made from the
     line table the GPU extracts (``sai_text_line_starts`` / ``_heads``: line offsets + the fixed
     columns of every line, a few MB) or, ``index_from="text"``, from the whole text copied back once;
     the text is tokenised where it lies in HBM either way.  Batch k+1 is inflated and scanned while
-    the host indexes batch k.  Returns None when the file is not bgzip (or a tabix index serves the
-    region): the caller falls back to the host-inflating stream.  ``positions_only`` (no samples):
+    the host indexes batch k.  Returns None when the file is not bgzip: the caller falls back to the
+    host-inflating stream.  ``positions_only`` (no samples):
     the record index alone, nothing is tokenised."""
     import torch
 
@@ -219,7 +221,15 @@ def _load_bgzf_device(eng, vcf_file, chr_name, samples, ploidies, start, end, an
     if rc:
         raise _io_error(lib)
     ploidy_dev = torch.tensor([int(p) for p in ploidies], dtype=torch.int32, device=eng.device)
-    state = {"slot_dev": None, "n_cols": 0}
+    f_begin, f_stop, f_skip = C.c_int64(), C.c_int64(), C.c_int64()
+    if lib.sai_bgzf_stream_region(handle, C.byref(f_begin), C.byref(f_stop), C.byref(f_skip)):
+        lib.sai_bgzf_stream_close(handle)
+        raise _io_error(lib)
+    # text of the first member that belongs to records before the region (a tabix seek lands inside a member)
+    state = {"slot_dev": None, "n_cols": 0, "skip": int(f_skip.value)}
+    # what the last read took from the file (tests and tools/bgzf_rate.py look at it)
+    st["last"] = {"file_begin": int(f_begin.value), "file_stop": int(f_stop.value), "first_text_skip": int(f_skip.value),
+                  "members": 0, "comp_bytes": 0, "text_bytes": 0}  # fmt: skip
     outs, stats, pos_parts = [], [], []
     usable, n_lines, idone = C.c_int64(), C.c_int64(), C.c_int32()
     p_off, p_len, p_pos, p_flip, p_gi = (C.c_void_p() for _ in range(5))
@@ -299,6 +309,9 @@ def _load_bgzf_device(eng, vcf_file, chr_name, samples, ploidies, start, end, an
         if done.value:
             return None
         b, nc, nm, nt = int(buf.value), int(n_comp.value), int(n_mem.value), int(n_text.value)
+        st["last"]["members"] += nm
+        st["last"]["comp_bytes"] += nc
+        st["last"]["text_bytes"] += nt
         table = np.ctypeslib.as_array(C.cast(table_p, C.POINTER(C.c_uint8)), shape=(nm * _MEMBER_BYTES,)).copy()
         with torch.cuda.stream(copy):
             if last_inflate[b] is not None:
@@ -307,7 +320,12 @@ def _load_bgzf_device(eng, vcf_file, chr_name, samples, ploidies, start, end, an
             h2d = torch.cuda.Event()
             h2d.record(copy)
         lap("copy_table")
-        return {"b": b, "n_comp": nc, "n_members": nm, "n_text": nt, "table": table, "h2d": h2d, "carry": 0}
+        # "carry" = bytes in front of the batch's own text that belong to it (the incomplete last line of the
+        # batch before); negative for the first batch of a region: that many bytes of its text are not its own
+        carry, state["skip"] = -state["skip"], 0
+        if -carry > nt:
+            raise ValueError(f"{vcf_file}: the tabix index points behind the end of a BGZF block")
+        return {"b": b, "n_comp": nc, "n_members": nm, "n_text": nt, "table": table, "h2d": h2d, "carry": carry}
 
     def launch(batch):
         """Inflate + CRC of a fetched batch.  Its H2D copy was started one batch earlier -- a copy issued
@@ -379,7 +397,7 @@ def _load_bgzf_device(eng, vcf_file, chr_name, samples, ploidies, start, end, an
                     if int(flag_host[prev["b"]][0]):
                         raise ValueError(f"{vcf_file}: BGZF block fails to inflate or its CRC")
                     pb, base, total = prev["b"], room - prev["carry"], prev["carry"] + prev["n_text"]
-                    index_text_and_tokenize(text_host[pb].data_ptr() + base, pb, base, total, prev["carry"], False)
+                    index_text_and_tokenize(text_host[pb].data_ptr() + base, pb, base, total, max(prev["carry"], 0), False)
                     lap("index_and_tokenize")
                     left, at = total - int(usable.value), base + int(usable.value)
                     if idone.value:

@@ -277,7 +277,7 @@ def test_site_absdiff_exact_at_extremes(_gpu):
 # ---- sharded score: two ranks (both on this box's one GPU, gloo for the final gather) ---------
 
 
-def _sharded_worker(rank, world, port, out_file, chunks_per_rank):
+def _sharded_worker(rank, world, port, out_file, chunks_per_rank, vcf="tests/data/test.data.vcf", log_dir=None):
     import os
 
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
@@ -287,9 +287,17 @@ def _sharded_worker(rank, world, port, out_file, chunks_per_rank):
     import sai_amd.stats  # noqa: F401
     from sai_amd.distributed import score_sharded
 
-    items = score_sharded("tests/data/test.data.vcf", "21", 10000, 5000, None, out_file, "tests/data/test.uq.config.yaml",
+    items = score_sharded(vcf, "21", 10000, 5000, None, out_file, "tests/data/test.uq.config.yaml",
                           chunks_per_rank=chunks_per_rank)  # fmt: skip
     assert (items is not None) == (rank == 0)
+    if log_dir is not None:  # what this rank's last region read took from the file
+        import json
+
+        from sai_amd.engine import Engine
+
+        last = Engine.get().__dict__.get("_inflate_state", {}).get("last")
+        with open(os.path.join(log_dir, f"rank{rank}.json"), "w") as f:
+            json.dump(last, f)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -319,6 +327,43 @@ def test_score_sharded_equals_single_process_byte_for_byte(in_repo_root, tmp_pat
     assert sharded.read_text() == single.read_text()
     for k in ("U", "Q"):
         assert (tmp_path / f"sharded.{k}.log").read_text() == (tmp_path / f"single.{k}.log").read_text()
+
+
+def test_score_sharded_reads_only_its_regions_of_an_indexed_bgzip_file(in_repo_root, tmp_path):
+    """Two ranks on a bgzip file with a tabix index: each rank's chunk is a seek on the GPU-inflate route
+    (only the members of its own region cross PCIe, utils.py:117-138 / chunk_generator.py:130-142) and
+    the files equal the one-process `score` of the same file byte for byte."""
+    import json
+    import socket
+
+    import torch.multiprocessing as mp
+
+    from sai_amd.sai import score
+    from test_ingest_native import write_bgzf, write_tbi
+
+    vcf = tmp_path / "indexed.vcf.gz"
+    write_bgzf(vcf, open("tests/data/test.data.vcf", "rb").read(), np.random.default_rng(3), max_block=700)
+    write_tbi(vcf)
+    single = tmp_path / "single.tsv"
+    score(vcf_file=str(vcf), chr_name="21", win_len=10000, win_step=5000, anc_allele_file=None, output_file=str(single),
+          config="tests/data/test.uq.config.yaml", num_workers=1)  # fmt: skip
+    plain = tmp_path / "plain.tsv"
+    score(vcf_file="tests/data/test.data.vcf", chr_name="21", win_len=10000, win_step=5000, anc_allele_file=None,
+          output_file=str(plain), config="tests/data/test.uq.config.yaml", num_workers=1)  # fmt: skip
+    assert single.read_text() == plain.read_text()
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    sharded = tmp_path / "sharded.tsv"
+    mp.spawn(_sharded_worker, args=(2, port, str(sharded), 1, str(vcf), str(tmp_path)), nprocs=2, join=True)
+    assert sharded.read_text() == single.read_text()
+    for k in ("U", "Q"):
+        assert (tmp_path / f"sharded.{k}.log").read_text() == (tmp_path / f"single.{k}.log").read_text()
+    size = os.path.getsize(vcf)
+    reads = [json.load(open(tmp_path / f"rank{r}.json")) for r in range(2)]
+    assert all(r is not None and 0 < r["comp_bytes"] for r in reads)
+    assert reads[1]["file_begin"] > 0 and reads[0]["file_stop"] > 0  # rank 1 seeks into the file, rank 0 stops early
+    assert reads[0]["comp_bytes"] < size and reads[1]["comp_bytes"] < size
 
 
 import os

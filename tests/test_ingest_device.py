@@ -119,6 +119,62 @@ def test_tabix_region_through_the_device_reader(eng, tmp_path):
             assert got[0].tolist() == want[0].tolist() and np.array_equal(got[1].cpu().numpy(), want[1]) and got[2] == want[2]
 
 
+def test_region_of_an_indexed_bgzip_file_is_a_seek_on_the_gpu_route(eng, tmp_path, monkeypatch):
+    """A region of a bgzip file with a usable .tbi takes the GPU-inflate route too, and only the members
+    that hold the region cross PCIe: first / middle / last / empty regions, regions that start in the
+    middle of a member, one-record regions -- positions, dosage bytes and match counts of the
+    host-inflating stream (which seeks through the same index) and of the host reader; both index
+    modes; a stale index means the full pass, same answer."""
+    import os
+
+    from sai_amd.utils import device_vcf
+    from sai_amd.utils.native_vcf import load_dosage
+
+    rng = np.random.default_rng(31)
+    path = tmp_path / "r.vcf.gz"
+    names = write_vcf(path, rng, 6000, 150, gz="bgzf")  # ~4 MB of text: some 70 members over three chromosomes
+    write_tbi(path)
+    pick, ploidies = names[10:90], [2] * 80
+    whole = {c: load_dosage(str(path), c, pick, ploidies, None, None, None, 2)[0] for c in ("7", "21", "22")}
+    file_bytes = os.path.getsize(path)
+    seen_partial = 0
+    for chrom, pos in whole.items():
+        n = len(pos)
+        assert n > 1500
+        regions = [(1, int(pos[40])), (int(pos[n // 2]), int(pos[n // 2 + 300])), (int(pos[-200]), int(pos[-1]) + 5000),
+                   (int(pos[-1]) + 1, int(pos[-1]) + 10), (int(pos[n // 3]) + 1, int(pos[n // 3 + 1]) - 1),
+                   (int(pos[700]), int(pos[700])), (int(pos[n // 4]), None), (1, 10**9)]  # fmt: skip
+        for start, end in regions:
+            want = load_dosage(str(path), chrom, pick, ploidies, start, end, None, 2)
+            for mode in ("heads", "text"):
+                monkeypatch.setenv("SAI_AMD_BGZF_INDEX", mode)
+                for cap in (1 << 17, None):
+                    got = device_vcf.load_dosage_device(eng, str(path), chrom, pick, ploidies, start, end, None, 4, cap)
+                    last = eng._inflate_state["last"]
+                    assert got[0].tolist() == want[0].tolist() and got[2] == want[2], (chrom, start, end, mode, cap)
+                    assert np.array_equal(got[1].cpu().numpy(), want[1])
+                    if end is not None and end < pos[-1] and start > pos[0]:  # an inner region: a small part of the file
+                        assert 0 < last["comp_bytes"] < file_bytes // 3 and last["file_stop"] >= last["file_begin"] > 0
+                        seen_partial += 1
+            monkeypatch.delenv("SAI_AMD_BGZF_INDEX")
+            monkeypatch.setenv("SAI_AMD_GPU_INFLATE", "0")  # the host-inflating stream, seeking through the same index
+            host = device_vcf.load_dosage_device(eng, str(path), chrom, pick, ploidies, start, end, None, 4, 1 << 18)
+            monkeypatch.delenv("SAI_AMD_GPU_INFLATE")
+            assert host[0].tolist() == want[0].tolist() and np.array_equal(host[1].cpu().numpy(), want[1])
+    assert seen_partial >= 12
+    # a chromosome the index does not know: nothing is read, nothing is found
+    got = device_vcf.load_dosage_device(eng, str(path), "nope", pick, ploidies, 1, 10**6)
+    assert got[0].size == 0 and eng._inflate_state["last"]["members"] == 0
+    # a stale index (older than its file) is ignored: the full pass, the same records
+    old = os.stat(path).st_mtime - 100
+    os.utime(str(path) + ".tbi", (old, old))
+    pos = whole["21"]
+    got = device_vcf.load_dosage_device(eng, str(path), "21", pick, ploidies, int(pos[900]), int(pos[950]))
+    want = load_dosage(str(path), "21", pick, ploidies, int(pos[900]), int(pos[950]), None, 2)
+    assert got[0].tolist() == want[0].tolist() and np.array_equal(got[1].cpu().numpy(), want[1])
+    assert eng._inflate_state["last"]["file_begin"] == 0 and eng._inflate_state["last"]["comp_bytes"] > file_bytes // 2
+
+
 @pytest.mark.parametrize("vcf,chrom,cfgfile,anc", [
     ("tests/data/test.with.outgroup.vcf.gz", "1", "tests/data/test.with.outgroup.config.yaml", "tests/data/test.with.outgroup.anc.alleles"),
     ("tests/data/test.mixed.ploidy.data.vcf.gz", "21", "tests/data/test_mixed_ploidy.config.yaml", "tests/data/test.mixed.ploidy.data.anc.alleles"),

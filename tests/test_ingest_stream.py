@@ -152,6 +152,9 @@ def test_stream_errors_and_tabix_region(tmp_path, monkeypatch):
 BGZF_MEMBER = np.dtype([("data_off", "<i8"), ("out_off", "<i8"), ("data_len", "<u4"), ("isize", "<u4"), ("crc", "<u4"), ("reserved", "<u4")])
 
 
+READ_LOG: list = []  # per bgzf_stream_batches call: what sai_bgzf_stream_region said, compressed bytes handed over
+
+
 def bgzf_stream_batches(path, chrom, names, ploidies, start=None, end=None, anc=None, threads=3, cap=1 << 17, text_cap=1 << 16,
                         damage=None, heads=False):  # fmt: skip
     """Drive sai_bgzf_stream_* + sai_vcf_index_text the way device_vcf does, inflating the members
@@ -174,6 +177,10 @@ def bgzf_stream_batches(path, chrom, names, ploidies, start=None, end=None, anc=
         raise (NotImplementedError if rc == _ffi.SAI_ERR_UNSUPPORTED else ValueError)(err)
     out, sel, carry = [], None, b""
     try:
+        f_begin, f_stop, f_skip = C.c_int64(), C.c_int64(), C.c_int64()
+        assert lib.sai_bgzf_stream_region(h, C.byref(f_begin), C.byref(f_stop), C.byref(f_skip)) == 0
+        skip = int(f_skip.value)  # text of the first member that precedes the region's first record (tabix seek)
+        READ_LOG.append({"file_begin": int(f_begin.value), "file_stop": int(f_stop.value), "skip": skip, "comp_bytes": 0})
         b, nc, nm, nt, done = C.c_int32(), C.c_int64(), C.c_int32(), C.c_int64(), C.c_int32()
         table_p = C.c_void_p()
         usable, nl, idone = C.c_int64(), C.c_int64(), C.c_int32()
@@ -239,6 +246,7 @@ def bgzf_stream_batches(path, chrom, names, ploidies, start=None, end=None, anc=
                     carry = index(carry, len(carry), None, 0, 1)
                 break
             n_batches += 1
+            READ_LOG[-1]["comp_bytes"] += nc.value
             assert nc.value % 4 == 0 and nc.value <= cap
             table = np.ctypeslib.as_array(C.cast(table_p, C.POINTER(C.c_uint8)), shape=(nm.value * BGZF_MEMBER.itemsize,)).copy().view(BGZF_MEMBER)
             comp = bufs[b.value][: nc.value].tobytes()
@@ -249,6 +257,10 @@ def bgzf_stream_batches(path, chrom, names, ploidies, start=None, end=None, anc=
                 text[row["out_off"] : row["out_off"] + row["isize"]] = raw
             if damage is not None and n_batches == damage and text:
                 text[len(text) // 2] ^= 0x20
+            if skip:  # the line table starts behind those bytes; the CRCs of a cut batch are the kernel's business
+                assert n_batches == 1 and skip <= len(text)
+                carry, skip = index(bytes(text[skip:]), 0, None, 0, 0), 0
+                continue
             carry = index(carry + bytes(text), len(carry), table.ctypes.data_as(C.c_void_p), nm.value, 0)
         cols, n_match, n_anc = C.c_int32(), C.c_int64(), C.c_int64()
         if lib.sai_bgzf_stream_selection(h, None, 0, C.byref(cols), C.byref(n_match), C.byref(n_anc)) == 0:
@@ -306,9 +318,6 @@ def test_bgzf_stream_refusals(tmp_path):
         bgzf_stream_batches(gz, "21", names[:2], [2, 2])
     bg = tmp_path / "b.vcf.gz"
     names = write_vcf(bg, rng, 300, 5, gz="bgzf")
-    write_tbi(bg)
-    with pytest.raises(NotImplementedError, match="tabix"):  # a region of an indexed file: the seeking stream does that
-        bgzf_stream_batches(bg, "21", names[:2], [2, 2], start=100, end=200)
     assert bgzf_stream_batches(bg, "21", names[:2], [2, 2])[1] is not None  # the whole file is fine
     with pytest.raises(ValueError, match="CRC"):  # text that differs from what the trailer promises
         bgzf_stream_batches(bg, "21", names[:2], [2, 2], damage=1)
@@ -324,3 +333,56 @@ def test_bgzf_stream_refusals(tmp_path):
     open(bad, "wb").write(raw)
     with pytest.raises((ValueError, Exception)):
         bgzf_stream_batches(bad, "22", names[:2], [2, 2])
+
+
+@pytest.fixture(scope="module")
+def indexed_bgzf(tmp_path_factory):
+    rng = np.random.default_rng(123)
+    path = tmp_path_factory.mktemp("region") / "r.vcf.gz"
+    names = write_vcf(path, rng, 2400, 80, gz="bgzf")  # written once: the generator is the slow part
+    write_tbi(path)
+    return path, names
+
+
+@pytest.mark.parametrize("heads", [False, True])
+def test_bgzf_stream_region_seek_through_the_tabix_index(indexed_bgzf, heads):
+    """A region of an indexed bgzip file: the reader hands over only the members from the region's
+    first record to the member of the first record of a later 16 kb window (sai_bgzf_stream_region);
+    the records equal the host reader's for first / inner / last / empty / one-record regions and
+    regions that begin in the middle of a member; a stale index means the whole file."""
+    from sai_amd.utils.native_vcf import load_dosage
+
+    path, names = indexed_bgzf
+    size = os.path.getsize(path)
+    pick, ploidies = [names[i] for i in (7, 3, 70, 41)], [2, 1, 2, 4]
+    inner = 0
+    for chrom in ("7", "22"):
+        pos = load_dosage(str(path), chrom, pick, ploidies, None, None, None, 2)[0]
+        n = len(pos)
+        regions = [(1, int(pos[30])), (int(pos[n // 2]), int(pos[n // 2 + 200])), (int(pos[-100]), int(pos[-1]) + 999),
+                   (int(pos[-1]) + 1, int(pos[-1]) + 5), (int(pos[n // 3]) + 1, int(pos[n // 3 + 1]) - 1),
+                   (int(pos[500]), int(pos[500])), (int(pos[n // 4]), None)]  # fmt: skip
+        for k, (start, end) in enumerate(regions):
+            for text_cap in ((1 << 16, 1 << 22)[k % 2],):
+                batches, sel, _ = bgzf_stream_batches(path, chrom, pick, ploidies, start, end, text_cap=text_cap, heads=heads)
+                want = load_dosage(str(path), chrom, pick, ploidies, start, end, None, 2)
+                got_pos, got_dos = python_tokenize(batches, sel[0], ploidies)
+                assert got_pos.tolist() == want[0].tolist(), (chrom, start, end, text_cap)
+                assert np.array_equal(got_dos, want[1]) and sel[1] == want[2]
+                log = READ_LOG[-1]
+                if end is not None and pos[0] < start and end < pos[-1]:
+                    assert 0 < log["comp_bytes"] < size // 3 and log["file_begin"] > 0 and log["file_stop"] >= log["file_begin"]
+                    inner += 1
+    assert inner >= 3
+    batches, sel, n_batches = bgzf_stream_batches(path, "nope", pick, ploidies, 1, 10**6, heads=heads)
+    assert n_batches == 0 and READ_LOG[-1]["file_begin"] == -1 and not batches
+    fresh = os.stat(str(path) + ".tbi")
+    old = os.stat(path).st_mtime - 100
+    os.utime(str(path) + ".tbi", (old, old))  # stale: ignored
+    try:
+        pos = load_dosage(str(path), "22", pick, ploidies, None, None, None, 2)[0]
+        batches, sel, _ = bgzf_stream_batches(path, "22", pick, ploidies, int(pos[300]), int(pos[330]), heads=heads)
+        assert python_tokenize(batches, sel[0], ploidies)[0].tolist() == pos[300:331].tolist()
+        assert READ_LOG[-1]["file_begin"] == 0 and READ_LOG[-1]["file_stop"] == -1
+    finally:
+        os.utime(str(path) + ".tbi", (fresh.st_atime, fresh.st_mtime))
