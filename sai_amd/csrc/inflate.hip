@@ -440,6 +440,13 @@ __global__ __launch_bounds__(64) void inflate_bgzf_kernel(InflateArgs a) {
         // (a match that overlaps its own output repeats with period `dist`)
         int k0 = lane;
         if (dist < len) k0 = dist == 1 ? 0 : lane % dist;  // uniform branch; the division only where the text repeats
+        // The history window is shared by the lanes of this one wavefront: a byte stored by one lane (a
+        // literal, an earlier match) is read here by another.  The hardware executes a wavefront's LDS
+        // operations in order; the wavefront-scope fence states that order to the compiler as well (no
+        // instruction is emitted for it) instead of leaving it to what alias analysis cannot prove.
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         uint8_t b0 = 0;
         if (lane < len) b0 = s.win[(src + k0) & (kWin - 1)];
         in.fill();

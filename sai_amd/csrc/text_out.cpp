@@ -11,6 +11,7 @@
 #include <cstring>
 #include <exception>
 #include <new>
+#include <memory>
 #include <string>
 
 #include "saihip.h"
@@ -99,7 +100,7 @@ int sai_format_score_rows(const char* chr_name_host, const char* pop_columns_hos
         return sai_set_error(SAI_ERR_ARG, "column %d: bad kind", c);
       if (n_windows > 0 && !cols_host[c].data) return sai_set_error(SAI_ERR_ARG, "column %d: NULL data", c);
     }
-    sai_text* t = new sai_text;
+    std::unique_ptr<sai_text> t(new sai_text);  // freed if an append below throws (guarded_text turns that into a status)
     std::string& out = t->s;
     out.reserve(static_cast<size_t>(n_windows) * (48 + 12 * static_cast<size_t>(n_cols)));
     const std::string chr(chr_name_host), pops(pop_columns_host);
@@ -130,7 +131,7 @@ int sai_format_score_rows(const char* chr_name_host, const char* pop_columns_hos
       }
       out += '\n';
     }
-    *text_out = t;
+    *text_out = t.release();
     return SAI_OK;
   });
 }
@@ -145,7 +146,7 @@ int sai_format_log_rows(const char* chr_name_host, int32_t n_windows, const int6
     if (n_windows < 0) return sai_set_error(SAI_ERR_ARG, "negative size");
     if (position_bytes != 4 && position_bytes != 8) return sai_set_error(SAI_ERR_ARG, "positions must be int32 or int64");
     if (n_windows > 0 && (!windows_host || !counts_host || !offsets_host)) return sai_set_error(SAI_ERR_ARG, "NULL buffer");
-    sai_text* t = new sai_text;
+    std::unique_ptr<sai_text> t(new sai_text);  // freed if an append below throws (guarded_text turns that into a status)
     std::string& out = t->s;
     const std::string chr(chr_name_host);
     for (int32_t w = 0; w < n_windows; ++w) {
@@ -161,7 +162,7 @@ int sai_format_log_rows(const char* chr_name_host, int32_t n_windows, const int6
         out += "NA\n";
         continue;
       }
-      if (!positions_host) { delete t; return sai_set_error(SAI_ERR_ARG, "NULL candidate list"); }
+      if (!positions_host) return sai_set_error(SAI_ERR_ARG, "NULL candidate list");
       const int64_t o = offsets_host[static_cast<int64_t>(w) * offset_stride_words];
       for (int32_t k = 0; k < n; ++k) {
         if (k) out += ',';
@@ -181,20 +182,22 @@ int sai_format_log_rows(const char* chr_name_host, int32_t n_windows, const int6
       }
       out += '\n';
     }
-    *text_out = t;
+    *text_out = t.release();
     return SAI_OK;
   });
 }
 
 int sai_format_doubles(const double* values_host, int64_t n, sai_text** text_out) {
   return guarded_text("sai_format_doubles", [&]() -> int {
-    if (!text_out || (n > 0 && !values_host) || n < 0) return sai_set_error(SAI_ERR_ARG, "bad argument");
-    sai_text* t = new sai_text;
+    if (!text_out) return sai_set_error(SAI_ERR_ARG, "bad argument");
+    *text_out = nullptr;
+    if ((n > 0 && !values_host) || n < 0) return sai_set_error(SAI_ERR_ARG, "bad argument");
+    std::unique_ptr<sai_text> t(new sai_text);  // freed if an append below throws (guarded_text turns that into a status)
     for (int64_t i = 0; i < n; ++i) {
       append_double(t->s, values_host[i]);
       t->s += '\n';
     }
-    *text_out = t;
+    *text_out = t.release();
     return SAI_OK;
   });
 }

@@ -97,6 +97,23 @@ def _finish(data_processor, results: list) -> list:
     return [it for per_task in results for it in per_task]
 
 
+class ShardFailure(RuntimeError):
+    """Another rank of the sharded job failed; this rank stops instead of waiting for it."""
+
+
+def _failed_ranks(i_failed: bool, group=None) -> list:
+    """Ranks that report a failure (one small all_gather: every rank takes part, failed or not)."""
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+    mine = torch.tensor([1 if i_failed else 0], dtype=torch.int32, device=dev)
+    every = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(every, mine, group=group)
+    return [r for r, t in enumerate(every) if int(t.item())]
+
+
 def run_sharded(data_processor, data_generator, group=None, as_items: bool = True) -> Optional[list]:
     """mp_pool's decomposition over ranks: every rank runs its share of ``data_generator.get()``
     (``run_compact`` when the processor has the numeric protocol, else ``run``), the per-task results
@@ -119,9 +136,22 @@ def run_sharded(data_processor, data_generator, group=None, as_items: bool = Tru
         data_processor.process_items(items)
         return items
     rank, world = dist.get_rank(group), dist.get_world_size(group)
-    mine = [compute(**tasks[i]) for i in my_chunk_indices(len(tasks), rank, world)]
     if hasattr(data_processor, "run_compact") and not hasattr(data_processor, "pack_result"):
         raise TypeError("a processor with run_compact must also offer pack_result / unpack_result")
+    # A rank that fails in its own chunks (a malformed VCF line, a CRC, a full candidate buffer) must not
+    # leave the others waiting in the gather until the collective times out: every rank reports one
+    # status word first, and if any failed nobody enters the data exchange -- the failing rank raises
+    # its own error, the others say which ranks failed.
+    error, mine = None, []
+    try:
+        mine = [compute(**tasks[i]) for i in my_chunk_indices(len(tasks), rank, world)]
+    except Exception as exc:  # noqa: BLE001 - re-raised below, after the status exchange
+        error = exc
+    failed = _failed_ranks(error is not None, group)
+    if failed:
+        if error is not None:
+            raise error
+        raise ShardFailure(f"rank(s) {failed} failed while computing their chunks (their own messages say why)")
     results = _exchange_task_results(data_processor, mine, group)
     if rank != 0:
         return None
@@ -241,4 +271,13 @@ def score_sharded(vcf_file: str, chr_name: str, win_len: int, win_step: int, anc
         write_headers(output_file, cfg.statistics, cfg.ploidies)
     if world > 1:
         dist.barrier()
-    return run_sharded(preprocessor, generator, as_items=False)
+    try:
+        return run_sharded(preprocessor, generator, as_items=False)
+    except Exception:
+        if rank == 0:  # a header-only TSV and empty logs would look like a finished run without windows
+            from pathlib import Path
+
+            out = Path(output_file)
+            for f in (out, out.with_suffix(".U.log"), out.with_suffix(".Q.log")):
+                f.unlink(missing_ok=True)
+        raise

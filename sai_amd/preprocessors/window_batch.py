@@ -107,7 +107,16 @@ class WindowBatch:
                 for k, name in enumerate(("u_count", "n_cdd_q")):
                     flat = rec[name].reshape(-1).astype(np.int64)
                     off[:, :, k] = (np.cumsum(flat) - flat).reshape(m["n_sets"], n_w)
-                uq = WindowResults(rec, off, get(m["cdd_u"]), get(m["cdd_q"]))
+                cdd_u, cdd_q = get(m["cdd_u"]), get(m["cdd_q"])
+                # a truncated or mismatched row must not become shifted candidate lists in the log files
+                if int(rec["u_count"].sum()) != cdd_u.size or int(rec["n_cdd_q"].sum()) != cdd_q.size:
+                    raise ValueError("window batch: candidate lists do not match the records' counts")
+                uq = WindowResults(rec, off, cdd_u, cdd_q)
+            n_w = int(windows.shape[0])
+            for name, ndim in (("nsnps", 1), ("four", 3), ("dd", 2)):
+                arr = get(m[name])
+                if arr is not None and (arr.ndim != ndim or arr.shape[0] != n_w):
+                    raise ValueError(f"window batch: '{name}' of shape {arr.shape} for {n_w} windows")
             combos.append(
                 ComboBatch(m["ref"], m["tgt"], tuple(m["src"]), m["out"], windows, get(m["nsnps"]), list(m["uq_names"]), uq,
                            get(m["four"]), get(m["dd"]), m["pos_dtype"])  # fmt: skip

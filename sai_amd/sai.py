@@ -91,6 +91,12 @@ def score(vcf_file: str, chr_name: str, win_len: int, win_step: int, anc_allele_
     # numeric batches -> text, natively; the item-dictionary route (driver.run + process_items)
     # writes the same bytes and stays what plug-ins and the sharded executors use
     driver.write_results([driver.run_compact(**chunk) for chunk in chunks.get()])
+    if os.environ.get("SAI_AMD_KEEP_INGEST_BUFFERS", "1") == "0":
+        # the readers' staging (about 650 MB of HBM + 125 MB pinned for a large bgzip file) is kept for the
+        # next call by default -- allocating and page-locking it costs more than a small `score`
+        from .engine import Engine
+
+        Engine.get().release_ingest_buffers()
 
 
 def outlier(score_file: str, output_prefix: str, quantile: float) -> None:

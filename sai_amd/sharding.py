@@ -204,6 +204,8 @@ def merge_rank_results(per_rank: Sequence, plan: Sequence[Sequence[Piece]], n_se
             n_w = sum(pc.n_windows for pc in pieces)
             if res is None or res.records.shape != (n_sets, n_w):
                 raise ValueError("a rank's records do not match the shard plan")
+            if s == 0 and (int(res.records["u_count"].sum()) != res.cdd_u.size or int(res.records["n_cdd_q"].sum()) != res.cdd_q.size):
+                raise ValueError("a rank's candidate lists do not match its records (overflowed or truncated row)")
             rec[s, g0 : g0 + n_w] = res.records[s]
             if n_w:
                 a = int(res.offsets[s, 0, 0])

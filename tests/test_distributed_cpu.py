@@ -66,6 +66,21 @@ def _worker(rank: int, world: int, port: int, out_dir: str) -> None:
     else:
         assert pre2.written is None
 
+    # a rank that fails inside its chunks: nobody waits in the gather for it -- the failing rank raises its own
+    # error, the other says which rank failed (it used to block until the collective timed out)
+    class Failing(Pre):
+        def run(self, chr_name, start, end):
+            if start == 501:  # chunk 5: rank 1's
+                raise ValueError("malformed line at 1:501")
+            return super().run(chr_name, start, end)
+
+    from sai_amd.distributed import ShardFailure
+
+    bad = Failing()
+    with pytest.raises(ValueError if rank == 1 else ShardFailure, match="malformed line" if rank == 1 else r"rank\(s\) \[1\] failed"):
+        run_sharded(bad, Gen())
+    assert bad.written is None
+
     # records of different lengths per rank -> rank 0, in rank order
     local = torch.arange(10 + 5 * rank, dtype=torch.uint8) + 100 * rank
     got = gather_window_records(local)
