@@ -25,13 +25,17 @@ from .data_generator import DataGenerator
 class AlignedSites:
     """Row selection of one population combination (``WindowGenerator.aligned``)."""
 
-    __slots__ = ("keys", "pos_rows", "uniq", "rows")
+    __slots__ = ("keys", "pos_rows", "uniq", "rows", "file_order")
 
-    def __init__(self, keys, pos_rows, uniq, rows):
+    def __init__(self, keys, pos_rows, uniq, rows, file_order=None):
         self.keys = keys  # [(group, population)] in ref, tgt, sources, outgroup order
         self.pos_rows = pos_rows  # position of every selected row, non-decreasing
         self.uniq = uniq  # the unique common positions when rows repeat a position, else None
         self.rows = rows  # {(group, population): selected row indices}, or None when every row is kept
+        # populations that share ONE position array which does not ascend (an unsorted VCF): the rows are
+        # gathered in position order (`rows`), and file_order[j] = index in the file of sorted row j -- the
+        # reference's matrices keep the file order while its `pos` is sorted (window_generator.py:193-231)
+        self.file_order = file_order
 
 
 class WindowGenerator(DataGenerator):
@@ -179,10 +183,16 @@ class WindowGenerator(DataGenerator):
         same = all(b.POS is pos or (b.POS.shape == pos.shape and np.array_equal(b.POS, pos)) for b in blocks[1:])
         if same and (pos.size < 2 or np.all(pos[1:] > pos[:-1])):
             out = AlignedSites(keys, pos, None, None)
+        elif same and np.unique(pos).size == pos.size:
+            # one unsorted position array for all: work on the rows in position order, remember the file order
+            order = np.argsort(pos, kind="stable")
+            out = AlignedSites(keys, pos[order], None, {k: order for k in keys}, file_order=order)
         else:
             for b in blocks:
                 if b.POS.size > 1 and not np.all(b.POS[1:] >= b.POS[:-1]):
-                    raise NotImplementedError("positions must be sorted within a population")
+                    # populations whose unsorted positions differ: the reference pairs row k of one matrix with
+                    # row k of the other per window; no batched form of that is offered
+                    raise NotImplementedError("populations with different unsorted position arrays")
             common = np.unique(pos)
             for b in blocks[1:]:
                 common = np.intersect1d(common, b.POS)
@@ -263,6 +273,16 @@ class WindowGenerator(DataGenerator):
                     yield self._empty_item(ref_pop, tgt_pop, src_comb, out_pop, start, end)
                     continue
                 item = self._empty_item(ref_pop, tgt_pop, src_comb, out_pop, start, end)
+                if al.file_order is not None:  # the window's rows in FILE order next to the sorted positions
+                    in_file = np.sort(al.file_order[lo:hi])
+                    full = {key: group_data[key[0]][key[1]].GT for key in al.keys}
+                    item.update(
+                        pos=al.pos_rows[lo:hi], ref_gts=full[("ref", ref_pop)][in_file], tgt_gts=full[("tgt", tgt_pop)][in_file],
+                        src_gts_list=[full[("src", s)][in_file] for s in src_comb],
+                        out_gts=None if out_pop is None else full[("outgroup", out_pop)][in_file],
+                    )  # fmt: skip
+                    yield item
+                    continue
                 item.update(
                     # the reference hands over the UNIQUE common positions next to matrices that keep
                     # every row of a repeated position (window_generator.py:193-197 vs :217-231)

@@ -67,6 +67,27 @@ def _repeated_position_semantics(res, uq_names, lo, win, uniq) -> np.ndarray:
     return n_uniq.astype(np.int32)
 
 
+def _file_order_semantics(res, uq_names, lo, hi, pos_sorted, file_order) -> None:
+    """What the reference reports when the positions of a region do not ascend (an unsorted VCF): its
+    window matrices keep the FILE order of the rows (``GT.compress`` of a mask, window_generator.py:217-231)
+    while ``pos`` is intersect1d's SORTED array (:193-197), so U's ``pos[idx]`` and Q's ``pos[condition]``
+    name, for the k-th row of the window in file order, the k-th smallest position.  The counts and Q do
+    not depend on the order.  ``res`` holds block-relative indices of the position-sorted rows in its
+    lists; they are replaced in place by those positions, each list ascending as the reference's."""
+    for si, name in enumerate(uq_names):
+        count_field, col, flat = ("u_count", 0, res.cdd_u) if name == "U" else ("n_cdd_q", 1, res.cdd_q)
+        counts = res.records[si][count_field].astype(np.int64)
+        at = int(res.offsets[si, 0, col]) if counts.size else 0
+        first = np.cumsum(counts) - counts
+        for w in np.flatnonzero(counts):
+            a, b = int(lo[w]), int(hi[w])
+            rows = flat[at + int(first[w]) : at + int(first[w] + counts[w])]
+            in_file = file_order[a:b]  # file index of every sorted row of the window
+            rank = np.empty(b - a, dtype=np.int64)
+            rank[np.argsort(in_file, kind="stable")] = np.arange(b - a)  # k of each sorted row
+            rows[:] = np.sort(pos_sorted[a + rank[rows.astype(np.int64) - a]]).astype(rows.dtype)
+
+
 class FeaturePreprocessor(DataPreprocessor):
     def __init__(self, output_file: str, stat_config, anc_allele_available: bool = False):
         self.output_file = output_file
@@ -272,19 +293,22 @@ class FeaturePreprocessor(DataPreprocessor):
                 # one scorer per (window grid, block length, number of sets) serves every combination of the
                 # region -- and the next call on the same generator: only its launch sequences are re-recorded
                 key = (tgt_pop, n_sites, len(sets))
+                as_indices = al.uniq is not None or al.file_order is not None
                 scorer = scorers.get(key)
                 if scorer is None:
                     scorer = scorers[key] = ResidentScorer(eng, block, windows, sets, cap_u=1 << 16, cap_q=1 << 16,
                                                            counts_in=counts_of(uq_keys) if shared else None,
-                                                           lists_as_indices=al.uniq is not None)  # fmt: skip
+                                                           lists_as_indices=as_indices)  # fmt: skip
                 else:
-                    scorer.rebind(block, sets, counts_of(uq_keys) if shared else None, lists_as_indices=al.uniq is not None)
+                    scorer.rebind(block, sets, counts_of(uq_keys) if shared else None, lists_as_indices=as_indices)
                 scorer.step()
                 cb.uq = scorer.results(grow=True)
                 lo, hi = scorer.lo, scorer.hi
                 cb.nsnps = cb.uq.records[0]["n_sites"].astype(np.int32)
                 if al.uniq is not None:
                     cb.nsnps = _repeated_position_semantics(cb.uq, uq_names, lo.cpu().numpy(), win, al.uniq)
+                elif al.file_order is not None:
+                    _file_order_semantics(cb.uq, uq_names, lo.cpu().numpy(), hi.cpu().numpy(), pos, al.file_order)
             else:
                 lo, hi = eng.window_bounds(pos_dev, win[:, 0], win[:, 1])
                 cb.nsnps = (hi - lo).cpu().numpy().astype(np.int32)

@@ -138,7 +138,10 @@ def read_data_device(eng, vcf_file: str, chr_name: str, ploidy_config, ref_ind_f
     groups = [("ref", ref_ind_file), ("tgt", tgt_ind_file), ("src", src_ind_file)]
     if out_ind_file is not None and "outgroup" in ploidy_config.root:
         groups.append(("outgroup", out_ind_file))
-    samples_by_group, column, names, ploidies = {}, {}, [], []
+    # One streaming pass maps a VCF column to ONE output slot, so a sample that sits in populations of
+    # different ploidy (the reference reads every population on its own, with its own ploidy:
+    # utils.py:123-138) is tokenised in a further pass: passes[k] holds each sample at most once.
+    samples_by_group, column, passes = {}, {}, []
     for group, ind_file in groups:
         if ind_file is None:
             samples_by_group[group] = None
@@ -158,22 +161,27 @@ def read_data_device(eng, vcf_file: str, chr_name: str, ploidy_config, ref_ind_f
             ploidy = ploidy_config.root[group][population]
             for nme in pop_names:  # one output column per (sample, ploidy): the first occurrence keeps its place
                 if (nme, ploidy) not in column:
-                    column[(nme, ploidy)] = len(names)
-                    names.append(nme)
-                    ploidies.append(ploidy)
+                    k = next((i for i, p in enumerate(passes) if nme not in p["seen"]), len(passes))
+                    if k == len(passes):
+                        passes.append({"names": [], "ploidies": [], "seen": set()})
+                    column[(nme, ploidy)] = (k, len(passes[k]["names"]))
+                    passes[k]["names"].append(nme)
+                    passes[k]["ploidies"].append(ploidy)
+                    passes[k]["seen"].add(nme)
     results: dict = {"outgroup": (None, None)}
-    if not names:
+    if not passes:
         for group, _ in groups:
             results[group] = (None, samples_by_group[group])
         return results, None
-    if len(set(names)) != len(names):
-        # a sample read at two ploidies: the streaming reader maps a VCF column to one slot
-        raise NotImplementedError("a sample that belongs to populations of different ploidy needs the host reader")
     where = chr_name if start is None and end is None else f"{chr_name}:{start}-{end}"
     if not os.path.exists(vcf_file):
         raise ValueError(f"Failed to read VCF file {vcf_file} from {where}: cannot open VCF {vcf_file}")
     try:
-        pos, dos, n_matched, n_anc = load_dosage_device(eng, vcf_file, chr_name, names, ploidies, start, end, anc_allele_file)
+        blocks = []
+        for p in passes:  # one pass unless a sample is read at two ploidies
+            pos, dos, n_matched, n_anc = load_dosage_device(eng, vcf_file, chr_name, p["names"], p["ploidies"], start, end,
+                                                            anc_allele_file)  # fmt: skip
+            blocks.append(dos)
     except FileNotFoundError:
         raise
     except Exception as e:  # utils.py:139-140
@@ -199,8 +207,13 @@ def read_data_device(eng, vcf_file: str, chr_name: str, ploidy_config, ref_ind_f
             if n_matched == 0:
                 continue
             ploidy = ploidy_config.root[group][population]
-            cols = [column[(nme, ploidy)] for nme in pop_names]
-            data[population] = ChromosomeData(POS=pos, REF=None, ALT=None, GT=eng.tile_columns(dos, cols))
+            where_cols = [column[(nme, ploidy)] for nme in pop_names]
+            used = {k for k, _ in where_cols}
+            if len(used) == 1:
+                tiled = eng.tile_columns(blocks[used.pop()], [c for _, c in where_cols])
+            else:  # the population's samples were tokenised in different passes: gather its columns first
+                tiled = eng._tile_device(torch.stack([blocks[k][:, c] for k, c in where_cols], dim=1).contiguous())
+            data[population] = ChromosomeData(POS=pos, REF=None, ALT=None, GT=tiled)
         results[group] = (data if data else None, samples)
     return results, pos_dev
 

@@ -87,6 +87,9 @@ def siteset_scenario(kind, seed):
                         through and reports candidate positions shifted by the repeats)
           "dup_uq"      the same with U and Q configured
           "dup_uneven"  a position repeated in the target population only
+          "unsorted"    all populations share one position array that is NOT ascending (blocks of an
+                        unsorted VCF swapped): the reference's matrices keep the file order while its
+                        `pos` is intersect1d's sorted array, so candidate positions come out permuted
     Returns dict(pos={group: {pop: int32}}, gts={group: {pop: int64}}, pl, stats, win, step, anc)."""
     rng = np.random.default_rng(seed)
     n_sites = int(rng.integers(300, 700))
@@ -123,6 +126,12 @@ def siteset_scenario(kind, seed):
                 keep = np.concatenate([[True], rows[1:] != rows[:-1]])  # only T0 keeps the second rows
             pos[grp][name] = base[rows][keep]
             gts[grp][name] = g[keep]
+            if kind == "unsorted":  # the same file order in every population: a few blocks of records swapped
+                order = np.arange(n_sites)
+                cuts = np.sort(np.random.default_rng(seed + 1000).choice(np.arange(20, n_sites - 20), 6, replace=False))
+                parts = np.split(order, cuts)
+                order = np.concatenate([parts[i] for i in (0, 2, 1, 3, 5, 4, 6)])
+                pos[grp][name], gts[grp][name] = pos[grp][name][order], gts[grp][name][order]
     uq = lambda tgt: {"ref": {"R": 0.3}, "tgt": dict(tgt), "src": {"S0": "=1", "S1": ">=0.5"}}  # noqa: E731
     stats = {"U": uq({"T0": 0.2, "T1": 0.0})}
     if kind not in ("dup_u", "dup_rare"):

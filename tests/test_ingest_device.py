@@ -212,6 +212,40 @@ def test_read_data_device_and_score_equal_the_host_path(eng, in_repo_root, tmp_p
     assert outs["device"] == outs["host"] and len(outs["device"][""].splitlines()) > 1
 
 
+def test_a_sample_in_populations_of_different_ploidy(eng, tmp_path):
+    """The reference reads every population on its own, with its own ploidy (utils.py:123-138), so one
+    sample may sit in a diploid reference population and a tetraploid target population.  The streaming
+    reader maps a VCF column to one slot per pass and tokenises such a sample in a second pass: same
+    blocks as the host reader (which reads per population), also when a population's samples come from
+    different passes; and `score` runs on it with either reader."""
+    from sai_amd.configs import PloidyConfig
+    from sai_amd.utils.read_data import read_data, read_data_device
+
+    rng = np.random.default_rng(77)
+    vcf = tmp_path / "m.vcf.gz"
+    names = write_vcf(vcf, rng, 400, 12, gz="bgzf", chroms=("21",))
+    files = {}
+    for group, pops in (("ref", {"A": names[0:5], "B": names[3:7]}), ("tgt", {"T": names[4:10]}), ("src", {"S": names[10:12]})):
+        files[group] = tmp_path / f"{group}.txt"
+        files[group].write_text("".join(f"{pop}\t{n}\n" for pop, members in pops.items() for n in members))
+    # names[3] and names[4] are read at ploidy 2 (A), 4 (B) and, names[4], 3 (T): three passes for names[4]
+    pc = PloidyConfig({"ref": {"A": 2, "B": 4}, "tgt": {"T": 3}, "src": {"S": 2}})
+    kw = dict(vcf_file=str(vcf), chr_name="21", ploidy_config=pc, ref_ind_file=str(files["ref"]), tgt_ind_file=str(files["tgt"]),
+              src_ind_file=str(files["src"]))  # fmt: skip
+    host = read_data(**kw)
+    dev, pos_dev = read_data_device(eng, **kw)
+    n_blocks = 0
+    for group in ("ref", "tgt", "src"):
+        for pop, cd in host[group][0].items():
+            got = dev[group][0][pop]
+            assert cd.POS.tolist() == got.POS.tolist() == pos_dev.cpu().numpy().tolist()
+            assert np.array_equal(untile(got.GT), cd.GT), (group, pop)
+            n_blocks += 1
+    assert n_blocks == 4
+    a, b = host["ref"][0]["A"].GT, host["ref"][0]["B"].GT
+    assert not np.array_equal(a[:, 3], b[:, 0])  # the shared sample really reads differently at the two ploidies
+
+
 import os  # noqa: E402
 
 
