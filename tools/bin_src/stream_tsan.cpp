@@ -2,7 +2,8 @@
 // sai_vcf_stream_* with small staging buffers (many hand-overs between producer and consumer, many
 // runs of the worker pool), loads it with sai_vcf_load, scans it, and closes one stream early.
 //   g++ -O1 -g -std=c++17 -fsanitize=thread -Iinclude tools/bin_src/stream_tsan.cpp \
-//       sai_amd/csrc/host_core.cpp sai_amd/csrc/vcf_ingest.cpp -lz -lpthread -ldl -o /tmp/stream_tsan
+//       sai_amd/csrc/host_core.cpp sai_amd/csrc/vcf_ingest.cpp sai_amd/csrc/vcf_stream.cpp sai_amd/csrc/bgzf_stream.cpp \
+//       sai_amd/csrc/narrow.cpp -lz -lpthread -ldl -o /tmp/stream_tsan
 //   /tmp/stream_tsan file.vcf[.gz] chrom sample [sample...]
 #include <cstdio>
 #include <cstdlib>
