@@ -18,3 +18,10 @@ rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write 
 # keep what the summariser reads (the raw traces of a C4 run are large)
 find $OUT -name "*.csv" -size +40M -delete
 find $OUT -name "*.csv" | head -20
+# optional fourth pass: shader-engine counters of the dominant kernel (what the wavefronts spend their
+# cycles on) -- SAI_PROFILE_SQ=1 bash tools/profile.sh ...
+if [ -n "$SAI_PROFILE_SQ" ]; then
+  rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --kernel-trace --output-format csv -d $OUT/pmc_sq -- $CMD > $OUT/pmc_sq.log 2>&1 || echo "SQ counter pass failed (see pmc_sq.log)"
+  rocprofv3 --pmc SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_INST_CYCLES_VMEM GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc_sq2 -- $CMD > $OUT/pmc_sq2.log 2>&1 || echo "SQ counter pass 2 failed (see pmc_sq2.log)"
+fi
+find $OUT -name "*.csv" -size +40M -delete
