@@ -39,6 +39,7 @@ from __future__ import annotations
 
 import argparse
 import ctypes as C
+import gc
 import datetime
 import json
 import os
@@ -355,6 +356,62 @@ def score_path_rate(eng, wl, block, lay, repeats: int = 3) -> dict:
     }
 
 
+def measure_traffic(argv: list, kernel: str, timeout_s: float = 420.0):
+    """HBM bytes per launch of the dominant kernel, measured NOW: two short child runs of this same
+    command under `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (each with --kernel-trace only, as
+    MI355X_MICROARCH.md prescribes; the program itself follows `--`), corrected as the guide says for
+    gfx950 (FETCH_SIZE counts 64 B per 128-byte request of a wide coalesced read: x 2; both in KiB).
+    Returns (bytes, how) or (None, why not).  The caller has released its own HBM before."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+
+    prof = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if prof is None:
+        return None, "rocprofv3 not found"
+    keep = [a for a in argv if a not in ("--traffic",)]
+    child = [sys.executable, str(Path(__file__).resolve()), *_without(keep, {"--steps": 1, "--warmup": 1, "--cpu-sites": 1, "--score-path": 1, "--traffic": 1}),
+             "--steps", "3", "--warmup", "1", "--cpu-sites", "0", "--score-path", "off", "--traffic", "off"]  # fmt: skip
+    got = {}
+    with tempfile.TemporaryDirectory(dir="/tmp") as tmp:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, counter)
+            cmd = [prof, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", out, "--", *child]
+            try:
+                res = subprocess.run(cmd, cwd="/tmp", env={**os.environ, "TMPDIR": "/tmp"}, capture_output=True, text=True,
+                                     timeout=timeout_s)  # fmt: skip
+            except (subprocess.TimeoutExpired, OSError) as exc:
+                return None, f"rocprofv3 --pmc {counter}: {type(exc).__name__}"
+            files = glob.glob(os.path.join(out, "*", "*_counter_collection.csv"))
+            if res.returncode != 0 or not files:
+                return None, f"rocprofv3 --pmc {counter} failed (rc {res.returncode})"
+            vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(files[0]))
+                    if r["Counter_Name"] == counter and f"{kernel}_kernel" in r["Kernel_Name"]]  # fmt: skip
+            if not vals:
+                return None, f"no {counter} rows for {kernel}"
+            got[counter] = sum(vals) / len(vals)
+    total = int(got["FETCH_SIZE"] * 1024 * 2 + got["WRITE_SIZE"] * 1024)
+    return total, (f"measured in this run: two child runs of this command (3 steps) under rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE; "
+                   f"FETCH_SIZE {got['FETCH_SIZE']:.0f} KiB x 1024 x 2 + WRITE_SIZE {got['WRITE_SIZE']:.0f} KiB x 1024 per launch of {kernel}")  # fmt: skip
+
+
+def _without(argv: list, flags: dict) -> list:
+    """argv without the given flags and their values ({flag: number of values})."""
+    out, skip = [], 0
+    for a in argv:
+        if skip:
+            skip -= 1
+            continue
+        if a in flags:
+            skip = flags[a]
+            continue
+        if any(a.startswith(f + "=") for f in flags):
+            continue
+        out.append(a)
+    return out
+
+
 def one_gpu_base(wl, args) -> dict:
     """What an N > 1 line is to be divided by: the SAME job on one GPU.  `--gpus 1` runs C3, the
     configuration the metric is quoted on, `--gpus N` the whole-genome job C4 cut into N window ranges,
@@ -430,6 +487,10 @@ def main() -> None:
     ap.add_argument("--anc", choices=["true", "false"], default="true",
                     help="anc_allele_available of every parameter set: true = the headline; false = SURVEY 8(d)'s "
                     "second row (sources also matched against 1 - y, matching sites inverted; stat_utils.py:146-160)")
+    ap.add_argument("--traffic", choices=["auto", "live", "static", "off"], default="auto",
+                    help="roofline.traffic: live = two short child runs of this command under rocprofv3 --pmc (FETCH_SIZE, "
+                    "WRITE_SIZE) after the timed region; static = the figure kept in profiles/traffic.json; auto = live on "
+                    "one GPU for a full-size workload when rocprofv3 is there, else static")
     ap.add_argument("--cpu-runs", type=int, default=3, help="timed runs of the CPU baseline (the median is reported)")
     ap.add_argument("--cpu-run-seconds", type=float, default=5.0, help="minimum length of one CPU run (whole passes)")
     ap.add_argument("--cpu-sites", type=float, default=1e6, help="site prefix timed on the CPU (0 = skip)")
@@ -586,7 +647,7 @@ def main() -> None:
         path_bytes = alg_bytes + 4 * n_sites_rank0 + 24 * n_sets * scorer.n_windows
         traffic, traffic_source = None, None
         tfile = ROOT / "profiles" / "traffic.json"
-        if tfile.exists() and world == 1 and not args.sites and not args.chroms:
+        if args.traffic != "off" and tfile.exists() and world == 1 and not args.sites and not args.chroms:
             rec = json.loads(tfile.read_text())
             key = wl.name + ("" if args.layout == "int8" else f":{args.layout}") + ("" if args.anc == "true" else ":noanc")
             if key in rec:
@@ -659,6 +720,18 @@ def main() -> None:
             "cpu_baseline": cpu,
             "score_path": score_path,
         }
+        reduced = bool(args.sites or args.chroms)
+        if world == 1 and not dist_on and (args.traffic == "live" or (args.traffic == "auto" and not reduced)):
+            # the counters need their own runs (the profiler changes the clock): release this process's HBM first
+            kernel = line["roofline"]["kernel"]
+            del scorer, block, res, probe_buf
+            gc.collect()
+            torch.cuda.empty_cache()
+            live, how = measure_traffic(sys.argv[1:], kernel)
+            if live is not None:
+                line["roofline"]["traffic"], line["roofline"]["traffic_source"] = live, how
+            else:
+                line["roofline"]["traffic_source"] = f"{traffic_source or 'none stored'}; live measurement unavailable ({how})"
         print(json.dumps(line), file=result_out, flush=True)
     if dist_on:
         dist.barrier()

@@ -12,7 +12,9 @@ import sys
 import numpy as np
 import pytest
 
-from conftest import ROOT
+from conftest import ROOT, same_f64
+
+SEED = 20260630
 
 pytestmark = pytest.mark.gpu
 
@@ -141,6 +143,58 @@ def test_more_than_sixteen_sets_in_one_scorer(eng):
     assert len({int(r["n_cond"].sum()) for r in res.records}) > 3  # the sets really differ
 
 
+def test_more_sets_than_one_call_carries(eng):
+    """45 parameter sets: more than SAI_MAX_SETS = SAI_FUSED_SETS = 20, so the scorer reduces the
+    genotypes once (site_counts), evaluates the sets in three site_flags launches that each write their
+    own columns of the shared plane rows (row stride 135 words), and runs three windows stages on column
+    slices of those rows -- every record and list against the per-window oracle on sampled windows, and
+    against one-set-at-a-time scorers (the fused single-launch path)."""
+    from oracle import sai_oracle as O
+    from sai_amd import _ffi
+    from sai_amd.resident import ResidentScorer, default_windows, synth_block
+
+    rng = np.random.default_rng(45)
+    block = synth_block(eng, SEED + 9, 1, 60_000, 40, 30, [2], missing_per_million=3000)
+    windows = default_windows(int(block.pos[0]), int(block.pos[-1]), 20_000, 10_000)
+    specs = [dict(w=float(rng.choice([0.05, 0.2, 0.5, 1.0])), x=float(rng.choice([0.0, 0.3, 0.6])),
+                  quantile=float(rng.choice([0.5, 0.9, 0.95, 1.0])), y_list=[(str(rng.choice(["=", ">=", "<="])), float(rng.choice([0.0, 0.5, 1.0])))],
+                  anc=bool(s % 3)) for s in range(45)]  # fmt: skip
+    sets = [_ffi.make_params(s["w"], s["x"], s["quantile"], s["y_list"], s["anc"]) for s in specs]
+    sc = ResidentScorer(eng, block, windows, sets, cap_u=1 << 20, cap_q=1 << 20, overlap=True)
+    assert not sc.fused and len(sc.chunks) == 3 and tuple(sc.flags.shape) == ((60_000 + 63) // 64, 135)
+    for _ in range(3):
+        sc.step()
+    res = sc.results()
+    assert res.records.shape == (45, len(windows))
+    for si in (0, 19, 20, 39, 40, 44):  # both sides of every chunk boundary
+        one = ResidentScorer(eng, block, windows, [sets[si]], cap_u=1 << 20, cap_q=1 << 20)
+        assert one.fused
+        one.step()
+        want = one.results()
+        assert want.records[0].tobytes() == res.records[si].tobytes(), si
+        for wi in range(0, len(windows), 7):
+            assert want.u_list(0, wi).tolist() == res.u_list(si, wi).tolist()
+            assert want.q_list(0, wi).tolist() == res.q_list(si, wi).tolist()
+    from test_hip_fullsize import untile
+
+    lo, hi = sc.lo.cpu().numpy(), sc.hi.cpu().numpy()
+    pos = block.pos.cpu().numpy()
+    n_checked = 0
+    for wi in (0, len(windows) // 2, len(windows) - 1):
+        a, b = int(lo[wi]), int(hi[wi])
+        mats = [untile(p, a, b) for p in block.pops]
+        for si in range(0, 45, 4):
+            s = specs[si]
+            kw = dict(ref_gts=mats[0], tgt_gts=mats[1], src_gts_list=mats[2:], ref_ploidy=2, tgt_ploidy=2, src_ploidy_list=[2],
+                      pos=pos[a:b], w=s["w"], y_list=s["y_list"], anc_allele_available=s["anc"])  # fmt: skip
+            eu, eq = O.u_stat(x=s["x"], **kw), O.q_stat(quantile=s["quantile"], **kw)
+            rec = res.records[si, wi]
+            assert rec["u_count"] == eu["value"] and res.u_list(si, wi).tolist() == eu["cdd_pos"].tolist()
+            assert same_f64(rec["q"], eq["value"]) and res.q_list(si, wi).tolist() == np.asarray(eq["cdd_pos"]).astype(np.int64).tolist()
+            n_checked += int(eu["value"] > 0)
+    assert n_checked > 5
+
+
 def _bench(args, env_extra=None, nproc=1):
     env = dict(os.environ)
     env.update(env_extra or {})
@@ -228,6 +282,10 @@ def test_bench_default_line_has_the_contract_fields():
     assert line["metric"].startswith("windows/sec") and line["unit"] == "windows/s" and line["n_gpus"] == 1
     assert line["dtype"] == "u8" and line["vs_baseline"] is None and line["higher_is_better"] is True
     assert set(line["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source"}
+    # full-size C2: the counters are read in this very run (two rocprofv3 --pmc child passes), and what moved is
+    # the algorithmic bytes within a percent
+    assert "measured in this run" in line["roofline"]["traffic_source"], line["roofline"]["traffic_source"]
+    assert 1.0 <= line["roofline"]["traffic"] / line["roofline"]["algorithmic_bytes_per_launch"] < 1.01
     assert line["cpu_baseline"]["kind"] == "port" and line["cpu_baseline"]["cpu_model"] and line["cpu_baseline"]["cores"] >= 1
     cb = line["cpu_baseline"]
     assert cb["runs"] == 3 and cb["min"] <= cb["value"] <= cb["max"] and len(cb["wall_s"]) == 3 and min(cb["wall_s"]) >= 0.3
