@@ -19,6 +19,7 @@ SAI_MAX_SRC = 6
 SAI_MAX_SETS = 20
 SAI_FUSED_SETS = SAI_MAX_SETS
 SAI_PLANES_PER_SET = 3
+SAI_ERR_ARG = -1
 SAI_ERR_UNSUPPORTED = -4  # enum sai_status
 FREQ_MODES = {"dense": 0, "candidates": 1}  # enum sai_freq_mode
 SAI_ABI_VERSION = 12

@@ -11,8 +11,12 @@
 #include <cstring>
 #include <exception>
 #include <new>
+#include <algorithm>
 #include <memory>
+#include <mutex>
 #include <string>
+
+#include "host_threads.hpp"
 
 #include "saihip.h"
 
@@ -66,6 +70,49 @@ void append_int(std::string& out, long long v) {
   out.append(buf, static_cast<size_t>(res.ptr - buf));
 }
 
+// Rows of different windows are independent: above a few thousand windows the range is cut into pieces
+// that persistent workers format into strings of their own, joined in order afterwards (10^4 windows of
+// C3 with both logs: 1.5 ms on one core, the largest host item of the product path after the GPU pass).
+// `rows(w0, w1, out)` appends the rows of windows [w0, w1) and returns a status.
+constexpr int kTextThreads = 8;
+constexpr int32_t kRowsPerPiece = 1024;
+
+WorkerPool& text_pool() {
+  static WorkerPool p(kTextThreads);
+  return p;
+}
+std::mutex text_pool_mutex;
+
+template <typename Rows>
+int format_rows(int32_t n_windows, std::string& out, Rows&& rows) {
+  const int nt = static_cast<int>(std::min<int64_t>(kTextThreads, n_windows / kRowsPerPiece));
+  if (nt <= 1) return rows(0, n_windows, out);
+  std::string part[kTextThreads];
+  int rc[kTextThreads] = {0};
+  bool threw[kTextThreads] = {false};
+  {
+    std::lock_guard<std::mutex> lk(text_pool_mutex);
+    text_pool().run(nt, [&](int t) {
+      const int32_t w0 = static_cast<int32_t>(static_cast<int64_t>(n_windows) * t / nt);
+      const int32_t w1 = static_cast<int32_t>(static_cast<int64_t>(n_windows) * (t + 1) / nt);
+      try {
+        rc[t] = rows(w0, w1, part[t]);
+      } catch (...) {  // a worker must not throw: the caller reports it as out of memory
+        threw[t] = true;
+      }
+    });
+  }
+  size_t total = out.size();
+  for (int t = 0; t < nt; ++t) {
+    if (threw[t]) throw std::bad_alloc();
+    if (rc[t]) return rc[t];  // the piece's own sai_set_error message went to its thread: repeat the class here
+    total += part[t].size();
+  }
+  out.reserve(total);
+  for (int t = 0; t < nt; ++t) out += part[t];
+  return SAI_OK;
+}
+
 template <typename F>
 int guarded_text(const char* what, F&& body) {
   try {
@@ -101,10 +148,10 @@ int sai_format_score_rows(const char* chr_name_host, const char* pop_columns_hos
       if (n_windows > 0 && !cols_host[c].data) return sai_set_error(SAI_ERR_ARG, "column %d: NULL data", c);
     }
     std::unique_ptr<sai_text> t(new sai_text);  // freed if an append below throws (guarded_text turns that into a status)
-    std::string& out = t->s;
-    out.reserve(static_cast<size_t>(n_windows) * (48 + 12 * static_cast<size_t>(n_cols)));
     const std::string chr(chr_name_host), pops(pop_columns_host);
-    for (int32_t w = 0; w < n_windows; ++w) {
+    const int frc = format_rows(n_windows, t->s, [&](int32_t w_begin, int32_t w_end, std::string& out) -> int {
+    out.reserve(out.size() + static_cast<size_t>(w_end - w_begin) * (48 + 12 * static_cast<size_t>(n_cols)));
+    for (int32_t w = w_begin; w < w_end; ++w) {
       out += chr;
       out += '\t';
       append_int(out, windows_host[2 * w]);
@@ -131,6 +178,9 @@ int sai_format_score_rows(const char* chr_name_host, const char* pop_columns_hos
       }
       out += '\n';
     }
+    return SAI_OK;
+    });
+    if (frc) return frc;
     *text_out = t.release();
     return SAI_OK;
   });
@@ -147,9 +197,15 @@ int sai_format_log_rows(const char* chr_name_host, int32_t n_windows, const int6
     if (position_bytes != 4 && position_bytes != 8) return sai_set_error(SAI_ERR_ARG, "positions must be int32 or int64");
     if (n_windows > 0 && (!windows_host || !counts_host || !offsets_host)) return sai_set_error(SAI_ERR_ARG, "NULL buffer");
     std::unique_ptr<sai_text> t(new sai_text);  // freed if an append below throws (guarded_text turns that into a status)
-    std::string& out = t->s;
     const std::string chr(chr_name_host);
-    for (int32_t w = 0; w < n_windows; ++w) {
+    if (!positions_host)  // checked up front: the pieces run on worker threads, whose error text is their own
+      for (int32_t w = 0; w < n_windows; ++w) {
+        int32_t n;
+        std::memcpy(&n, static_cast<const char*>(counts_host) + static_cast<int64_t>(w) * count_stride_bytes, sizeof(n));
+        if (n > 0) return sai_set_error(SAI_ERR_ARG, "NULL candidate list");
+      }
+    const int frc = format_rows(n_windows, t->s, [&](int32_t w_begin, int32_t w_end, std::string& out) -> int {
+    for (int32_t w = w_begin; w < w_end; ++w) {
       out += chr;
       out += '\t';
       append_int(out, windows_host[2 * w]);
@@ -162,7 +218,6 @@ int sai_format_log_rows(const char* chr_name_host, int32_t n_windows, const int6
         out += "NA\n";
         continue;
       }
-      if (!positions_host) return sai_set_error(SAI_ERR_ARG, "NULL candidate list");
       const int64_t o = offsets_host[static_cast<int64_t>(w) * offset_stride_words];
       for (int32_t k = 0; k < n; ++k) {
         if (k) out += ',';
@@ -182,6 +237,9 @@ int sai_format_log_rows(const char* chr_name_host, int32_t n_windows, const int6
       }
       out += '\n';
     }
+    return SAI_OK;
+    });
+    if (frc) return frc;
     *text_out = t.release();
     return SAI_OK;
   });

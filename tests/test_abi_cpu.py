@@ -74,6 +74,24 @@ def test_fails_loudly_without_gpu(lib):
     assert _ffi.SaiHipError(-3, "x").status == -3
 
 
+def test_plan_and_plane_entry_points_refuse_bad_arguments(lib):
+    """The round-3 entry points without a GPU: sizes, NULL handles and a ctx that cannot exist are
+    answered with a status and a message, never a crash."""
+    from sai_amd import _ffi
+
+    assert lib.sai_plane_words(64, 1) == 3 and lib.sai_plane_words(65, 2) == 12 and lib.sai_plane_words(0, 5) == 0
+    assert lib.sai_plane_words(-1, 1) == -1 and lib.sai_plane_words(10, -1) == -1
+    plan = C.c_void_p()
+    assert lib.sai_plan_create(None, C.byref(plan)) == _ffi.SAI_ERR_ARG and not plan.value
+    assert lib.sai_plan_run(None, None) == _ffi.SAI_ERR_ARG and b"NULL" in lib.sai_last_error()
+    assert lib.sai_plan_add_copy_to_host(None, None, None, 0) == _ffi.SAI_ERR_ARG
+    assert lib.sai_plan_add_copy_to_host(None, None, None, -5) == _ffi.SAI_ERR_ARG
+    assert lib.sai_plan_add_window_bounds(None, None, 0, 0, None, None, None, None, None, None) == _ffi.SAI_ERR_ARG
+    assert lib.sai_plan_destroy(None) == 0
+    a = C.c_int64()
+    assert lib.sai_bgzf_stream_region(None, C.byref(a), C.byref(a), C.byref(a)) == _ffi.SAI_ERR_ARG
+
+
 def test_params_packing():
     from sai_amd import _ffi
 

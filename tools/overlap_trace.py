@@ -13,12 +13,12 @@ prm = _ffi.make_params(0.01, 0.5, 0.95, [("=", 1.0)], True)
 for overlap in (True, False):
     sc = ResidentScorer(eng, block, windows, [prm], cap_u=1 << 22, cap_q=1 << 22, overlap=overlap)
     stage_ev = []
-    orig = sc._window_stage
-    def timed_stage(tf, fl, orig=orig, stage_ev=stage_ev):
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record(); orig(tf, fl); b.record()
-        stage_ev.append((a, b))
-    sc._window_stage = timed_stage
+    for plan in sc._stage_plans:  # the windows stage is one prepared launch sequence per buffer set
+        def timed_run(orig=plan.run, stage_ev=stage_ev):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(); orig(); b.record()
+            stage_ev.append((a, b))
+        plan.run = timed_run
     for _ in range(3):
         sc.step()
     torch.cuda.synchronize()
