@@ -94,3 +94,24 @@ class WorkerPool {
   bool stop_ = false;
 };
 
+// A pool shared by all calls of a process (narrow.cpp, text_out.cpp).  A fork()ed child inherits the
+// object but not its threads -- a run() there would wait for workers that do not exist -- so the pool
+// says whether it still belongs to the calling process and the callers fall back to the calling thread.
+#include <unistd.h>
+
+class ProcessPool {
+ public:
+  explicit ProcessPool(int n) : pool_(n), owner_(getpid()) {}
+  bool usable() const { return getpid() == owner_; }
+  template <typename F>
+  void run(int nt, F&& fn) {
+    std::lock_guard<std::mutex> lk(m_);
+    pool_.run(nt, std::forward<F>(fn));
+  }
+
+ private:
+  WorkerPool pool_;
+  pid_t owner_;
+  std::mutex m_;
+};
+

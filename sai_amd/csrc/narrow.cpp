@@ -82,11 +82,10 @@ constexpr int64_t kElementsPerThread = 1 << 18;  // 2 MB of int64 per piece
 
 // One pool per process, created on first use; run() is serialised (callers come from one Python
 // thread per process, but nothing here relies on that).
-WorkerPool& pool() {
-  static WorkerPool p(kPoolThreads);
+ProcessPool& pool() {
+  static ProcessPool p(kPoolThreads);
   return p;
 }
-std::mutex pool_mutex;
 
 int narrow_impl(const void* src, int32_t itemsize, int32_t is_signed, int64_t n_rows, int64_t n_cols,
                 int64_t row_stride_bytes, int8_t* dst, int32_t n_threads) {
@@ -115,10 +114,9 @@ int narrow_impl(const void* src, int32_t itemsize, int32_t is_signed, int64_t n_
     }
     ok[t] = good ? 1 : 0;
   };
-  if (nt == 1) {
-    work(0);
+  if (nt == 1 || !pool().usable()) {  // a forked child has the pool object but not its threads
+    for (int t = 0; t < nt; ++t) work(t);
   } else {
-    std::lock_guard<std::mutex> lk(pool_mutex);
     pool().run(nt, work);
   }
   for (int t = 0; t < nt; ++t)

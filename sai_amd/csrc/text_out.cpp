@@ -77,21 +77,19 @@ void append_int(std::string& out, long long v) {
 constexpr int kTextThreads = 8;
 constexpr int32_t kRowsPerPiece = 1024;
 
-WorkerPool& text_pool() {
-  static WorkerPool p(kTextThreads);
+ProcessPool& text_pool() {
+  static ProcessPool p(kTextThreads);
   return p;
 }
-std::mutex text_pool_mutex;
 
 template <typename Rows>
 int format_rows(int32_t n_windows, std::string& out, Rows&& rows) {
   const int nt = static_cast<int>(std::min<int64_t>(kTextThreads, n_windows / kRowsPerPiece));
-  if (nt <= 1) return rows(0, n_windows, out);
+  if (nt <= 1 || !text_pool().usable()) return rows(0, n_windows, out);  // (a forked child: no worker threads)
   std::string part[kTextThreads];
   int rc[kTextThreads] = {0};
   bool threw[kTextThreads] = {false};
   {
-    std::lock_guard<std::mutex> lk(text_pool_mutex);
     text_pool().run(nt, [&](int t) {
       const int32_t w0 = static_cast<int32_t>(static_cast<int64_t>(n_windows) * t / nt);
       const int32_t w1 = static_cast<int32_t>(static_cast<int64_t>(n_windows) * (t + 1) / nt);

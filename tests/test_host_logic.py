@@ -343,6 +343,33 @@ def test_registry_behaviour():
         r.register("a")(float)
 
 
+def test_worker_pools_survive_a_fork():
+    """The narrowing pass and the text writer run on process-wide worker pools; a fork()ed child inherits
+    the pool object without its threads and must fall back to the calling thread instead of waiting for
+    workers that do not exist (bench.py forks a multiprocessing pool after the library is loaded)."""
+    import os
+    import time
+
+    from sai_amd.engine import to_int8_dosage
+
+    g = np.random.default_rng(0).integers(-2, 3, (3000, 400)).astype(np.int64)
+    want = to_int8_dosage(g)  # the pool exists in this process from here on
+    pid = os.fork()
+    if pid == 0:
+        ok = np.array_equal(to_int8_dosage(g), want)
+        os._exit(0 if ok else 1)
+    for _ in range(200):  # 20 s: a hang is a failure, not a stuck suite
+        done, status = os.waitpid(pid, os.WNOHANG)
+        if done:
+            break
+        time.sleep(0.1)
+    else:
+        os.kill(pid, 9)
+        os.waitpid(pid, 0)
+        raise AssertionError("the forked child hung in sai_narrow_to_int8")
+    assert os.WIFEXITED(status) and os.WEXITSTATUS(status) == 0
+
+
 def test_to_int8_dosage():
     from sai_amd.engine import to_int8_dosage
 
