@@ -195,6 +195,97 @@ def test_more_sets_than_one_call_carries(eng):
     assert n_checked > 5
 
 
+@pytest.mark.parametrize("trial", range(int(os.environ.get("SAI_SCORER_FUZZ", "8"))))
+def test_scorer_forms_agree_on_random_blocks(eng, trial):
+    """Random blocks (1 .. 6 000 sites, some in several pieces), populations, 1 .. 25 parameter sets, window
+    grids with empty and very wide windows: the resident scorer in all its forms -- fused pass, counts
+    handed in, more sets than one launch carries, packed2, pipelined over three steps, rebound to the same
+    block -- returns the bytes of the engine-level calls (site_counts + site_flags + window_stats, which
+    tests/test_hip_kernels.py pins to the oracle).  SAI_SCORER_FUZZ=300 was run once on the GPU box."""
+    import torch
+
+    from sai_amd import _ffi
+    from sai_amd.engine import TiledPop
+    from sai_amd.resident import ResidentBlock, ResidentScorer
+
+    rng = np.random.default_rng(9000 + trial)
+    n_src = int(rng.integers(1, 4))
+    sizes = [int(rng.integers(1, 90)), int(rng.integers(1, 90))] + [int(rng.integers(1, 4)) for _ in range(n_src)]
+    n_pieces = int(rng.choice([1, 1, 2, 3]))
+    piece_sites = [int(rng.integers(1, 2500)) for _ in range(n_pieces)]
+    tile0 = np.concatenate([[0], np.cumsum([(n + 63) // 64 for n in piece_sites])])
+    n_total = int(tile0[-1]) * 64
+    max_dosage = int(rng.choice([1, 2, 2, 3]))
+    mats, pos = [], np.zeros(n_total, dtype=np.int32)
+    for n_ind in sizes:
+        g = np.zeros((n_total, n_ind), dtype=np.int8)
+        for k, n in enumerate(piece_sites):
+            blk = rng.integers(0, max_dosage + 1, size=(n, n_ind)).astype(np.int8)
+            blk[rng.random(blk.shape) < 0.05] = -max_dosage
+            g[tile0[k] * 64 : tile0[k] * 64 + n] = blk
+        mats.append(g)
+    segments = []
+    for k, n in enumerate(piece_sites):
+        pos[tile0[k] * 64 : tile0[k] * 64 + n] = np.cumsum(rng.integers(1, 60, n)) + 10
+        segments.append((int(tile0[k]) * 64, int(tile0[k]) * 64 + n))
+    pops = [eng.tile(m) for m in mats]
+    block = ResidentBlock(pops, [int(rng.integers(1, 4)) if max_dosage > 2 else 2 for _ in sizes], torch.from_numpy(pos).to(eng.device),
+                          segments=segments if n_pieces > 1 or rng.random() < 0.3 else None)  # fmt: skip
+    if block.segments is None and n_pieces == 1:
+        block = ResidentBlock([TiledPop(p.tiles, piece_sites[0], p.n_ind) for p in pops], block.ploidies, block.pos[: piece_sites[0]])
+    windows, wseg = [], []
+    for k, (a, b) in enumerate(segments):
+        p_lo, p_hi = int(pos[a]), int(pos[b - 1])
+        win, step = int(rng.integers(50, 4000)), int(rng.integers(25, 3000))
+        for start in range(max(p_lo - win, 1), p_hi + step, step):
+            windows.append((start, start + win - 1))
+            wseg.append(k)
+        windows.append((1, p_hi + 100))  # everything
+        wseg.append(k)
+        windows.append((p_hi + 1000, p_hi + 2000))  # nothing
+        wseg.append(k)
+    n_sets = int(rng.choice([1, 2, 5, 18, 21, 25]))
+    ops = ["=", "<", ">", "<=", ">="]
+    sets = [_ffi.make_params(float(rng.choice([0.05, 0.3, 1.0])), float(rng.choice([0.0, 0.2, 0.6])), float(rng.choice([0.0, 0.5, 0.95, 1.0])),
+                             [(str(rng.choice(ops)), float(rng.choice([0.0, 0.5, 1.0]))) for _ in range(n_src)], bool(rng.integers(2)))
+            for _ in range(n_sets)]  # fmt: skip
+    kw = dict(cap_u=1 << 20, cap_q=1 << 20, window_segment=wseg if block.segments is not None else None)
+    # engine-level reference
+    counts = eng.site_counts(block.pops)
+    tgt_freq, planes, _ = eng.site_flags(counts, block.ploidies, sets)
+    ref_sc = ResidentScorer(eng, block, windows, sets[:1], **kw)
+    ref_sc.step()
+    ref_sc.results()
+    want = eng.window_stats(tgt_freq, planes, sets, ref_sc.lo, ref_sc.hi, pos=block.pos, cap_hint=1 << 18)
+
+    def same(res, what):
+        assert res.records.tobytes() == want.records.tobytes(), what
+        assert np.array_equal(res.offsets, want.offsets), what
+        assert np.array_equal(res.cdd_u, want.cdd_u) and np.array_equal(res.cdd_q, want.cdd_q), what
+
+    plain = ResidentScorer(eng, block, windows, sets, **kw)
+    assert plain.fused == (n_sets <= _ffi.SAI_FUSED_SETS)
+    plain.step()
+    same(plain.results(grow=True), "plain")
+    piped = ResidentScorer(eng, block, windows, sets, overlap=True, **kw)
+    for _ in range(3):
+        piped.step()
+    same(piped.results(grow=True), "pipelined")
+    given = ResidentScorer(eng, block, windows, sets, counts_in=counts, **kw)
+    given.step()
+    same(given.results(grow=True), "counts handed in")
+    plain.rebind(block, sets, counts_in=counts)
+    plain.step()
+    same(plain.results(grow=True), "rebound to counts")
+    plain.rebind(block, sets)
+    plain.step()
+    same(plain.results(grow=True), "rebound back")
+    if max_dosage <= 2 and n_sets <= _ffi.SAI_FUSED_SETS:
+        packed = ResidentScorer(eng, block, windows, sets, layout="packed2", **kw)
+        packed.step()
+        same(packed.results(grow=True), "packed2")
+
+
 def _bench(args, env_extra=None, nproc=1):
     env = dict(os.environ)
     env.update(env_extra or {})
