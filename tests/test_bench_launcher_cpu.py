@@ -71,3 +71,45 @@ def test_plain_bench_gpus_2_without_a_gpu_fails_loudly():
     assert res.returncode != 0
     assert not [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
     assert "launch with torch.distributed.run" not in res.stderr
+
+
+def test_live_traffic_reads_the_counters_of_two_child_runs(tmp_path, monkeypatch):
+    """bench.measure_traffic with a stand-in for rocprofv3 on PATH: one child run per counter (the program
+    behind `--`, --kernel-trace as the only other option, the parent's step / baseline flags replaced),
+    FETCH_SIZE doubled as the guide prescribes for gfx950, WRITE_SIZE as it is, both KiB; a failing
+    profiler is reported, not raised."""
+    sys.path.insert(0, str(ROOT))
+    import bench
+
+    fake = tmp_path / "bin" / "rocprofv3"
+    fake.parent.mkdir()
+    log = tmp_path / "calls.txt"
+    fake.write_text(textwrap.dedent(
+        f"""\
+        #!{sys.executable}
+        import os, sys
+        a = sys.argv[1:]
+        open({str(log)!r}, "a").write(" ".join(a) + "\\n")
+        if os.environ.get("FAKE_PROF_FAIL"):
+            sys.exit(3)
+        counter, out = a[a.index("--pmc") + 1], a[a.index("-d") + 1]
+        os.makedirs(os.path.join(out, "host"), exist_ok=True)
+        rows = ["Kernel_Name,Counter_Name,Counter_Value"]
+        for v in ((1000.0, 1004.0) if counter == "FETCH_SIZE" else (10.0, 14.0)):
+            rows.append(f'"void (anonymous namespace)::site_counts_kernel<false, true>(A, B)",{{counter}},{{v}}')
+        rows.append(f'"(anonymous namespace)::window_lists_kernel(W)",{{counter}},999999')
+        open(os.path.join(out, "host", "1_counter_collection.csv"), "w").write("\\n".join(rows) + "\\n")
+        """
+    ))
+    fake.chmod(0o755)
+    monkeypatch.setenv("PATH", f"{fake.parent}:{os.environ['PATH']}")
+    total, how = bench.measure_traffic(["--workload", "c2", "--steps", "50", "--warmup=7", "--cpu-sites", "1e5", "--anc", "false"], "site_counts")
+    assert total == int(1002.0 * 1024 * 2 + 12.0 * 1024) and "measured in this run" in how
+    calls = log.read_text().splitlines()
+    assert len(calls) == 2 and "--pmc FETCH_SIZE --kernel-trace" in calls[0] and "--pmc WRITE_SIZE --kernel-trace" in calls[1]
+    child = calls[0].split(" -- ", 1)[1]
+    assert child.endswith("--workload c2 --anc false --steps 3 --warmup 1 --cpu-sites 0 --score-path off --traffic off")
+    assert "bench.py" in child and "--steps 50" not in child and "--warmup=7" not in child
+    monkeypatch.setenv("FAKE_PROF_FAIL", "1")
+    total, why = bench.measure_traffic(["--workload", "c2"], "site_counts")
+    assert total is None and "failed" in why
