@@ -130,6 +130,12 @@ __device__ __forceinline__ void wave_lds_fence() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// lo / hi come from the caller's device arrays: clamped into the block, so that a bad range can never
+// turn into a load beyond the planes or the per-site arrays
+__device__ __forceinline__ int clamp_site(int v, int64_t n_sites) {
+  return v < 0 ? 0 : (v > n_sites ? static_cast<int>(n_sites) : v);
+}
+
 // bits of tile t that lie inside the site range [lo, hi)
 __device__ __forceinline__ uint64_t range_mask(int t, int lo, int hi) {
   const int64_t base = static_cast<int64_t>(t) * kTile;
@@ -197,7 +203,7 @@ __global__ __launch_bounds__(256) void window_stats_wave_kernel(WinArgs a) {
   const int w = xcd_contiguous(blockIdx.x, gridDim.x) * 4 + wv;
   if (w >= a.n_windows) return;  // whole wave
   const int set = blockIdx.y;
-  const int lo = a.lo[w], hi = a.hi[w];
+  const int lo = clamp_site(a.lo[w], a.n_sites), hi = clamp_site(a.hi[w], a.n_sites);
   const uint64_t* pl = a.planes + kPlanes * set;
   const int64_t ridx = static_cast<int64_t>(set) * a.n_windows + w;
   double* vals = sh_vals[wv];
@@ -279,7 +285,7 @@ __global__ __launch_bounds__(256) void window_stats_wave_kernel(WinArgs a) {
   }
   if (lane == 0) {
     sai_window_record rec;
-    rec.n_sites = hi - lo;
+    rec.n_sites = hi > lo ? hi - lo : 0;
     rec.u_count = static_cast<int32_t>(n_u);
     rec.n_cond = static_cast<int32_t>(n_c);
     rec.n_cdd_q = static_cast<int32_t>(n_q);
@@ -493,7 +499,7 @@ __global__ __launch_bounds__(kWinThreads) void window_stats_heavy_kernel(WinArgs
   const int set = blockIdx.y;
   const int64_t ridx = static_cast<int64_t>(set) * a.n_windows + w;
   if (a.records[ridx].n_cdd_q != kHeavyMark) return;  // uniform over the workgroup
-  const int lo = a.lo[w], hi = a.hi[w];
+  const int lo = clamp_site(a.lo[w], a.n_sites), hi = clamp_site(a.hi[w], a.n_sites);
   const SetPlanes fl{a.planes + kPlanes * set, a.stride};
   const uint32_t n_c = static_cast<uint32_t>(a.records[ridx].n_cond);
   const bool in_lds = n_c <= kSelCap;
@@ -664,7 +670,7 @@ __global__ __launch_bounds__(256) void window_lists_kernel(WinArgs a) {
   const bool write_u = rec.u_count > 0 && off_u >= 0 && a.cdd_u != nullptr;
   const bool write_q = rec.n_cdd_q > 0 && off_q >= 0 && a.cdd_q != nullptr;
   if (!write_u && !write_q) return;
-  const int lo = a.lo[w], hi = a.hi[w];
+  const int lo = clamp_site(a.lo[w], a.n_sites), hi = clamp_site(a.hi[w], a.n_sites);
   const uint64_t* pl = a.planes + kPlanes * set;
   const double q = rec.q;
   const unsigned long long lt_mask = (1ull << lane) - 1ull;

@@ -323,6 +323,29 @@ def test_flag_planes_are_the_oracle_decisions_bit_for_bit(eng, n_sites):
         mats[0].astype(np.int64), mats[1].astype(np.int64), [m.astype(np.int64) for m in mats[2:]], 0.9, specs[1][2], pl, False)[2])
 
 
+def test_window_ranges_outside_the_block_are_clamped(eng):
+    """lo / hi are the caller's device arrays: a range that reaches outside the block, or runs backwards, is
+    clamped to the block (an empty window), never followed into memory that is not there."""
+    import torch
+
+    from sai_amd import _ffi
+
+    rng = np.random.default_rng(8)
+    n = 1000
+    mats = [rng.integers(0, 3, size=(n, k)).astype(np.int8) for k in (6, 5, 1)]
+    sets = [_ffi.make_params(1.0, 0.0, 0.5, [(">=", 0.0)], True)]
+    pops = [eng.tile(m) for m in mats]
+    tgt_freq, planes, _ = eng.site_flags(eng.site_counts(pops), [2, 2, 2], sets)
+    lo = torch.tensor([-5, 10, 900, 0, 2_000_000_000, -2_000_000_000], dtype=torch.int32, device=eng.device)
+    hi = torch.tensor([3, 5, 5000, 1000, 2_100_000_000, 2_000_000_000], dtype=torch.int32, device=eng.device)
+    res = eng.window_stats(tgt_freq, planes, sets, lo, hi)
+    assert res.records[0]["n_sites"].tolist() == [3, 0, 100, 1000, 0, 1000]
+    cond = (eng.flag_bytes(planes, n)[0].cpu().numpy() & 1).astype(np.int64)
+    ranges = [(0, 3), (10, 10), (900, 1000), (0, 1000), (1000, 1000), (0, 1000)]  # what the six clamp to
+    assert res.records[0]["n_cond"].tolist() == [int(cond[a:b].sum()) for a, b in ranges] and cond.sum() > 900
+    assert all(900 <= i < 1000 for i in res.q_list(0, 2).tolist()) and len(res.q_list(0, 2)) > 0
+
+
 def test_randomized_windows_against_oracle(eng):
     """Fuzz: random population sizes, ploidies, missing rates, operators, thresholds, window
     grids; every record and candidate list against the per-window oracle."""
