@@ -149,7 +149,9 @@ __global__ __launch_bounds__(256) void window_dd_kernel(DdArgs a) {
   const int lane = threadIdx.x & 63;
   const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (w >= a.n_windows) return;
-  const int lo = a.lo[w], hi = a.hi[w];
+  // the caller's ranges, clamped into the block
+  const int lo = static_cast<int>(min(max(static_cast<int64_t>(a.lo[w]), int64_t{0}), a.n_sites));
+  const int hi = static_cast<int>(min(max(static_cast<int64_t>(a.hi[w]), int64_t{0}), a.n_sites));
   double* d = a.scratch + static_cast<int64_t>(w) * a.n_src_ind;
   for (int s = 0; s < a.n_src_ind; ++s) {
     const uint32_t* pr = a.ad_ref + static_cast<int64_t>(s) * a.n_sites;

@@ -264,7 +264,9 @@ __global__ __launch_bounds__(64 * kSumWaves) void window_pattern_sums_kernel(Pat
   e.ft = a.freqs + a.n_sites;
   e.fs = a.freqs + static_cast<int64_t>(2 + src) * a.n_sites;
   e.fo = a.has_out ? a.freqs + static_cast<int64_t>(2 + a.n_src) * a.n_sites : nullptr;
-  const int lo = a.lo[w], hi = a.hi[w];
+  // the caller's ranges, clamped into the block
+  const int lo = static_cast<int>(min(max(static_cast<int64_t>(a.lo[w]), int64_t{0}), a.n_sites));
+  const int hi = static_cast<int>(min(max(static_cast<int64_t>(a.hi[w]), int64_t{0}), a.n_sites));
   const double total = wave_numpy_sum(e, lo, hi - lo, lane, &lists[wv], leaf_sums[wv]);
   if (lane < kPatternSlots) a.sums[item * kPatternSlots + lane] = total;
 }
