@@ -727,7 +727,10 @@ def main() -> None:
             del scorer, block, res, probe_buf
             gc.collect()
             torch.cuda.empty_cache()
-            live, how = measure_traffic(sys.argv[1:], kernel)
+            try:
+                live, how = measure_traffic(sys.argv[1:], kernel)
+            except Exception as exc:  # noqa: BLE001 - the line must come out whatever the profiler does
+                live, how = None, f"{type(exc).__name__}: {exc}"
             if live is not None:
                 line["roofline"]["traffic"], line["roofline"]["traffic_source"] = live, how
             else:
