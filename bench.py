@@ -656,7 +656,10 @@ def main() -> None:
         score_path = None
         want_sp = args.score_path == "on" or (args.score_path == "auto" and world == 1)
         if want_sp and world == 1 and len(wl.chroms) == 1 and args.layout == "int8":
-            score_path = score_path_rate(eng, wl, block, lay)
+            try:
+                score_path = score_path_rate(eng, wl, block, lay)
+            except Exception as exc:  # noqa: BLE001 - a secondary figure must not cost the headline line
+                score_path = {"error": f"{type(exc).__name__}: {exc}"}
         line = {
             "metric": METRIC,
             "value": round(total_windows * args.steps / dt, 1),
