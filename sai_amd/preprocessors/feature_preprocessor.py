@@ -67,6 +67,29 @@ def _repeated_position_semantics(res, uq_names, lo, win, uniq) -> np.ndarray:
     return n_uniq.astype(np.int32)
 
 
+def _rows_per_statistic(res, set_of):
+    """WindowResults with one row per configured statistic from the results of the merged parameter sets
+    (``set_of[i]`` = set that answers statistic i): rows copied, each row's candidate lists laid out behind
+    each other again, so that the batch keeps its plain form (lists of every row in row order)."""
+    from ..engine import WindowResults
+
+    if list(set_of) == list(range(res.records.shape[0])):
+        return res
+    rec = res.records[list(set_of)]
+    n_w = rec.shape[1]
+    parts = {0: [], 1: []}
+    for s in set_of:
+        for col, flat, field in ((0, res.cdd_u, "u_count"), (1, res.cdd_q, "n_cdd_q")):
+            a = int(res.offsets[s, 0, col]) if n_w else 0
+            parts[col].append(flat[a : a + int(res.records[s][field].sum())])
+    off = np.zeros((len(set_of), n_w, 2), dtype=np.int64)
+    for col, field in ((0, "u_count"), (1, "n_cdd_q")):
+        counts = rec[field].reshape(-1).astype(np.int64)
+        off[:, :, col] = (np.cumsum(counts) - counts).reshape(len(set_of), n_w)
+    cat = lambda p, like: np.concatenate(p) if p else like[:0]  # noqa: E731
+    return WindowResults(rec, off, cat(parts[0], res.cdd_u), cat(parts[1], res.cdd_q))
+
+
 def _file_order_semantics(res, uq_names, lo, hi, pos_sorted, file_order) -> None:
     """What the reference reports when the positions of a region do not ascend (an unsorted VCF): its
     window matrices keep the FILE order of the rows (``GT.compress`` of a mask, window_generator.py:217-231)
@@ -266,14 +289,23 @@ class FeaturePreprocessor(DataPreprocessor):
             src_ploidies = pc.get_ploidy("src")
             ploidy = [pc.get_ploidy("ref", ref_pop), pc.get_ploidy("tgt", tgt_pop)] + list(src_ploidies)
             n_eff = min(len(src_comb), len(src_ploidies))
-            sets = []
+            # U and Q that share w, the source conditions and the polarity mode are ONE parameter set (a record
+            # carries the U count and Q): the usual configuration then costs one evaluation and one windows stage
+            sets, set_of, merged = [], [], {}
             for name in uq_names:
                 kw = self._stat_kwargs(name, ref_pop, tgt_pop)
                 validate_thresholds(kw["w"], kw["y_list"], len(src_comb))
-                sets.append(
-                    _ffi.make_params(kw["w"], kw.get("x", 0.0), kw.get("quantile", 0.5), kw["y_list"],
-                                     kw["anc_allele_available"], n_src=n_eff)  # fmt: skip
-                )
+                key = (float(kw["w"]), tuple((op, float(y)) for op, y in kw["y_list"]), bool(kw["anc_allele_available"]))
+                field, value = ("x", kw["x"]) if name == "U" else ("quantile", kw["quantile"])
+                at = next((i for i in merged.get(key, ()) if field not in sets[i][1]), None)
+                if at is None:
+                    at = len(sets)
+                    sets.append((kw, {}))
+                    merged.setdefault(key, []).append(at)
+                sets[at][1][field] = value
+                set_of.append(at)
+            sets = [_ffi.make_params(kw["w"], got.get("x", 0.0), got.get("quantile", 0.5), kw["y_list"],
+                                     kw["anc_allele_available"], n_src=n_eff) for kw, got in sets]  # fmt: skip
             for p in ploidy[: 2 + len(src_comb)]:
                 _check_ploidy(p)
             n_sites = int(pos.size)
@@ -302,7 +334,7 @@ class FeaturePreprocessor(DataPreprocessor):
                 else:
                     scorer.rebind(block, sets, counts_of(uq_keys) if shared else None, lists_as_indices=as_indices)
                 scorer.step()
-                cb.uq = scorer.results(grow=True)
+                cb.uq = _rows_per_statistic(scorer.results(grow=True), set_of)
                 lo, hi = scorer.lo, scorer.hi
                 cb.nsnps = cb.uq.records[0]["n_sites"].astype(np.int32)
                 if al.uniq is not None:
