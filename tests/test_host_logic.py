@@ -343,6 +343,36 @@ def test_registry_behaviour():
         r.register("a")(float)
 
 
+def test_rows_per_statistic_lays_merged_sets_out_per_name():
+    """score_windows answers U and Q from ONE parameter set when they share w / sources / polarity; the
+    batch still carries one row per configured statistic, each row's lists behind each other."""
+    from sai_amd.engine import RECORD_DTYPE, WindowResults
+    from sai_amd.preprocessors.feature_preprocessor import _rows_per_statistic
+
+    rng = np.random.default_rng(3)
+    n_w = 7
+    rec = np.zeros((2, n_w), dtype=RECORD_DTYPE)
+    rec["u_count"] = rng.integers(0, 4, (2, n_w))
+    rec["n_cdd_q"] = rng.integers(0, 3, (2, n_w))
+    rec["q"] = rng.random((2, n_w))
+    off = np.zeros((2, n_w, 2), dtype=np.int64)
+    for k, name in enumerate(("u_count", "n_cdd_q")):
+        flat = rec[name].reshape(-1).astype(np.int64)
+        off[:, :, k] = (np.cumsum(flat) - flat).reshape(2, n_w)
+    res = WindowResults(rec, off, np.arange(int(rec["u_count"].sum()), dtype=np.int32) + 100,
+                        np.arange(int(rec["n_cdd_q"].sum()), dtype=np.int32) + 900)  # fmt: skip
+    assert _rows_per_statistic(res, [0, 1]) is res
+    for set_of in ([0, 0], [1, 0], [1, 1, 0]):
+        out = _rows_per_statistic(res, set_of)
+        assert out.records.shape == (len(set_of), n_w)
+        assert out.cdd_u.size == int(out.records["u_count"].sum()) and out.cdd_q.size == int(out.records["n_cdd_q"].sum())
+        for i, s_i in enumerate(set_of):
+            assert out.records[i].tobytes() == res.records[s_i].tobytes()
+            for w in range(n_w):
+                assert out.u_list(i, w).tolist() == res.u_list(s_i, w).tolist()
+                assert out.q_list(i, w).tolist() == res.q_list(s_i, w).tolist()
+
+
 def test_worker_pools_survive_a_fork():
     """The narrowing pass and the text writer run on process-wide worker pools; a fork()ed child inherits
     the pool object without its threads and must fall back to the calling thread instead of waiting for
