@@ -90,6 +90,27 @@ class WindowResults:
     offsets: np.ndarray  # int64 [n_sets][n_windows][2]
     cdd_u: np.ndarray  # int32 flat
     cdd_q: np.ndarray  # int32 flat
+    # rows that answer several statistics from one parameter set point into the same lists (their offsets
+    # are then not the running sums of their own counts); ``separate_lists()`` lays every row's lists out
+    shared_lists: bool = False
+
+    def separate_lists(self) -> "WindowResults":
+        """The plain form -- the lists of every row behind each other in row order, offsets = running sums of
+        the rows' counts -- which is what travels between ranks (WindowBatch.to_bytes)."""
+        if not self.shared_lists:
+            return self
+        n_rows, n_w = self.records.shape
+        parts = {0: [], 1: []}
+        for i in range(n_rows):
+            for col, flat, field in ((0, self.cdd_u, "u_count"), (1, self.cdd_q, "n_cdd_q")):
+                a = int(self.offsets[i, 0, col]) if n_w else 0
+                parts[col].append(flat[a : a + int(self.records[i][field].sum())])
+        off = np.zeros((n_rows, n_w, 2), dtype=np.int64)
+        for col, field in ((0, "u_count"), (1, "n_cdd_q")):
+            counts = self.records[field].reshape(-1).astype(np.int64)
+            off[:, :, col] = (np.cumsum(counts) - counts).reshape(n_rows, n_w)
+        cat = lambda p, like: np.concatenate(p) if p else like[:0]  # noqa: E731
+        return WindowResults(self.records, off, cat(parts[0], self.cdd_u), cat(parts[1], self.cdd_q))
 
     def u_list(self, s: int, w: int) -> np.ndarray:
         o = int(self.offsets[s, w, 0])

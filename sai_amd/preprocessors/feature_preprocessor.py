@@ -69,25 +69,15 @@ def _repeated_position_semantics(res, uq_names, lo, win, uniq) -> np.ndarray:
 
 def _rows_per_statistic(res, set_of):
     """WindowResults with one row per configured statistic from the results of the merged parameter sets
-    (``set_of[i]`` = set that answers statistic i): rows copied, each row's candidate lists laid out behind
-    each other again, so that the batch keeps its plain form (lists of every row in row order)."""
+    (``set_of[i]`` = set that answers statistic i).  Rows and offsets are copied, the candidate lists are
+    shared (``shared_lists``): laying them out per row costs more than everything else the host does for a
+    C3 region, and only the transport between ranks needs it (``WindowResults.separate_lists``)."""
     from ..engine import WindowResults
 
     if list(set_of) == list(range(res.records.shape[0])):
         return res
-    rec = res.records[list(set_of)]
-    n_w = rec.shape[1]
-    parts = {0: [], 1: []}
-    for s in set_of:
-        for col, flat, field in ((0, res.cdd_u, "u_count"), (1, res.cdd_q, "n_cdd_q")):
-            a = int(res.offsets[s, 0, col]) if n_w else 0
-            parts[col].append(flat[a : a + int(res.records[s][field].sum())])
-    off = np.zeros((len(set_of), n_w, 2), dtype=np.int64)
-    for col, field in ((0, "u_count"), (1, "n_cdd_q")):
-        counts = rec[field].reshape(-1).astype(np.int64)
-        off[:, :, col] = (np.cumsum(counts) - counts).reshape(len(set_of), n_w)
-    cat = lambda p, like: np.concatenate(p) if p else like[:0]  # noqa: E731
-    return WindowResults(rec, off, cat(parts[0], res.cdd_u), cat(parts[1], res.cdd_q))
+    idx = list(set_of)
+    return WindowResults(res.records[idx], res.offsets[idx], res.cdd_u, res.cdd_q, shared_lists=True)
 
 
 def _file_order_semantics(res, uq_names, lo, hi, pos_sorted, file_order) -> None:

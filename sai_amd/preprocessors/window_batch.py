@@ -60,8 +60,9 @@ class WindowBatch:
             meta = dict(ref=c.ref_pop, tgt=c.tgt_pop, src=list(c.src_comb), out=c.out_pop, uq_names=list(c.uq_names),
                         pos_dtype=c.pos_dtype, windows=put(c.windows), nsnps=put(c.nsnps), four=put(c.four), dd=put(c.dd))  # fmt: skip
             if c.uq is not None:
-                meta.update(rec=put(c.uq.records.view(np.uint8).reshape(-1)), n_sets=int(c.uq.records.shape[0]),
-                            cdd_u=put(c.uq.cdd_u), cdd_q=put(c.uq.cdd_q))  # fmt: skip
+                uq = c.uq.separate_lists()  # rows that share lists (merged U / Q sets) get their own for the trip
+                meta.update(rec=put(np.ascontiguousarray(uq.records).view(np.uint8).reshape(-1)), n_sets=int(uq.records.shape[0]),
+                            cdd_u=put(uq.cdd_u), cdd_q=put(uq.cdd_q))  # fmt: skip
             combos.append(meta)
         head = json.dumps(
             dict(chr=self.chr_name, combos=combos,

@@ -363,8 +363,14 @@ def test_rows_per_statistic_lays_merged_sets_out_per_name():
                         np.arange(int(rec["n_cdd_q"].sum()), dtype=np.int32) + 900)  # fmt: skip
     assert _rows_per_statistic(res, [0, 1]) is res
     for set_of in ([0, 0], [1, 0], [1, 1, 0]):
-        out = _rows_per_statistic(res, set_of)
-        assert out.records.shape == (len(set_of), n_w)
+        shared = _rows_per_statistic(res, set_of)
+        assert shared.shared_lists and shared.cdd_u is res.cdd_u and shared.records.shape == (len(set_of), n_w)
+        for i, s_i in enumerate(set_of):  # local consumers read through the offsets: the same lists
+            for w in range(n_w):
+                assert shared.u_list(i, w).tolist() == res.u_list(s_i, w).tolist()
+                assert shared.q_list(i, w).tolist() == res.q_list(s_i, w).tolist()
+        out = shared.separate_lists()  # the form that travels
+        assert not out.shared_lists and out.records.shape == (len(set_of), n_w)
         assert out.cdd_u.size == int(out.records["u_count"].sum()) and out.cdd_q.size == int(out.records["n_cdd_q"].sum())
         for i, s_i in enumerate(set_of):
             assert out.records[i].tobytes() == res.records[s_i].tobytes()
