@@ -3,8 +3,10 @@
 
     python bench.py                      # N = 1: BASELINE.json configs[2] (C3), the metric's configuration
     python bench.py --workload c2|c4|c5  # the other configs (C4 on one GPU holds 220 GB)
+    python bench.py --gpus N             # N > 1: configs[3] (C4) over N GPUs; starts its own ranks (a child
+                                         # torch.distributed.run on 127.0.0.1) and relays rank 0's line
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-        --master-port P bench.py --gpus N --steps K --warmup W     # N > 1: configs[3] (C4)
+        --master-port P bench.py --gpus N --steps K --warmup W     # the same job under the driver's launcher
 
 Workloads (BASELINE.json `configs`; all synthetic "synth-v1" data generated
 in place in HBM by the counter-based generator, so a shard holds exactly the bytes a one-GPU run
