@@ -726,7 +726,12 @@ def main() -> None:
             "score_path": score_path,
         }
         reduced = bool(args.sites or args.chroms)
-        if world == 1 and not dist_on and (args.traffic == "live" or (args.traffic == "auto" and not reduced)):
+        # never under a profiler: its preloaded library has initialised the GPU in every process of the tree, and a
+        # nested rocprofv3 would exec its target from such a process (refused on this pool, for good reason)
+        profiled = "rocprof" in os.environ.get("LD_PRELOAD", "").lower() or any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ)
+        if profiled and args.traffic in ("auto", "live"):
+            line["roofline"]["traffic_source"] = f"{traffic_source or 'none stored'}; not measured live: this run is itself under a profiler"
+        elif world == 1 and not dist_on and (args.traffic == "live" or (args.traffic == "auto" and not reduced)):
             # the counters need their own runs (the profiler changes the clock): release this process's HBM first
             kernel = line["roofline"]["kernel"]
             del scorer, block, res, probe_buf
