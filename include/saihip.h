@@ -50,7 +50,7 @@
 extern "C" {
 #endif
 
-#define SAI_ABI_VERSION 12
+#define SAI_ABI_VERSION 13
 #define SAI_TILE_SITES 64
 #define SAI_MAX_SRC 6   /* source populations per call */
 #define SAI_MAX_SETS 20 /* parameter sets per call: 3 * 20 plane words of a tile = one wave store (C5's 18 sets fit) */
@@ -533,6 +533,29 @@ int sai_format_log_rows(const char* chr_name_host, int32_t n_windows, const int6
 int sai_format_doubles(const double* values_host, int64_t n, sai_text** text_out); /* one str(x) per line */
 const char* sai_text_data(const sai_text* text, int64_t* n_bytes);
 int sai_text_free(sai_text* text);
+
+/* The same rows written straight to open files: the TSV rows of sai_format_score_rows go to tsv_fd and
+ * the rows of sai_format_log_rows for each of the n_logs candidate lists to its own fd (any fd < 0 =
+ * that output is not wanted).  ONE fan-out over the windows formats every output of a piece, and the
+ * pieces are handed to writev() in window order -- no joined copy, no text crossing into the caller's
+ * language (10^4 windows of C3, TSV + .U.log + .Q.log: 1.2 ms through the three sai_format_* calls, a
+ * third of that here).  The files are the caller's (opened for appending, unbuffered); bytes_out, if not
+ * NULL, receives the 1 + n_logs byte counts.  A failed write is SAI_ERR_ARG with errno's text (the fd is the caller's argument); what was
+ * written before it stays in the files, as with process_items' row-by-row writes. */
+#define SAI_MAX_LOGS 8
+typedef struct sai_log_rows {
+  const void* counts_host;     /* int32 at counts + w * count_stride_bytes */
+  int64_t count_stride_bytes;
+  const int64_t* offsets_host; /* first entry of window w at positions[offsets[w * offset_stride_words]] */
+  int64_t offset_stride_words;
+  const void* positions_host;  /* int32 or int64 (position_bytes); may be NULL when every count is 0 */
+  int32_t position_bytes;
+  int32_t fd;
+} sai_log_rows;
+int sai_write_window_rows(const char* chr_name_host, const char* pop_columns_host, int32_t n_windows,
+                          const int64_t* windows_host, const int32_t* nsnps_host, int32_t n_cols,
+                          const sai_text_column* cols_host, int32_t tsv_fd, int32_t n_logs,
+                          const sai_log_rows* logs_host, int64_t* bytes_out);
 
 /* In-memory counterpart of the ingest: narrow a reference-style [rows][cols] integer matrix (the
  * reference holds genotypes as int64 after utils.py:410) to the int8 the device layout uses, in one

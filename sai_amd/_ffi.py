@@ -22,7 +22,7 @@ SAI_PLANES_PER_SET = 3
 SAI_ERR_ARG = -1
 SAI_ERR_UNSUPPORTED = -4  # enum sai_status
 FREQ_MODES = {"dense": 0, "candidates": 1}  # enum sai_freq_mode
-SAI_ABI_VERSION = 12
+SAI_ABI_VERSION = 13
 
 OPS = {"=": 0, "<": 1, ">": 2, "<=": 3, ">=": 4}
 
@@ -54,6 +54,15 @@ class SaiParams(C.Structure):
 
 class SaiTextColumn(C.Structure):
     _fields_ = [("data", C.c_void_p), ("stride_bytes", C.c_int64), ("kind", C.c_int32), ("reserved", C.c_int32)]
+
+
+class SaiLogRows(C.Structure):
+    _fields_ = [("counts_host", C.c_void_p), ("count_stride_bytes", C.c_int64), ("offsets_host", C.c_void_p),
+                ("offset_stride_words", C.c_int64), ("positions_host", C.c_void_p), ("position_bytes", C.c_int32),
+                ("fd", C.c_int32)]  # fmt: skip
+
+
+SAI_MAX_LOGS = 8
 
 
 class SaiWindowRecord(C.Structure):
@@ -181,6 +190,10 @@ SIGNATURES = {
     ),
     "sai_format_log_rows": (C.c_int, [C.c_char_p, _i32, _p, _p, _i64, _p, _i64, _p, _i32, C.POINTER(_p)]),
     "sai_format_doubles": (C.c_int, [_p, _i64, C.POINTER(_p)]),
+    "sai_write_window_rows": (
+        C.c_int,
+        [C.c_char_p, C.c_char_p, _i32, _p, _p, _i32, C.POINTER(SaiTextColumn), _i32, _i32, C.POINTER(SaiLogRows), C.POINTER(_i64)],
+    ),
     "sai_text_data": (_p, [_p, C.POINTER(_i64)]),
     "sai_text_free": (C.c_int, [_p]),
     "sai_vcf_block_info": (C.c_int, [_p, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)]),
@@ -195,6 +208,7 @@ HOST_SYMBOLS = (
     "sai_vcf_stream_open", "sai_vcf_stream_next", "sai_vcf_stream_selection", "sai_vcf_stream_close",
     "sai_bgzf_stream_open", "sai_bgzf_stream_next", "sai_bgzf_stream_release", "sai_bgzf_stream_region", "sai_vcf_index_text", "sai_vcf_index_heads", "sai_bgzf_stream_selection", "sai_bgzf_stream_close",
     "sai_format_score_rows", "sai_format_log_rows", "sai_format_doubles", "sai_text_data", "sai_text_free",
+    "sai_write_window_rows",
 )  # fmt: skip
 
 _lib = None

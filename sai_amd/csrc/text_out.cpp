@@ -16,6 +16,10 @@
 #include <mutex>
 #include <string>
 
+#include <cerrno>
+#include <sys/uio.h>
+#include <unistd.h>
+
 #include "host_threads.hpp"
 
 #include "saihip.h"
@@ -111,6 +115,132 @@ int format_rows(int32_t n_windows, std::string& out, Rows&& rows) {
   return SAI_OK;
 }
 
+// The TSV rows of windows [w0, w1) (feature_preprocessor.py:232-236).
+struct ScoreRows {
+  const std::string& chr;
+  const std::string& pops;
+  const int64_t* windows;
+  const int32_t* nsnps;
+  int32_t n_cols;
+  const sai_text_column* cols;
+  void append(int32_t w_begin, int32_t w_end, std::string& out) const {
+    out.reserve(out.size() + static_cast<size_t>(w_end - w_begin) * (48 + 12 * static_cast<size_t>(n_cols)));
+    for (int32_t w = w_begin; w < w_end; ++w) {
+      out += chr;
+      out += '\t';
+      append_int(out, windows[2 * w]);
+      out += '\t';
+      append_int(out, windows[2 * w + 1]);
+      out += '\t';
+      out += pops;
+      out += '\t';
+      append_int(out, nsnps[w]);
+      const bool empty = nsnps[w] == 0;  // no site in the window: every statistic prints nan
+      for (int32_t c = 0; c < n_cols; ++c) {
+        out += '\t';
+        if (empty) { out += "nan"; continue; }
+        const char* p = static_cast<const char*>(cols[c].data) + static_cast<int64_t>(w) * cols[c].stride_bytes;
+        if (cols[c].kind == SAI_TEXT_I32) {
+          int32_t v;
+          std::memcpy(&v, p, sizeof(v));
+          append_int(out, v);
+        } else {
+          double v;
+          std::memcpy(&v, p, sizeof(v));
+          append_double(out, v);
+        }
+      }
+      out += '\n';
+    }
+  }
+};
+
+// The .U.log / .Q.log rows of windows [w0, w1) (feature_preprocessor.py:241-258).
+struct LogRows {
+  const std::string& chr;
+  const int64_t* windows;
+  const void* counts;
+  int64_t count_stride_bytes;
+  const int64_t* offsets;
+  int64_t offset_stride_words;
+  const void* positions;
+  int32_t position_bytes;
+  void append(int32_t w_begin, int32_t w_end, std::string& out) const {
+    for (int32_t w = w_begin; w < w_end; ++w) {
+      out += chr;
+      out += '\t';
+      append_int(out, windows[2 * w]);
+      out += '\t';
+      append_int(out, windows[2 * w + 1]);
+      out += '\t';
+      int32_t n;
+      std::memcpy(&n, static_cast<const char*>(counts) + static_cast<int64_t>(w) * count_stride_bytes, sizeof(n));
+      if (n <= 0) {
+        out += "NA\n";
+        continue;
+      }
+      const int64_t o = offsets[static_cast<int64_t>(w) * offset_stride_words];
+      for (int32_t k = 0; k < n; ++k) {
+        if (k) out += ',';
+        out += chr;
+        out += ':';
+        long long p;
+        if (position_bytes == 4) {
+          int32_t v;
+          std::memcpy(&v, static_cast<const char*>(positions) + (o + k) * 4, 4);
+          p = v;
+        } else {
+          int64_t v;
+          std::memcpy(&v, static_cast<const char*>(positions) + (o + k) * 8, 8);
+          p = v;
+        }
+        append_int(out, p);
+      }
+      out += '\n';
+    }
+  }
+};
+
+// A list may be NULL only when no window has an entry (checked up front: the pieces run on worker
+// threads, whose error text is their own).
+bool lists_present(int32_t n_windows, const void* counts, int64_t count_stride_bytes, const void* positions) {
+  if (positions) return true;
+  for (int32_t w = 0; w < n_windows; ++w) {
+    int32_t n;
+    std::memcpy(&n, static_cast<const char*>(counts) + static_cast<int64_t>(w) * count_stride_bytes, sizeof(n));
+    if (n > 0) return false;
+  }
+  return true;
+}
+
+// writev() of the pieces of one output, in order, until everything is out.
+int write_pieces(int fd, const std::string* const* piece, int n_pieces, int64_t* bytes) {
+  iovec iov[kTextThreads];
+  int n = 0;
+  for (int t = 0; t < n_pieces; ++t) {
+    if (piece[t]->empty()) continue;
+    iov[n].iov_base = const_cast<char*>(piece[t]->data());
+    iov[n].iov_len = piece[t]->size();
+    *bytes += static_cast<int64_t>(piece[t]->size());
+    ++n;
+  }
+  int at = 0;
+  while (at < n) {
+    const ssize_t got = ::writev(fd, iov + at, n - at);
+    if (got < 0) {
+      if (errno == EINTR) continue;
+      return sai_set_error(SAI_ERR_ARG, "sai_write_window_rows: write to fd %d failed: %s", fd, std::strerror(errno));
+    }
+    size_t left = static_cast<size_t>(got);
+    while (at < n && left >= iov[at].iov_len) left -= iov[at++].iov_len;
+    if (at < n && left) {
+      iov[at].iov_base = static_cast<char*>(iov[at].iov_base) + left;
+      iov[at].iov_len -= left;
+    }
+  }
+  return SAI_OK;
+}
+
 template <typename F>
 int guarded_text(const char* what, F&& body) {
   try {
@@ -147,36 +277,10 @@ int sai_format_score_rows(const char* chr_name_host, const char* pop_columns_hos
     }
     std::unique_ptr<sai_text> t(new sai_text);  // freed if an append below throws (guarded_text turns that into a status)
     const std::string chr(chr_name_host), pops(pop_columns_host);
+    const ScoreRows rows{chr, pops, windows_host, nsnps_host, n_cols, cols_host};
     const int frc = format_rows(n_windows, t->s, [&](int32_t w_begin, int32_t w_end, std::string& out) -> int {
-    out.reserve(out.size() + static_cast<size_t>(w_end - w_begin) * (48 + 12 * static_cast<size_t>(n_cols)));
-    for (int32_t w = w_begin; w < w_end; ++w) {
-      out += chr;
-      out += '\t';
-      append_int(out, windows_host[2 * w]);
-      out += '\t';
-      append_int(out, windows_host[2 * w + 1]);
-      out += '\t';
-      out += pops;
-      out += '\t';
-      append_int(out, nsnps_host[w]);
-      const bool empty = nsnps_host[w] == 0;  // no site in the window: every statistic prints nan
-      for (int32_t c = 0; c < n_cols; ++c) {
-        out += '\t';
-        if (empty) { out += "nan"; continue; }
-        const char* p = static_cast<const char*>(cols_host[c].data) + static_cast<int64_t>(w) * cols_host[c].stride_bytes;
-        if (cols_host[c].kind == SAI_TEXT_I32) {
-          int32_t v;
-          std::memcpy(&v, p, sizeof(v));
-          append_int(out, v);
-        } else {
-          double v;
-          std::memcpy(&v, p, sizeof(v));
-          append_double(out, v);
-        }
-      }
-      out += '\n';
-    }
-    return SAI_OK;
+      rows.append(w_begin, w_end, out);
+      return SAI_OK;
     });
     if (frc) return frc;
     *text_out = t.release();
@@ -196,50 +300,88 @@ int sai_format_log_rows(const char* chr_name_host, int32_t n_windows, const int6
     if (n_windows > 0 && (!windows_host || !counts_host || !offsets_host)) return sai_set_error(SAI_ERR_ARG, "NULL buffer");
     std::unique_ptr<sai_text> t(new sai_text);  // freed if an append below throws (guarded_text turns that into a status)
     const std::string chr(chr_name_host);
-    if (!positions_host)  // checked up front: the pieces run on worker threads, whose error text is their own
-      for (int32_t w = 0; w < n_windows; ++w) {
-        int32_t n;
-        std::memcpy(&n, static_cast<const char*>(counts_host) + static_cast<int64_t>(w) * count_stride_bytes, sizeof(n));
-        if (n > 0) return sai_set_error(SAI_ERR_ARG, "NULL candidate list");
-      }
+    if (!lists_present(n_windows, counts_host, count_stride_bytes, positions_host)) return sai_set_error(SAI_ERR_ARG, "NULL candidate list");
+    const LogRows rows{chr, windows_host, counts_host, count_stride_bytes, offsets_host, offset_stride_words, positions_host,
+                       position_bytes};
     const int frc = format_rows(n_windows, t->s, [&](int32_t w_begin, int32_t w_end, std::string& out) -> int {
-    for (int32_t w = w_begin; w < w_end; ++w) {
-      out += chr;
-      out += '\t';
-      append_int(out, windows_host[2 * w]);
-      out += '\t';
-      append_int(out, windows_host[2 * w + 1]);
-      out += '\t';
-      int32_t n;
-      std::memcpy(&n, static_cast<const char*>(counts_host) + static_cast<int64_t>(w) * count_stride_bytes, sizeof(n));
-      if (n <= 0) {
-        out += "NA\n";
-        continue;
-      }
-      const int64_t o = offsets_host[static_cast<int64_t>(w) * offset_stride_words];
-      for (int32_t k = 0; k < n; ++k) {
-        if (k) out += ',';
-        out += chr;
-        out += ':';
-        long long p;
-        if (position_bytes == 4) {
-          int32_t v;
-          std::memcpy(&v, static_cast<const char*>(positions_host) + (o + k) * 4, 4);
-          p = v;
-        } else {
-          int64_t v;
-          std::memcpy(&v, static_cast<const char*>(positions_host) + (o + k) * 8, 8);
-          p = v;
-        }
-        append_int(out, p);
-      }
-      out += '\n';
-    }
-    return SAI_OK;
+      rows.append(w_begin, w_end, out);
+      return SAI_OK;
     });
     if (frc) return frc;
     *text_out = t.release();
     return SAI_OK;
+  });
+}
+
+int sai_write_window_rows(const char* chr_name_host, const char* pop_columns_host, int32_t n_windows,
+                          const int64_t* windows_host, const int32_t* nsnps_host, int32_t n_cols,
+                          const sai_text_column* cols_host, int32_t tsv_fd, int32_t n_logs,
+                          const sai_log_rows* logs_host, int64_t* bytes_out) {
+  return guarded_text("sai_write_window_rows", [&]() -> int {
+    if (!chr_name_host || !pop_columns_host) return sai_set_error(SAI_ERR_ARG, "NULL argument");
+    if (n_windows < 0 || n_cols < 0 || n_logs < 0 || n_logs > SAI_MAX_LOGS) return sai_set_error(SAI_ERR_ARG, "bad size");
+    if (n_logs > 0 && !logs_host) return sai_set_error(SAI_ERR_ARG, "NULL argument");
+    if (n_windows > 0 && (!windows_host || (tsv_fd >= 0 && !nsnps_host))) return sai_set_error(SAI_ERR_ARG, "NULL buffer");
+    if (tsv_fd >= 0)
+      for (int32_t c = 0; c < n_cols; ++c) {
+        if (!cols_host || (cols_host[c].kind != SAI_TEXT_I32 && cols_host[c].kind != SAI_TEXT_F64))
+          return sai_set_error(SAI_ERR_ARG, "column %d: bad kind", c);
+        if (n_windows > 0 && !cols_host[c].data) return sai_set_error(SAI_ERR_ARG, "column %d: NULL data", c);
+      }
+    for (int32_t k = 0; k < n_logs; ++k) {
+      const sai_log_rows& lg = logs_host[k];
+      if (lg.fd < 0) continue;
+      if (lg.position_bytes != 4 && lg.position_bytes != 8) return sai_set_error(SAI_ERR_ARG, "positions must be int32 or int64");
+      if (n_windows > 0 && (!lg.counts_host || !lg.offsets_host)) return sai_set_error(SAI_ERR_ARG, "NULL buffer");
+      if (!lists_present(n_windows, lg.counts_host, lg.count_stride_bytes, lg.positions_host))
+        return sai_set_error(SAI_ERR_ARG, "NULL candidate list");
+    }
+    for (int32_t k = 0; bytes_out && k <= n_logs; ++k) bytes_out[k] = 0;
+    const std::string chr(chr_name_host), pops(pop_columns_host);
+    const ScoreRows score{chr, pops, windows_host, nsnps_host, n_cols, cols_host};
+    // the pieces' strings live as long as the library: a later call appends into memory that is already
+    // mapped (a fresh MB costs more in page faults than the formatting of its text)
+    static std::mutex busy;
+    static std::string piece[kTextThreads][1 + SAI_MAX_LOGS];
+    std::lock_guard<std::mutex> lk(busy);
+    int nt = static_cast<int>(std::min<int64_t>(kTextThreads, n_windows / kRowsPerPiece));
+    if (nt < 1 || !text_pool().usable()) nt = 1;  // (a forked child: no worker threads)
+    bool threw[kTextThreads] = {false};
+    const auto job = [&](int t) {
+      const int32_t w0 = static_cast<int32_t>(static_cast<int64_t>(n_windows) * t / nt);
+      const int32_t w1 = static_cast<int32_t>(static_cast<int64_t>(n_windows) * (t + 1) / nt);
+      try {
+        for (int32_t k = 0; k <= n_logs; ++k) piece[t][k].clear();
+        if (tsv_fd >= 0) score.append(w0, w1, piece[t][0]);
+        for (int32_t k = 0; k < n_logs; ++k) {
+          const sai_log_rows& lg = logs_host[k];
+          if (lg.fd < 0) continue;
+          const LogRows rows{chr, windows_host, lg.counts_host, lg.count_stride_bytes, lg.offsets_host, lg.offset_stride_words,
+                             lg.positions_host, lg.position_bytes};
+          rows.append(w0, w1, piece[t][1 + k]);
+        }
+      } catch (...) {  // a worker must not throw: reported as out of memory below
+        threw[t] = true;
+      }
+    };
+    if (nt > 1) text_pool().run(nt, job);
+    else job(0);
+    int rc = SAI_OK;
+    for (int t = 0; t < nt; ++t)
+      if (threw[t]) rc = sai_set_error(SAI_ERR_HIP, "sai_write_window_rows: out of host memory");
+    for (int32_t k = 0; rc == SAI_OK && k <= n_logs; ++k) {
+      const int fd = k == 0 ? tsv_fd : logs_host[k - 1].fd;
+      if (fd < 0) continue;
+      const std::string* of[kTextThreads];
+      for (int t = 0; t < nt; ++t) of[t] = &piece[t][k];
+      int64_t n = 0;
+      rc = write_pieces(fd, of, nt, &n);
+      if (bytes_out) bytes_out[k] = n;
+    }
+    for (int t = 0; t < nt; ++t)
+      for (int32_t k = 0; k <= n_logs; ++k)
+        if (piece[t][k].capacity() > (size_t{32} << 20)) std::string().swap(piece[t][k]);  // a whole-genome piece: give it back
+    return rc;
   });
 }
 

@@ -77,6 +77,10 @@ def _rows_per_statistic(res, set_of):
     if list(set_of) == list(range(res.records.shape[0])):
         return res
     idx = list(set_of)
+    if len(set(idx)) == 1:  # the usual configuration (U and Q of one set): read-only views, nothing copied
+        shape = (len(idx), res.records.shape[1])
+        return WindowResults(np.broadcast_to(res.records[idx[0]], shape), np.broadcast_to(res.offsets[idx[0]], shape + (2,)),
+                             res.cdd_u, res.cdd_q, shared_lists=True)  # fmt: skip
     return WindowResults(res.records[idx], res.offsets[idx], res.cdd_u, res.cdd_q, shared_lists=True)
 
 
@@ -320,7 +324,7 @@ class FeaturePreprocessor(DataPreprocessor):
                 if scorer is None:
                     scorer = scorers[key] = ResidentScorer(eng, block, windows, sets, cap_u=1 << 16, cap_q=1 << 16,
                                                            counts_in=counts_of(uq_keys) if shared else None,
-                                                           lists_as_indices=as_indices)  # fmt: skip
+                                                           lists_as_indices=as_indices, fetch_lists=1 << 16)  # fmt: skip
                 else:
                     scorer.rebind(block, sets, counts_of(uq_keys) if shared else None, lists_as_indices=as_indices)
                 scorer.step()
@@ -437,71 +441,60 @@ class FeaturePreprocessor(DataPreprocessor):
             raise ValueError("chunks disagree about the population combinations")
         keep = []  # arrays the column descriptors point into
 
-        def text_of(handle) -> bytes:
-            n = C.c_int64()
-            ptr = lib.sai_text_data(handle, C.byref(n))
-            data = C.string_at(ptr, n.value)
-            lib.sai_text_free(handle)
-            return data
-
         def column(arr, kind):
             keep.append(arr)
             return _ffi.SaiTextColumn(arr.ctypes.data, arr.strides[0] if arr.ndim else 0, kind, 0)
 
-        tsv, logs = [], {key: [] for key in _HIP_STATS if key in self.stat_config.root}
-        for k in range(n_combos):
-            for b in batches:
-                cb = b.combos[k]
-                n_w = int(cb.windows.shape[0])
-                win = np.ascontiguousarray(cb.windows, dtype=np.int64)
-                nsnps = np.ascontiguousarray(cb.nsnps, dtype=np.int32)
-                n_src = len(cb.src_comb)
-                zeros = np.zeros(max(n_w, 1), dtype=np.float64)
-                cols = []
-                for name in names:
-                    if name in _HIP_STATS:
-                        if cb.uq is None:
-                            cols.append(column(zeros, 1))
-                            continue
-                        si = cb.uq_names.index(name)
-                        rec = cb.uq.records[si]
-                        cols.append(column(rec["u_count"], 0) if name == "U" else column(rec["q"], 1))
-                    elif name == "DD":
-                        for s_i in range(max(n_src, 1)):
-                            cols.append(column(zeros if cb.dd is None else cb.dd[:, s_i], 1))
-                    else:
-                        for s_i in range(max(n_src, 1)):
-                            cols.append(column(zeros if cb.four is None else cb.four[:, s_i, _FOURPOP.index(name)], 1))
-                arr = (_ffi.SaiTextColumn * max(len(cols), 1))(*cols)
-                pops = f"{cb.ref_pop}\t{cb.tgt_pop}\t{','.join(cb.src_comb)}\t{'NA' if cb.out_pop is None else cb.out_pop}"
-                h = C.c_void_p()
-                _ffi.check(lib.sai_format_score_rows(str(b.chr_name).encode(), pops.encode(), n_w, win.ctypes.data_as(C.c_void_p),
-                                                     nsnps.ctypes.data_as(C.c_void_p), len(cols), arr, C.byref(h)), lib)  # fmt: skip
-                tsv.append(text_of(h))
-                for key in logs:
-                    if cb.uq is None or key not in cb.uq_names:
-                        counts, offs, lists = np.zeros(max(n_w, 1), dtype=np.int32), np.zeros(max(n_w, 1), dtype=np.int64), None
-                        off_stride = 1
-                    else:
-                        si = cb.uq_names.index(key)
-                        counts = cb.uq.records[si]["u_count" if key == "U" else "n_cdd_q"]
-                        offs = np.ascontiguousarray(cb.uq.offsets[si, :, 0 if key == "U" else 1])
-                        off_stride = 1
-                        lists = np.ascontiguousarray(cb.uq.cdd_u if key == "U" else cb.uq.cdd_q)
-                    keep.extend([counts, offs, lists])
-                    h = C.c_void_p()
-                    _ffi.check(
-                        lib.sai_format_log_rows(str(b.chr_name).encode(), n_w, win.ctypes.data_as(C.c_void_p),
-                                                C.c_void_p(counts.ctypes.data), counts.strides[0], offs.ctypes.data_as(C.c_void_p),
-                                                off_stride, None if lists is None or lists.size == 0 else C.c_void_p(lists.ctypes.data),
-                                                4 if lists is None else lists.dtype.itemsize, C.byref(h)), lib)  # fmt: skip
-                    logs[key].append(text_of(h))
-        with open(self.output_file, "ab") as f:
-            f.write(b"".join(tsv))
-        for key, parts in logs.items():
-            with open(Path(self.output_file).with_suffix(f".{key}.log"), "ab") as f:
-                f.write(b"".join(parts))
-
+        log_keys = [key for key in _HIP_STATS if key in self.stat_config.root]
+        # unbuffered: the library writes to the descriptors itself (one fan-out formats a piece of every file,
+        # writev() in window order), nothing of the text passes through Python
+        files = [open(self.output_file, "ab", buffering=0)]
+        try:
+            files += [open(Path(self.output_file).with_suffix(f".{key}.log"), "ab", buffering=0) for key in log_keys]
+            for k in range(n_combos):
+                for b in batches:
+                    cb = b.combos[k]
+                    n_w = int(cb.windows.shape[0])
+                    win = np.ascontiguousarray(cb.windows, dtype=np.int64)
+                    nsnps = np.ascontiguousarray(cb.nsnps, dtype=np.int32)
+                    n_src = len(cb.src_comb)
+                    zeros = np.zeros(max(n_w, 1), dtype=np.float64)
+                    cols = []
+                    for name in names:
+                        if name in _HIP_STATS:
+                            if cb.uq is None:
+                                cols.append(column(zeros, 1))
+                                continue
+                            si = cb.uq_names.index(name)
+                            rec = cb.uq.records[si]
+                            cols.append(column(rec["u_count"], 0) if name == "U" else column(rec["q"], 1))
+                        elif name == "DD":
+                            for s_i in range(max(n_src, 1)):
+                                cols.append(column(zeros if cb.dd is None else cb.dd[:, s_i], 1))
+                        else:
+                            for s_i in range(max(n_src, 1)):
+                                cols.append(column(zeros if cb.four is None else cb.four[:, s_i, _FOURPOP.index(name)], 1))
+                    arr = (_ffi.SaiTextColumn * max(len(cols), 1))(*cols)
+                    pops = f"{cb.ref_pop}\t{cb.tgt_pop}\t{','.join(cb.src_comb)}\t{'NA' if cb.out_pop is None else cb.out_pop}"
+                    logs = (_ffi.SaiLogRows * max(len(log_keys), 1))()
+                    for i, key in enumerate(log_keys):
+                        if cb.uq is None or key not in cb.uq_names:
+                            counts, offs, lists = np.zeros(max(n_w, 1), dtype=np.int32), np.zeros(max(n_w, 1), dtype=np.int64), None
+                        else:
+                            si = cb.uq_names.index(key)
+                            counts = cb.uq.records[si]["u_count" if key == "U" else "n_cdd_q"]
+                            offs = np.ascontiguousarray(cb.uq.offsets[si, :, 0 if key == "U" else 1])
+                            lists = np.ascontiguousarray(cb.uq.cdd_u if key == "U" else cb.uq.cdd_q)
+                        keep.extend([counts, offs, lists])
+                        logs[i] = _ffi.SaiLogRows(counts.ctypes.data, counts.strides[0], offs.ctypes.data, 1,
+                                                  None if lists is None or lists.size == 0 else lists.ctypes.data,
+                                                  4 if lists is None else lists.dtype.itemsize, files[1 + i].fileno())  # fmt: skip
+                    _ffi.check(lib.sai_write_window_rows(str(b.chr_name).encode(), pops.encode(), n_w, win.ctypes.data_as(C.c_void_p),
+                                                         nsnps.ctypes.data_as(C.c_void_p), len(cols), arr, files[0].fileno(),
+                                                         len(log_keys), logs, None), lib)  # fmt: skip
+        finally:
+            for f in files:
+                f.close()
 
     def process_items(self, items: list[dict[str, Any]]) -> None:
         """Append TSV rows and ``.U.log`` / ``.Q.log`` rows (feature_preprocessor.py:193-258):

@@ -82,13 +82,21 @@ def synth_block(eng: Engine, seed: int, chrom: int, n_sites: int, n_ref: int, n_
 class _SetChunk:
     """Window-stage buffers of up to SAI_MAX_SETS parameter sets (one sai_window_stats call)."""
 
-    def __init__(self, eng: Engine, s0: int, s1: int, n_windows: int, cap_u: int, cap_q: int):
+    def __init__(self, eng: Engine, s0: int, s1: int, n_windows: int, cap_u: int, cap_q: int, fetch_lists: int = 0):
         import torch
 
         self.s0, self.s1 = s0, s1
         self.bufs = eng.alloc_window_bufs(s1 - s0, n_windows, cap_u, cap_q)
         # pinned mirror of the records | offsets | totals buffer: one copy per step
         self._eng, self._pinned = eng, eng.pinned_acquire(self.bufs[5].numel())
+        # ... and, when asked for, of the first `fetch_lists` entries of both candidate lists: their sizes
+        # are known only from the totals, so the lists would otherwise cost a second round trip
+        self.n_fetch = (min(int(fetch_lists), self.bufs[2].numel()), min(int(fetch_lists), self.bufs[3].numel()))
+        self._pinned_lists = eng.pinned_acquire(4 * sum(self.n_fetch)) if sum(self.n_fetch) else None
+        self.host_lists = None
+        if self._pinned_lists is not None:
+            flat = self._pinned_lists[: 4 * sum(self.n_fetch)].view(torch.int32)
+            self.host_lists = (flat[: self.n_fetch[0]], flat[self.n_fetch[0] :])
         self.host_head = self._pinned[: self.bufs[5].numel()]
         rec_bytes = (s1 - s0) * n_windows * RECORD_DTYPE.itemsize
         self.rec_bytes = rec_bytes
@@ -103,13 +111,16 @@ class _SetChunk:
             buf, self._pinned = self._pinned, None
             self.host_head = self.host_records = self.host_offsets = self.host_totals = None
             self._eng.pinned_release(buf, streams)
+        if self._pinned_lists is not None:
+            buf, self._pinned_lists, self.host_lists = self._pinned_lists, None, None
+            self._eng.pinned_release(buf, streams)
 
 
 class ResidentScorer:
     def __init__(self, eng: Engine, block: ResidentBlock, windows: Sequence[tuple], sets: Sequence[_ffi.SaiParams],
                  cap_u: int = 1 << 20, cap_q: int = 1 << 20, layout: str = "int8", overlap: bool = False,
                  window_segment: Optional[Sequence[int]] = None, counts_out=None, counts_in=None,
-                 lists_as_indices: bool = False):  # fmt: skip
+                 lists_as_indices: bool = False, fetch_lists: int = 0):  # fmt: skip
         """``windows`` = inclusive ``(start, end)`` position pairs; for a block of several pieces
         ``window_segment[w]`` is the index into ``block.segments`` of the piece window w lies in.
 
@@ -126,9 +137,12 @@ class ResidentScorer:
         shape) says the counts of these populations already exist -- several population combinations
         share blocks that were reduced once -- so a step starts at the per-site decision and no
         genotype byte is read.  ``lists_as_indices``: the candidate lists hold block-relative
-        site indices instead of positions."""
+        site indices instead of positions.  ``fetch_lists`` = n: every step also copies the first n
+        entries of both candidate lists to pinned host memory with the records, and ``results()`` needs
+        no second round trip when the lists are that short (the product path; bench.py's steps gather rows)."""
         import torch
 
+        self.fetch_lists = int(fetch_lists)
         if layout not in ("int8", "packed2"):
             raise ValueError("layout must be 'int8' or 'packed2'")
         self.layout = layout
@@ -196,7 +210,7 @@ class ResidentScorer:
         self.cap_u, self.cap_q = int(cap_u), int(cap_q)
         self._release_chunks()
         self.chunks = [
-            _SetChunk(self.eng, s0, min(s0 + m, self.n_sets), self.n_windows, cap_u, cap_q)
+            _SetChunk(self.eng, s0, min(s0 + m, self.n_sets), self.n_windows, cap_u, cap_q, self.fetch_lists)
             for s0 in range(0, self.n_sets, m)
         ]
         first = self.chunks[0]  # the whole scorer when n_sets <= SAI_MAX_SETS
@@ -268,6 +282,10 @@ class ResidentScorer:
                 sp.add_window_stats(tgt_freq, planes[:, PLANES * ch.s0 : PLANES * ch.s1], self.sets[ch.s0 : ch.s1], self.lo,
                                     self.hi, self.list_pos, ch.bufs)  # fmt: skip
                 sp.add_copy_to_host(ch.host_head, ch.bufs[5])
+                if ch.host_lists is not None:
+                    for host, dev, n in zip(ch.host_lists, ch.bufs[2:4], ch.n_fetch):
+                        if n:
+                            sp.add_copy_to_host(host, dev[:n])
             self._stage_plans.append(sp)
 
     def _release_chunks(self) -> None:
@@ -426,11 +444,16 @@ class ResidentScorer:
             off[:, :, 0] += base_u
             off[:, :, 1] += base_q
             offs.append(off)
-            with self.window_stream():
-                us.append(ch.bufs[2][:nu].cpu().numpy())
-                qs.append(ch.bufs[3][:nq].cpu().numpy())
+            for out, n, k in ((us, nu, 0), (qs, nq, 1)):
+                if ch.host_lists is not None and n <= ch.n_fetch[k]:
+                    out.append(ch.host_lists[k][:n].numpy().copy())  # came with the records
+                else:
+                    with self.window_stream():
+                        out.append(ch.bufs[2 + k][:n].cpu().numpy())
             base_u += nu
             base_q += nq
+        if len(self.chunks) == 1:
+            return WindowResults(recs[0], offs[0], us[0], qs[0])
         return WindowResults(np.concatenate(recs), np.concatenate(offs), np.concatenate(us), np.concatenate(qs))
 
     # -- the row a rank contributes to the multi-GPU gather -------------------------------------

@@ -94,3 +94,121 @@ def test_native_rows_equal_process_items(tmp_path, n_src, with_extra, pos_dtype)
     for k in ("U", "Q"):
         assert b.with_suffix(f".{k}.log").read_text() == a.with_suffix(f".{k}.log").read_text()
     assert "NA\n" in a.with_suffix(".Q.log").read_text() and "\tnan" in a.read_text()
+
+
+def _text(lib, handle) -> bytes:
+    n = C.c_int64()
+    ptr = lib.sai_text_data(handle, C.byref(n))
+    data = C.string_at(ptr, n.value)
+    lib.sai_text_free(handle)
+    return data
+
+
+def _row_args(batch):
+    """The C arguments of one combination's rows, as write_batches builds them."""
+    from sai_amd import _ffi
+
+    cb = batch.combos[0]
+    win = np.ascontiguousarray(cb.windows, dtype=np.int64)
+    nsnps = np.ascontiguousarray(cb.nsnps, dtype=np.int32)
+    u, q = cb.uq.records[0]["u_count"], cb.uq.records[1]["q"]
+    cols = (_ffi.SaiTextColumn * 2)(_ffi.SaiTextColumn(u.ctypes.data, u.strides[0], 0, 0), _ffi.SaiTextColumn(q.ctypes.data, q.strides[0], 1, 0))
+    lists = []
+    for si, (cnt, k, arr) in enumerate((("u_count", 0, cb.uq.cdd_u), ("n_cdd_q", 1, cb.uq.cdd_q))):
+        lists.append((cb.uq.records[si][cnt], np.ascontiguousarray(cb.uq.offsets[si, :, k]), np.ascontiguousarray(arr)))
+    return cb, win, nsnps, cols, lists, (u, q)
+
+
+@pytest.mark.parametrize("n_w", [300, 9000])
+def test_written_files_equal_the_in_memory_text(tmp_path, n_w):
+    """sai_write_window_rows (what write_batches calls: files written by the library) against
+    sai_format_score_rows / sai_format_log_rows (the same rows as text in memory), both sizes of fan-out;
+    an fd < 0 leaves that output out; byte counts are reported per output."""
+    import os
+
+    from sai_amd import _ffi
+
+    lib = _ffi.load_host()
+    batch = _random_batch(np.random.default_rng(n_w), n_w, 1, False, "int32")
+    cb, win, nsnps, cols, lists, _keep = _row_args(batch)
+    pops = b"refA\ttgtB\ts0\tNA"
+    h = C.c_void_p()
+    _ffi.check(lib.sai_format_score_rows(b"chr7", pops, n_w, win.ctypes.data_as(C.c_void_p), nsnps.ctypes.data_as(C.c_void_p), 2, cols, C.byref(h)), lib)
+    want = [_text(lib, h)]
+    for counts, offs, arr in lists:
+        h = C.c_void_p()
+        _ffi.check(lib.sai_format_log_rows(b"chr7", n_w, win.ctypes.data_as(C.c_void_p), C.c_void_p(counts.ctypes.data), counts.strides[0],
+                                           offs.ctypes.data_as(C.c_void_p), 1, C.c_void_p(arr.ctypes.data), 4, C.byref(h)), lib)  # fmt: skip
+        want.append(_text(lib, h))
+    assert want[0].count(b"\n") == n_w and b"NA\n" in want[2]
+    for skip in (None, 0, 2):
+        paths = [tmp_path / f"{n_w}_{skip}_{k}" for k in range(3)]
+        fds = [-1 if k == skip else os.open(p, os.O_WRONLY | os.O_CREAT | os.O_APPEND) for k, p in enumerate(paths)]
+        logs = (_ffi.SaiLogRows * 2)(*[_ffi.SaiLogRows(c.ctypes.data, c.strides[0], o.ctypes.data, 1, a.ctypes.data, 4, fds[1 + k])
+                                       for k, (c, o, a) in enumerate(lists)])  # fmt: skip
+        nbytes = (C.c_int64 * 3)()
+        for _ in range(2):  # appended twice: the pieces' buffers are reused from call to call
+            _ffi.check(lib.sai_write_window_rows(b"chr7", pops, n_w, win.ctypes.data_as(C.c_void_p), nsnps.ctypes.data_as(C.c_void_p), 2, cols,
+                                                 fds[0], 2, logs, nbytes), lib)  # fmt: skip
+        for k, p in enumerate(paths):
+            if k == skip:
+                assert not p.exists() and nbytes[k] == 0
+            else:
+                os.close(fds[k])
+                assert p.read_bytes() == want[k] * 2 and nbytes[k] == len(want[k])
+
+
+def test_write_failure_is_reported(tmp_path):
+    import os
+
+    from sai_amd import _ffi
+
+    lib = _ffi.load_host()
+    batch = _random_batch(np.random.default_rng(3), 50, 1, False, "int32")
+    cb, win, nsnps, cols, lists, _keep = _row_args(batch)
+    fd = os.open(tmp_path / "ro", os.O_RDONLY | os.O_CREAT)  # not open for writing
+    try:
+        with pytest.raises(_ffi.SaiHipError, match="write to fd"):
+            _ffi.check(lib.sai_write_window_rows(b"c", b"a\tb\tc\tNA", 50, win.ctypes.data_as(C.c_void_p), nsnps.ctypes.data_as(C.c_void_p), 2, cols,
+                                                 fd, 0, None, None), lib)  # fmt: skip
+    finally:
+        os.close(fd)
+    with pytest.raises(_ffi.SaiHipError):  # a list that is NULL although a window has entries
+        bad = (_ffi.SaiLogRows * 1)(_ffi.SaiLogRows(lists[0][0].ctypes.data, lists[0][0].strides[0], lists[0][1].ctypes.data, 1, None, 4, 1))
+        assert lists[0][0].sum() > 0
+        _ffi.check(lib.sai_write_window_rows(b"c", b"a\tb\tc\tNA", 50, win.ctypes.data_as(C.c_void_p), nsnps.ctypes.data_as(C.c_void_p), 2, cols,
+                                             -1, 1, bad, None), lib)  # fmt: skip
+    with pytest.raises(_ffi.SaiHipError):
+        _ffi.check(lib.sai_write_window_rows(b"c", b"a", 50, win.ctypes.data_as(C.c_void_p), nsnps.ctypes.data_as(C.c_void_p), 2, cols, -1, 9, None, None), lib)
+
+
+def test_writer_in_a_forked_child(tmp_path):
+    """After a fork the pool's threads are gone: the child formats on its own thread, same bytes."""
+    import os
+    import time
+
+    from sai_amd.configs import StatConfig
+    from sai_amd.preprocessors import FeaturePreprocessor
+
+    stats = {"U": {"ref": {"refA": 0.1}, "tgt": {"tgtB": 0.5}, "src": {"s0": "=1"}}, "Q": {"ref": {"refA": 0.1}, "tgt": {"tgtB": 0.9}, "src": {"s0": "=1"}}}
+    batch = _random_batch(np.random.default_rng(11), 9000, 1, False, "int32")
+    FeaturePreprocessor(str(tmp_path / "parent.tsv"), StatConfig(dict(stats))).write_batches([batch])  # the pool's threads exist now
+    pid = os.fork()
+    if pid == 0:
+        try:
+            FeaturePreprocessor(str(tmp_path / "child.tsv"), StatConfig(dict(stats))).write_batches([batch])
+            os._exit(0)
+        except BaseException:
+            os._exit(1)
+    for _ in range(200):
+        done, status = os.waitpid(pid, os.WNOHANG)
+        if done:
+            break
+        time.sleep(0.1)
+    else:
+        os.kill(pid, 9)
+        os.waitpid(pid, 0)
+        raise AssertionError("the forked child hung in sai_write_window_rows")
+    assert os.WIFEXITED(status) and os.WEXITSTATUS(status) == 0
+    for sfx in (".tsv", ".U.log", ".Q.log"):
+        assert (tmp_path / f"child{sfx}").read_bytes() == (tmp_path / f"parent{sfx}").read_bytes()
