@@ -22,11 +22,13 @@ def default_threads() -> int:
 
 
 def scan_first_last(vcf_file: str, chr_name: str) -> tuple[Optional[int], Optional[int]]:
-    """First and last POS of the first contiguous run of ``chr_name`` (None, None if absent).  A bgzip
-    file is scanned with the GPU-inflate pass when a GPU is there (the host would inflate the whole
-    file for it: 53 ms against 12 for 480 MB of text); everything else, and every machine without a
-    GPU, takes the host scan."""
-    if str(vcf_file).endswith((".gz", ".bgz")) and os.environ.get("SAI_AMD_INGEST") != "host":
+    """First and last POS of the first contiguous run of ``chr_name`` (None, None if absent).  With a
+    usable tabix index next to the file the host scan reads two records (the chromosome's first chunk
+    and its last one) whatever the size of the file -- every rank of a sharded run asks this question.
+    Otherwise a bgzip file is scanned with the GPU-inflate pass when a GPU is there (the host would
+    inflate the whole file for it: 53 ms against 12 for 480 MB of text); everything else, and every
+    machine without a GPU, takes the host scan."""
+    if str(vcf_file).endswith((".gz", ".bgz")) and os.environ.get("SAI_AMD_INGEST") != "host" and not _index_usable(vcf_file):
         got = _scan_on_device(vcf_file, chr_name)
         if got is not None:
             return got
@@ -36,6 +38,15 @@ def scan_first_last(vcf_file: str, chr_name: str) -> tuple[Optional[int], Option
     if first.value < 0:
         return None, None
     return int(first.value), int(last.value)
+
+
+def _index_usable(vcf_file: str) -> bool:
+    """``<vcf>.tbi`` exists and is not older than its file (whole seconds, the rule of load_tbi in
+    ingest_base.hpp and of htslib)."""
+    try:
+        return int(os.stat(str(vcf_file) + ".tbi").st_mtime) >= int(os.stat(vcf_file).st_mtime)
+    except OSError:
+        return False
 
 
 def _scan_on_device(vcf_file: str, chr_name: str):

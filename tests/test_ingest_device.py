@@ -417,3 +417,12 @@ def test_chromosome_scan_of_a_bgzip_file_runs_on_the_gpu(eng, tmp_path, monkeypa
     before = calls["n"]
     assert native_vcf.scan_first_last(str(plain), "21")[0] is not None and native_vcf.scan_first_last(str(gz), "21")[0] is not None
     assert calls["n"] == before
+    # with a usable index the host reads two records and the GPU pass over the whole file is not started;
+    # an index older than its file is not trusted and the GPU scans again
+    spans = {chrom: native_vcf.scan_first_last(str(path), chrom) for chrom in ("7", "21", "22", "X")}
+    before = calls["n"]
+    write_tbi(path)
+    assert {chrom: native_vcf.scan_first_last(str(path), chrom) for chrom in spans} == spans and calls["n"] == before
+    st = os.stat(path)
+    os.utime(str(path) + ".tbi", (st.st_atime - 100, st.st_mtime - 100))
+    assert native_vcf.scan_first_last(str(path), "21") == spans["21"] and calls["n"] == before + 1
