@@ -358,7 +358,7 @@ def score_path_rate(eng, wl, block, lay, repeats: int = 3) -> dict:
     }
 
 
-def measure_traffic(argv: list, kernel: str, timeout_s: float = 420.0):
+def measure_traffic(argv: list, kernel: str, timeout_s: float = 240.0):
     """HBM bytes per launch of the dominant kernel, measured NOW: two short child runs of this same
     command under `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (each with --kernel-trace only, as
     MI355X_MICROARCH.md prescribes; the program itself follows `--`), corrected as the guide says for
@@ -380,14 +380,25 @@ def measure_traffic(argv: list, kernel: str, timeout_s: float = 420.0):
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             out = os.path.join(tmp, counter)
             cmd = [prof, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", out, "--", *child]
-            try:
-                res = subprocess.run(cmd, cwd="/tmp", env={**os.environ, "TMPDIR": "/tmp"}, capture_output=True, text=True,
-                                     timeout=timeout_s)  # fmt: skip
-            except (subprocess.TimeoutExpired, OSError) as exc:
+            try:  # its own session: a run that overstays is ended together with the program it profiles
+                proc = subprocess.Popen(cmd, cwd="/tmp", env={**os.environ, "TMPDIR": "/tmp"}, stdout=subprocess.DEVNULL,
+                                        stderr=subprocess.DEVNULL, start_new_session=True)  # fmt: skip
+            except OSError as exc:
                 return None, f"rocprofv3 --pmc {counter}: {type(exc).__name__}"
+            try:
+                rc = proc.wait(timeout=timeout_s)
+            except subprocess.TimeoutExpired:
+                import signal
+
+                try:
+                    os.killpg(proc.pid, signal.SIGKILL)
+                except OSError:
+                    pass
+                proc.wait()
+                return None, f"rocprofv3 --pmc {counter}: no result within {timeout_s:.0f} s"
             files = glob.glob(os.path.join(out, "*", "*_counter_collection.csv"))
-            if res.returncode != 0 or not files:
-                return None, f"rocprofv3 --pmc {counter} failed (rc {res.returncode})"
+            if rc != 0 or not files:
+                return None, f"rocprofv3 --pmc {counter} failed (rc {rc})"
             vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(files[0]))
                     if r["Counter_Name"] == counter and f"{kernel}_kernel" in r["Kernel_Name"]]  # fmt: skip
             if not vals:

@@ -92,6 +92,11 @@ def test_live_traffic_reads_the_counters_of_two_child_runs(tmp_path, monkeypatch
         open({str(log)!r}, "a").write(" ".join(a) + "\\n")
         if os.environ.get("FAKE_PROF_FAIL"):
             sys.exit(3)
+        if os.environ.get("FAKE_PROF_HANG"):  # a profiler that never comes back, with the program it started
+            import subprocess, time
+            kid = subprocess.Popen([sys.executable, "-c", "import time; time.sleep(600)"])
+            open(os.environ["FAKE_PROF_HANG"], "w").write(f"{{os.getpid()}} {{kid.pid}}")
+            time.sleep(600)
         counter, out = a[a.index("--pmc") + 1], a[a.index("-d") + 1]
         os.makedirs(os.path.join(out, "host"), exist_ok=True)
         rows = ["Kernel_Name,Counter_Name,Counter_Value"]
@@ -113,3 +118,18 @@ def test_live_traffic_reads_the_counters_of_two_child_runs(tmp_path, monkeypatch
     monkeypatch.setenv("FAKE_PROF_FAIL", "1")
     total, why = bench.measure_traffic(["--workload", "c2"], "site_counts")
     assert total is None and "failed" in why
+    # a run that overstays is ended together with the program it profiles (its own process group)
+    monkeypatch.delenv("FAKE_PROF_FAIL")
+    pids = tmp_path / "pids.txt"
+    monkeypatch.setenv("FAKE_PROF_HANG", str(pids))
+    total, why = bench.measure_traffic(["--workload", "c2"], "site_counts", timeout_s=3.0)
+    assert total is None and "no result within" in why
+    import time
+
+    time.sleep(0.5)
+    for pid in map(int, pids.read_text().split()):
+        try:
+            stat = open(f"/proc/{pid}/stat").read().split()
+            assert stat[2] == "Z", (pid, stat[2])  # at most a zombie waiting for init
+        except FileNotFoundError:
+            pass
