@@ -29,16 +29,29 @@
  *   contiguous memory and a tile is one contiguous n_ind * 64 byte run.  The last tile is padded
  *   with zero bytes.  sai_tiled_bytes() gives the allocation size.
  *
- * Flag planes (what the per-site decision hands to the windows stage)
- *   Per tile of 64 sites and parameter set three 64-bit words, bit b = site tile * 64 + b:
- *       planes[tile * plane_stride + 3 * set + 0]   condition of compute_matching_loci (stat_utils.py:166)
- *       planes[tile * plane_stride + 3 * set + 1]   condition && tgt_freq > x           (u_statistic.py:92)
- *       planes[tile * plane_stride + 3 * set + 2]   site inverted: its effective target frequency is
- *                                                   1 - tgt_freq[site]                  (stat_utils.py:156-160)
- *   plane_stride = words per tile row (>= 3 * n_sets of the call; a caller that evaluates more than
- *   SAI_MAX_SETS sets in several calls hands each call the row offset of its first set).  Bits of
- *   sites >= n_sites are 0.  A tile's row is written by one store instruction of the wavefront that
- *   evaluated the tile, and a window of 2 000 sites is 32 words per plane for the windows stage.
+ * Flag planes and target frequencies (what the per-site decision hands to the windows stage)
+ *   Per tile of 64 sites ONE row of 64-bit words, bit b of a word = site tile * 64 + b; for a call
+ *   with n parameter sets:
+ *       planes[tile * plane_stride + 0]           "any": sites whose tgt_freq is stored -- the OR of the
+ *                                                 sets' conditions (SAI_FREQ_CANDIDATES), all ones (SAI_FREQ_DENSE)
+ *       planes[tile * plane_stride + 1 + s]       condition of compute_matching_loci for set s (stat_utils.py:166)
+ *       planes[tile * plane_stride + 1 + n + s]   site inverted for set s: its effective target frequency is
+ *                                                 1 - tgt_freq (stat_utils.py:156-160).  Written, and read, only
+ *                                                 when some set of the call has anc_allele_available == 0
+ *                                                 (with ancestral alleles nothing is ever inverted).
+ *   The target frequency of site (tile, b) with its "any" bit up lies at
+ *       tgt_freq[tile * 64 + popcount(any & ((1 << b) - 1))]
+ *   i.e. a tile's stored frequencies sit packed at the start of the tile's 64 slots (all ones: slot b).
+ *   U's last test, tgt_freq > x (u_statistic.py:92), is taken by the windows stage from these
+ *   frequencies: round 3's first layout also kept a "condition && tgt > x" plane and the inverted plane
+ *   of every set, and each site's frequency in its own slot -- 7.5 + 8 partly written 64-byte lines per
+ *   tile for C5's 20 sets where this layout writes 2.6 + 2.5, and in the middle of a read stream a
+ *   written LINE is what costs.
+ *   plane_stride = words per tile row, >= SAI_PLANES_PER_SET * n (room for 1 + 2 n words; a caller that
+ *   evaluates more than SAI_MAX_SETS sets in several calls hands each call the row offset
+ *   SAI_PLANES_PER_SET * first_set and must use SAI_FREQ_DENSE, whose slots do not depend on the sets).
+ *   Bits of sites >= n_sites are 0 in the condition and inverted words.  A tile's row is written by one
+ *   store instruction of the wavefront that evaluated the tile.
  */
 #ifndef SAIHIP_H
 #define SAIHIP_H
@@ -50,12 +63,12 @@
 extern "C" {
 #endif
 
-#define SAI_ABI_VERSION 13
+#define SAI_ABI_VERSION 14
 #define SAI_TILE_SITES 64
 #define SAI_MAX_SRC 6   /* source populations per call */
-#define SAI_MAX_SETS 20 /* parameter sets per call: 3 * 20 plane words of a tile = one wave store (C5's 18 sets fit) */
+#define SAI_MAX_SETS 20 /* parameter sets per call: 1 + 2 * 20 plane words of a tile = one wave store (C5's 18 sets fit) */
 #define SAI_FUSED_SETS SAI_MAX_SETS /* parameter sets the fused site pass carries */
-#define SAI_PLANES_PER_SET 3
+#define SAI_PLANES_PER_SET 3 /* words of a tile row reserved per set (1 + 2 n <= 3 n are used) */
 
 enum sai_status {
   SAI_OK = 0,
@@ -132,8 +145,8 @@ int sai_tile_from_site_major(sai_ctx* ctx, const int8_t* src, int64_t n_sites, i
 int sai_site_counts(sai_ctx* ctx, int64_t n_sites, int32_t n_pops, const sai_pop* pops,
                     uint32_t* counts, void* stream);
 
-/* Words of a flag-plane buffer with rows of exactly 3 * n_sets words: ceil(n_sites / 64) * 3 * n_sets
- * (-1 on bad arguments). */
+/* Words of a flag-plane buffer with rows of exactly SAI_PLANES_PER_SET * n_sets words:
+ * ceil(n_sites / 64) * 3 * n_sets (-1 on bad arguments). */
 int64_t sai_plane_words(int64_t n_sites, int32_t n_sets);
 
 /* Kernels 1+2 fused (the fast path when there are at most SAI_FUSED_SETS parameter sets): one pass over the
@@ -141,19 +154,21 @@ int64_t sai_plane_words(int64_t n_sites, int32_t n_sets);
  * tile, while the counts are still on chip.  `counts` may be NULL (then the 8 bytes per site and
  * population are neither written nor re-read); pops[p].ploidy is used.  Results are identical to
  * sai_site_counts followed by sai_site_flags.
- * freq_mode = SAI_FREQ_DENSE writes tgt_freq[site] for every site; SAI_FREQ_CANDIDATES writes it
- * only where some set's condition bit is set -- the only entries sai_window_stats reads -- and
- * leaves the rest of the buffer untouched (dense 8-byte stores interleaved with the genotype
- * stream cost about 10 % of the pass on MI355X). */
+ * freq_mode = SAI_FREQ_DENSE writes tgt_freq[site] for every site ("any" word all ones);
+ * SAI_FREQ_CANDIDATES writes it only for sites at which some set's condition bit is up -- the only
+ * entries sai_window_stats reads -- packed at the start of the tile's 64 slots in site order ("any" =
+ * the OR of the conditions; see the top of this header) and leaves the rest of the buffer untouched
+ * (dense 8-byte stores interleaved with the genotype stream cost about 10 % of the pass on MI355X,
+ * a tile's candidates in slots of their own a fifth of that for sets as loose as C5's). */
 int sai_site_pass(sai_ctx* ctx, int64_t n_sites, int32_t n_pops, const sai_pop* pops,
                   uint32_t* counts, int32_t n_sets, const sai_params* sets_host, int32_t freq_mode,
                   double* tgt_freq, uint64_t* planes, int64_t plane_stride, void* stream);
 
 /* Kernel 2: calc_freq's f64 division (stat_utils.py:51-52) and compute_matching_loci
- * (stat_utils.py:114-166) for every site and parameter set, plus U's final test
- * (u_statistic.py:92).  tgt_freq[site] is the UNinverted target frequency (NaN when nothing is
- * called); the decisions go to the flag planes described at the top of this header (condition,
- * condition && tgt_freq > x, site inverted).
+ * (stat_utils.py:114-166) for every site and parameter set.  tgt_freq[site] is the UNinverted
+ * target frequency (NaN when nothing is called), written for every site (SAI_FREQ_DENSE: "any" all
+ * ones); the decisions go to the flag planes described at the top of this header (condition, site
+ * inverted).  U's final test (u_statistic.py:92) is sai_window_stats'.
  * ploidy[p] pairs with population p of sai_site_counts.  adj_freq may be NULL; otherwise it
  * receives compute_matching_loci's returned (possibly inverted) frequencies:
  * adj_freq[(set * 2 + 0) * n_sites + site] = ref_freq, [(set * 2 + 1) * n_sites + site] = tgt_freq. */
@@ -178,7 +193,8 @@ int sai_window_bounds_seg(sai_ctx* ctx, const int32_t* pos, int64_t n_sites, int
                           const int64_t* win_start, const int64_t* win_end, const int32_t* seg_lo,
                           const int32_t* seg_hi, int32_t* lo, int32_t* hi, void* stream);
 
-/* Kernel 4 (four launches): one record per (set, window): U count (u_statistic.py:94-96),
+/* Kernel 4 (four launches): one record per (set, window): U count (u_statistic.py:92-96: condition
+ * sites whose effective target frequency is > sets_host[set].x),
  * numpy 'linear' nanquantile of the effective target frequency over condition sites
  * (q_statistic.py:92-100), and both candidate lists (u_statistic.py:95, q_statistic.py:101) in
  * ascending site order, laid out as a CSR in (set, window) order -- deterministic, so 1-GPU and
@@ -191,9 +207,11 @@ int sai_window_bounds_seg(sai_ctx* ctx, const int32_t* pos, int64_t n_sites, int
  *   cdd_total[0..1] = entries needed for all U / Q lists: when a total exceeds its capacity,
  *     re-run with larger buffers.  cdd_total must hold sai_window_total_words(n_sets, n_windows)
  *     int64 words: the two totals, then scratch of the parallel prefix sum (one pair per 1024 records).
- * `quantile` is taken from sets_host[set].quantile.  `planes` / `plane_stride`: the flag planes of
- * these n_sets sets (rows of plane_stride words per tile, this call's first set at word 0 of the
- * pointer).  tgt_freq is read only at sites whose condition bit is set (see SAI_FREQ_CANDIDATES). */
+ * `quantile` and `x` are taken from sets_host[set]; whether the rows carry inverted words from the
+ * sets' anc_allele_available, exactly as the call that wrote them decided it -- so sets_host must be
+ * the array that call was given.  `planes` / `plane_stride`: the rows of these n_sets sets (plane_stride
+ * words per tile, this call's "any" word at word 0 of the pointer).  tgt_freq is read only at sites
+ * whose condition bit is set, at the slot the "any" word gives them. */
 int64_t sai_window_total_words(int32_t n_sets, int32_t n_windows); /* -1 on bad arguments */
 int sai_window_stats(sai_ctx* ctx, int64_t n_sites, const double* tgt_freq, const uint64_t* planes,
                      int64_t plane_stride, int32_t n_sets, const sai_params* sets_host, int32_t n_windows,

@@ -22,7 +22,7 @@ SAI_PLANES_PER_SET = 3
 SAI_ERR_ARG = -1
 SAI_ERR_UNSUPPORTED = -4  # enum sai_status
 FREQ_MODES = {"dense": 0, "candidates": 1}  # enum sai_freq_mode
-SAI_ABI_VERSION = 13
+SAI_ABI_VERSION = 14
 
 OPS = {"=": 0, "<": 1, ">": 2, "<=": 3, ">=": 4}
 

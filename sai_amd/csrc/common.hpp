@@ -64,6 +64,13 @@ inline int check_launch(const char* what) {
 int check_sets(int32_t n_sets, const sai_params* sets, int32_t n_src, int32_t max_sets = SAI_MAX_SETS);
 // site_pass.hip: a flag-plane row of plane_stride words holds n_sets sets
 int check_plane_stride(int64_t plane_stride, int32_t n_sets);
+// the rows of these sets carry inverted words (some set lacks ancestral alleles): decided the same way
+// by the call that writes the rows and the call that reads them
+inline bool sets_with_inverted(int32_t n_sets, const sai_params* sets) {
+  for (int32_t s = 0; s < n_sets; ++s)
+    if (sets[s].anc_allele_available == 0) return true;
+  return false;
+}
 
 inline unsigned stream_grid(const sai_ctx* ctx, int64_t n_tiles) {
   static const int waves_per_cu = [] {  // SAI_STREAM_WAVES_PER_CU: tuning knob for sweeps

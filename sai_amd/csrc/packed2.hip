@@ -148,7 +148,7 @@ __global__ __launch_bounds__(64) void site_counts_packed2_kernel(PackedArgs a, F
     if (FUSED)  // lane = site inside the tile already: the ballots of eval_site are the tile's flag planes
       eval_site(
           a.n_pops, fa.ploidy, [&](int p) { return stash[p][lane]; }, fa.n_sets, fa.sets, tile, lane, site < a.n_sites,
-          a.n_sites, fa.tgt_freq, fa.planes, fa.plane_stride, nullptr, fa.sparse_freq != 0);
+          a.n_sites, fa.tgt_freq, fa.planes, fa.plane_stride, nullptr, fa.sparse_freq != 0, fa.with_inv != 0);
   }
 }
 
@@ -223,6 +223,7 @@ int sai_site_pass_packed2(sai_ctx* ctx, int64_t n_sites, int32_t n_pops, const s
   a.counts = reinterpret_cast<uint2*>(counts);
   fa.n_sets = n_sets;
   fa.sparse_freq = freq_mode == SAI_FREQ_CANDIDATES;
+  fa.with_inv = n_sets > 0 && sets_with_inverted(n_sets, sets_host);
   fa.tgt_freq = tgt_freq;
   fa.planes = planes;
   fa.plane_stride = plane_stride;

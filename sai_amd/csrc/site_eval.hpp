@@ -20,17 +20,18 @@ __device__ __forceinline__ bool cmp_op(int op, double f, double y) {
   }
 }
 
-// Flag planes: what the per-site decision leaves behind for the windows stage.  Per tile of 64
-// sites and parameter set three 64-bit words -- bit b of a word = site tile * 64 + b --
-//   planes[tile * stride + 3 * set + 0]  condition (compute_matching_loci's, stat_utils.py:166)
-//   planes[tile * stride + 3 * set + 1]  condition && tgt_freq > x (u_statistic.py:92)
-//   planes[tile * stride + 3 * set + 2]  site inverted (stat_utils.py:156)
-// The decisions of a tile are taken by the 64 lanes of one wavefront (lane = site), three
-// ballots per set collect them, and ONE store instruction per tile writes the tile's row (lane k
-// holds word k).  Round 2 kept a byte per site and set, stored by every lane in the middle of the
-// genotype stream: 18 B per site for the 18 sets of C5, which cost 8 % of the pass; a row of
-// planes is 6.75 B per site there and 0.375 B for one set.
-constexpr int kPlanesPerSet = SAI_PLANES_PER_SET;
+// Flag planes: what the per-site decision leaves behind for the windows stage (layout: saihip.h).  A
+// tile's decisions are taken by the 64 lanes of one wavefront (lane = site), two ballots per set
+// collect them, and ONE store instruction per tile writes the tile's row (lane k holds word k):
+//   word 0          "any": the sites whose tgt_freq is stored (OR of the conditions, or all ones)
+//   word 1 + s      condition of set s (compute_matching_loci's, stat_utils.py:166)
+//   word 1 + n + s  site inverted for set s (stat_utils.py:156) -- only when a set lacks ancestral alleles
+// and the stored frequencies of the tile go to its first popcount(any) slots in site order.  What is
+// written in the middle of the genotype stream is paid per 64-byte LINE: round 2
+// kept a byte per site and set (18 B per site for C5), the first plane layout three words per set and
+// every candidate's frequency in its own slot (7.5 + 8 partly written lines per tile for C5's 20 sets);
+// this one writes 2.6 + 2.5 there and 0.25 + 0.06 for one set.
+constexpr int kPlanesPerSet = SAI_PLANES_PER_SET;  // row words RESERVED per set (1 + 2 n <= 3 n are used)
 
 // get(p) -> uint2 {alt_sum, n_called} of population p at this lane's site (site = tile * 64 + lane;
 // `live` = the site exists).  Must be called by the whole wavefront.
@@ -38,7 +39,7 @@ template <typename GetCounts>
 __device__ __forceinline__ void eval_site(int n_pops, const int32_t* ploidy, GetCounts get, int n_sets,
                                           const sai_params* sets, int64_t tile, int lane, bool live, int64_t n_sites,
                                           double* tgt_freq, uint64_t* planes, int64_t plane_stride, double* adj_freq,
-                                          bool sparse_freq = false) {
+                                          bool sparse_freq, bool with_inv) {
   const int64_t site = tile * kTile + lane;
   double f[kMaxPops];
   bool valid = live;
@@ -55,9 +56,9 @@ __device__ __forceinline__ void eval_site(int n_pops, const int32_t* ploidy, Get
       f[p] = 0.0;
     }
   }
-  bool any_cond = false;
   const int n_src = n_pops - 2;
   uint64_t row_word = 0;  // lane k ends up with word k of the tile's row
+  uint64_t any = sparse_freq ? 0ull : ~0ull;
   for (int s = 0; s < n_sets; ++s) {
     const sai_params& ps = sets[s];
     bool hit_y = true, hit_m = true;
@@ -72,25 +73,28 @@ __device__ __forceinline__ void eval_site(int n_pops, const int32_t* ploidy, Get
     const bool inverted = !anc && hit_m && valid;
     const bool hit = anc ? hit_y : (hit_y || hit_m);
     const double rf = inverted ? 1.0 - f[0] : f[0];
-    const double tf = inverted ? 1.0 - f[1] : f[1];
     const bool cond = valid && hit && (rf < ps.w);
-    const bool ucand = cond && (tf > ps.x);
-    any_cond = any_cond || cond;
-    const uint64_t bc = __ballot(cond), bu = __ballot(ucand), bi = __ballot(inverted);
-    const int k = lane - kPlanesPerSet * s;
-    row_word = k == 0 ? bc : k == 1 ? bu : k == 2 ? bi : row_word;
+    const uint64_t bc = __ballot(cond);
+    any |= bc;
+    row_word = lane == 1 + s ? bc : row_word;
+    if (with_inv) {  // uniform
+      const uint64_t bi = __ballot(inverted);
+      row_word = lane == 1 + n_sets + s ? bi : row_word;
+    }
     if (adj_freq && live) {
       adj_freq[(static_cast<int64_t>(s) * 2 + 0) * n_sites + site] = rf;
-      adj_freq[(static_cast<int64_t>(s) * 2 + 1) * n_sites + site] = tf;
+      adj_freq[(static_cast<int64_t>(s) * 2 + 1) * n_sites + site] = inverted ? 1.0 - f[1] : f[1];
     }
   }
+  row_word = lane == 0 ? any : row_word;
   // non-temporal stores: measured on MI355X, plain stores in the middle of the genotype stream cost
   // twice as much of the pass as streaming ones
-  if (lane < kPlanesPerSet * n_sets) __builtin_nontemporal_store(row_word, planes + tile * plane_stride + lane);
-  // The windows stage reads tgt_freq only where a set's condition bit is up (about 1 site in 1000),
-  // and dense f64 stores in the middle of the genotype stream cost ~10 % of the pass (HBM read/write
-  // turnarounds): SAI_FREQ_CANDIDATES leaves every other entry untouched.
-  if (live && (!sparse_freq || any_cond)) __builtin_nontemporal_store(f[1], tgt_freq + site);
+  if (lane < 1 + (with_inv ? 2 : 1) * n_sets) __builtin_nontemporal_store(row_word, planes + tile * plane_stride + lane);
+  // The windows stage reads tgt_freq only where a set's condition bit is up (about 1 site in 1000; one in
+  // three for C5's loosest sets), and dense f64 stores in the middle of the genotype stream cost ~10 % of
+  // the pass: SAI_FREQ_CANDIDATES stores those sites' values only, packed at the start of the tile's slots.
+  if (live && ((any >> lane) & 1ull))
+    __builtin_nontemporal_store(f[1], tgt_freq + tile * kTile + __popcll(any & ((1ull << lane) - 1ull)));
 }
 
 // LDS operations of one wavefront execute in order; this only stops the compiler from moving
@@ -107,7 +111,8 @@ constexpr int kFusedSets = SAI_FUSED_SETS;
 
 struct FusedArgs {
   int32_t n_sets;  // 0 = plain site_counts
-  int32_t sparse_freq;
+  int16_t sparse_freq;
+  int16_t with_inv;  // some set lacks ancestral alleles: the rows carry inverted words
   int32_t ploidy[kMaxPops];
   double* tgt_freq;
   uint64_t* planes;

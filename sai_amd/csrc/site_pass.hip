@@ -8,7 +8,8 @@ namespace {
 struct FlagArgs {
   int64_t n_sites;
   int32_t n_pops;
-  int32_t n_sets;
+  int16_t n_sets;
+  int16_t with_inv;
   int32_t ploidy[kMaxPops];
   const uint2* counts;
   double* tgt_freq;
@@ -28,7 +29,7 @@ __global__ __launch_bounds__(256) void site_flags_kernel(FlagArgs a) {
       a.n_pops, a.ploidy,
       [&](int p) { return live ? a.counts[static_cast<int64_t>(p) * a.n_sites + site] : make_uint2(0u, 0u); }, a.n_sets,
       a.sets, site >> 6, static_cast<int>(threadIdx.x & 63), live, a.n_sites, a.tgt_freq, a.planes, a.plane_stride,
-      a.adj_freq);
+      a.adj_freq, false, a.with_inv != 0);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -63,7 +64,7 @@ static_assert(sizeof(CountsArgs) + sizeof(FusedArgs) <= 4096, "kernel arguments 
 // widened several times per population (keeps 32 more registers live across the load loop).
 // FUSED: evaluate the parameter sets at the end of each tile (site_flags folded in).
 template <bool MULTI, bool FUSED>
-__global__ __launch_bounds__(64) void site_counts_kernel(CountsArgs a, FusedArgs fa) {
+__global__ __launch_bounds__(64, MULTI ? 4 : 5) void site_counts_kernel(CountsArgs a, FusedArgs fa) {
   // FUSED: the butterfly leaves lane l with site (l%4)*16 + l/4 of the tile; each lane parks those
   // {alt_sum, n_called} per population in LDS AT ITS SITE'S INDEX, and once all populations of the
   // tile are done lane l takes site l back and evaluates the parameter sets for it -- lanes in site
@@ -113,7 +114,7 @@ __global__ __launch_bounds__(64) void site_counts_kernel(CountsArgs a, FusedArgs
       eval_site(
           a.n_pops, fa.ploidy, [&](int p) { return stash[p][lane]; }, fa.n_sets, fa.sets, tile, lane,
           tile * kTile + lane < a.n_sites, a.n_sites, fa.tgt_freq, fa.planes, fa.plane_stride, nullptr,
-          fa.sparse_freq != 0);
+          fa.sparse_freq != 0, fa.with_inv != 0);
       wave_lds_fence();  // the next tile's counts must not overtake these reads
     }
   }
@@ -175,6 +176,7 @@ static int launch_site_counts(sai_ctx* ctx, int64_t n_sites, int32_t n_pops, con
   a.counts = reinterpret_cast<uint2*>(counts);
   fa.n_sets = n_sets;
   fa.sparse_freq = freq_mode == SAI_FREQ_CANDIDATES;
+  fa.with_inv = n_sets > 0 && sets_with_inverted(n_sets, sets_host);
   fa.tgt_freq = tgt_freq;
   fa.planes = planes;
   fa.plane_stride = plane_stride;
@@ -238,7 +240,8 @@ int sai_site_flags(sai_ctx* ctx, int64_t n_sites, int32_t n_pops, const int32_t*
   std::memset(&a, 0, sizeof(a));
   a.n_sites = n_sites;
   a.n_pops = n_pops;
-  a.n_sets = n_sets;
+  a.n_sets = static_cast<int16_t>(n_sets);
+  a.with_inv = sets_with_inverted(n_sets, sets_host);
   for (int p = 0; p < n_pops; ++p) {
     if (ploidy_host[p] <= 0) return fail(SAI_ERR_ARG, "ploidy[%d] must be positive", p);
     a.ploidy[p] = ploidy_host[p];

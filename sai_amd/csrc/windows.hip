@@ -99,18 +99,29 @@ struct WinArgs {
   int32_t* cdd_q;
   int64_t cap_q;
   int64_t* cdd_total;
+  int32_t with_inv;  // the rows carry inverted words (some set lacks ancestral alleles)
   double quantile[SAI_MAX_SETS];
+  double x[SAI_MAX_SETS];  // U's threshold on the effective target frequency (u_statistic.py:92)
 };
 
 constexpr int kWinThreads = 256;
 constexpr int kWaveCap = 256;       // qualifying sites a wave keeps in LDS; more -> heavy kernel
 constexpr int kSelCap = 4096;       // values the heavy kernel keeps in LDS (32 KiB); beyond: re-read
 constexpr int32_t kHeavyMark = -1;  // records[].n_cdd_q value that hands a window to the fallback
-constexpr int kPlanes = SAI_PLANES_PER_SET;
-enum { kCond = 0, kUcand = 1, kInv = 2 };
+// Words of a tile's row (saihip.h): 0 = "any" (sites whose frequency is stored), 1 + s = condition of
+// set s, 1 + n + s = inverted for set s (present only with a.with_inv).
+constexpr int kAny = 0;
+__device__ __forceinline__ int cond_word(int set) { return 1 + set; }
+__device__ __forceinline__ int inv_word(const int32_t with_inv, int n_sets, int set) { return with_inv ? 1 + n_sets + set : -1; }
 
-__device__ __forceinline__ double eff_freq(const double* tgt_freq, bool inverted, int64_t i) {
-  const double v = tgt_freq[i];
+// slot of site (tile t, bit b) in tgt_freq: the tile's stored frequencies are packed at the start of its
+// 64 slots in site order ("any" all ones: slot b)
+__device__ __forceinline__ int64_t freq_slot(int64_t t, uint64_t any, int b) {
+  return t * kTile + __popcll(any & ((1ull << b) - 1ull));
+}
+
+__device__ __forceinline__ double eff_freq(const double* tgt_freq, bool inverted, int64_t slot) {
+  const double v = tgt_freq[slot];
   return inverted ? 1.0 - v : v;
 }
 
@@ -204,52 +215,54 @@ __global__ __launch_bounds__(256) void window_stats_wave_kernel(WinArgs a) {
   if (w >= a.n_windows) return;  // whole wave
   const int set = blockIdx.y;
   const int lo = clamp_site(a.lo[w], a.n_sites), hi = clamp_site(a.hi[w], a.n_sites);
-  const uint64_t* pl = a.planes + kPlanes * set;
+  const int ci = cond_word(set), ii = inv_word(a.with_inv, a.n_sets, set);
   const int64_t ridx = static_cast<int64_t>(set) * a.n_windows + w;
   double* vals = sh_vals[wv];
   const unsigned long long lt_mask = (1ull << lane) - 1ull;
+  const double x = a.x[set];
 
-  // pass 1: counts + order-preserving compaction of the qualifying effective frequencies into LDS
-  uint32_t n_c = 0, n_u_lane = 0;
+  // pass 1: counts + order-preserving compaction of the qualifying effective frequencies into LDS; U's
+  // tgt > x is taken here, from the same values
+  uint32_t n_c = 0, n_u = 0;
   walk_tiles(lo, hi, lane, [&](int t, bool live, uint64_t mask) {
-    const uint64_t* row = pl + static_cast<int64_t>(t) * a.stride;
-    const uint64_t c = live ? row[kCond] & mask : 0ull;
-    const uint64_t u = live ? row[kUcand] & mask : 0ull;
-    n_u_lane += __popcll(u);
+    const uint64_t* row = a.planes + static_cast<int64_t>(t) * a.stride;
+    const uint64_t c = live ? row[ci] & mask : 0ull;
     const uint32_t mine = __popcll(c);
     const unsigned long long nonempty = __ballot(mine != 0u);
     if (nonempty == 0ull) return;  // no condition site among these 4 096: the usual case
-    if (n_c >= kWaveCap) {  // uniform: the window goes to the workgroup kernel and only the count matters
+    if (n_c >= kWaveCap) {  // uniform: the window goes to the workgroup kernel (which also counts U) and only the count matters
       uint32_t tot = mine;
 #pragma unroll
       for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o, 64);
       n_c += tot;
       return;
     }
-    const uint64_t iv = c ? row[kInv] : 0ull;
+    const uint64_t iv = (c && ii >= 0) ? row[ii] : 0ull;
+    const uint64_t an = c ? row[kAny] : 0ull;
     const int tb = t - lane;  // first tile of the chunk
     for_nonempty_tiles(nonempty, [&](int n, const int (&tl)[kTileBatch]) {
-      uint64_t cw[kTileBatch], iw[kTileBatch];
+      uint64_t cw[kTileBatch], iw[kTileBatch], aw[kTileBatch];
       double v[kTileBatch];
 #pragma unroll
       for (int u = 0; u < kTileBatch; ++u) {
         cw[u] = u < n ? read_lane64(c, tl[u]) : 0ull;
         iw[u] = u < n ? read_lane64(iv, tl[u]) : 0ull;
+        aw[u] = u < n ? read_lane64(an, tl[u]) : 0ull;
       }
 #pragma unroll
       for (int u = 0; u < kTileBatch; ++u)
-        v[u] = ((cw[u] >> lane) & 1ull) ? a.tgt_freq[static_cast<int64_t>(tb + tl[u]) * kTile + lane] : 0.0;
+        v[u] = ((cw[u] >> lane) & 1ull) ? a.tgt_freq[static_cast<int64_t>(tb + tl[u]) * kTile + __popcll(aw[u] & lt_mask)] : 0.0;
 #pragma unroll
       for (int u = 0; u < kTileBatch; ++u) {
+        const bool mine_c = (cw[u] >> lane) & 1ull;
+        const double e = ((iw[u] >> lane) & 1ull) ? 1.0 - v[u] : v[u];
         const uint32_t slot = n_c + __popcll(cw[u] & lt_mask);  // tiles ascend, sites ascend inside a tile
-        if (((cw[u] >> lane) & 1ull) && slot < kWaveCap) vals[slot] = ((iw[u] >> lane) & 1ull) ? 1.0 - v[u] : v[u];
+        if (mine_c && slot < kWaveCap) vals[slot] = e;
+        n_u += __popcll(__ballot(mine_c && e > x));
         n_c += __popcll(cw[u]);
       }
     });
   });
-  uint32_t n_u = n_u_lane;
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) n_u += __shfl_xor(n_u, o, 64);
   double q = std::numeric_limits<double>::quiet_NaN();
   uint32_t n_q = 0;
   if (n_c > kWaveCap) {
@@ -370,22 +383,27 @@ __device__ __forceinline__ int digit_on_path(double v, int level, const int (&pa
 // One set's planes as the workgroup kernel walks them: eight threads per tile, each owning eight
 // sites (one byte of the tile's condition word), so a 2 000-site window keeps all 256 threads busy.
 struct SetPlanes {
-  const uint64_t* pl;  // word 0 of this set in row 0
+  const uint64_t* rows;  // row 0 of this call's planes
   int64_t stride;
+  int cond;  // word of this set's condition in a row
+  int inv;   // word of its inverted plane, or -1
 };
 constexpr int kSubs = 8;  // threads per tile
 
-// on_byte(first_site, cond_bits, inv_bits) for every byte of the window that holds a condition site
+// on_byte(first_slot, any_bits, cond_bits, inv_bits) for every byte of the window that holds a condition
+// site: bit b of the byte has its frequency at tgt_freq[first_slot + popcount(any_bits below b)]
 template <typename F>
 __device__ __forceinline__ void for_each_cond_byte(const SetPlanes& sp, int lo, int hi, int tid, F&& on_byte) {
   if (hi <= lo) return;
   const int t0 = lo >> 6, t1 = (hi + kTile - 1) >> 6;
   const int sub = tid % kSubs;
   for (int t = t0 + tid / kSubs; t < t1; t += kWinThreads / kSubs) {
-    const uint64_t* row = sp.pl + static_cast<int64_t>(t) * sp.stride;
-    const uint32_t c = static_cast<uint32_t>((row[kCond] & range_mask(t, lo, hi)) >> (8 * sub)) & 0xFFu;
+    const uint64_t* row = sp.rows + static_cast<int64_t>(t) * sp.stride;
+    const uint32_t c = static_cast<uint32_t>((row[sp.cond] & range_mask(t, lo, hi)) >> (8 * sub)) & 0xFFu;
     if (c == 0u) continue;
-    on_byte(static_cast<int64_t>(t) * kTile + 8 * sub, c, static_cast<uint32_t>(row[kInv] >> (8 * sub)) & 0xFFu);
+    const uint64_t any = row[kAny];
+    on_byte(freq_slot(t, any, 8 * sub), static_cast<uint32_t>(any >> (8 * sub)) & 0xFFu, c,
+            sp.inv >= 0 ? static_cast<uint32_t>(row[sp.inv] >> (8 * sub)) & 0xFFu : 0u);
   }
 }
 
@@ -397,11 +415,11 @@ __device__ __forceinline__ void for_each_selected(const WinShared& sh, const dou
   if (IN_LDS) {
     for (uint32_t i = tid; i < n_sel; i += kWinThreads) use(sh.vals[i]);
   } else {
-    for_each_cond_byte(sp, lo, hi, tid, [&](int64_t site0, uint32_t c, uint32_t iv) {
+    for_each_cond_byte(sp, lo, hi, tid, [&](int64_t slot0, uint32_t ab, uint32_t c, uint32_t iv) {
       while (c) {
         const int b = __ffs(static_cast<int>(c)) - 1;
         c &= c - 1u;
-        use(eff_freq(tgt_freq, (iv >> b) & 1u, site0 + b));
+        use(eff_freq(tgt_freq, (iv >> b) & 1u, slot0 + __popc(ab & ((1u << b) - 1u))));
       }
     });
   }
@@ -500,7 +518,7 @@ __global__ __launch_bounds__(kWinThreads) void window_stats_heavy_kernel(WinArgs
   const int64_t ridx = static_cast<int64_t>(set) * a.n_windows + w;
   if (a.records[ridx].n_cdd_q != kHeavyMark) return;  // uniform over the workgroup
   const int lo = clamp_site(a.lo[w], a.n_sites), hi = clamp_site(a.hi[w], a.n_sites);
-  const SetPlanes fl{a.planes + kPlanes * set, a.stride};
+  const SetPlanes fl{a.planes, a.stride, cond_word(set), inv_word(a.with_inv, a.n_sets, set)};
   const uint32_t n_c = static_cast<uint32_t>(a.records[ridx].n_cond);
   const bool in_lds = n_c <= kSelCap;
   if (tid == 0) sh.n_stored = 0;
@@ -509,10 +527,10 @@ __global__ __launch_bounds__(kWinThreads) void window_stats_heavy_kernel(WinArgs
     // a thread's eight sites: all frequencies first (independent loads), then one reservation in LDS --
     // a byte costs two memory latencies, not one per site (under the next step's genotype stream a
     // latency is several microseconds, and this kernel's time was mostly that chain)
-    for_each_cond_byte(fl, lo, hi, tid, [&](int64_t site0, uint32_t c, uint32_t iv) {
+    for_each_cond_byte(fl, lo, hi, tid, [&](int64_t slot0, uint32_t ab, uint32_t c, uint32_t iv) {
       double val[8];
 #pragma unroll
-      for (int b = 0; b < 8; ++b) val[b] = ((c >> b) & 1u) ? a.tgt_freq[site0 + b] : 0.0;
+      for (int b = 0; b < 8; ++b) val[b] = ((c >> b) & 1u) ? a.tgt_freq[slot0 + __popc(ab & ((1u << b) - 1u))] : 0.0;
       uint32_t slot = atomicAdd(&sh.n_stored, static_cast<uint32_t>(__popc(c)));
 #pragma unroll
       for (int b = 0; b < 8; ++b)
@@ -543,15 +561,23 @@ __global__ __launch_bounds__(kWinThreads) void window_stats_heavy_kernel(WinArgs
     const double x1 = n_le > k + 1 ? x0 : above;
     q = numpy_lerp(x0, x1, v, fl_v);
   }
-  uint32_t c_q = 0;
+  // the Q list's size, and U's count (the wave kernel stopped looking at values when it handed the window over)
+  const double x = a.x[set];
+  uint32_t c_q = 0, c_u = 0;
+  auto tally = [&](double u) {
+    c_q += u >= q ? 1u : 0u;
+    c_u += u > x ? 1u : 0u;
+  };
   if (in_lds) {
-    for (uint32_t i = tid; i < n_c; i += kWinThreads) c_q += sh.vals[i] >= q ? 1u : 0u;
+    for (uint32_t i = tid; i < n_c; i += kWinThreads) tally(sh.vals[i]);
   } else {
-    for_each_selected<false>(sh, a.tgt_freq, fl, lo, hi, n_c, tid, [&](double u) { c_q += u >= q ? 1u : 0u; });
+    for_each_selected<false>(sh, a.tgt_freq, fl, lo, hi, n_c, tid, tally);
   }
   const uint32_t n_q = block_sum(c_q, sh.red, tid);
+  const uint32_t n_u = block_sum(c_u, sh.red, tid);
   if (tid == 0) {
     a.records[ridx].n_cdd_q = static_cast<int32_t>(n_q);
+    a.records[ridx].u_count = static_cast<int32_t>(n_u);
     a.records[ridx].q = q;
   }
 }
@@ -671,43 +697,47 @@ __global__ __launch_bounds__(256) void window_lists_kernel(WinArgs a) {
   const bool write_q = rec.n_cdd_q > 0 && off_q >= 0 && a.cdd_q != nullptr;
   if (!write_u && !write_q) return;
   const int lo = clamp_site(a.lo[w], a.n_sites), hi = clamp_site(a.hi[w], a.n_sites);
-  const uint64_t* pl = a.planes + kPlanes * set;
-  const double q = rec.q;
+  const int ci = cond_word(set), ii = inv_word(a.with_inv, a.n_sets, set);
+  const double q = rec.q, x = a.x[set];
   const unsigned long long lt_mask = (1ull << lane) - 1ull;
   uint32_t done_u = 0, done_q = 0;
   walk_tiles(lo, hi, lane, [&](int t, bool live, uint64_t mask) {
-    const uint64_t* row = pl + static_cast<int64_t>(t) * a.stride;
-    const uint64_t um = (live && write_u) ? row[kUcand] & mask : 0ull;
-    const uint64_t c = (live && write_q) ? row[kCond] & mask : 0ull;
-    const unsigned long long nonempty = __ballot((um | c) != 0ull);
+    const uint64_t* row = a.planes + static_cast<int64_t>(t) * a.stride;
+    const uint64_t c = live ? row[ci] & mask : 0ull;
+    const unsigned long long nonempty = __ballot(c != 0ull);
     if (nonempty == 0ull) return;
-    const uint64_t iv = c ? row[kInv] : 0ull;
+    const uint64_t iv = (c && ii >= 0) ? row[ii] : 0ull;
+    const uint64_t an = c ? row[kAny] : 0ull;
     const int tb = t - lane;
     // lane = site: a tile's marked sites leave in site order, placed by the popcount of the lanes below
     for_nonempty_tiles(nonempty, [&](int n, const int (&tl)[kTileBatch]) {
-      uint64_t uw[kTileBatch], cw[kTileBatch], iw[kTileBatch];
+      uint64_t cw[kTileBatch], iw[kTileBatch], aw[kTileBatch];
       double v[kTileBatch];
       int32_t p[kTileBatch];
 #pragma unroll
       for (int u = 0; u < kTileBatch; ++u) {
-        uw[u] = u < n ? read_lane64(um, tl[u]) : 0ull;
         cw[u] = u < n ? read_lane64(c, tl[u]) : 0ull;
         iw[u] = u < n ? read_lane64(iv, tl[u]) : 0ull;
+        aw[u] = u < n ? read_lane64(an, tl[u]) : 0ull;
       }
 #pragma unroll
       for (int u = 0; u < kTileBatch; ++u) {
-        const int64_t site = static_cast<int64_t>(tb + tl[u]) * kTile + lane;
-        v[u] = ((cw[u] >> lane) & 1ull) ? a.tgt_freq[site] : 0.0;
-        p[u] = (((uw[u] | cw[u]) >> lane) & 1ull) ? (a.pos ? a.pos[site] : static_cast<int32_t>(site)) : 0;
+        const int64_t tile = tb + tl[u];
+        const int64_t site = tile * kTile + lane;
+        const bool mine_c = (cw[u] >> lane) & 1ull;
+        v[u] = mine_c ? a.tgt_freq[tile * kTile + __popcll(aw[u] & lt_mask)] : 0.0;
+        p[u] = mine_c ? (a.pos ? a.pos[site] : static_cast<int32_t>(site)) : 0;
       }
 #pragma unroll
       for (int u = 0; u < kTileBatch; ++u) {
+        const bool mine_c = (cw[u] >> lane) & 1ull;
         const double e = ((iw[u] >> lane) & 1ull) ? 1.0 - v[u] : v[u];
-        const bool mine_q = ((cw[u] >> lane) & 1ull) && e >= q;
-        const unsigned long long qw = __ballot(mine_q);
-        if ((uw[u] >> lane) & 1ull) a.cdd_u[off_u + done_u + __popcll(uw[u] & lt_mask)] = p[u];
+        const bool mine_u = write_u && mine_c && e > x;
+        const bool mine_q = write_q && mine_c && e >= q;
+        const unsigned long long uw = __ballot(mine_u), qw = __ballot(mine_q);
+        if (mine_u) a.cdd_u[off_u + done_u + __popcll(uw & lt_mask)] = p[u];
         if (mine_q) a.cdd_q[off_q + done_q + __popcll(qw & lt_mask)] = p[u];
-        done_u += __popcll(uw[u]);
+        done_u += __popcll(uw);
         done_q += __popcll(qw);
       }
     });
@@ -789,7 +819,11 @@ int sai_window_stats(sai_ctx* ctx, int64_t n_sites, const double* tgt_freq, cons
   a.cdd_q = cdd_q;
   a.cap_q = cap_q;
   a.cdd_total = cdd_total;
-  for (int s = 0; s < n_sets; ++s) a.quantile[s] = sets_host[s].quantile;
+  a.with_inv = sets_with_inverted(n_sets, sets_host);
+  for (int s = 0; s < n_sets; ++s) {
+    a.quantile[s] = sets_host[s].quantile;
+    a.x[s] = sets_host[s].x;
+  }
   const dim3 wave_grid(static_cast<unsigned>((n_windows + 3) / 4), static_cast<unsigned>(n_sets));
   const dim3 block_grid(static_cast<unsigned>(n_windows), static_cast<unsigned>(n_sets));
   hipLaunchKernelGGL(window_stats_wave_kernel, wave_grid, dim3(256), 0, st, a);

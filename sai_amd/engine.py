@@ -21,7 +21,7 @@ RECORD_DTYPE = np.dtype(
 )
 assert RECORD_DTYPE.itemsize == C.sizeof(_ffi.SaiWindowRecord) == 24
 
-FLAG_COND, FLAG_UCAND, FLAG_INVERTED = 1, 2, 4  # bits of flag_bytes()' bytes = plane 0, 1, 2 of a set
+FLAG_COND, FLAG_UCAND, FLAG_INVERTED = 1, 2, 4  # bits of flag_bytes()' bytes: condition, condition and tgt > x, site inverted
 PLANES = _ffi.SAI_PLANES_PER_SET
 
 
@@ -494,12 +494,14 @@ class Engine:
         return out
 
     def alloc_planes(self, n_sites: int, n_sets: int):
-        """Flag planes of ``n_sets`` parameter sets (saihip.h): int64 tensor [tiles][3 * n_sets], bit b
-        of planes[t, 3 * s + k] = site 64 t + b; k = 0 condition, 1 condition and tgt_freq > x, 2 site
-        inverted.  A column slice ``planes[:, 3 * s0 : 3 * s1]`` is the planes of sets s0..s1-1."""
+        """Flag planes of ``n_sets`` parameter sets (saihip.h): int64 tensor [tiles][3 * n_sets], zeroed.
+        A call with n sets uses words 0 ("any": sites whose tgt_freq is stored), 1 + s (condition of set s)
+        and, when a set lacks ancestral alleles, 1 + n + s (site inverted) of a row; bit b = site 64 t + b.
+        Sets beyond SAI_MAX_SETS are evaluated in several calls: the column slice
+        ``planes[:, 3 * s0 : 3 * s1]`` is the row space of the call for sets s0..s1-1."""
         torch = _torch()
         n_tiles = (int(n_sites) + _ffi.SAI_TILE_SITES - 1) // _ffi.SAI_TILE_SITES
-        return self._empty((n_tiles, PLANES * int(n_sets)), torch.int64)
+        return torch.zeros((n_tiles, PLANES * int(n_sets)), dtype=torch.int64, device=self.device)
 
     @staticmethod
     def _planes_arg(planes, n_sets: int, n_sites: int):
@@ -512,19 +514,53 @@ class Engine:
         stride = int(planes.stride(0)) if n_tiles > 1 else max(int(planes.stride(0)), PLANES * n_sets)
         return C.c_void_p(planes.data_ptr() if planes.numel() else 0), stride
 
-    def flag_bytes(self, planes, n_sites: int):
+    @staticmethod
+    def _row_words(sets, s0: int, s1: int):
+        """(word of "any", words of the conditions, words of the inverted planes or None) of the call that
+        evaluated sets s0..s1-1 of ``sets``, as columns of the whole planes tensor."""
+        base, n = PLANES * s0, s1 - s0
+        with_inv = any(not p.anc_allele_available for p in sets[s0:s1])
+        return base, [base + 1 + k for k in range(n)], ([base + 1 + n + k for k in range(n)] if with_inv else None)
+
+    def flag_bytes(self, planes, n_sites: int, sets, tgt_freq=None):
         """The planes as one byte per set and site (uint8 tensor [n_sets][n_sites]; FLAG_COND |
-        FLAG_UCAND | FLAG_INVERTED) -- for tests and for the single-window helpers, not on the hot path."""
+        FLAG_INVERTED) -- for tests and for the single-window helpers, not on the hot path.  ``sets`` = the
+        parameter sets the planes were written for (they decide whether inverted words exist).  With the
+        pass's ``tgt_freq`` the bytes also carry FLAG_UCAND = condition and effective target frequency > x
+        (u_statistic.py:92), evaluated here in torch f64 the way the windows stage evaluates it."""
         torch = _torch()
-        n_tiles, n_words = int(planes.shape[0]), int(planes.shape[1])
-        n_sets = n_words // PLANES
+        n_tiles, n_sets = int(planes.shape[0]), len(sets)
+        if int(planes.shape[1]) != PLANES * n_sets:
+            raise ValueError(f"planes of {planes.shape[1] // PLANES} sets, {n_sets} parameter sets")
         shifts = torch.arange(_ffi.SAI_TILE_SITES, dtype=torch.int64, device=planes.device)
         out = torch.zeros((n_sets, n_tiles * _ffi.SAI_TILE_SITES), dtype=torch.uint8, device=planes.device)
-        for s in range(n_sets):
-            for k in range(PLANES):
-                bits = (planes[:, PLANES * s + k].unsqueeze(1) >> shifts) & 1
-                out[s] |= (bits.reshape(-1) << k).to(torch.uint8)
-        return out[:, : int(n_sites)].contiguous()
+        for s0 in range(0, n_sets, _ffi.SAI_MAX_SETS):
+            s1 = min(s0 + _ffi.SAI_MAX_SETS, n_sets)
+            _, cond, inv = self._row_words(sets, s0, s1)
+            for k, s in enumerate(range(s0, s1)):
+                out[s] |= (((planes[:, cond[k]].unsqueeze(1) >> shifts) & 1).reshape(-1) * FLAG_COND).to(torch.uint8)
+                if inv is not None:
+                    out[s] |= (((planes[:, inv[k]].unsqueeze(1) >> shifts) & 1).reshape(-1) * FLAG_INVERTED).to(torch.uint8)
+        out = out[:, : int(n_sites)].contiguous()
+        if tgt_freq is not None:
+            f = self.site_tgt_freq(planes, tgt_freq, n_sites)
+            for s in range(n_sets):
+                eff = torch.where((out[s] & FLAG_INVERTED) != 0, 1.0 - f, f)
+                out[s] |= (((out[s] & FLAG_COND) != 0) & (eff > float(sets[s].x))).to(torch.uint8) * FLAG_UCAND
+        return out
+
+    def site_tgt_freq(self, planes, tgt_freq, n_sites: int):
+        """tgt_freq per SITE (f64 [n_sites], NaN where the pass stored nothing) from the packed slots of the
+        first call's "any" word (saihip.h) -- for tests; the windows stage reads the slots directly."""
+        torch = _torch()
+        n_tiles = int(planes.shape[0])
+        shifts = torch.arange(_ffi.SAI_TILE_SITES, dtype=torch.int64, device=planes.device)
+        stored = ((planes[:, 0].unsqueeze(1) >> shifts) & 1).to(torch.int64)  # [tiles][64]
+        slot = torch.cumsum(stored, dim=1) - stored + torch.arange(n_tiles, device=planes.device).unsqueeze(1) * _ffi.SAI_TILE_SITES
+        padded = torch.full((n_tiles * _ffi.SAI_TILE_SITES,), float("nan"), dtype=torch.float64, device=planes.device)
+        padded[: int(tgt_freq.numel())] = tgt_freq
+        out = torch.where(stored.bool(), padded[slot.clamp(max=padded.numel() - 1)], torch.full_like(padded, float("nan")).reshape(n_tiles, -1))
+        return out.reshape(-1)[: int(n_sites)].contiguous()
 
     def _pass_out(self, n_sites: int, n_sets: int, freq_mode: str):
         torch = _torch()

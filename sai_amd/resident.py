@@ -315,7 +315,11 @@ class ResidentScorer:
 
     def flag_bytes(self):
         """The most recent step's decisions as one byte per set and site (Engine.flag_bytes)."""
-        return self.eng.flag_bytes(self.flags, self.block.n_sites)
+        return self.eng.flag_bytes(self.flags, self.block.n_sites, self.sets, self.tgt_freq)
+
+    def site_tgt_freq(self):
+        """The most recent step's target frequencies per site (Engine.site_tgt_freq): NaN where none was stored."""
+        return self.eng.site_tgt_freq(self.flags, self.tgt_freq, self.block.n_sites)
 
     def window_stream(self):
         """Context manager selecting the stream on which window records are produced (for follow-up

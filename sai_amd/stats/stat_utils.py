@@ -81,7 +81,7 @@ def compute_matching_loci(
     prm = _ffi.make_params(w, 0.0, 0.5, y_list, anc_allele_available, n_src=n_eff)
     eng, _, planes, adj, _ = evaluate_sites(ref_gts, tgt_gts, src_gts_list, ploidy, [prm], want_adj=True)
     adj = adj.cpu().numpy()
-    cond = (eng.flag_bytes(planes, adj.shape[2])[0].cpu().numpy() & FLAG_COND).astype(bool)
+    cond = (eng.flag_bytes(planes, adj.shape[2], [prm])[0].cpu().numpy() & FLAG_COND).astype(bool)
     return adj[0, 0].copy(), adj[0, 1].copy(), cond
 
 

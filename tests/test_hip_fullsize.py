@@ -205,7 +205,7 @@ def test_c5_two_sources_sweep(eng):
     assert res.records.shape == (18, len(windows))
     lo64, hi64 = lo.to(torch.int64), hi.to(torch.int64)
     zero = torch.zeros(1, dtype=torch.int64, device=flags.device)
-    flag_bytes = eng.flag_bytes(flags, block.n_sites)
+    flag_bytes = eng.flag_bytes(flags, block.n_sites, sets, tgt_freq)
     for si in range(18):
         cu = torch.cat([zero, torch.cumsum(((flag_bytes[si] >> 1) & 1).to(torch.int64), 0)])
         assert (cu[hi64] - cu[lo64]).cpu().numpy().tolist() == res.records[si]["u_count"].tolist()

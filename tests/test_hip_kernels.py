@@ -269,17 +269,26 @@ def test_fused_site_pass_equals_two_kernels(eng):
             for a, b in ((tf, tf2), (tf, tf3)):
                 assert a.cpu().numpy().tobytes() == b.cpu().numpy().tobytes()
             assert torch.equal(fl, fl2) and torch.equal(fl, fl3) and torch.equal(counts, c3)
-            # SAI_FREQ_CANDIDATES: same flags; tgt_freq written exactly where a set has bit 0 up
+            # SAI_FREQ_CANDIDATES: same condition / inverted words; "any" = the OR of the conditions instead of
+            # all ones, and tgt_freq written for exactly those sites, packed at the start of each tile's slots
+            assert bool((fl[:, 0] == -1).all())
             sentinel = -7.25
             out = (torch.full_like(tf, sentinel), torch.zeros_like(fl))
             eng.site_pass(pops, pl, sets, out=out, freq_mode="candidates")
-            cand = ((eng.flag_bytes(fl, n_sites) & 1) != 0).any(dim=0)
-            assert torch.equal(out[1], fl) and (int(cand.sum()) < n_sites or n_sets == 18)
+            cand = ((eng.flag_bytes(fl, n_sites, sets) & 1) != 0).any(dim=0)
+            assert torch.equal(out[1][:, 1:], fl[:, 1:]) and (int(cand.sum()) < n_sites or n_sets == 18)
+            bits = (out[1][:, 0].unsqueeze(1) >> torch.arange(64, device=fl.device)) & 1
+            assert torch.equal(bits.reshape(-1)[:n_sites].bool(), cand)
             n_cand_seen += int(cand.sum())
-            assert out[0][cand].cpu().numpy().tobytes() == tf[cand].cpu().numpy().tobytes()
-            assert bool((out[0][~cand] == sentinel).all())
+            per_site = eng.site_tgt_freq(out[1], out[0], n_sites)
+            assert per_site[cand].cpu().numpy().tobytes() == tf[cand].cpu().numpy().tobytes()
+            assert bool(torch.isnan(per_site[~cand]).all())
+            n_tiles = (n_sites + 63) // 64
+            used = torch.zeros(n_tiles * 64, dtype=torch.bool, device=fl.device)
+            used.view(n_tiles, 64)[torch.arange(64, device=fl.device).unsqueeze(0) < bits.sum(dim=1, keepdim=True)] = True
+            assert bool((out[0][~used[:n_sites]] == sentinel).all())  # nothing written beyond a tile's packed slots
             tf4, fl4 = eng.site_pass(pops, pl, sets, freq_mode="candidates")  # fresh buffer: NaN elsewhere
-            assert torch.equal(fl4, fl) and bool(torch.isnan(tf4[~cand]).all())
+            assert torch.equal(fl4, out[1]) and bool(torch.isnan(eng.site_tgt_freq(fl4, tf4, n_sites)[~cand]).all())
     assert n_cand_seen > 0
     with pytest.raises(ValueError, match="at most"):
         eng.site_pass(pops, pl, sets * 2)
@@ -287,9 +296,11 @@ def test_fused_site_pass_equals_two_kernels(eng):
 
 @pytest.mark.parametrize("n_sites", [1, 63, 64, 65, 1000])
 def test_flag_planes_are_the_oracle_decisions_bit_for_bit(eng, n_sites):
-    """The documented plane layout (saihip.h): bit b of planes[t, 3 s + k] = site 64 t + b of set s;
-    k = 0 compute_matching_loci's condition, 1 condition and tgt_freq > x, 2 site inverted -- from the
-    stand-alone kernel, the fused pass and the packed2 pass alike, spare bits of the last tile 0."""
+    """The documented row layout (saihip.h): bit b of a word = site 64 t + b; word 0 "any" (all ones from
+    a dense pass), word 1 + s compute_matching_loci's condition of set s, word 1 + n + s site inverted (the
+    call has a set without ancestral alleles) -- from the stand-alone kernel, the fused pass and the packed2
+    pass alike, spare bits of the last tile 0; with ancestral alleles everywhere the inverted words do not
+    exist; and flag_bytes' U candidates are the oracle's."""
     from oracle import sai_oracle as O
     from sai_amd import _ffi
 
@@ -300,27 +311,36 @@ def test_flag_planes_are_the_oracle_decisions_bit_for_bit(eng, n_sites):
              (1.0, 0.0, [(">=", 0.0), (">=", 0.0)], False)]  # fmt: skip
     sets = [_ffi.make_params(w, x, 0.9, y, anc) for w, x, y, anc in specs]
     pops = [eng.tile(m) for m in mats]
-    _, planes, _ = eng.site_flags(eng.site_counts(pops), pl, sets)
+    tf, planes, _ = eng.site_flags(eng.site_counts(pops), pl, sets)
     assert tuple(planes.shape) == ((n_sites + 63) // 64, 9)
     _, fused = eng.site_pass(pops, pl, sets)
     _, packed = eng.site_pass_packed2([eng.pack2(p) for p in pops], pl, sets)
     words = planes.cpu().numpy().view(np.uint64)
     assert np.array_equal(words, fused.cpu().numpy().view(np.uint64)) and np.array_equal(words, packed.cpu().numpy().view(np.uint64))
+    assert np.all(words[:, 0] == np.uint64(0xFFFFFFFFFFFFFFFF)) and np.all(words[:, 7:] == 0)  # 1 + 2 * 3 words used
     site = np.arange(n_sites)
+    m64 = [m.astype(np.int64) for m in mats]
+    plain = [O.allele_freq(g, 2) for g in m64]
+    ok = np.all([np.isfinite(f) & (f >= 0) & (f <= 1) for f in plain], axis=0)
+    bytes_ = eng.flag_bytes(planes, n_sites, sets, tf).cpu().numpy()
     for s, (w, x, y, anc) in enumerate(specs):
-        m64 = [m.astype(np.int64) for m in mats]
-        _, tf, cond = O.matching_loci(m64[0], m64[1], m64[2:], w, y, pl, anc)
-        plain = [O.allele_freq(g, 2) for g in m64]
-        ok = np.all([np.isfinite(f) & (f >= 0) & (f <= 1) for f in plain], axis=0)
+        _, tfo, cond = O.matching_loci(m64[0], m64[1], m64[2:], w, y, pl, anc)
         mirror = np.all([O._COMPARE[op](f, 1 - yy) for f, (op, yy) in zip(plain[2:], y)], axis=0)
-        want = [cond, cond & (tf > x), np.zeros(n_sites, bool) if anc else (mirror & ok)]
-        for k in range(3):
-            got = (words[site // 64, 3 * s + k] >> (site % 64).astype(np.uint64)) & np.uint64(1)
-            assert np.array_equal(got.astype(bool), want[k]), (s, k)
+        want = {1 + s: cond, 1 + 3 + s: np.zeros(n_sites, bool) if anc else (mirror & ok)}
+        for k, bits in want.items():
+            got = (words[site // 64, k] >> (site % 64).astype(np.uint64)) & np.uint64(1)
+            assert np.array_equal(got.astype(bool), bits), (s, k)
             if n_sites % 64:  # spare bits of the last tile
-                assert int(words[-1, 3 * s + k]) >> (n_sites % 64) == 0
-    assert np.array_equal(eng.flag_bytes(planes, n_sites).cpu().numpy()[1] & 1, O.matching_loci(
-        mats[0].astype(np.int64), mats[1].astype(np.int64), [m.astype(np.int64) for m in mats[2:]], 0.9, specs[1][2], pl, False)[2])
+                assert int(words[-1, k]) >> (n_sites % 64) == 0
+        assert np.array_equal((bytes_[s] & 1).astype(bool), cond) and np.array_equal((bytes_[s] & 4).astype(bool), want[1 + 3 + s])
+        assert np.array_equal((bytes_[s] & 2).astype(bool), cond & (tfo > x)), s  # U's candidates (u_statistic.py:92)
+    # every set polarised by ancestral alleles: one word per set behind "any", no inverted words
+    anc_sets = [_ffi.make_params(w, x, 0.9, y, True) for w, x, y, _ in specs]
+    _, p2, _ = eng.site_flags(eng.site_counts(pops), pl, anc_sets)
+    _, f2 = eng.site_pass(pops, pl, anc_sets, freq_mode="candidates")
+    w2, wf2 = p2.cpu().numpy().view(np.uint64), f2.cpu().numpy().view(np.uint64)
+    assert np.all(w2[:, 4:] == 0) and np.array_equal(w2[:, 1:], wf2[:, 1:])
+    assert np.array_equal(wf2[:, 0], w2[:, 1] | w2[:, 2] | w2[:, 3])
 
 
 def test_window_ranges_outside_the_block_are_clamped(eng):
@@ -340,7 +360,7 @@ def test_window_ranges_outside_the_block_are_clamped(eng):
     hi = torch.tensor([3, 5, 5000, 1000, 2_100_000_000, 2_000_000_000], dtype=torch.int32, device=eng.device)
     res = eng.window_stats(tgt_freq, planes, sets, lo, hi)
     assert res.records[0]["n_sites"].tolist() == [3, 0, 100, 1000, 0, 1000]
-    cond = (eng.flag_bytes(planes, n)[0].cpu().numpy() & 1).astype(np.int64)
+    cond = (eng.flag_bytes(planes, n, sets)[0].cpu().numpy() & 1).astype(np.int64)
     ranges = [(0, 3), (10, 10), (900, 1000), (0, 1000), (1000, 1000), (0, 1000)]  # what the six clamp to
     assert res.records[0]["n_cond"].tolist() == [int(cond[a:b].sum()) for a, b in ranges] and cond.sum() > 900
     assert all(900 <= i < 1000 for i in res.q_list(0, 2).tolist()) and len(res.q_list(0, 2)) > 0
@@ -460,9 +480,10 @@ def test_packed2_layout_equals_int8_path(eng, sizes):
     eng.site_pass_packed2(packed, pl, [], counts=c3)
     assert torch.equal(counts, c3)
     tf4, fl4 = eng.site_pass_packed2(packed, pl, sets, freq_mode="candidates")
-    cand = ((eng.flag_bytes(fl, n_sites) & 1) != 0).any(dim=0)
-    assert torch.equal(fl4, fl) and tf4[cand].cpu().numpy().tobytes() == tf[cand].cpu().numpy().tobytes()
-    assert bool(torch.isnan(tf4[~cand]).all())
+    cand = ((eng.flag_bytes(fl, n_sites, sets) & 1) != 0).any(dim=0)
+    per_site = eng.site_tgt_freq(fl4, tf4, n_sites)
+    assert torch.equal(fl4[:, 1:], fl[:, 1:]) and per_site[cand].cpu().numpy().tobytes() == tf[cand].cpu().numpy().tobytes()
+    assert bool(torch.isnan(per_site[~cand]).all())
     bad = mats[0].copy()
     bad[3, 0] = 3
     with pytest.raises(ValueError, match="dosage above 2"):
