@@ -117,7 +117,7 @@ static int vcf_scan_impl(const char* path, const char* chrom, int64_t* first_pos
   TbiRef idx;
   if (file_is_bgzf(path) && load_tbi(path, c, idx)) {
     // indexed: the first record sits at the smallest chunk start, the last one inside the chunk that
-    // starts last -- two short reads instead of the whole file
+    // starts last / the last 16 kb window -- two short reads instead of the whole file
     if (idx.present && idx.first_voff != ~0ull) {
       int64_t lo = -1;
       int rc = for_each_block_from(path, 1, idx.first_voff, size_t(1) << 16, [&](const char* p, const char* end) -> int {
@@ -127,7 +127,11 @@ static int vcf_scan_impl(const char* path, const char* chrom, int64_t* first_pos
       if (rc) return rc;
       lo = first;
       first = -1;
-      rc = for_each_block_from(path, kScanThreads, idx.last_chunk_voff, size_t(4) << 20, scan);
+      // the last record lies behind the start of the chunk that starts last AND behind the first record of
+      // the last 16 kb window that holds one (the linear index's last entry) -- an index with one long
+      // chunk per chromosome would otherwise send this read back to the chromosome's first record
+      const uint64_t tail_voff = std::max(idx.last_chunk_voff, idx.ioff.empty() ? uint64_t{0} : idx.ioff.back());
+      rc = for_each_block_from(path, kScanThreads, tail_voff, size_t(4) << 20, scan);
       if (rc) return rc;
       if (lo >= 0 && last >= 0) {
         *first_pos = lo;

@@ -194,9 +194,11 @@ def test_bgzf_batches_and_damage(tmp_path, monkeypatch):
         load_dosage(str(bad), "21", names, [2] * len(names))
 
 
-def write_tbi(gz_path):
+def write_tbi(gz_path, one_chunk=False):
     """A tabix index (TBI, SAM/tabix spec) for a bgzip VCF written by ``write_bgzf``: bins with one
-    chunk each, the linear index with the htslib back-fill, plain-gzip compressed."""
+    chunk each, the linear index with the htslib back-fill, plain-gzip compressed.  ``one_chunk``: every
+    record of a chromosome in bin 0 -- one chunk from its first record to its last, as a coarse writer
+    may leave it (legal: a bin's chunk only has to cover the bin's records)."""
     import struct
     import zlib
 
@@ -238,7 +240,7 @@ def write_tbi(gz_path):
             order.append(name)
         r = refs[name]
         v0, v1 = voff(start_t), voff(t)
-        b = r["bins"].setdefault(reg2bin(beg, end), [v0, v1])
+        b = r["bins"].setdefault(0 if one_chunk else reg2bin(beg, end), [v0, v1])
         b[1] = v1
         for w in range(beg >> 14, ((end - 1) >> 14) + 1):
             r["lin"][w] = min(r["lin"].get(w, v0), v0)
@@ -294,6 +296,23 @@ def test_tabix_index_seek_equals_full_pass(tmp_path, monkeypatch):
     for chrom, reg in (("7", (5000, 40000)), ("22", (5000, 40000))):
         got = load_dosage(str(path), chrom, names, [2] * len(names), reg[0], reg[1], None, 3)
         assert np.array_equal(got[1], plain[chrom, reg][1])
+        assert scan_first_last(str(path), chrom) == plain[chrom, "scan"]  # two short reads, none of them near the damage
+    raw[victim + 30] ^= 0xFF
+    path.write_bytes(bytes(raw))  # intact again, to write the coarse index from it
+    write_tbi(path, one_chunk=True)
+    raw[victim + 30] ^= 0xFF
+    path.write_bytes(bytes(raw))
+    os.utime(str(path) + ".tbi")
+    # one chunk per chromosome: the last record is found through the linear index's last entry -- also for
+    # chromosome 21, whose chunk runs across the damaged member
+    for chrom in ("7", "21", "22"):
+        assert scan_first_last(str(path), chrom) == plain[chrom, "scan"], chrom
+    raw[victim + 30] ^= 0xFF
+    path.write_bytes(bytes(raw))
+    write_tbi(path)
+    raw[victim + 30] ^= 0xFF
+    path.write_bytes(bytes(raw))
+    os.utime(str(path) + ".tbi")
     # an index older than the file is not trusted: the full pass runs and meets the damaged block
     st = os.stat(path)
     os.utime(str(path) + ".tbi", (st.st_atime - 100, st.st_mtime - 100))
