@@ -421,6 +421,60 @@ def test_randomized_windows_against_oracle(eng):
                 assert res.q_list(si, wi).tolist() == np.asarray(eq["cdd_pos"]).astype(np.int64).tolist()
 
 
+@pytest.mark.parametrize("n_sets,polarised", [(20, "none"), (20, "all"), (27, "first chunk only"), (27, "second chunk only"), (45, "mixed")])
+def test_rows_of_many_sets_and_both_polarity_modes(eng, n_sets, polarised):
+    """A full row (20 sets: 1 + 20 condition words, + 20 inverted words when a set lacks ancestral alleles)
+    and sets beyond SAI_MAX_SETS evaluated in several calls whose rows differ in shape -- whether a chunk's
+    rows carry inverted words is decided per call, by its own sets, in the call that writes and in the call
+    that reads.  Fused pass (<= 20 sets), site_flags + window_stats, and a ResidentScorer; every record and
+    list against the oracle."""
+    from oracle import sai_oracle as O
+    from sai_amd import _ffi
+    from sai_amd.resident import ResidentBlock, ResidentScorer
+
+    rng = np.random.default_rng(n_sets * 7 + len(polarised))
+    n_sites, sizes, pl = 700, [11, 9, 1, 2], [2, 2, 2, 1]
+    p = rng.random(n_sites) ** 2
+    mats = []
+    for n, ploidy in zip(sizes, pl):
+        g = rng.binomial(ploidy, np.broadcast_to(p[:, None], (n_sites, n))).astype(np.int64)
+        g[rng.random(n_sites) < 0.25] = ploidy * int(rng.integers(0, 2))
+        g[rng.random(g.shape) < 0.02] = -ploidy
+        mats.append(g)
+    pos = np.cumsum(rng.integers(1, 60, n_sites)).astype(np.int64)
+    windows = O.split_windows(pos, 4000, 1500)
+    anc_of = {"none": lambda s: False, "all": lambda s: True, "first chunk only": lambda s: s < 20,
+              "second chunk only": lambda s: s >= 20, "mixed": lambda s: s % 3 != 0}[polarised]
+    ops = ["=", "<", ">", "<=", ">="]
+    specs = [dict(w=float(rng.choice([0.3, 0.6, 1.0])), x=float(rng.choice([0.0, 0.2, 0.5])), quantile=float(rng.choice([0.5, 0.9, 1.0])),
+                  y_list=[(str(rng.choice(ops)), float(rng.choice([0.0, 0.5, 1.0]))) for _ in range(2)], anc=anc_of(s))
+             for s in range(n_sets)]  # fmt: skip
+    sets = [_ffi.make_params(s["w"], s["x"], s["quantile"], s["y_list"], s["anc"]) for s in specs]
+    ws, we = np.array([w[0] for w in windows]), np.array([w[1] for w in windows])
+    res, lo, hi = _window_pass(eng, mats, pl, sets, pos, ws, we)
+    import torch
+
+    pops = [eng.tile(m) for m in mats]
+    block = ResidentBlock(pops, pl, torch.as_tensor(pos.astype(np.int32)).to(eng.device))
+    scorer = ResidentScorer(eng, block, windows, sets, cap_u=1 << 12, cap_q=1 << 12)
+    assert scorer.fused == (n_sets <= _ffi.SAI_FUSED_SETS)
+    scorer.step()
+    res2 = scorer.results(grow=True)
+    for r in (res, res2):
+        for si, s in enumerate(specs):
+            for wi, (a, b) in enumerate(windows):
+                m = (pos >= a) & (pos <= b)
+                kw = dict(ref_gts=mats[0][m], tgt_gts=mats[1][m], src_gts_list=[g[m] for g in mats[2:]], ref_ploidy=pl[0],
+                          tgt_ploidy=pl[1], src_ploidy_list=pl[2:], pos=pos[m], w=s["w"], y_list=s["y_list"],
+                          anc_allele_available=s["anc"])  # fmt: skip
+                eu, eq = O.u_stat(x=s["x"], **kw), O.q_stat(quantile=s["quantile"], **kw)
+                rec = r.records[si, wi]
+                assert rec["u_count"] == eu["value"] and r.u_list(si, wi).tolist() == eu["cdd_pos"].tolist(), (si, wi)
+                assert same_f64(rec["q"], eq["value"]), (si, wi)
+                assert r.q_list(si, wi).tolist() == np.asarray(eq["cdd_pos"]).astype(np.int64).tolist()
+    assert int(res.records["u_count"].sum()) > 0 and np.isfinite(res.records["q"]).any()
+
+
 @pytest.mark.parametrize("sizes", [[1, 1, 1], [64, 65, 2], [200, 129, 1, 3], [1000, 1008, 2], [4097, 513, 2], [17, 33, 49, 128]])
 def test_packed2_layout_equals_int8_path(eng, sizes):
     """The optional 2-bit layout: packing is exact, the packed site pass gives the same counts,
