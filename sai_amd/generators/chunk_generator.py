@@ -15,9 +15,11 @@ class ChunkGenerator(DataGenerator):
     ``{"chr_name", "start", "end"}`` = first window's start .. last window's end.  The same
     rule shards windows over GPUs (sai_amd.distributed)."""
 
-    def __init__(self, vcf_file: str, chr_name: str, step_size: int, window_size: int, num_chunks: int):
+    def __init__(self, vcf_file: str, chr_name: str, step_size: int, window_size: int, num_chunks: int, span=None):
+        """``span`` = (first, last) position of the chromosome when the caller already has it (``score``
+        scans a plain-text file while it is being read)."""
         chr_name = str(chr_name)
-        first, last = scan_first_last(vcf_file, chr_name)
+        first, last = scan_first_last(vcf_file, chr_name) if span is None else span
         if first is None:
             raise ValueError(f"Chromosome {chr_name} not found in VCF.")  # chunk_generator.py:75-76
         self.windows = split_genome([first, last], window_size, step_size)

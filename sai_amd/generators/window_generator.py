@@ -55,10 +55,13 @@ class WindowGenerator(DataGenerator):
         anc_allele_file: str = None,
         num_src: int = 1,
         resident: bool = False,
+        preloaded=None,
     ):
         """``resident=True`` (the batched GPU driver, ChunkPreprocessor): the region is streamed to
         the GPU and tokenised there, the populations exist only as tiled blocks in HBM and ``get()``
-        is not available; otherwise the populations are host matrices, as in the reference."""
+        is not available; otherwise the populations are host matrices, as in the reference.
+        ``preloaded`` = what ``read_data_device`` returned for exactly this region (the caller read it
+        before it knew the chunk bounds, ChunkPreprocessor.preload)."""
         if win_len <= 0:
             raise ValueError("`win_len` must be greater than 0.")
         if win_step < 0:
@@ -69,7 +72,9 @@ class WindowGenerator(DataGenerator):
                   tgt_ind_file=tgt_ind_file, src_ind_file=src_ind_file, out_ind_file=out_ind_file,
                   ploidy_config=ploidy_config, anc_allele_file=anc_allele_file)  # fmt: skip
         pos_dev = None
-        if resident:
+        if preloaded is not None:
+            results, pos_dev = preloaded
+        elif resident:
             from ..engine import Engine
             from ..utils.read_data import read_data_device
 

@@ -49,10 +49,31 @@ class ChunkPreprocessor(DataPreprocessor):
         """Items of all windows of [start, end] (chunk_preprocessor.py:105-147)."""
         return self.feature_preprocessor.items_from_batch(self.run_compact(chr_name, start, end))
 
-    def run_compact(self, chr_name: str, start: int, end: int):
+    def preload(self, chr_name: str):
+        """Every record of the chromosome, read and tokenised into HBM before the chunk bounds are known
+        (``read_data_device`` without a region): ``(results, pos_dev, (lowest, highest position))``, the
+        span None when nothing was kept.  ``run_compact(..., preloaded=)`` takes it when the chunk turns
+        out to contain all of it."""
+        from ..engine import Engine
+        from ..utils.read_data import read_data_device
+
+        results, pos_dev = read_data_device(
+            Engine.get(), vcf_file=self.vcf_file, chr_name=chr_name, start=None, end=None, ref_ind_file=self.ref_ind_file,
+            tgt_ind_file=self.tgt_ind_file, src_ind_file=self.src_ind_file, out_ind_file=self.out_ind_file,
+            ploidy_config=self.ploidy_config, anc_allele_file=self.anc_allele_file)  # fmt: skip
+        span = None
+        for data, _ in (results.get(g, (None, None)) for g in ("ref", "tgt", "src", "outgroup")):
+            for block in (data or {}).values():
+                if block.POS.size:
+                    lo, hi = int(block.POS.min()), int(block.POS.max())
+                    span = (lo, hi) if span is None else (min(span[0], lo), max(span[1], hi))
+        return results, pos_dev, span
+
+    def run_compact(self, chr_name: str, start: int, end: int, preloaded=None):
         """The same work unit in numeric form (a ``WindowBatch``): what a rank of a sharded run
         computes and sends to rank 0, where ``unpack_results`` turns the batches into items."""
         window_generator = WindowGenerator(
+            preloaded=preloaded,
             vcf_file=self.vcf_file,
             chr_name=chr_name,
             start=start,

@@ -77,6 +77,41 @@ def chunk_preprocessor_for(cfg: GlobalConfig, vcf_file, win_len, win_step, outpu
                              output_file, cfg.ploidies, cfg.statistics, anc_allele_file=anc_allele_file)  # fmt: skip
 
 
+def _reads_in_one_pass(vcf_file: str) -> bool:
+    """A plain-text VCF on a machine with a GPU: the chromosome's first and last position (a host scan of
+    the file, chunk_generator.py:64-82) are found WHILE the one streaming read fills HBM -- the scan was 10
+    of the 24 ms of a 482 MB file.  Compressed files keep the order scan, then read: an indexed one scans
+    two records, and the scan of an unindexed bgzip file is itself a pass of the GPU reader."""
+    if str(vcf_file).endswith((".gz", ".bgz")) or os.environ.get("SAI_AMD_INGEST", "device") == "host":
+        return False
+    if os.environ.get("SAI_AMD_ONE_PASS", "1") == "0" or not os.path.isfile(vcf_file):
+        return False
+    try:
+        import torch
+
+        return bool(torch.cuda.is_available())
+    except ImportError:
+        return False
+
+
+def _scan_while_reading(driver: ChunkPreprocessor, vcf_file: str, chr_name: str):
+    """((first, last) of the scan, what ``ChunkPreprocessor.preload`` read meanwhile or None).  The scan's
+    answer decides: a chromosome it does not find is reported as ``ChunkGenerator`` reports it, and a
+    read that failed is left to be repeated -- and to fail with its own message -- in the usual order."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    from .utils.native_vcf import scan_first_last
+
+    with ThreadPoolExecutor(1) as pool:
+        scan = pool.submit(scan_first_last, vcf_file, chr_name)  # host threads inside libsaihip; the GIL is released
+        try:
+            preloaded = driver.preload(chr_name)
+        except Exception:  # noqa: BLE001 -- repeated by run_compact without the preload
+            preloaded = None
+        span = scan.result()
+    return span, preloaded
+
+
 def score(vcf_file: str, chr_name: str, win_len: int, win_step: int, anc_allele_file: str, output_file: str, config: str,
           num_workers: int) -> None:  # fmt: skip
     """Sliding-window scores of one chromosome, written as the reference writes them (TSV +
@@ -85,12 +120,20 @@ def score(vcf_file: str, chr_name: str, win_len: int, win_step: int, anc_allele_
     (``sai_amd.distributed.score_sharded`` under torchrun shards window ranges over several GPUs)."""
     cfg = load_config(config)
     require_polarised_input(cfg.statistics, anc_allele_file)
-    chunks = ChunkGenerator(vcf_file=vcf_file, chr_name=chr_name, window_size=win_len, step_size=win_step, num_chunks=1)
     driver = chunk_preprocessor_for(cfg, vcf_file, win_len, win_step, output_file, anc_allele_file)
+    span, preloaded = None, None
+    if _reads_in_one_pass(vcf_file):
+        span, preloaded = _scan_while_reading(driver, vcf_file, str(chr_name))
+    chunks = ChunkGenerator(vcf_file=vcf_file, chr_name=chr_name, window_size=win_len, step_size=win_step, num_chunks=1,
+                            span=span)  # fmt: skip
     write_headers(output_file, cfg.statistics, cfg.ploidies)
     # numeric batches -> text, natively; the item-dictionary route (driver.run + process_items)
     # writes the same bytes and stays what plug-ins and the sharded executors use
-    driver.write_results([driver.run_compact(**chunk) for chunk in chunks.get()])
+    batches = []
+    for chunk in chunks.get():
+        fits = preloaded is not None and (preloaded[2] is None or (chunk["start"] <= preloaded[2][0] and preloaded[2][1] <= chunk["end"]))
+        batches.append(driver.run_compact(**chunk, preloaded=preloaded[:2] if fits else None))
+    driver.write_results(batches)
     if os.environ.get("SAI_AMD_KEEP_INGEST_BUFFERS", "1") == "0":
         # the readers' staging (about 650 MB of HBM + 125 MB pinned for a large bgzip file) is kept for the
         # next call by default -- allocating and page-locking it costs more than a small `score`

@@ -125,6 +125,56 @@ def test_score_example_vcf(in_repo_root, tmp_path):
     assert res[0]["Q"] == 0.9 and res[0]["U"] == 1 and res[0]["cdd_pos"]["U"].tolist() == [777]
 
 
+def test_score_reads_a_plain_file_once(in_repo_root, tmp_path, monkeypatch):
+    """A plain-text VCF is scanned for the chromosome's span WHILE it is read (sai._scan_while_reading):
+    same bytes as scan-then-read, with and without ancestral alleles; the chunk takes the preloaded blocks
+    only when it contains all of them -- a chromosome that returns later in the file, beyond the span of
+    its first run (chunk_generator.py:64-73 stops at the first run), is read again by region."""
+    from sai_amd.preprocessors import ChunkPreprocessor
+    from sai_amd.sai import score
+
+    taken = []
+    real = ChunkPreprocessor.run_compact
+
+    def spy(self, chr_name, start, end, preloaded=None):
+        taken.append(preloaded is not None)
+        return real(self, chr_name, start, end, preloaded=preloaded)
+
+    monkeypatch.setattr(ChunkPreprocessor, "run_compact", spy)
+
+    def both(vcf, chrom, anc, tag):
+        outs = []
+        for one_pass in ("1", "0"):
+            monkeypatch.setenv("SAI_AMD_ONE_PASS", one_pass)
+            out = tmp_path / f"{tag}_{one_pass}.tsv"
+            score(vcf_file=str(vcf), chr_name=chrom, win_len=10000, win_step=5000, anc_allele_file=anc, output_file=str(out),
+                  config="tests/data/test.uq.config.yaml", num_workers=1)  # fmt: skip
+            outs.append([out.read_bytes(), out.with_suffix(".U.log").read_bytes(), out.with_suffix(".Q.log").read_bytes()])
+        assert outs[0] == outs[1] and outs[0][0].count(b"\n") > 3, tag
+        return taken[-2:]
+
+    assert both("tests/data/test.data.vcf", "21", None, "plain") == [True, False]
+    assert both("tests/data/test.data.vcf", "21", "tests/data/test.anc.allele.bed", "anc") == [True, False]
+    # the chromosome's records once more behind another chromosome, at positions beyond the first run's
+    lines = open("tests/data/test.data.vcf").read().splitlines(keepends=True)
+    head = [ln for ln in lines if ln.startswith("#")]
+    recs = [ln for ln in lines if not ln.startswith("#") and ln.split("\t", 1)[0] == "21"]
+    last = int(recs[-1].split("\t")[1])
+    other = [ln.replace("21\t", "22\t", 1) for ln in recs[:5]]
+    again = []
+    for k, ln in enumerate(recs[:40]):
+        f = ln.split("\t")
+        f[1] = str(last + 100_000 + 10 * k)
+        again.append("\t".join(f))
+    two_runs = tmp_path / "two_runs.vcf"
+    two_runs.write_text("".join(head + recs + other + again))
+    assert both(two_runs, "21", None, "runs") == [False, False]
+    with pytest.raises(ValueError, match="Chromosome 9 not found"):
+        monkeypatch.setenv("SAI_AMD_ONE_PASS", "1")
+        score(vcf_file="tests/data/test.data.vcf", chr_name="9", win_len=10000, win_step=5000, anc_allele_file=None,
+              output_file=str(tmp_path / "none.tsv"), config="tests/data/test.uq.config.yaml", num_workers=1)  # fmt: skip
+
+
 def test_score_mixed_ploidy_with_anc_alleles(in_repo_root, tmp_path):
     """tests/test_sai.py:127-151: gz VCF, tetraploid targets/sources, two sources, polarised:
     U of the two rows = 0 and 1 (the df columns of that test are outside this path)."""
