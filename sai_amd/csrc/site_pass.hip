@@ -63,12 +63,15 @@ static_assert(sizeof(CountsArgs) + sizeof(FusedArgs) <= 4096, "kernel arguments 
 // MULTI: some population has more than 16 * kChunkIters individuals, so the packed fields are
 // widened several times per population (keeps 32 more registers live across the load loop).
 // FUSED: evaluate the parameter sets at the end of each tile (site_flags folded in).
+// The second launch bound keeps the usual form at 5 waves per SIMD (<= 96 VGPRs): four resident waves of
+// more than that leave the windows stage's waves no room next to the pass, and the pipelined step loses
+// what the overlap gives (measured at 99 VGPRs: C5 3.63 -> 3.79 ms per step).
 template <bool MULTI, bool FUSED>
 __global__ __launch_bounds__(64, MULTI ? 4 : 5) void site_counts_kernel(CountsArgs a, FusedArgs fa) {
   // FUSED: the butterfly leaves lane l with site (l%4)*16 + l/4 of the tile; each lane parks those
   // {alt_sum, n_called} per population in LDS AT ITS SITE'S INDEX, and once all populations of the
   // tile are done lane l takes site l back and evaluates the parameter sets for it -- lanes in site
-  // order, so three ballots per set are the tile's flag planes and tgt_freq is stored coalesced
+  // order, so the ballots per set are the tile's flag planes and the candidates' tgt_freq leave packed
   __shared__ uint2 stash[FUSED ? kMaxPops : 1][FUSED ? 64 : 1];
   const int lane = threadIdx.x;
   const int r = lane >> 2;
