@@ -304,6 +304,43 @@ def test_score_config_errors_without_gpu(in_repo_root, tmp_path):
         score(config="tests/data/test_mixed_ploidy.config.yaml", **kw)
 
 
+def test_score_takes_the_preloaded_blocks_only_when_the_chunk_holds_them(in_repo_root, tmp_path, monkeypatch):
+    """Host logic of ``score``'s one-pass order for a plain-text file (sai._scan_while_reading), with the
+    GPU reader stood in for: the scan's span lays out the chunk; the blocks read meanwhile are handed to
+    ``run_compact`` when every kept position lies inside the chunk, not otherwise; a read that failed is
+    repeated in the usual order; a chromosome the scan does not find is ChunkGenerator's error."""
+    from sai_amd import sai as sai_mod
+    from sai_amd.preprocessors import ChunkPreprocessor
+
+    calls = []
+    monkeypatch.setattr(sai_mod, "_reads_in_one_pass", lambda vcf: True)
+    monkeypatch.setattr(ChunkPreprocessor, "write_results", lambda self, batches: calls.append(("write", len(batches))))
+    monkeypatch.setattr(ChunkPreprocessor, "run_compact",
+                        lambda self, chr_name, start, end, preloaded=None: calls.append(("run", start, end, preloaded)) or "batch")  # fmt: skip
+    kw = dict(vcf_file="tests/data/test.data.vcf", win_len=10000, win_step=5000, anc_allele_file=None,
+              output_file=str(tmp_path / "o.tsv"), config="tests/data/test.uq.config.yaml", num_workers=1)  # fmt: skip
+
+    def preload_with(span):
+        def preload(self, chr_name):
+            if span == "fails":
+                raise ValueError("reader says no")
+            return {"ref": "blocks"}, "pos_dev", span
+        return preload
+
+    for span, want in (((2309, 48989), ({"ref": "blocks"}, "pos_dev")), (None, ({"ref": "blocks"}, "pos_dev")),
+                       ((2309, 200_000), None), ((1, 48989), ({"ref": "blocks"}, "pos_dev")), ((0, 48989), None), ("fails", None)):  # fmt: skip
+        calls.clear()
+        monkeypatch.setattr(ChunkPreprocessor, "preload", preload_with(span))
+        sai_mod.score(chr_name="21", **kw)
+        assert calls == [("run", 1, 55000, want), ("write", 1)], span  # chr 21: 2309 .. 48989 -> windows 1 .. 55000
+    with pytest.raises(ValueError, match="Chromosome 9 not found in VCF"):
+        sai_mod.score(chr_name="9", **kw)
+    monkeypatch.setattr(sai_mod, "_reads_in_one_pass", lambda vcf: False)  # compressed file / no GPU: scan, then read
+    calls.clear()
+    sai_mod.score(chr_name="21", **kw)
+    assert calls == [("run", 1, 55000, None), ("write", 1)]
+
+
 def test_cli_parser(in_repo_root):
     import argparse
 
