@@ -451,24 +451,12 @@ def self_launch(n_ranks: int, argv: list, result_out, script: str = "") -> int:
     ranks as ONE child process tree (`python -m torch.distributed.run ... bench.py <same arguments>`,
     one rank per GPU, rendezvous on 127.0.0.1) whose stdout is this process's stdout, and return the
     child's exit code.  Nothing here touches the GPU -- no torch.cuda call, no library context -- and
-    the child is started with subprocess, never exec'd over this process.  The reference starts its
-    workers the same way from the parent that owns the task list (mp_pool.py:45-73)."""
-    import socket
-    import subprocess
+    the child is started with subprocess, never exec'd over this process.  The same launcher starts the
+    ranks of `sai score --num-workers N` (sai_amd/launcher.py); the reference starts its workers the
+    same way from the parent that owns the task list (mp_pool.py:45-73)."""
+    from sai_amd.launcher import launch_ranks
 
-    import __graft_entry__ as entry
-
-    entry.build()  # once, before N ranks would all find the tree stale
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_ranks}",
-           "--master-addr", "127.0.0.1", "--master-port", str(port), script or str(Path(__file__).resolve()), *argv]  # fmt: skip
-    result_out.flush()
-    child = subprocess.run(cmd, stdout=result_out.fileno(), cwd=str(ROOT))
-    if child.returncode != 0:
-        print(f"bench.py: the {n_ranks}-rank child job exited with {child.returncode}", file=sys.stderr)
-    return child.returncode
+    return launch_ranks(n_ranks, argv, script=script or str(Path(__file__).resolve()), stdout=result_out, who="bench.py")
 
 
 def main() -> None:

@@ -22,22 +22,54 @@ def env_rank_world() -> tuple[int, int, int]:
     return int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
 
 
-def init_process_group(backend: Optional[str] = None) -> tuple[int, int]:
-    """Join the default group when launched under torchrun; returns (rank, world_size)."""
+_STATUS_GROUP = None  # host-side (gloo) group of the same ranks, for the failure report of run_sharded
+
+
+def init_process_group(backend: Optional[str] = None, force: bool = False) -> tuple[int, int]:
+    """Join the default group when launched under torchrun; returns (rank, world_size).  ``force``
+    joins even as the only rank (the collectives then really run: tests of the RCCL calls on one GPU).
+
+    With RCCL as the data backend a second, gloo group of the same ranks is made for the status
+    exchange of ``run_sharded``: a rank that failed in a HIP / RCCL call must not report that through
+    another collective on the communicator and device that just failed."""
+    import datetime
+
     import torch
     import torch.distributed as dist
 
+    global _STATUS_GROUP
     rank, local_rank, world = env_rank_world()
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force) and not dist.is_initialized():
         if backend is None:  # SAI_AMD_DIST_BACKEND=gloo: several ranks on one GPU (tests, rehearsals)
             backend = os.environ.get("SAI_AMD_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29541")
+        timeout = datetime.timedelta(minutes=float(os.environ.get("SAI_AMD_DIST_TIMEOUT_MIN", "30")))
         if backend == "nccl":
+            n_dev = torch.cuda.device_count()
+            if local_rank >= n_dev:
+                raise RuntimeError(
+                    f"rank {rank} (local rank {local_rank}) has no GPU of its own: {n_dev} device(s) visible; one worker "
+                    "process per GPU (SAI_AMD_DIST_BACKEND=gloo lets several ranks share a device for rehearsals)"
+                )
             torch.cuda.set_device(local_rank)
-            dist.init_process_group(backend=backend, rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+            dist.init_process_group(backend=backend, rank=rank, world_size=world, timeout=timeout,
+                                    device_id=torch.device("cuda", local_rank))  # fmt: skip
+            _STATUS_GROUP = dist.new_group(backend="gloo", timeout=timeout)
         else:
-            dist.init_process_group(backend=backend, rank=rank, world_size=world)
+            if torch.cuda.is_available():  # ranks sharing a box's devices round-robin (one GPU: all on it)
+                torch.cuda.set_device(local_rank % torch.cuda.device_count())
+            dist.init_process_group(backend=backend, rank=rank, world_size=world, timeout=timeout)
     return rank, world
+
+
+def shutdown_process_group() -> None:
+    import torch.distributed as dist
+
+    global _STATUS_GROUP
+    if dist.is_available() and dist.is_initialized():
+        _STATUS_GROUP = None
+        dist.destroy_process_group()
 
 
 def my_chunk_indices(n_chunks: int, rank: int, world: int) -> range:
@@ -102,15 +134,21 @@ class ShardFailure(RuntimeError):
 
 
 def _failed_ranks(i_failed: bool, group=None) -> list:
-    """Ranks that report a failure (one small all_gather: every rank takes part, failed or not)."""
+    """Ranks that report a failure (one small all_gather: every rank takes part, failed or not).  Always
+    on host tensors: over the gloo side group when the data backend is RCCL (``init_process_group``)."""
     import torch
     import torch.distributed as dist
 
-    world = dist.get_world_size(group)
-    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+    status_group, dev = group, torch.device("cpu")
+    if dist.get_backend(group) == "nccl":
+        if group is None and _STATUS_GROUP is not None:
+            status_group = _STATUS_GROUP
+        else:  # a caller's own RCCL group without a host-side twin: the report has to travel on it
+            dev = torch.device("cuda", torch.cuda.current_device())
+    world = dist.get_world_size(status_group)
     mine = torch.tensor([1 if i_failed else 0], dtype=torch.int32, device=dev)
     every = [torch.zeros_like(mine) for _ in range(world)]
-    dist.all_gather(every, mine, group=group)
+    dist.all_gather(every, mine, group=status_group)
     return [r for r, t in enumerate(every) if int(t.item())]
 
 
@@ -145,7 +183,7 @@ def run_sharded(data_processor, data_generator, group=None, as_items: bool = Tru
     error, mine = None, []
     try:
         mine = [compute(**tasks[i]) for i in my_chunk_indices(len(tasks), rank, world)]
-    except Exception as exc:  # noqa: BLE001 - re-raised below, after the status exchange
+    except BaseException as exc:  # noqa: BLE001 - any way out (KeyboardInterrupt, SystemExit too): re-raised below, after the status exchange
         error = exc
     failed = _failed_ranks(error is not None, group)
     if failed:
@@ -273,7 +311,7 @@ def score_sharded(vcf_file: str, chr_name: str, win_len: int, win_step: int, anc
         dist.barrier()
     try:
         return run_sharded(preprocessor, generator, as_items=False)
-    except Exception:
+    except BaseException:
         if rank == 0:  # a header-only TSV and empty logs would look like a finished run without windows
             from pathlib import Path
 

@@ -5,6 +5,7 @@ from __future__ import annotations
 
 import argparse
 
+from ..launcher import workers_from_env
 from ..sai import score
 from .argument_validation import existed_file, positive_int
 
@@ -18,7 +19,7 @@ def _run_score(args: argparse.Namespace) -> None:
         anc_allele_file=args.anc_alleles,
         output_file=args.output,
         config=args.config,
-        num_workers=1,
+        num_workers=args.num_workers,
     )
 
 
@@ -38,4 +39,8 @@ def add_score_parser(subparsers) -> None:
     parser.add_argument("--config", type=existed_file, required=True,
                         help="Path to the YAML configuration file specifying the statistics to compute, ploidy "
                         "settings, and population group file paths.")  # fmt: skip
+    # not a flag of the reference, whose CLI passes num_workers=1 (score_parser.py:64): the number of GPUs,
+    # one worker process each (sai.py:42); the default, 1, is the reference's behaviour
+    parser.add_argument("--num-workers", dest="num_workers", type=positive_int, default=workers_from_env(),
+                        help="Number of GPUs to use, one worker process per GPU. Default: $SAI_AMD_GPUS, else 1.")  # fmt: skip
     parser.set_defaults(runner=_run_score)

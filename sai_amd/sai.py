@@ -112,12 +112,57 @@ def _scan_while_reading(driver: ChunkPreprocessor, vcf_file: str, chr_name: str)
     return span, preloaded
 
 
+def _score_over_ranks(vcf_file, chr_name, win_len, win_step, anc_allele_file, output_file, config) -> None:
+    """This process is one rank of a launched job: take the sharded route and leave the group cleanly."""
+    from .distributed import score_sharded, shutdown_process_group
+    from .launcher import chunks_per_worker
+
+    try:
+        score_sharded(vcf_file, chr_name, win_len, win_step, anc_allele_file, output_file, config,
+                      chunks_per_rank=chunks_per_worker())  # fmt: skip
+    finally:
+        shutdown_process_group()
+
+
+def _score_cli_arguments(vcf_file, chr_name, win_len, win_step, anc_allele_file, output_file, config, num_workers) -> list:
+    argv = ["score", "--vcf", vcf_file, "--chr-name", chr_name, "--win-len", win_len, "--win-step", win_step,
+            "--output", output_file, "--config", config, "--num-workers", num_workers]  # fmt: skip
+    if anc_allele_file is not None:
+        argv += ["--anc-alleles", anc_allele_file]
+    return [str(a) for a in argv]
+
+
 def score(vcf_file: str, chr_name: str, win_len: int, win_step: int, anc_allele_file: str, output_file: str, config: str,
           num_workers: int) -> None:  # fmt: skip
     """Sliding-window scores of one chromosome, written as the reference writes them (TSV +
-    ``.U.log`` + ``.Q.log``; interface of sai.py:33-42).  ``num_workers`` is accepted for signature
-    compatibility: the windows of the chromosome are computed in batched GPU launches by one process
-    (``sai_amd.distributed.score_sharded`` under torchrun shards window ranges over several GPUs)."""
+    ``.U.log`` + ``.Q.log``; interface of sai.py:33-42).
+
+    ``num_workers`` is the reference's worker-process count (sai.py:42, grain ``num_workers * 8`` chunks at
+    :91) with one process per GPU: 1 computes every window in this process; N > 1 starts N ranks as a
+    child job (``sai_amd.launcher``: before this process has touched the GPU) whose ranks cut the window
+    list into ``N * 8`` ChunkGenerator chunks, each rank reading and scoring its own contiguous share on
+    its own GPU, with one final gather to rank 0, which writes the files -- byte-identical to the
+    one-process files for any N (``sai_amd.distributed.score_sharded``).  Inside such a job
+    (``WORLD_SIZE`` > 1: torchrun's environment) the call IS a rank and takes the sharded route."""
+    from . import launcher
+
+    num_workers = 1 if num_workers is None else int(num_workers)
+    if num_workers < 1:
+        raise ValueError("`num_workers` must be a positive integer.")
+    if launcher.in_rank_job():
+        _score_over_ranks(vcf_file, chr_name, win_len, win_step, anc_allele_file, output_file, config)
+        return
+    if num_workers > 1:
+        # the errors a one-process run raises before any work (configuration, polarisation) are raised here,
+        # by the caller's own process, not as a failed child job
+        cfg = load_config(config)
+        require_polarised_input(cfg.statistics, anc_allele_file)
+        rc = launcher.launch_ranks(
+            num_workers, _score_cli_arguments(vcf_file, chr_name, win_len, win_step, anc_allele_file, output_file, config, num_workers),
+            module="sai_amd", who="sai score")  # fmt: skip
+        if rc != 0:
+            raise launcher.RankJobFailed(num_workers, rc)
+        return
     cfg = load_config(config)
     require_polarised_input(cfg.statistics, anc_allele_file)
     driver = chunk_preprocessor_for(cfg, vcf_file, win_len, win_step, output_file, anc_allele_file)

@@ -385,3 +385,101 @@ def test_bench_default_line_has_the_contract_fields():
     sp = line["score_path"]
     assert sp["windows"] == line["config"]["windows_total"] and sp["value"] > 0
     assert sp["item_protocol"]["same_bytes_as_native"] is True
+
+
+# ---- the product entry point over several worker processes ----------------------------
+
+
+def _sai_score(args, out, workers, env_extra=None):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(env_extra or {})
+    res = subprocess.run([sys.executable, "-m", "sai_amd", "score", *args, "--output", str(out), "--num-workers", str(workers)],
+                         cwd=str(ROOT), env=env, capture_output=True, text=True, timeout=900)  # fmt: skip
+    assert res.returncode == 0, res.stderr[-3000:]
+    return res
+
+
+SCORE_INPUTS = {
+    "plain": ["--vcf", "tests/data/test.data.vcf", "--chr-name", "21", "--win-len", "10000", "--win-step", "5000",
+              "--config", "tests/data/test.uq.config.yaml"],  # fmt: skip
+    "bgzip+tbi": ["--vcf", "{tmp}/indexed.vcf.gz", "--chr-name", "21", "--win-len", "10000", "--win-step", "5000",
+                  "--config", "tests/data/test.uq.config.yaml"],  # fmt: skip
+    "outgroup": ["--vcf", "tests/data/test.with.outgroup.vcf.gz", "--chr-name", "1", "--win-len", "8000", "--win-step", "4000",
+                 "--anc-alleles", "tests/data/test.with.outgroup.anc.alleles", "--config", "tests/data/test.with.outgroup.config.yaml"],  # fmt: skip
+    "mixed ploidy": ["--vcf", "tests/data/test.mixed.ploidy.data.vcf.gz", "--chr-name", "21", "--win-len", "10000", "--win-step", "5000",
+                     "--anc-alleles", "tests/data/test.mixed.ploidy.data.anc.alleles", "--config", "tests/data/test_mixed_ploidy.config.yaml"],  # fmt: skip
+}
+
+
+@pytest.mark.parametrize("case", list(SCORE_INPUTS))
+def test_sai_score_with_two_workers_writes_the_one_process_files(case, tmp_path):
+    """Plain `python -m sai_amd score ... --num-workers 2` (no launcher on the command line): the process
+    starts its two ranks as a child job, both on this box's one GPU with gloo for the gather, each reads
+    and scores its own 8 chunks (sai.py:91), rank 0 writes -- TSV, .U.log and .Q.log byte-identical to
+    the one-process run of the same command."""
+    if case == "bgzip+tbi":
+        from test_ingest_native import write_bgzf, write_tbi
+
+        vcf = tmp_path / "indexed.vcf.gz"
+        write_bgzf(vcf, open(ROOT / "tests/data/test.data.vcf", "rb").read(), np.random.default_rng(3), max_block=700)
+        write_tbi(vcf)
+    args = [a.format(tmp=tmp_path) for a in SCORE_INPUTS[case]]
+    one, two = tmp_path / "one" / "s.tsv", tmp_path / "two" / "s.tsv"
+    _sai_score(args, one, 1)
+    _sai_score(args, two, 2, {"SAI_AMD_DIST_BACKEND": "gloo"})
+    assert len(one.read_text().splitlines()) > 2
+    names = sorted(p.name for p in one.parent.iterdir())
+    assert names == sorted(p.name for p in two.parent.iterdir()) and "s.tsv" in names
+    for name in names:
+        assert (two.parent / name).read_bytes() == (one.parent / name).read_bytes(), name
+
+
+def test_sai_score_workers_from_the_environment_and_the_function(tmp_path):
+    """SAI_AMD_GPUS=2 without the flag, and score(num_workers=3) from Python (uneven shares): same files."""
+    args = SCORE_INPUTS["plain"]
+    one, env_two, fn_three = tmp_path / "a" / "s.tsv", tmp_path / "b" / "s.tsv", tmp_path / "c" / "s.tsv"
+    _sai_score(args, one, 1)
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(SAI_AMD_DIST_BACKEND="gloo", SAI_AMD_GPUS="2")
+    res = subprocess.run([sys.executable, "-m", "sai_amd", "score", *args, "--output", str(env_two)], cwd=str(ROOT), env=env,
+                         capture_output=True, text=True, timeout=900)  # fmt: skip
+    assert res.returncode == 0, res.stderr[-3000:]
+    code = ("import sai_amd.stats; from sai_amd.sai import score; score(vcf_file='tests/data/test.data.vcf', chr_name='21', win_len=10000, "
+            f"win_step=5000, anc_allele_file=None, output_file={str(fn_three)!r}, config='tests/data/test.uq.config.yaml', num_workers=3)")
+    env.pop("SAI_AMD_GPUS")
+    res = subprocess.run([sys.executable, "-c", code], cwd=str(ROOT), env=env, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stderr[-3000:]
+    for other in (env_two, fn_three):
+        for sfx in (".tsv", ".U.log", ".Q.log"):
+            assert other.with_suffix(sfx).read_bytes() == one.with_suffix(sfx).read_bytes(), (other, sfx)
+
+
+def test_score_rank_on_real_rccl(tmp_path):
+    """The sharded route's collectives on RCCL itself with the one rank a one-GPU box can give: process group
+    with device_id + the gloo status group, the status exchange, the size all_gather and the padded gather of
+    the packed batches in HBM."""
+    code = f"""
+import os, sys
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29571", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+import torch.distributed as dist
+import sai_amd.stats
+from sai_amd import distributed as D
+from sai_amd.sai import chunk_preprocessor_for, load_config, write_headers
+from sai_amd.generators import ChunkGenerator
+assert D.init_process_group("nccl", force=True) == (0, 1)
+assert dist.get_backend() == "nccl" and D._STATUS_GROUP is not None and dist.get_backend(D._STATUS_GROUP) == "gloo"
+cfg = load_config("tests/data/test.uq.config.yaml")
+out = {str(tmp_path / 'rccl.tsv')!r}
+gen = ChunkGenerator(vcf_file="tests/data/test.data.vcf", chr_name="21", window_size=10000, step_size=5000, num_chunks=4)
+pre = chunk_preprocessor_for(cfg, "tests/data/test.data.vcf", 10000, 5000, out, None)
+write_headers(out, cfg.statistics, cfg.ploidies)
+res = D.run_sharded(pre, gen, as_items=False)
+assert len(res) == 4
+D.shutdown_process_group()
+"""
+    res = subprocess.run([sys.executable, "-c", code], cwd=str(ROOT), capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stderr[-3000:]
+    one = tmp_path / "one.tsv"
+    _sai_score(SCORE_INPUTS["plain"], one, 1)
+    for sfx in (".tsv", ".U.log", ".Q.log"):
+        assert (tmp_path / "rccl.tsv").with_suffix(sfx).read_bytes() == one.with_suffix(sfx).read_bytes(), sfx
