@@ -358,7 +358,7 @@ def score_path_rate(eng, wl, block, lay, repeats: int = 3) -> dict:
     }
 
 
-def measure_traffic(argv: list, kernel: str, timeout_s: float = 240.0):
+def measure_traffic(argv: list, kernel: str, timeout_s: float = 90.0):
     """HBM bytes per launch of the dominant kernel, measured NOW: two short child runs of this same
     command under `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (each with --kernel-trace only, as
     MI355X_MICROARCH.md prescribes; the program itself follows `--`), corrected as the guide says for
@@ -425,19 +425,79 @@ def _without(argv: list, flags: dict) -> list:
     return out
 
 
+def source_digest() -> str:
+    """sha256 over the sources a stored figure depends on (kernels, C ABI, the resident scorer, the shard
+    layout): the GPU box has no git history, so a stored number names the tree it was measured on this way."""
+    import hashlib
+
+    h = hashlib.sha256()
+    files = sorted((ROOT / "sai_amd" / "csrc").glob("*")) + [ROOT / "include" / "saihip.h"] + [
+        ROOT / "sai_amd" / f for f in ("engine.py", "resident.py", "sharding.py", "_ffi.py")]  # fmt: skip
+    for f in files:
+        if f.is_file():
+            h.update(f.name.encode() + b"\0" + f.read_bytes())
+    return h.hexdigest()[:16]
+
+
 def one_gpu_base(wl, args) -> dict:
     """What an N > 1 line is to be divided by: the SAME job on one GPU.  `--gpus 1` runs C3, the
     configuration the metric is quoted on, `--gpus N` the whole-genome job C4 cut into N window ranges,
     so the strong-scaling denominator is C4 on one GPU (`python bench.py --workload c4`: 220 GB
-    resident) as measured and kept under profiles/ -- per window the two jobs move the same bytes."""
+    resident) as measured and kept under profiles/ -- per window the two jobs move the same bytes.
+    The stored figure carries the digest of the sources it was measured on (`source_digest`) and the box;
+    a figure from another tree is NOT handed out as this tree's base: `value` is then null and the stale
+    number stays visible under `stale`."""
     rec = {"workload_id": wl.name, "command": f"python bench.py --workload {wl.name}", "value": None, "unit": "windows/s"}
     f = ROOT / "profiles" / "one_gpu_base.json"
     reduced = bool(args.sites or args.chroms or args.scaling != "strong" or args.layout != "int8")
-    if f.exists() and not reduced:
-        rec.update(json.loads(f.read_text()).get(wl.name, {}))
-    elif reduced:
+    if reduced:
         rec["note"] = "reduced / non-default job: run the same arguments with --gpus 1 for the base"
+    elif f.exists():
+        stored = json.loads(f.read_text()).get(wl.name, {})
+        if stored.get("source_digest") == source_digest():
+            rec.update(stored)
+        elif stored:
+            rec["stale"] = stored
+            rec["note"] = ("the stored one-GPU figure was measured on other sources than this tree's "
+                           f"({stored.get('source_digest')} != {source_digest()}): run the command above on this tree for the base")  # fmt: skip
     return rec
+
+
+def per_rank_figures(dist_on: bool, cdev, dt: float, steps: int, site_ms: list, n_windows: int, n_sites: int,
+                     t_setup: float) -> list:  # fmt: skip
+    """One entry per rank, all_gathered after the timed region (outside it): the rank's own wall time
+    per step, its site-pass average (HIP events), its windows and sites -- a straggler or a slow gather
+    shows in ONE record of the scaling run."""
+    import torch
+    import torch.distributed as dist
+
+    mine = [dt / max(steps, 1) * 1e3, sum(site_ms) / len(site_ms) if site_ms else 0.0, float(n_windows), float(n_sites), t_setup]
+    rows = [mine]
+    if dist_on:
+        t = torch.tensor(mine, dtype=torch.float64, device=cdev)
+        every = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+        dist.all_gather(every, t)
+        rows = [e.cpu().tolist() for e in every]
+    return [{"rank": r, "ms_per_step_wall": round(v[0], 4), "site_pass_avg_ms": round(v[1], 4), "windows": int(v[2]),
+             "sites": int(v[3]), "setup_s": round(v[4], 2)} for r, v in enumerate(rows)]  # fmt: skip
+
+
+def static_traffic(wl, args, world: int, sites_rank0: int):
+    """(bytes, source) from profiles/traffic.json, or (None, None): the stored counter figure of this job; for
+    N > 1 rank 0's share of it (the pass is a stream over the sites a rank holds: bytes scale with them)."""
+    tfile = ROOT / "profiles" / "traffic.json"
+    if args.traffic == "off" or not tfile.exists() or args.sites or args.chroms or args.scaling != "strong":
+        return None, None
+    rec = json.loads(tfile.read_text())
+    key = wl.name + ("" if args.layout == "int8" else f":{args.layout}") + ("" if args.anc == "true" else ":noanc")
+    if key not in rec:
+        return None, None
+    whole = rec[key].get("site_counts_hbm_bytes_per_launch")
+    src = f"profiles/traffic.json[{key}] ({rec[key].get('source', 'rocprofv3 --pmc passes of this command')}); not measured in this run"
+    if world == 1 or whole is None:
+        return whole, src
+    total_sites = len(wl.chroms) * wl.n_sites
+    return int(whole * sites_rank0 / total_sites), src + f"; static: rank 0's share ({sites_rank0} of {total_sites} sites) of the one-GPU job's counters"
 
 
 def _trim(pop, n_sites):
@@ -459,18 +519,100 @@ def self_launch(n_ranks: int, argv: list, result_out, script: str = "") -> int:
     return launch_ranks(n_ranks, argv, script=script or str(Path(__file__).resolve()), stdout=result_out, who="bench.py")
 
 
-def main() -> None:
+class HipDevice:
+    """Everything of a bench run that touches the GPU, behind one seam: the library context, the resident
+    synthetic shard and its scorer, device buffers, synchronisation and the event-timed site pass.
+    tests/test_bench_sharded_cpu.py passes its own stand-in (the oracle answering from the same synthetic
+    bytes) to ``main`` to run the N > 1 line end to end over gloo; nothing but a test can do that -- there
+    is no flag or environment switch for it, and without the library and a gfx950 device this class raises."""
+
+    name = "hip"
+
+    def start(self, local_rank: int) -> None:
+        import torch
+
+        from sai_amd.engine import Engine
+
+        torch.cuda.set_device(local_rank)
+        self.local_rank = local_rank
+        self.eng = Engine.get(local_rank)
+        self.device = self.eng.device
+
+    def process_group_options(self, backend: str) -> dict:
+        import torch
+
+        return {"device_id": torch.device("cuda", self.local_rank)} if backend == "nccl" else {}
+
+    def collective_device(self, backend: str):
+        import torch
+
+        return self.device if backend == "nccl" else torch.device("cpu")  # where the small collectives live
+
+    def build(self, wl, rank: int, world: int, args):
+        """(block, layout, windows per chromosome, scorer) -- the scorer has run one untimed step: the list
+        sizes of a resident block are fixed, the row layout comes from them."""
+        from sai_amd.resident import ResidentScorer
+        from sai_amd.sharding import build_synth_shard
+
+        block, lay, win_counts = build_synth_shard(self.eng, wl, rank, world)
+        scorer = None
+        if block is not None:
+            scorer = ResidentScorer(self.eng, block, [(s, e) for _, s, e in lay.windows], wl.params(), cap_u=1 << 22,
+                                    cap_q=1 << 22, layout=args.layout, overlap=args.overlap != "off",
+                                    window_segment=lay.window_segment)  # fmt: skip
+            scorer.step()
+        return block, lay, win_counts, scorer
+
+    def synchronize(self) -> None:
+        import torch
+
+        torch.cuda.synchronize()
+
+    def empty_rows(self, n_rows: int, row_bytes: int):
+        import torch
+
+        return torch.empty((n_rows, row_bytes), dtype=torch.uint8, device=self.device)
+
+    def current_stream_context(self):
+        import torch
+
+        return torch.cuda.stream(torch.cuda.current_stream())
+
+    def site_pass_ms(self, scorer) -> list:
+        return [a.elapsed_time(b) for a, b in scorer.count_events]
+
+    def genotype_bytes(self, block, layout: str) -> int:
+        return block.genotype_bytes if layout == "int8" else block.packed2_bytes
+
+    def stream_read_probe(self, block) -> float:
+        """On-box ceiling: plain 16-B-per-lane streaming read of the ref block (outside the timed region)."""
+        buf = block.pops[0].tiles[: min(block.pops[0].tiles.numel(), 10_000_000_000)]
+        return self.eng.probe_stream_read(buf)
+
+    def score_path(self, wl, block, lay) -> dict:
+        return score_path_rate(self.eng, wl, block, lay)
+
+    def release(self) -> None:
+        import torch
+
+        gc.collect()
+        torch.cuda.empty_cache()
+
+
+def main(argv=None, device=None) -> None:
     # stdout carries exactly one line, the JSON record: everything libraries print while the job runs
     # (RCCL's version banner at communicator creation, gloo's rank messages, ...) goes to stderr
     sys.stdout.flush()
     result_out = os.fdopen(os.dup(1), "w")
     os.dup2(2, 1)
+    argv = sys.argv[1:] if argv is None else list(argv)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", choices=["auto", "c2", "c3", "c4", "c5"], default="auto",
-                    help="auto = c3 on one GPU (the configuration the metric is quoted on), c4 on several")
+                    help="auto = c3 on one GPU (the configuration the metric is quoted on), c4 on several; "
+                    "`--workload c4` on one GPU runs the N > 1 job itself (220 GB resident), so ONE job can be used for every N")
     ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
                     help="N>1: strong = the fixed job sharded over the GPUs (default); weak = N chromosomes of the "
                     "workload's size, still sharded by contiguous window ranges")
@@ -490,8 +632,9 @@ def main() -> None:
                     "second row (sources also matched against 1 - y, matching sites inverted; stat_utils.py:146-160)")
     ap.add_argument("--traffic", choices=["auto", "live", "static", "off"], default="auto",
                     help="roofline.traffic: live = two short child runs of this command under rocprofv3 --pmc (FETCH_SIZE, "
-                    "WRITE_SIZE) after the timed region; static = the figure kept in profiles/traffic.json; auto = live on "
-                    "one GPU for a full-size workload when rocprofv3 is there, else static")
+                    "WRITE_SIZE) after the timed region (each ended after 90 s at the latest); static = the figure kept in "
+                    "profiles/traffic.json (N > 1: rank 0's share of it); auto = live on one GPU for a full-size workload "
+                    "when rocprofv3 is there, else static")
     ap.add_argument("--cpu-runs", type=int, default=3, help="timed runs of the CPU baseline (the median is reported)")
     ap.add_argument("--cpu-run-seconds", type=float, default=5.0, help="minimum length of one CPU run (whole passes)")
     ap.add_argument("--cpu-sites", type=float, default=1e6, help="site prefix timed on the CPU (0 = skip)")
@@ -499,15 +642,17 @@ def main() -> None:
     ap.add_argument("--score-path", choices=["auto", "on", "off"], default="auto",
                     help="also time the product entry point (run_windows + items + text) on the resident block "
                     "(auto = on for one GPU and a one-chromosome workload)")
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         # plain `python bench.py --gpus N`: this process only builds and starts the ranks
-        sys.exit(self_launch(args.gpus, sys.argv[1:], result_out))
+        sys.exit(self_launch(args.gpus, argv, result_out))
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     args.gpus = world
+    if device is None:
+        device = HipDevice()
 
     # build first, before anything touches the GPU or joins a process group: hipcc children are
     # forked from a process that has not initialised HIP; concurrent ranks serialise on a file lock
@@ -517,16 +662,22 @@ def main() -> None:
 
     name = args.workload if args.workload != "auto" else ("c3" if world == 1 else "c4")
     wl = make_workload(name, args.sites, args.chroms, args.scaling, world)
+    if hasattr(device, "adapt_workload"):
+        device.adapt_workload(wl)
     if args.anc == "false":
         for spec in wl.specs:
             spec["anc"] = False
         wl.description += "; anc_allele_available=False (mirror match + inversion)"
 
     cpu = None
-    if rank == 0 and world == 1 and args.cpu_sites > 0:
-        # a one-GPU box grants a 16-CPU share of the host whatever nproc says
+    if rank == 0 and args.cpu_sites > 0:
+        # a one-GPU box grants a 16-CPU share of the host whatever nproc says.  In an N > 1 job rank 0 times the
+        # baseline HERE, before it joins the process group: the other ranks wait for it in init_process_group
+        # (timeout 10 minutes; the baseline takes about half a minute) and their cores are idle meanwhile
         workers = args.cpu_workers or min(usable_cores(), 16)
         cpu = cpu_baseline(wl, min(int(args.cpu_sites), wl.n_sites), workers, args.cpu_runs, args.cpu_run_seconds)
+        if world > 1:
+            cpu["sample"] += f"; timed by rank 0 of the {world}-rank job before it joined the process group"
 
     import torch
     import torch.distributed as dist
@@ -540,39 +691,31 @@ def main() -> None:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
 
-    torch.cuda.set_device(local_rank)
+    device.start(local_rank)
     backend = os.environ.get("SAI_BENCH_BACKEND", "nccl")  # "gloo" only for rehearsals on a 1-GPU box
-    if dist_on:
-        kw = dict(backend=backend, rank=rank, world_size=world, timeout=datetime.timedelta(minutes=10))
-        if backend == "nccl":
-            kw["device_id"] = torch.device("cuda", local_rank)
-        dist.init_process_group(**kw)
+    own_group = False
+    if dist_on and not dist.is_initialized():
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, timeout=datetime.timedelta(minutes=10),
+                                **device.process_group_options(backend))  # fmt: skip
+        own_group = True
+    elif dist_on:
+        backend = dist.get_backend()
     from sai_amd.distributed import RowGather
-    from sai_amd.engine import Engine
-    from sai_amd.resident import ResidentScorer
-    from sai_amd.sharding import build_synth_shard, merge_rank_results, plan_shards
+    from sai_amd.sharding import merge_rank_results, plan_shards
 
-    eng = Engine.get(local_rank)
     t_setup = time.perf_counter()
-    block, lay, win_counts = build_synth_shard(eng, wl, rank, world)
+    block, lay, win_counts, scorer = device.build(wl, rank, world, args)
     total_windows = int(sum(win_counts))
     overlap = args.overlap != "off"
-    scorer = None
-    if block is not None:
-        scorer = ResidentScorer(eng, block, [(s, e) for _, s, e in lay.windows], wl.params(), cap_u=1 << 22, cap_q=1 << 22,
-                                layout=args.layout, overlap=overlap, window_segment=lay.window_segment)  # fmt: skip
-        scorer.step()  # untimed: the list sizes of a resident block are fixed, the row layout comes from them
-        row_layout = scorer.row_layout()
-    else:
-        row_layout = None
-    torch.cuda.synchronize()
+    row_layout = scorer.row_layout() if scorer is not None else None
+    device.synchronize()
     t_setup = time.perf_counter() - t_setup
 
-    cdev = eng.device if backend == "nccl" else torch.device("cpu")  # where the small collectives live
+    cdev = device.collective_device(backend)
     gather = RowGather(row_layout, cdev)
     row_bytes = max(gather.sizes[gather.rank], 1)
     n_rows = max(args.steps, args.warmup, 1) if (dist_on and args.gather == "end") else 1
-    ring = torch.empty((n_rows, row_bytes), dtype=torch.uint8, device=eng.device)
+    ring = device.empty_rows(n_rows, row_bytes)
 
     def row_of(k: int):
         return ring[k % n_rows]
@@ -580,7 +723,7 @@ def main() -> None:
     def gather_ring(n: int):
         if n == 0:
             return None
-        ctx = scorer.window_stream() if scorer is not None else torch.cuda.stream(torch.cuda.current_stream())
+        ctx = scorer.window_stream() if scorer is not None else device.current_stream_context()
         with ctx:
             from sai_amd.distributed import gather_padded
 
@@ -590,13 +733,16 @@ def main() -> None:
         return [r.reshape(n, -1)[n - 1] if r.numel() else r for r in rows]  # the last pass's rows
 
     def fence() -> None:
-        torch.cuda.synchronize()
+        device.synchronize()
         if dist_on:
             dist.barrier()
-        torch.cuda.synchronize()
+        device.synchronize()
 
     out = run_passes(scorer, gather, row_of, args.steps, args.warmup, args.gather, fence, gather_ring)
     dt = out["dt"]
+    rank_figures = per_rank_figures(dist_on, cdev, dt, args.steps, device.site_pass_ms(scorer) if scorer is not None else [],
+                                    scorer.n_windows if scorer is not None else 0,
+                                    block.n_real_sites if block is not None else 0, t_setup)  # fmt: skip
     if dist_on:
         tmax = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -604,11 +750,11 @@ def main() -> None:
 
     # what the job produced: on rank 0 the gathered rows of the last pass, merged over the global list
     n_sets = len(wl.specs)
+    gather_check = None
     if dist_on:
         res = None
         if rank == 0:
-            per_rank = gather.decode(out["rows"])
-            res = merge_rank_results(per_rank, plan_shards(win_counts, world), n_sets)
+            res = merge_rank_results(gather.decode(out["rows"]), plan_shards(win_counts, world), n_sets)
         # every rank's own results against what rank 0 received from it: CRC of the records, sizes and
         # sums of the candidate lists (outside the timed region)
         import zlib
@@ -637,28 +783,19 @@ def main() -> None:
         res = scorer.results()  # also checks the candidate buffers were large enough
 
     if rank == 0:
-        kernel_ms = [a.elapsed_time(b) for a, b in scorer.count_events]
+        kernel_ms = device.site_pass_ms(scorer)
         avg_ms = sum(kernel_ms) / len(kernel_ms)
-        alg_bytes = block.genotype_bytes if args.layout == "int8" else block.packed2_bytes
+        alg_bytes = device.genotype_bytes(block, args.layout)
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
-        # on-box ceiling: plain 16-B-per-lane streaming read of the ref block (outside the timed region)
-        probe_buf = block.pops[0].tiles[: min(block.pops[0].tiles.numel(), 10_000_000_000)]
-        stream_read = eng.probe_stream_read(probe_buf)
+        stream_read = device.stream_read_probe(block)
         n_sites_rank0 = block.n_real_sites
         path_bytes = alg_bytes + 4 * n_sites_rank0 + 24 * n_sets * scorer.n_windows
-        traffic, traffic_source = None, None
-        tfile = ROOT / "profiles" / "traffic.json"
-        if args.traffic != "off" and tfile.exists() and world == 1 and not args.sites and not args.chroms:
-            rec = json.loads(tfile.read_text())
-            key = wl.name + ("" if args.layout == "int8" else f":{args.layout}") + ("" if args.anc == "true" else ":noanc")
-            if key in rec:
-                traffic = rec[key].get("site_counts_hbm_bytes_per_launch")
-                traffic_source = f"profiles/traffic.json[{key}] ({rec[key].get('source', 'rocprofv3 --pmc passes of this command')}); not measured in this run"
+        traffic, traffic_source = static_traffic(wl, args, world, n_sites_rank0)
         score_path = None
         want_sp = args.score_path == "on" or (args.score_path == "auto" and world == 1)
         if want_sp and world == 1 and len(wl.chroms) == 1 and args.layout == "int8":
             try:
-                score_path = score_path_rate(eng, wl, block, lay)
+                score_path = device.score_path(wl, block, lay)
             except Exception as exc:  # noqa: BLE001 - a secondary figure must not cost the headline line
                 score_path = {"error": f"{type(exc).__name__}: {exc}"}
         line = {
@@ -672,11 +809,16 @@ def main() -> None:
             "higher_is_better": True,
             "scaling": args.scaling,
             "vs_baseline": None,
-            "dtype": "u8",
+            "dtype": "i8",  # signed int8 dosages in HBM; sums in integer fields, frequencies and compares in f64
             "data": "synthetic",
             "config": {
                 "workload": wl.description,
                 "workload_id": wl.name,
+                # which job this line ran, and what the other N run by default: a 1 -> N curve over ONE job uses
+                # `--workload c4` at every N (on one GPU: 220 GB resident)
+                "job": (f"{wl.name}: " + ("the default of --gpus 1 (the metric's configuration)" if wl.name == "c3" and world == 1 else
+                                          "the default of --gpus N > 1" if wl.name == "c4" and world > 1 else "chosen with --workload")
+                        + "; --gpus 1 defaults to c3, --gpus N > 1 to c4; `--workload c4` runs the N > 1 job at any N incl. 1"),  # fmt: skip
                 "layout": args.layout,
                 "steps_pipelined": overlap,
                 "chromosomes": len(wl.chroms),
@@ -697,6 +839,8 @@ def main() -> None:
                 "gather_row_bytes": gather.sizes if dist_on else None,
                 "gather_check": gather_check if dist_on else None,
                 "one_gpu_base": one_gpu_base(wl, args) if world > 1 else None,
+                "per_rank": rank_figures,
+                "source_digest": source_digest(),
                 "setup_s": round(t_setup, 2),
                 "u_sum": int(res.records["u_count"].sum()),
                 "q_finite": int(np.isfinite(res.records["q"]).sum()),
@@ -730,14 +874,13 @@ def main() -> None:
         profiled = "rocprof" in os.environ.get("LD_PRELOAD", "").lower() or any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ)
         if profiled and args.traffic in ("auto", "live"):
             line["roofline"]["traffic_source"] = f"{traffic_source or 'none stored'}; not measured live: this run is itself under a profiler"
-        elif world == 1 and not dist_on and (args.traffic == "live" or (args.traffic == "auto" and not reduced)):
+        elif device.name == "hip" and world == 1 and not dist_on and (args.traffic == "live" or (args.traffic == "auto" and not reduced)):
             # the counters need their own runs (the profiler changes the clock): release this process's HBM first
             kernel = line["roofline"]["kernel"]
-            del scorer, block, res, probe_buf
-            gc.collect()
-            torch.cuda.empty_cache()
+            del scorer, block, res
+            device.release()
             try:
-                live, how = measure_traffic(sys.argv[1:], kernel)
+                live, how = measure_traffic(argv, kernel)
             except Exception as exc:  # noqa: BLE001 - the line must come out whatever the profiler does
                 live, how = None, f"{type(exc).__name__}: {exc}"
             if live is not None:
@@ -747,7 +890,8 @@ def main() -> None:
         print(json.dumps(line), file=result_out, flush=True)
     if dist_on:
         dist.barrier()
-        dist.destroy_process_group()
+        if own_group:
+            dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -256,3 +256,145 @@ def test_row_layout_round_trip():
     assert np.array_equal(np.concatenate([res.u_list(s, w) for s in range(n_sets) for w in range(n_w)]), u)
     with pytest.raises(ValueError):
         lay.unpack(row[:-4])
+
+
+# ---- bench.main itself, N = 2 over gloo: the whole line ------------------------------
+
+
+class OracleDevice:
+    """Stand-in for bench.HipDevice (the one seam of bench.main that touches the GPU): the shard layout is the
+    product's, the windows are answered by the oracle from the same synthetic bytes."""
+
+    name = "oracle-double"
+
+    def start(self, local_rank):
+        import torch
+
+        self.device = torch.device("cpu")
+
+    def process_group_options(self, backend):
+        return {}
+
+    def collective_device(self, backend):
+        return self.device
+
+    def adapt_workload(self, wl):
+        wl.n_ref, wl.n_tgt = 12, 10
+        wl.win_len, wl.win_step = 3000, 1500
+        wl.missing_per_million = 20000
+        for s in wl.specs:
+            s.update(w=0.3, x=0.3, quantile=0.9)
+
+    def build(self, wl, rank, world, args):
+        from types import SimpleNamespace
+
+        from sai_amd import _ffi
+        from sai_amd.sharding import layout_shard, piece_site_range, plan_shards, synth_chrom_windows
+
+        all_pos, all_windows = synth_chrom_windows(_ffi.load_host(), wl)
+        counts = [len(w) for w in all_windows]
+        plan = plan_shards(counts, world)
+        lay = layout_shard(plan[rank], wl.chroms, all_windows,
+                           lambda pc: piece_site_range(all_pos[pc.chrom_index], all_windows[pc.chrom_index], pc.w0, pc.w1))  # fmt: skip
+        if not plan[rank]:
+            return None, lay, counts, None
+        scorer = OracleScorer(wl, lay, all_pos)
+        scorer.step()
+        n = int(sum(lay.n_sites))
+        return SimpleNamespace(n_real_sites=n, genotype_bytes=n * sum(wl.pop_sizes)), lay, counts, scorer
+
+    def synchronize(self):
+        pass
+
+    def empty_rows(self, n_rows, row_bytes):
+        import torch
+
+        return torch.zeros((n_rows, row_bytes), dtype=torch.uint8)
+
+    def current_stream_context(self):
+        import contextlib
+
+        return contextlib.nullcontext()
+
+    def site_pass_ms(self, scorer):
+        return [0.5, 1.5]
+
+    def genotype_bytes(self, block, layout):
+        return block.genotype_bytes
+
+    def stream_read_probe(self, block):
+        return 1.0
+
+    def release(self):
+        pass
+
+
+def _bench_main_worker(rank, world, port, out_dir, argv):
+    sys.path.insert(0, str(ROOT))
+    sys.path.insert(0, str(ROOT / "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      SAI_BENCH_BACKEND="gloo")  # fmt: skip
+    fd = os.open(os.path.join(out_dir, f"stdout{rank}.txt"), os.O_WRONLY | os.O_CREAT | os.O_TRUNC)
+    os.dup2(fd, 1)
+    import bench
+    from test_bench_sharded_cpu import OracleDevice
+
+    bench.main(argv, device=OracleDevice())
+
+
+def test_the_two_rank_line_is_complete(tmp_path):
+    """bench.main with two gloo ranks: the N > 1 line carries what the N = 1 line carries -- `roofline` (with a
+    stored-counter `traffic` source when the job is full size; a reduced job says none), `cpu_baseline` timed by
+    rank 0 before it joined the group, `config.per_rank` (every rank's wall time, site-pass average, windows and
+    sites) and `config.one_gpu_base` -- and exactly one line comes out, from rank 0."""
+    import json
+
+    import torch.multiprocessing as mp
+
+    argv = ["--gpus", "2", "--workload", "c4", "--sites", "2600", "--chroms", "5", "--steps", "2", "--warmup", "1",
+            "--cpu-sites", "2600", "--cpu-runs", "2", "--cpu-run-seconds", "0.2", "--cpu-workers", "2"]  # fmt: skip
+    mp.spawn(_bench_main_worker, args=(2, _free_port(), str(tmp_path), argv), nprocs=2, join=True)
+    assert (tmp_path / "stdout1.txt").read_text() == ""
+    (text,) = [ln for ln in (tmp_path / "stdout0.txt").read_text().splitlines() if ln.startswith("{")]
+    line = json.loads(text)
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["dtype"] == "i8" and line["steps"] == 2
+    cfg = line["config"]
+    assert cfg["workload_id"] == "c4" and "c4" in cfg["job"] and "--workload c4" in cfg["job"]
+    ranks = cfg["per_rank"]
+    assert [r["rank"] for r in ranks] == [0, 1] and sum(r["windows"] for r in ranks) == cfg["windows_total"]
+    assert ranks[0]["windows"] == cfg["windows_rank0"] and ranks[0]["sites"] == cfg["sites_rank0"]
+    assert all(r["ms_per_step_wall"] > 0 and r["site_pass_avg_ms"] == 1.0 and r["sites"] > 0 for r in ranks)
+    assert max(r["ms_per_step_wall"] for r in ranks) <= line["ms_per_step"] * 1.0001 + 1e-3
+    base = cfg["one_gpu_base"]
+    assert base["workload_id"] == "c4" and base["command"] == "python bench.py --workload c4" and "note" in base
+    assert "2 rank(s) match" in cfg["gather_check"] and len(cfg["source_digest"]) == 16
+    roof = line["roofline"]
+    assert roof["bound"] == "hbm" and roof["algorithmic_bytes_per_launch"] > 0 and roof["rank"] == 0 and "traffic" in roof and roof["avg_launch_ms"] == 1.0
+    cb = line["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] == 2 and cb["value"] > 0 and "before it joined the process group" in cb["sample"]
+    assert cfg["u_sum"] > 0 and cfg["q_finite"] > 0
+
+
+def test_static_traffic_and_one_gpu_base_of_the_full_size_job(monkeypatch):
+    """The figures an N > 1 line takes from profiles/: rank 0's share of the stored counters, and the one-GPU
+    base only when it was measured on this tree's sources (else null, the stale number kept visible)."""
+    import argparse
+
+    import bench
+
+    wl = bench.make_workload("c4")
+    args = argparse.Namespace(traffic="auto", sites=0, chroms=0, scaling="strong", layout="int8", anc="true")
+    whole, src = bench.static_traffic(wl, args, 1, 110_000_000)
+    share, src8 = bench.static_traffic(wl, args, 8, 13_752_000)
+    assert whole > 2.2e11 and "not measured in this run" in src
+    assert share == int(whole * 13_752_000 / 110_000_000) and "rank 0's share" in src8
+    assert bench.static_traffic(wl, argparse.Namespace(**{**vars(args), "sites": 1000}), 8, 10) == (None, None)
+    base = bench.one_gpu_base(wl, args)
+    assert base["workload_id"] == "c4"
+    if base["value"] is not None:
+        assert base["source_digest"] == bench.source_digest() and base["value"] > 1e6
+    else:
+        assert base["stale"]["value"] > 1e6 and "other sources" in base["note"]
+    monkeypatch.setattr(bench, "source_digest", lambda: "0" * 16)
+    stale = bench.one_gpu_base(wl, args)
+    assert stale["value"] is None and stale["stale"]["value"] > 1e6
