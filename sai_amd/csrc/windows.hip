@@ -75,11 +75,17 @@ __global__ __launch_bounds__(256) void window_bounds_kernel(const int32_t* __res
 // ------------------------------------------------------------------------------------------
 // window statistics.  Four launches, no atomics on shared words (a returning atomic on one
 // address saturates at ~90 per microsecond, which at one reservation per window was 85 % of the
-// old single-kernel version):
-//   window_stats_wave   one WAVEFRONT per (window, set): U count, condition count, Q, Q-list size
-//   window_stats_heavy  workgroup fallback for windows with > kWaveCap qualifying sites
-//   window_scan         exclusive prefix sums of the list sizes -> CSR offsets + totals
-//   window_lists        one wavefront per (window, set): candidate lists in ascending site order
+// first single-kernel version), and every window's data is read ONCE per kernel:
+//   window_stats   one WORKGROUP per window, all sets of the call: the window's plane rows and stored
+//                  target frequencies are brought into LDS once; each of the four waves then answers
+//                  sets (U count, condition count, Q, Q-list size) from LDS, and sets with more than
+//                  kWaveCap qualifying sites are finished by the whole workgroup (radix select)
+//   window_scan    exclusive prefix sums of the list sizes -> CSR offsets + totals (two launches)
+//   window_lists   one workgroup per window again: candidate lists in ascending site order
+// Round 3 ran one wavefront per (window, set) and a second workgroup kernel for the heavy pairs, all
+// reading global memory: C5's 18 sets x 2x window overlap x 64-byte lines re-read ~190 MB of planes
+// and frequencies as 1.36 GB per step (profiles/r03g_c5_pmc_summary.csv), under the next step's
+// genotype stream.
 // ------------------------------------------------------------------------------------------
 
 struct WinArgs {
@@ -105,25 +111,14 @@ struct WinArgs {
 };
 
 constexpr int kWinThreads = 256;
-constexpr int kWaveCap = 256;       // qualifying sites a wave keeps in LDS; more -> heavy kernel
-constexpr int kSelCap = 4096;       // values the heavy kernel keeps in LDS (32 KiB); beyond: re-read
-constexpr int32_t kHeavyMark = -1;  // records[].n_cdd_q value that hands a window to the fallback
+constexpr int kWinWaves = kWinThreads / 64;
+constexpr int kWaveCap = 256;       // qualifying sites a wave ranks directly; more -> the workgroup's radix select
+constexpr int kSelCap = kWinWaves * kWaveCap;  // values the radix select keeps in LDS (the waves' slices, 8 KiB); beyond: re-read
 // Words of a tile's row (saihip.h): 0 = "any" (sites whose frequency is stored), 1 + s = condition of
 // set s, 1 + n + s = inverted for set s (present only with a.with_inv).
 constexpr int kAny = 0;
 __device__ __forceinline__ int cond_word(int set) { return 1 + set; }
 __device__ __forceinline__ int inv_word(const int32_t with_inv, int n_sets, int set) { return with_inv ? 1 + n_sets + set : -1; }
-
-// slot of site (tile t, bit b) in tgt_freq: the tile's stored frequencies are packed at the start of its
-// 64 slots in site order ("any" all ones: slot b)
-__device__ __forceinline__ int64_t freq_slot(int64_t t, uint64_t any, int b) {
-  return t * kTile + __popcll(any & ((1ull << b) - 1ull));
-}
-
-__device__ __forceinline__ double eff_freq(const double* tgt_freq, bool inverted, int64_t slot) {
-  const double v = tgt_freq[slot];
-  return inverted ? 1.0 - v : v;
-}
 
 // numpy 'linear' quantile from the two neighbouring order statistics (numpy _quantile/_lerp):
 // virtual index v = (n-1)*q; a + (b-a)*g, or b - (b-a)*(1-g) when g >= 0.5.
@@ -163,15 +158,97 @@ __device__ __forceinline__ uint64_t read_lane64(uint64_t v, int src) {
   return (static_cast<uint64_t>(hi) << 32) | lo;
 }
 
-constexpr int kTileBatch = 4;  // tiles whose per-site loads are in flight together
+// ---- a window's own data, read once per workgroup ---------------------------------------------
+//
+// A window's sites are tiles [lo / 64, ceil(hi / 64)) of the planes: a C3 / C5 window (2 000 sites) is 32
+// or 33 rows of 1 + n_sets (+ n_sets) used words, and between a few and ~700 stored target frequencies
+// (the sites some set of the call selects).  Both fit a few KiB of LDS; a window they do not fit (a
+// dense real-data window, a dense frequency array) is served from global memory by the same code.
+
+constexpr int kRowWords = 1024;  // plane words of a window kept in LDS (8 KiB)
+constexpr int kFreqCap = 1024;   // stored target frequencies of a window kept in LDS (8 KiB)
+constexpr int kLdsTiles = 128;   // rows whose running count of stored frequencies is kept
+
+struct WinLds {
+  uint64_t rows[kRowWords];  // [tile - t0][used word]
+  double freq[kFreqCap];     // the tiles' stored frequencies back to back
+  uint32_t pre[kLdsTiles + 1];  // pre[j] = stored frequencies of the tiles before t0 + j
+};
+
+struct WinSrc {
+  const uint64_t* g_rows;
+  const double* g_freq;
+  int64_t g_stride;
+  const WinLds* lds;
+  int t0;
+  int used;  // words of a row that carry planes of this call: the LDS row pitch
+  bool rows_in_lds, freq_in_lds;
+
+  __device__ __forceinline__ uint64_t word(int t, int k) const {
+    return rows_in_lds ? lds->rows[(t - t0) * used + k] : g_rows[static_cast<int64_t>(t) * g_stride + k];
+  }
+  // the stored frequency number `rank` of tile t (rank = popcount of the tile's "any" bits below the site)
+  __device__ __forceinline__ double freq(int t, int rank) const {
+    return freq_in_lds ? lds->freq[lds->pre[t - t0] + rank] : g_freq[static_cast<int64_t>(t) * kTile + rank];
+  }
+};
+
+// Called by the whole workgroup (it synchronises).  what & 1: rows, what & 2: frequencies too.
+__device__ __forceinline__ WinSrc load_window(const WinArgs& a, int lo, int hi, WinLds& sh, int tid, bool want_freq) {
+  WinSrc s;
+  s.g_rows = a.planes;
+  s.g_freq = a.tgt_freq;
+  s.g_stride = a.stride;
+  s.lds = &sh;
+  s.t0 = lo >> 6;
+  s.used = 1 + a.n_sets * (a.with_inv ? 2 : 1);
+  s.rows_in_lds = false;
+  s.freq_in_lds = false;
+  const int nt = hi > lo ? ((hi + kTile - 1) >> 6) - s.t0 : 0;
+  if (nt <= 0 || nt > kLdsTiles || nt * s.used > kRowWords) return s;  // uniform over the workgroup
+  s.rows_in_lds = true;
+  const int lane = tid & 63, wv = tid >> 6;
+  const uint64_t* src = a.planes + static_cast<int64_t>(s.t0) * a.stride;
+  for (int i = tid; i < nt * s.used; i += kWinThreads) {  // a row's used words are contiguous: coalesced per row
+    const int j = i / s.used, k = i - j * s.used;
+    sh.rows[i] = src[static_cast<int64_t>(j) * a.stride + k];
+  }
+  __syncthreads();
+  if (!want_freq) return s;
+  if (wv == 0) {  // running count of the "any" bits: one wave, 64 rows per round
+    uint32_t running = 0;
+    for (int j0 = 0; j0 < nt; j0 += 64) {
+      const int j = j0 + lane;
+      const uint32_t cnt = j < nt ? __popcll(sh.rows[j * s.used + kAny]) : 0u;
+      uint32_t inc = cnt;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t t = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += t;
+      }
+      if (j < nt) sh.pre[j] = running + inc - cnt;
+      running += __shfl(inc, 63, 64);
+    }
+    if (lane == 0) sh.pre[nt] = running;
+  }
+  __syncthreads();
+  if (sh.pre[nt] > kFreqCap) return s;  // uniform
+  s.freq_in_lds = true;
+  for (int j = wv; j < nt; j += kWinWaves) {  // a tile's stored frequencies: one coalesced load of its first popcount slots
+    const uint32_t b = sh.pre[j], cnt = sh.pre[j + 1] - b;
+    if (static_cast<uint32_t>(lane) < cnt) sh.freq[b + lane] = a.tgt_freq[static_cast<int64_t>(s.t0 + j) * kTile + lane];
+  }
+  __syncthreads();
+  return s;
+}
+
+constexpr int kTileBatch = 4;  // tiles whose per-site values are fetched together
 
 // The per-site side of a chunk of 64 tiles.  Lane = tile while the plane words are fetched; the
 // tiles that hold a marked site (bit of `nonempty`, wave-uniform) are then visited one by one with
 // lane = SITE: on_tiles(n, tile_lane[], ...) gets up to kTileBatch of them at a time so that the
-// per-site loads of a batch (target frequency, position: 512 B coalesced per tile) are issued before
-// any is consumed.  A sparse window (C3: two condition sites in 2 000) visits one or two tiles, a
-// dense one (C5's loose sets: 600 in 2 000) all 32 with four loads in flight -- the first form of
-// this kernel walked the bits of its own word lane by lane, one dependent load per site.
+// per-site loads of a batch are issued before any is consumed.  A sparse window (C3: two condition
+// sites in 2 000) visits one or two tiles, a dense one (C5's loose sets: 600 in 2 000) all 32.
 template <typename F>
 __device__ __forceinline__ void for_nonempty_tiles(unsigned long long nonempty, F&& on_batch) {
   while (nonempty) {  // wave-uniform
@@ -189,10 +266,7 @@ __device__ __forceinline__ void for_nonempty_tiles(unsigned long long nonempty, 
   }
 }
 
-// A window's sites are tiles [lo / 64, ceil(hi / 64)) of the planes, one word per tile and plane:
-// a C3 window (2 000 sites) is 32 words of a plane, so ONE load instruction of the wave (lane =
-// tile) fetches a plane of the whole window -- the byte flags of round 2 took eight rounds of
-// four loads for it.  on_chunk(t, live, mask) is called by the whole wave for every 64 tiles.
+// on_chunk(t, live, mask) is called by the whole wave for every 64 tiles of the window (lane = tile).
 template <typename F>
 __device__ __forceinline__ void walk_tiles(int lo, int hi, int lane, F&& on_chunk) {
   if (hi <= lo) return;
@@ -203,124 +277,17 @@ __device__ __forceinline__ void walk_tiles(int lo, int hi, int lane, F&& on_chun
   }
 }
 
-__global__ __launch_bounds__(256) void window_stats_wave_kernel(WinArgs a) {
-  __shared__ double sh_vals[4][kWaveCap];
-  const int lane = threadIdx.x & 63;
-  const int wv = threadIdx.x >> 6;
-  // sets are the slow grid dimension.  (The sets of one window next to each other -- they share the
-  // 128-byte lines of the window's rows -- made this kernel three times faster under the next step's
-  // genotype stream for C5's 18 sets, 0.49 against 1.41 ms, and changed nothing in the step: A/B on one
-  // box, 3.55-3.76 ms either way.)
-  const int w = xcd_contiguous(blockIdx.x, gridDim.x) * 4 + wv;
-  if (w >= a.n_windows) return;  // whole wave
-  const int set = blockIdx.y;
-  const int lo = clamp_site(a.lo[w], a.n_sites), hi = clamp_site(a.hi[w], a.n_sites);
-  const int ci = cond_word(set), ii = inv_word(a.with_inv, a.n_sets, set);
-  const int64_t ridx = static_cast<int64_t>(set) * a.n_windows + w;
-  double* vals = sh_vals[wv];
-  const unsigned long long lt_mask = (1ull << lane) - 1ull;
-  const double x = a.x[set];
-
-  // pass 1: counts + order-preserving compaction of the qualifying effective frequencies into LDS; U's
-  // tgt > x is taken here, from the same values
-  uint32_t n_c = 0, n_u = 0;
-  walk_tiles(lo, hi, lane, [&](int t, bool live, uint64_t mask) {
-    const uint64_t* row = a.planes + static_cast<int64_t>(t) * a.stride;
-    const uint64_t c = live ? row[ci] & mask : 0ull;
-    const uint32_t mine = __popcll(c);
-    const unsigned long long nonempty = __ballot(mine != 0u);
-    if (nonempty == 0ull) return;  // no condition site among these 4 096: the usual case
-    if (n_c >= kWaveCap) {  // uniform: the window goes to the workgroup kernel (which also counts U) and only the count matters
-      uint32_t tot = mine;
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o, 64);
-      n_c += tot;
-      return;
-    }
-    const uint64_t iv = (c && ii >= 0) ? row[ii] : 0ull;
-    const uint64_t an = c ? row[kAny] : 0ull;
-    const int tb = t - lane;  // first tile of the chunk
-    for_nonempty_tiles(nonempty, [&](int n, const int (&tl)[kTileBatch]) {
-      uint64_t cw[kTileBatch], iw[kTileBatch], aw[kTileBatch];
-      double v[kTileBatch];
-#pragma unroll
-      for (int u = 0; u < kTileBatch; ++u) {
-        cw[u] = u < n ? read_lane64(c, tl[u]) : 0ull;
-        iw[u] = u < n ? read_lane64(iv, tl[u]) : 0ull;
-        aw[u] = u < n ? read_lane64(an, tl[u]) : 0ull;
-      }
-#pragma unroll
-      for (int u = 0; u < kTileBatch; ++u)
-        v[u] = ((cw[u] >> lane) & 1ull) ? a.tgt_freq[static_cast<int64_t>(tb + tl[u]) * kTile + __popcll(aw[u] & lt_mask)] : 0.0;
-#pragma unroll
-      for (int u = 0; u < kTileBatch; ++u) {
-        const bool mine_c = (cw[u] >> lane) & 1ull;
-        const double e = ((iw[u] >> lane) & 1ull) ? 1.0 - v[u] : v[u];
-        const uint32_t slot = n_c + __popcll(cw[u] & lt_mask);  // tiles ascend, sites ascend inside a tile
-        if (mine_c && slot < kWaveCap) vals[slot] = e;
-        n_u += __popcll(__ballot(mine_c && e > x));
-        n_c += __popcll(cw[u]);
-      }
-    });
-  });
-  double q = std::numeric_limits<double>::quiet_NaN();
-  uint32_t n_q = 0;
-  if (n_c > kWaveCap) {
-    n_q = static_cast<uint32_t>(kHeavyMark);  // uniform: the workgroup kernel finishes this window
-  } else if (n_c > 0) {
-    wave_lds_fence();
-    const double v = static_cast<double>(n_c - 1) * a.quantile[set];
-    const bool take_max = v >= static_cast<double>(n_c - 1);  // at/after the last index: maximum
-    const double fl_v = floor(v);
-    const uint32_t k0 = take_max ? n_c - 1 : static_cast<uint32_t>(fl_v);
-    const uint32_t k1 = take_max ? n_c - 1 : k0 + 1;
-    double x0 = 0.0, x1 = 0.0;
-    // rank counting: rank(e) = #{j: v_j < v_e or (v_j == v_e and j < e)} is a permutation
-    for (uint32_t e0 = 0; e0 < n_c; e0 += 64) {
-      const uint32_t e = e0 + lane;
-      const bool act = e < n_c;
-      const double ve = act ? vals[e] : 0.0;
-      uint32_t rank = 0;
-      for (uint32_t j = 0; j < n_c; ++j) {
-        const double vj = vals[j];  // same address in every lane: LDS broadcast
-        rank += (vj < ve) || (vj == ve && j < e);
-      }
-      const unsigned long long h0 = __ballot(act && rank == k0);
-      const unsigned long long h1 = __ballot(act && rank == k1);
-      if (h0) x0 = __shfl(ve, __ffsll(static_cast<long long>(h0)) - 1, 64);
-      if (h1) x1 = __shfl(ve, __ffsll(static_cast<long long>(h1)) - 1, 64);
-    }
-    q = take_max ? x0 : numpy_lerp(x0, x1, v, fl_v);
-    for (uint32_t e0 = 0; e0 < n_c; e0 += 64) {
-      const uint32_t e = e0 + lane;
-      n_q += __popcll(__ballot(e < n_c && vals[e] >= q));
-    }
-  }
-  if (lane == 0) {
-    sai_window_record rec;
-    rec.n_sites = hi > lo ? hi - lo : 0;
-    rec.u_count = static_cast<int32_t>(n_u);
-    rec.n_cond = static_cast<int32_t>(n_c);
-    rec.n_cdd_q = static_cast<int32_t>(n_q);
-    rec.q = q;
-    a.records[ridx] = rec;
-  }
-}
-
-// ---- heavy fallback ------------------------------------------------------------------------
+// ---- the workgroup's radix select (sets with more than kWaveCap qualifying sites) ---------------
 //
-// Windows with more than kWaveCap qualifying sites (loose source conditions: C5's ("=0", "=0") or
-// (">=0", ">=0") sets select hundreds of sites per window) are finished by one 256-thread workgroup
-// each.  The k-th smallest value is found by a radix select ON THE VALUE: all values lie in [0, 1],
-// so digit l of a value is floor(frac_l * 1024) with frac_0 = v, frac_{l+1} = frac_l * 1024 - digit_l
-// -- multiplications by a power of two and subtractions of the integer part, all exact in binary
-// floating point -- which makes the digits a monotone, lossless code of the value (twelve digits
-// use up the mantissa of every frequency a block can produce).  One histogram pass per level narrows the candidates to one of 1025 bins
-// (bin 1024 holds exactly 1.0); frequencies k / (called * ploidy) separate within two or three
-// levels, then the few members of the bin are gathered and ranked directly.  The first version
-// selected on the f64 bit pattern, 8 bits per pass: 8 passes per order statistic, two statistics per
-// window, the first two passes spent on exponent bits that hardly differ (0.63 ms per 16-set chunk
-// of C5 against 0.2 ms now).
+// Loose source conditions (C5's ("=0", "=0") and (">=0", ">=0") sets select ~630 of a window's 2 000
+// sites) are finished by the whole workgroup.  The k-th smallest value is found by a radix select ON
+// THE VALUE: all values lie in [0, 1], so digit l of a value is floor(frac_l * 1024) with frac_0 = v,
+// frac_{l+1} = frac_l * 1024 - digit_l -- multiplications by a power of two and subtractions of the
+// integer part, all exact in binary floating point -- which makes the digits a monotone, lossless code
+// of the value (twelve digits use up the mantissa of every frequency a block can produce).  One
+// histogram pass per level narrows the candidates to one of 1025 bins (bin 1024 holds exactly 1.0);
+// frequencies k / (called * ploidy) separate within two or three levels, then the few members of the
+// bin are gathered and ranked directly.
 
 constexpr int kBins = 1025;      // digits 0..1023, and 1024 for the value 1.0
 // 12 x 10 bits: a frequency is >= 1 / (n_called * ploidy) > 2^-55 (n_ind <= 2^24, ploidy < 2^31), so
@@ -330,17 +297,21 @@ constexpr int kMaxLevels = 12;
 constexpr int kSmallBin = 256;   // members ranked directly
 
 struct WinShared {
-  double vals[kSelCap];
+  WinLds win;
+  double vals[kSelCap];  // wave wv's slice [wv * kWaveCap, ...) while the waves answer sets; the select's values after
   uint32_t hist[kBins + 3];
   double small[kSmallBin];
-  uint32_t wave_tot[4];
-  uint32_t red[4];
-  double redf[4];
+  uint32_t wave_tot[kWinWaves];
+  uint32_t red[kWinWaves];
+  double redf[kWinWaves];
   uint32_t n_stored;
   uint32_t n_small;
   uint32_t digit;
   uint32_t k_rem;
   uint32_t bin_count;
+  int32_t n_heavy;
+  int32_t heavy_set[SAI_MAX_SETS];
+  uint32_t heavy_count[SAI_MAX_SETS];
 };
 
 __device__ __forceinline__ uint32_t block_sum(uint32_t v, uint32_t* red, int tid) {
@@ -380,54 +351,52 @@ __device__ __forceinline__ int digit_on_path(double v, int level, const int (&pa
   }
 }
 
-// One set's planes as the workgroup kernel walks them: eight threads per tile, each owning eight
-// sites (one byte of the tile's condition word), so a 2 000-site window keeps all 256 threads busy.
+// One set's planes as the workgroup walks them: eight threads per tile, each owning eight sites (one
+// byte of the tile's condition word), so a 2 000-site window keeps all 256 threads busy.
 struct SetPlanes {
-  const uint64_t* rows;  // row 0 of this call's planes
-  int64_t stride;
   int cond;  // word of this set's condition in a row
   int inv;   // word of its inverted plane, or -1
 };
 constexpr int kSubs = 8;  // threads per tile
 
-// on_byte(first_slot, any_bits, cond_bits, inv_bits) for every byte of the window that holds a condition
-// site: bit b of the byte has its frequency at tgt_freq[first_slot + popcount(any_bits below b)]
+// on_byte(tile, rank0, any_bits, cond_bits, inv_bits) for every byte of the window that holds a condition
+// site: bit b of the byte has its frequency at src.freq(tile, rank0 + popcount(any_bits below b))
 template <typename F>
-__device__ __forceinline__ void for_each_cond_byte(const SetPlanes& sp, int lo, int hi, int tid, F&& on_byte) {
+__device__ __forceinline__ void for_each_cond_byte(const WinSrc& src, const SetPlanes& sp, int lo, int hi, int tid, F&& on_byte) {
   if (hi <= lo) return;
   const int t0 = lo >> 6, t1 = (hi + kTile - 1) >> 6;
   const int sub = tid % kSubs;
   for (int t = t0 + tid / kSubs; t < t1; t += kWinThreads / kSubs) {
-    const uint64_t* row = sp.rows + static_cast<int64_t>(t) * sp.stride;
-    const uint32_t c = static_cast<uint32_t>((row[sp.cond] & range_mask(t, lo, hi)) >> (8 * sub)) & 0xFFu;
+    const uint32_t c = static_cast<uint32_t>((src.word(t, sp.cond) & range_mask(t, lo, hi)) >> (8 * sub)) & 0xFFu;
     if (c == 0u) continue;
-    const uint64_t any = row[kAny];
-    on_byte(freq_slot(t, any, 8 * sub), static_cast<uint32_t>(any >> (8 * sub)) & 0xFFu, c,
-            sp.inv >= 0 ? static_cast<uint32_t>(row[sp.inv] >> (8 * sub)) & 0xFFu : 0u);
+    const uint64_t any = src.word(t, kAny);
+    on_byte(t, __popcll(any & ((1ull << (8 * sub)) - 1ull)), static_cast<uint32_t>(any >> (8 * sub)) & 0xFFu, c,
+            sp.inv >= 0 ? static_cast<uint32_t>(src.word(t, sp.inv) >> (8 * sub)) & 0xFFu : 0u);
   }
 }
 
-// calls use(v) for every selected value of the window: from LDS, or from the per-site arrays when
-// the window holds more than kSelCap of them
-template <bool IN_LDS, typename F>
-__device__ __forceinline__ void for_each_selected(const WinShared& sh, const double* tgt_freq, const SetPlanes& sp, int lo,
+// calls use(v) for every selected value of the window: from the compact copy in LDS, or through the
+// window's planes when the set selects more than kSelCap of them
+template <bool COMPACT, typename F>
+__device__ __forceinline__ void for_each_selected(const WinShared& sh, const WinSrc& src, const SetPlanes& sp, int lo,
                                                   int hi, uint32_t n_sel, int tid, F&& use) {
-  if (IN_LDS) {
+  if (COMPACT) {
     for (uint32_t i = tid; i < n_sel; i += kWinThreads) use(sh.vals[i]);
   } else {
-    for_each_cond_byte(sp, lo, hi, tid, [&](int64_t slot0, uint32_t ab, uint32_t c, uint32_t iv) {
+    for_each_cond_byte(src, sp, lo, hi, tid, [&](int t, int rank0, uint32_t ab, uint32_t c, uint32_t iv) {
       while (c) {
         const int b = __ffs(static_cast<int>(c)) - 1;
         c &= c - 1u;
-        use(eff_freq(tgt_freq, (iv >> b) & 1u, slot0 + __popc(ab & ((1u << b) - 1u))));
+        const double v = src.freq(t, rank0 + __popc(ab & ((1u << b) - 1u)));
+        use(((iv >> b) & 1u) ? 1.0 - v : v);
       }
     });
   }
 }
 
 // k-th smallest (0-based) of the selected values
-template <bool IN_LDS>
-__device__ double select_kth(WinShared& sh, const double* tgt_freq, const SetPlanes& fl, int lo, int hi,
+template <bool COMPACT>
+__device__ double select_kth(WinShared& sh, const WinSrc& src, const SetPlanes& fl, int lo, int hi,
                              uint32_t n_sel, uint32_t k, int tid) {
   int path[kMaxLevels];
 #pragma unroll
@@ -435,7 +404,7 @@ __device__ double select_kth(WinShared& sh, const double* tgt_freq, const SetPla
   for (int level = 0; level < kMaxLevels; ++level) {
     for (int i = tid; i < kBins; i += kWinThreads) sh.hist[i] = 0;
     __syncthreads();
-    for_each_selected<IN_LDS>(sh, tgt_freq, fl, lo, hi, n_sel, tid, [&](double v) {
+    for_each_selected<COMPACT>(sh, src, fl, lo, hi, n_sel, tid, [&](double v) {
       const int d = digit_on_path(v, level, path);
       if (d >= 0) atomicAdd(&sh.hist[d], 1u);
     });
@@ -477,7 +446,7 @@ __device__ double select_kth(WinShared& sh, const double* tgt_freq, const SetPla
       // gather the bin (at the last level all its members are the same number) and rank directly
       if (tid == 0) sh.n_small = 0;
       __syncthreads();
-      for_each_selected<IN_LDS>(sh, tgt_freq, fl, lo, hi, n_sel, tid, [&](double v) {
+      for_each_selected<COMPACT>(sh, src, fl, lo, hi, n_sel, tid, [&](double v) {
         if (digit_on_path(v, level, path) == path[level]) {  // on the chosen path through this level
           const uint32_t slot = atomicAdd(&sh.n_small, 1u);
           if (slot < kSmallBin) sh.small[slot] = v;
@@ -485,7 +454,11 @@ __device__ double select_kth(WinShared& sh, const double* tgt_freq, const SetPla
       });
       __syncthreads();
       const uint32_t n = sh.n_small < kSmallBin ? sh.n_small : kSmallBin;
-      if (members > kSmallBin) return sh.small[0];  // last level: all equal
+      if (members > kSmallBin) {  // last level: all equal
+        const double same = sh.small[0];
+        __syncthreads();
+        return same;
+      }
       // rank counting with ties broken by slot: ranks are a permutation of 0..n-1
       double found = 0.0;
       bool have = false;
@@ -509,28 +482,20 @@ __device__ double select_kth(WinShared& sh, const double* tgt_freq, const SetPla
   return 0.0;  // not reached
 }
 
-// The grid covers every window; those not marked by the wave kernel exit at once.
-__global__ __launch_bounds__(kWinThreads) void window_stats_heavy_kernel(WinArgs a) {
-  __shared__ WinShared sh;
-  const int tid = threadIdx.x;
-  const int w = blockIdx.x;
-  const int set = blockIdx.y;
-  const int64_t ridx = static_cast<int64_t>(set) * a.n_windows + w;
-  if (a.records[ridx].n_cdd_q != kHeavyMark) return;  // uniform over the workgroup
-  const int lo = clamp_site(a.lo[w], a.n_sites), hi = clamp_site(a.hi[w], a.n_sites);
-  const SetPlanes fl{a.planes, a.stride, cond_word(set), inv_word(a.with_inv, a.n_sets, set)};
-  const uint32_t n_c = static_cast<uint32_t>(a.records[ridx].n_cond);
-  const bool in_lds = n_c <= kSelCap;
+// One set of the window with n_c > kWaveCap qualifying sites, by the whole workgroup: Q, the Q list's
+// size and U's count (the wave stopped looking at values when it handed the set over).
+__device__ void heavy_set(WinShared& sh, const WinArgs& a, const WinSrc& src, int set, int lo, int hi, uint32_t n_c,
+                          int64_t ridx, int tid) {
+  const SetPlanes fl{cond_word(set), inv_word(a.with_inv, a.n_sets, set)};
+  const bool compact = n_c <= kSelCap;
   if (tid == 0) sh.n_stored = 0;
   __syncthreads();
-  if (in_lds) {
-    // a thread's eight sites: all frequencies first (independent loads), then one reservation in LDS --
-    // a byte costs two memory latencies, not one per site (under the next step's genotype stream a
-    // latency is several microseconds, and this kernel's time was mostly that chain)
-    for_each_cond_byte(fl, lo, hi, tid, [&](int64_t slot0, uint32_t ab, uint32_t c, uint32_t iv) {
+  if (compact) {
+    // a thread's eight sites: all frequencies first (independent reads), then one reservation in LDS
+    for_each_cond_byte(src, fl, lo, hi, tid, [&](int t, int rank0, uint32_t ab, uint32_t c, uint32_t iv) {
       double val[8];
 #pragma unroll
-      for (int b = 0; b < 8; ++b) val[b] = ((c >> b) & 1u) ? a.tgt_freq[slot0 + __popc(ab & ((1u << b) - 1u))] : 0.0;
+      for (int b = 0; b < 8; ++b) val[b] = ((c >> b) & 1u) ? src.freq(t, rank0 + __popc(ab & ((1u << b) - 1u))) : 0.0;
       uint32_t slot = atomicAdd(&sh.n_stored, static_cast<uint32_t>(__popc(c)));
 #pragma unroll
       for (int b = 0; b < 8; ++b)
@@ -542,8 +507,8 @@ __global__ __launch_bounds__(kWinThreads) void window_stats_heavy_kernel(WinArgs
   const bool take_max = v >= static_cast<double>(n_c - 1);
   const double fl_v = floor(v);
   const uint32_t k = take_max ? n_c - 1 : static_cast<uint32_t>(fl_v);
-  const double x0 = in_lds ? select_kth<true>(sh, a.tgt_freq, fl, lo, hi, n_c, k, tid)
-                           : select_kth<false>(sh, a.tgt_freq, fl, lo, hi, n_c, k, tid);
+  const double x0 = compact ? select_kth<true>(sh, src, fl, lo, hi, n_c, k, tid)
+                            : select_kth<false>(sh, src, fl, lo, hi, n_c, k, tid);
   double q = x0;
   if (!take_max) {
     // the next order statistic: x0 again when more than k + 1 values are <= x0, else the smallest
@@ -554,31 +519,151 @@ __global__ __launch_bounds__(kWinThreads) void window_stats_heavy_kernel(WinArgs
       c_le += u <= x0 ? 1u : 0u;
       if (u > x0 && u < m_gt) m_gt = u;
     };
-    if (in_lds) for_each_selected<true>(sh, a.tgt_freq, fl, lo, hi, n_c, tid, look);
-    else for_each_selected<false>(sh, a.tgt_freq, fl, lo, hi, n_c, tid, look);
+    if (compact) for_each_selected<true>(sh, src, fl, lo, hi, n_c, tid, look);
+    else for_each_selected<false>(sh, src, fl, lo, hi, n_c, tid, look);
     const uint32_t n_le = block_sum(c_le, sh.red, tid);
     const double above = block_min(m_gt, sh.redf, tid);
     const double x1 = n_le > k + 1 ? x0 : above;
     q = numpy_lerp(x0, x1, v, fl_v);
   }
-  // the Q list's size, and U's count (the wave kernel stopped looking at values when it handed the window over)
   const double x = a.x[set];
   uint32_t c_q = 0, c_u = 0;
   auto tally = [&](double u) {
     c_q += u >= q ? 1u : 0u;
     c_u += u > x ? 1u : 0u;
   };
-  if (in_lds) {
-    for (uint32_t i = tid; i < n_c; i += kWinThreads) tally(sh.vals[i]);
-  } else {
-    for_each_selected<false>(sh, a.tgt_freq, fl, lo, hi, n_c, tid, tally);
-  }
+  if (compact) for_each_selected<true>(sh, src, fl, lo, hi, n_c, tid, tally);
+  else for_each_selected<false>(sh, src, fl, lo, hi, n_c, tid, tally);
   const uint32_t n_q = block_sum(c_q, sh.red, tid);
   const uint32_t n_u = block_sum(c_u, sh.red, tid);
   if (tid == 0) {
-    a.records[ridx].n_cdd_q = static_cast<int32_t>(n_q);
-    a.records[ridx].u_count = static_cast<int32_t>(n_u);
-    a.records[ridx].q = q;
+    sai_window_record rec;
+    rec.n_sites = hi > lo ? hi - lo : 0;
+    rec.u_count = static_cast<int32_t>(n_u);
+    rec.n_cond = static_cast<int32_t>(n_c);
+    rec.n_cdd_q = static_cast<int32_t>(n_q);
+    rec.q = q;
+    a.records[ridx] = rec;
+  }
+  __syncthreads();
+}
+
+// One set of the window answered by one wave from the window's data: counts + order-preserving
+// compaction of the qualifying effective frequencies into the wave's LDS slice (U's tgt > x is taken
+// from the same values), then Q = numpy's `linear` quantile by rank counting.  Returns false -- with
+// n_c_out = the condition count -- when the set selects more than kWaveCap sites.
+__device__ __forceinline__ bool wave_set(const WinArgs& a, const WinSrc& src, double* vals, int set, int lo, int hi,
+                                         int lane, int64_t ridx, uint32_t& n_c_out) {
+  const int ci = cond_word(set), ii = inv_word(a.with_inv, a.n_sets, set);
+  const unsigned long long lt_mask = (1ull << lane) - 1ull;
+  const double x = a.x[set];
+  uint32_t n_c = 0, n_u = 0;
+  walk_tiles(lo, hi, lane, [&](int t, bool live, uint64_t mask) {
+    const uint64_t c = live ? src.word(t, ci) & mask : 0ull;
+    const uint32_t mine = __popcll(c);
+    const unsigned long long nonempty = __ballot(mine != 0u);
+    if (nonempty == 0ull) return;  // no condition site among these 4 096: the usual case
+    if (n_c >= kWaveCap) {  // uniform: the set goes to the workgroup and only the count matters
+      uint32_t tot = mine;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o, 64);
+      n_c += tot;
+      return;
+    }
+    const uint64_t iv = (c && ii >= 0) ? src.word(t, ii) : 0ull;
+    const uint64_t an = c ? src.word(t, kAny) : 0ull;
+    const int tb = t - lane;  // first tile of the chunk
+    for_nonempty_tiles(nonempty, [&](int n, const int (&tl)[kTileBatch]) {
+      uint64_t cw[kTileBatch], iw[kTileBatch], aw[kTileBatch];
+      double v[kTileBatch];
+#pragma unroll
+      for (int u = 0; u < kTileBatch; ++u) {
+        cw[u] = u < n ? read_lane64(c, tl[u]) : 0ull;
+        iw[u] = u < n ? read_lane64(iv, tl[u]) : 0ull;
+        aw[u] = u < n ? read_lane64(an, tl[u]) : 0ull;
+      }
+#pragma unroll
+      for (int u = 0; u < kTileBatch; ++u)
+        v[u] = ((cw[u] >> lane) & 1ull) ? src.freq(tb + tl[u], __popcll(aw[u] & lt_mask)) : 0.0;
+#pragma unroll
+      for (int u = 0; u < kTileBatch; ++u) {
+        const bool mine_c = (cw[u] >> lane) & 1ull;
+        const double e = ((iw[u] >> lane) & 1ull) ? 1.0 - v[u] : v[u];
+        const uint32_t slot = n_c + __popcll(cw[u] & lt_mask);  // tiles ascend, sites ascend inside a tile
+        if (mine_c && slot < kWaveCap) vals[slot] = e;
+        n_u += __popcll(__ballot(mine_c && e > x));
+        n_c += __popcll(cw[u]);
+      }
+    });
+  });
+  n_c_out = n_c;
+  if (n_c > kWaveCap) return false;  // uniform
+  double q = std::numeric_limits<double>::quiet_NaN();
+  uint32_t n_q = 0;
+  if (n_c > 0) {
+    wave_lds_fence();
+    const double v = static_cast<double>(n_c - 1) * a.quantile[set];
+    const bool take_max = v >= static_cast<double>(n_c - 1);  // at/after the last index: maximum
+    const double fl_v = floor(v);
+    const uint32_t k0 = take_max ? n_c - 1 : static_cast<uint32_t>(fl_v);
+    const uint32_t k1 = take_max ? n_c - 1 : k0 + 1;
+    double x0 = 0.0, x1 = 0.0;
+    // rank counting: rank(e) = #{j: v_j < v_e or (v_j == v_e and j < e)} is a permutation
+    for (uint32_t e0 = 0; e0 < n_c; e0 += 64) {
+      const uint32_t e = e0 + lane;
+      const bool act = e < n_c;
+      const double ve = act ? vals[e] : 0.0;
+      uint32_t rank = 0;
+      for (uint32_t j = 0; j < n_c; ++j) {
+        const double vj = vals[j];  // same address in every lane: LDS broadcast
+        rank += (vj < ve) || (vj == ve && j < e);
+      }
+      const unsigned long long h0 = __ballot(act && rank == k0);
+      const unsigned long long h1 = __ballot(act && rank == k1);
+      if (h0) x0 = __shfl(ve, __ffsll(static_cast<long long>(h0)) - 1, 64);
+      if (h1) x1 = __shfl(ve, __ffsll(static_cast<long long>(h1)) - 1, 64);
+    }
+    q = take_max ? x0 : numpy_lerp(x0, x1, v, fl_v);
+    for (uint32_t e0 = 0; e0 < n_c; e0 += 64) {
+      const uint32_t e = e0 + lane;
+      n_q += __popcll(__ballot(e < n_c && vals[e] >= q));
+    }
+    wave_lds_fence();  // the slice is reused by this wave's next set
+  }
+  if (lane == 0) {
+    sai_window_record rec;
+    rec.n_sites = hi > lo ? hi - lo : 0;
+    rec.u_count = static_cast<int32_t>(n_u);
+    rec.n_cond = static_cast<int32_t>(n_c);
+    rec.n_cdd_q = static_cast<int32_t>(n_q);
+    rec.q = q;
+    a.records[ridx] = rec;
+  }
+  return true;
+}
+
+__global__ __launch_bounds__(kWinThreads) void window_stats_kernel(WinArgs a) {
+  __shared__ WinShared sh;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int w = xcd_contiguous(blockIdx.x, gridDim.x);  // each XCD works on a contiguous run of (overlapping) windows
+  if (w >= a.n_windows) return;
+  const int lo = clamp_site(a.lo[w], a.n_sites), hi = clamp_site(a.hi[w], a.n_sites);
+  if (tid == 0) sh.n_heavy = 0;
+  const WinSrc src = load_window(a, lo, hi, sh.win, tid, true);
+  __syncthreads();
+  for (int set = wv; set < a.n_sets; set += kWinWaves) {
+    uint32_t n_c = 0;
+    if (!wave_set(a, src, sh.vals + wv * kWaveCap, set, lo, hi, lane, static_cast<int64_t>(set) * a.n_windows + w, n_c) && lane == 0) {
+      const int slot = atomicAdd(&sh.n_heavy, 1);
+      sh.heavy_set[slot] = set;
+      sh.heavy_count[slot] = n_c;
+    }
+  }
+  __syncthreads();
+  const int n_heavy = sh.n_heavy;  // uniform
+  for (int h = 0; h < n_heavy; ++h) {
+    const int set = sh.heavy_set[h];
+    heavy_set(sh, a, src, set, lo, hi, sh.heavy_count[h], static_cast<int64_t>(set) * a.n_windows + w, tid);
   }
 }
 
@@ -685,63 +770,85 @@ __global__ __launch_bounds__(kScanThreads) void window_scan_apply_kernel(WinArgs
 
 // ---- candidate lists -----------------------------------------------------------------------
 
-__global__ __launch_bounds__(256) void window_lists_kernel(WinArgs a) {
-  const int lane = threadIdx.x & 63;
-  const int w = xcd_contiguous(blockIdx.x, gridDim.x) * 4 + (threadIdx.x >> 6);
+struct ListShared {
+  WinLds win;
+  int32_t any_list;
+};
+
+// One workgroup per window: the window's rows and stored frequencies come into LDS once more, then
+// each wave writes the lists of its sets -- a tile's U sites are the condition bits whose effective
+// frequency exceeds x, its Q sites those whose frequency reaches q (a ballot each); each leaves at
+// `offset + done + popcount(word & lanes below)`, i.e. in ascending site order.
+__global__ __launch_bounds__(kWinThreads) void window_lists_kernel(WinArgs a) {
+  __shared__ ListShared sh;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int w = xcd_contiguous(blockIdx.x, gridDim.x);
   if (w >= a.n_windows) return;
-  const int set = blockIdx.y;
-  const int64_t ridx = static_cast<int64_t>(set) * a.n_windows + w;
-  const sai_window_record rec = a.records[ridx];
-  const long long off_u = a.cdd_off[2 * ridx + 0], off_q = a.cdd_off[2 * ridx + 1];
-  const bool write_u = rec.u_count > 0 && off_u >= 0 && a.cdd_u != nullptr;
-  const bool write_q = rec.n_cdd_q > 0 && off_q >= 0 && a.cdd_q != nullptr;
-  if (!write_u && !write_q) return;
+  // nothing to write for any set of this window (C3: most windows have no U candidate; a window without
+  // condition sites has no Q list either): leave before touching the planes
+  if (tid == 0) sh.any_list = 0;
+  __syncthreads();
+  if (tid < a.n_sets) {
+    const int64_t r = static_cast<int64_t>(tid) * a.n_windows + w;
+    const sai_window_record rec = a.records[r];
+    if ((rec.u_count > 0 && a.cdd_off[2 * r] >= 0 && a.cdd_u != nullptr) || (rec.n_cdd_q > 0 && a.cdd_off[2 * r + 1] >= 0 && a.cdd_q != nullptr))
+      sh.any_list = 1;
+  }
+  __syncthreads();
+  if (!sh.any_list) return;  // uniform
   const int lo = clamp_site(a.lo[w], a.n_sites), hi = clamp_site(a.hi[w], a.n_sites);
-  const int ci = cond_word(set), ii = inv_word(a.with_inv, a.n_sets, set);
-  const double q = rec.q, x = a.x[set];
+  const WinSrc src = load_window(a, lo, hi, sh.win, tid, true);
   const unsigned long long lt_mask = (1ull << lane) - 1ull;
-  uint32_t done_u = 0, done_q = 0;
-  walk_tiles(lo, hi, lane, [&](int t, bool live, uint64_t mask) {
-    const uint64_t* row = a.planes + static_cast<int64_t>(t) * a.stride;
-    const uint64_t c = live ? row[ci] & mask : 0ull;
-    const unsigned long long nonempty = __ballot(c != 0ull);
-    if (nonempty == 0ull) return;
-    const uint64_t iv = (c && ii >= 0) ? row[ii] : 0ull;
-    const uint64_t an = c ? row[kAny] : 0ull;
-    const int tb = t - lane;
-    // lane = site: a tile's marked sites leave in site order, placed by the popcount of the lanes below
-    for_nonempty_tiles(nonempty, [&](int n, const int (&tl)[kTileBatch]) {
-      uint64_t cw[kTileBatch], iw[kTileBatch], aw[kTileBatch];
-      double v[kTileBatch];
-      int32_t p[kTileBatch];
+  for (int set = wv; set < a.n_sets; set += kWinWaves) {
+    const int64_t ridx = static_cast<int64_t>(set) * a.n_windows + w;
+    const sai_window_record rec = a.records[ridx];
+    const long long off_u = a.cdd_off[2 * ridx + 0], off_q = a.cdd_off[2 * ridx + 1];
+    const bool write_u = rec.u_count > 0 && off_u >= 0 && a.cdd_u != nullptr;
+    const bool write_q = rec.n_cdd_q > 0 && off_q >= 0 && a.cdd_q != nullptr;
+    if (!write_u && !write_q) continue;
+    const int ci = cond_word(set), ii = inv_word(a.with_inv, a.n_sets, set);
+    const double q = rec.q, x = a.x[set];
+    uint32_t done_u = 0, done_q = 0;
+    walk_tiles(lo, hi, lane, [&](int t, bool live, uint64_t mask) {
+      const uint64_t c = live ? src.word(t, ci) & mask : 0ull;
+      const unsigned long long nonempty = __ballot(c != 0ull);
+      if (nonempty == 0ull) return;
+      const uint64_t iv = (c && ii >= 0) ? src.word(t, ii) : 0ull;
+      const uint64_t an = c ? src.word(t, kAny) : 0ull;
+      const int tb = t - lane;
+      // lane = site: a tile's marked sites leave in site order, placed by the popcount of the lanes below
+      for_nonempty_tiles(nonempty, [&](int n, const int (&tl)[kTileBatch]) {
+        uint64_t cw[kTileBatch], iw[kTileBatch], aw[kTileBatch];
+        bool mu[kTileBatch], mq[kTileBatch];
 #pragma unroll
-      for (int u = 0; u < kTileBatch; ++u) {
-        cw[u] = u < n ? read_lane64(c, tl[u]) : 0ull;
-        iw[u] = u < n ? read_lane64(iv, tl[u]) : 0ull;
-        aw[u] = u < n ? read_lane64(an, tl[u]) : 0ull;
-      }
+        for (int u = 0; u < kTileBatch; ++u) {
+          cw[u] = u < n ? read_lane64(c, tl[u]) : 0ull;
+          iw[u] = u < n ? read_lane64(iv, tl[u]) : 0ull;
+          aw[u] = u < n ? read_lane64(an, tl[u]) : 0ull;
+        }
 #pragma unroll
-      for (int u = 0; u < kTileBatch; ++u) {
-        const int64_t tile = tb + tl[u];
-        const int64_t site = tile * kTile + lane;
-        const bool mine_c = (cw[u] >> lane) & 1ull;
-        v[u] = mine_c ? a.tgt_freq[tile * kTile + __popcll(aw[u] & lt_mask)] : 0.0;
-        p[u] = mine_c ? (a.pos ? a.pos[site] : static_cast<int32_t>(site)) : 0;
-      }
+        for (int u = 0; u < kTileBatch; ++u) {
+          const bool mine_c = (cw[u] >> lane) & 1ull;
+          const double v = mine_c ? src.freq(tb + tl[u], __popcll(aw[u] & lt_mask)) : 0.0;
+          const double e = ((iw[u] >> lane) & 1ull) ? 1.0 - v : v;
+          mu[u] = write_u && mine_c && e > x;
+          mq[u] = write_q && mine_c && e >= q;
+        }
 #pragma unroll
-      for (int u = 0; u < kTileBatch; ++u) {
-        const bool mine_c = (cw[u] >> lane) & 1ull;
-        const double e = ((iw[u] >> lane) & 1ull) ? 1.0 - v[u] : v[u];
-        const bool mine_u = write_u && mine_c && e > x;
-        const bool mine_q = write_q && mine_c && e >= q;
-        const unsigned long long uw = __ballot(mine_u), qw = __ballot(mine_q);
-        if (mine_u) a.cdd_u[off_u + done_u + __popcll(uw & lt_mask)] = p[u];
-        if (mine_q) a.cdd_q[off_q + done_q + __popcll(qw & lt_mask)] = p[u];
-        done_u += __popcll(uw);
-        done_q += __popcll(qw);
-      }
+        for (int u = 0; u < kTileBatch; ++u) {
+          const unsigned long long uw = __ballot(mu[u]), qw = __ballot(mq[u]);
+          if (uw | qw) {  // uniform: positions are read only for the sites that leave
+            const int64_t site = static_cast<int64_t>(tb + tl[u]) * kTile + lane;
+            const int32_t p = (mu[u] || mq[u]) ? (a.pos ? a.pos[site] : static_cast<int32_t>(site)) : 0;
+            if (mu[u]) a.cdd_u[off_u + done_u + __popcll(uw & lt_mask)] = p;
+            if (mq[u]) a.cdd_q[off_q + done_q + __popcll(qw & lt_mask)] = p;
+            done_u += __popcll(uw);
+            done_q += __popcll(qw);
+          }
+        }
+      });
     });
-  });
+  }
 }
 
 }  // namespace
@@ -824,12 +931,9 @@ int sai_window_stats(sai_ctx* ctx, int64_t n_sites, const double* tgt_freq, cons
     a.quantile[s] = sets_host[s].quantile;
     a.x[s] = sets_host[s].x;
   }
-  const dim3 wave_grid(static_cast<unsigned>((n_windows + 3) / 4), static_cast<unsigned>(n_sets));
-  const dim3 block_grid(static_cast<unsigned>(n_windows), static_cast<unsigned>(n_sets));
-  hipLaunchKernelGGL(window_stats_wave_kernel, wave_grid, dim3(256), 0, st, a);
-  if (int rc = check_launch("window_stats_wave")) return rc;
-  hipLaunchKernelGGL(window_stats_heavy_kernel, block_grid, dim3(kWinThreads), 0, st, a);
-  if (int rc = check_launch("window_stats_heavy")) return rc;
+  const dim3 win_grid(static_cast<unsigned>(n_windows));
+  hipLaunchKernelGGL(window_stats_kernel, win_grid, dim3(kWinThreads), 0, st, a);
+  if (int rc = check_launch("window_stats")) return rc;
   const int64_t n_rec = static_cast<int64_t>(n_sets) * n_windows;
   const unsigned scan_grid = static_cast<unsigned>((n_rec + kScanBlock - 1) / kScanBlock);
   long long* partials = reinterpret_cast<long long*>(cdd_total) + 2;  // the caller's scratch behind the two totals
@@ -837,7 +941,7 @@ int sai_window_stats(sai_ctx* ctx, int64_t n_sites, const double* tgt_freq, cons
   if (int rc = check_launch("window_scan_partials")) return rc;
   hipLaunchKernelGGL(window_scan_apply_kernel, dim3(scan_grid), dim3(kScanThreads), 0, st, a, partials);
   if (int rc = check_launch("window_scan_apply")) return rc;
-  hipLaunchKernelGGL(window_lists_kernel, wave_grid, dim3(256), 0, st, a);
+  hipLaunchKernelGGL(window_lists_kernel, win_grid, dim3(kWinThreads), 0, st, a);
   return check_launch("window_lists");
 }
 
