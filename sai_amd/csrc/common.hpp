@@ -72,14 +72,35 @@ inline bool sets_with_inverted(int32_t n_sets, const sai_params* sets) {
   return false;
 }
 
-inline unsigned stream_grid(const sai_ctx* ctx, int64_t n_tiles) {
+inline int stream_waves_override() {
   static const int waves_per_cu = [] {  // SAI_STREAM_WAVES_PER_CU: tuning knob for sweeps
     const char* e = std::getenv("SAI_STREAM_WAVES_PER_CU");
     const int v = e ? std::atoi(e) : 0;
-    return v > 0 ? v : kStreamWavesPerCu;
+    return v > 0 ? v : 0;
   }();
+  return waves_per_cu;
+}
+
+inline unsigned stream_grid(const sai_ctx* ctx, int64_t n_tiles, int waves_per_cu = kStreamWavesPerCu) {
+  if (stream_waves_override()) waves_per_cu = stream_waves_override();
   const int64_t max_grid = static_cast<int64_t>(ctx->n_cu) * waves_per_cu;  // grid-stride beyond this
   return static_cast<unsigned>(n_tiles < max_grid ? n_tiles : max_grid);
+}
+
+// Waves per CU of the int8 / packed2 site pass (profiles/r04_waves_per_cu.txt, same-box sweeps):
+//  * with many parameter sets (C5's 18) the pass alone is fastest at 16 (3.23 ms; 12: 3.28; 8: 3.89 -- every
+//    tile ends in the sets' evaluation, during which a wave loads nothing), but the PIPELINED step, with the
+//    previous step's windows stage next to it, is fastest at 12: 3.31 against 3.56 ms (13: 3.33, 14: 3.45,
+//    11: 3.38) whatever the stage's kernels look like -- three pass waves per SIMD leave the stage's waves
+//    registers and issue slots that a fourth takes away;
+//  * with one to three sets a long pass is a little faster at 8 -- two waves per SIMD, multiples of four
+//    only: 9 and 10 are slower than either -- C3 2.924 against 2.966 ms, three chromosomes of C4 4.37
+//    against 4.47-4.57, packed2 0.79-0.82 against 0.85;
+//  * a short pass (C2: 15 625 tiles, under four per wave at 16) needs its waves for the ramp and the
+//    tail: 16 (0.088 ms per step against 0.109 at 8).
+inline int site_pass_waves_per_cu(const sai_ctx* ctx, int64_t n_tiles, int32_t n_sets) {
+  if (n_sets >= 4) return 12;
+  return n_tiles >= static_cast<int64_t>(ctx->n_cu) * 8 * 32 ? 8 : kStreamWavesPerCu;
 }
 
 // XCD-aware block order: consecutive workgroup ids go round-robin over the 8 XCDs; give each XCD a

@@ -193,17 +193,24 @@ struct WinSrc {
   }
 };
 
-// Called by the whole workgroup (it synchronises).  what & 1: rows, what & 2: frequencies too.
-__device__ __forceinline__ WinSrc load_window(const WinArgs& a, int lo, int hi, WinLds& sh, int tid, bool want_freq) {
+// the window's data where it lies in global memory
+__device__ __forceinline__ WinSrc global_window(const WinArgs& a, int lo) {
   WinSrc s;
   s.g_rows = a.planes;
   s.g_freq = a.tgt_freq;
   s.g_stride = a.stride;
-  s.lds = &sh;
+  s.lds = nullptr;
   s.t0 = lo >> 6;
   s.used = 1 + a.n_sets * (a.with_inv ? 2 : 1);
   s.rows_in_lds = false;
   s.freq_in_lds = false;
+  return s;
+}
+
+// Called by the whole workgroup (it synchronises): rows, and the stored frequencies when asked for.
+__device__ __forceinline__ WinSrc load_window(const WinArgs& a, int lo, int hi, WinLds& sh, int tid, bool want_freq) {
+  WinSrc s = global_window(a, lo);
+  s.lds = &sh;
   const int nt = hi > lo ? ((hi + kTile - 1) >> 6) - s.t0 : 0;
   if (nt <= 0 || nt > kLdsTiles || nt * s.used > kRowWords) return s;  // uniform over the workgroup
   s.rows_in_lds = true;
@@ -277,327 +284,286 @@ __device__ __forceinline__ void walk_tiles(int lo, int hi, int lane, F&& on_chun
   }
 }
 
-// ---- the workgroup's radix select (sets with more than kWaveCap qualifying sites) ---------------
+// ---- sets with more than kWaveCap qualifying sites: the wave's radix select ----------------------
 //
 // Loose source conditions (C5's ("=0", "=0") and (">=0", ">=0") sets select ~630 of a window's 2 000
-// sites) are finished by the whole workgroup.  The k-th smallest value is found by a radix select ON
-// THE VALUE: all values lie in [0, 1], so digit l of a value is floor(frac_l * 1024) with frac_0 = v,
-// frac_{l+1} = frac_l * 1024 - digit_l -- multiplications by a power of two and subtractions of the
+// sites) are finished by the same wave.  The k-th smallest value is found by a radix select ON THE
+// VALUE: all values lie in [0, 1], so digit l of a value is floor(frac_l * 256) with frac_0 = v,
+// frac_{l+1} = frac_l * 256 - digit_l -- multiplications by a power of two and subtractions of the
 // integer part, all exact in binary floating point -- which makes the digits a monotone, lossless code
-// of the value (twelve digits use up the mantissa of every frequency a block can produce).  One
-// histogram pass per level narrows the candidates to one of 1025 bins (bin 1024 holds exactly 1.0);
-// frequencies k / (called * ploidy) separate within two or three levels, then the few members of the
-// bin are gathered and ranked directly.
+// of the value.  One histogram pass over the set's values (re-read through the window's planes: they
+// sit in LDS) narrows the candidates to one of 257 bins (bin 256 holds exactly 1.0); frequencies
+// k / (called * ploidy) near a high quantile separate within one or two levels, then the members of the
+// bin are gathered (ballot-ranked, no atomics) and ranked directly.  Round 3 gave such a set to a
+// 256-thread workgroup of its own (1 025 bins, ~25 workgroup barriers per set): under the next step's
+// genotype stream a barrier couples four waves that each wait microseconds for their turn.
 
-constexpr int kBins = 1025;      // digits 0..1023, and 1024 for the value 1.0
-// 12 x 10 bits: a frequency is >= 1 / (n_called * ploidy) > 2^-55 (n_ind <= 2^24, ploidy < 2^31), so
+constexpr int kDigitBits = 8;
+constexpr int kBins = (1 << kDigitBits) + 1;  // digits 0..255, and 256 for the value 1.0
+// 15 x 8 bits: a frequency is >= 1 / (n_called * ploidy) > 2^-55 (n_ind <= 2^24, ploidy < 2^31), so
 // its 53 mantissa bits end above 2^-108 -- 120 fractional bits tell any two distinct doubles apart,
 // and members that still share a bin after the last level are the same number
-constexpr int kMaxLevels = 12;
-constexpr int kSmallBin = 256;   // members ranked directly
+constexpr int kMaxLevels = 15;
+constexpr int kListCap = 1024;  // qualifying sites of a set whose LDS frequency slots a wave lists (16 bits each)
+static_assert(kFreqCap <= 0x8000, "a list entry keeps the frequency's LDS slot in 15 bits");
 
-struct WinShared {
-  WinLds win;
-  double vals[kSelCap];  // wave wv's slice [wv * kWaveCap, ...) while the waves answer sets; the select's values after
-  uint32_t hist[kBins + 3];
-  double small[kSmallBin];
-  uint32_t wave_tot[kWinWaves];
-  uint32_t red[kWinWaves];
-  double redf[kWinWaves];
-  uint32_t n_stored;
+struct WaveLds {
+  double vals[kWaveCap];      // the set's first qualifying values (all of them for a light set); the select's gathered bin
+  uint32_t hist[kBins + 63];  // padded so that 64 lanes x 5 bins stay inside
   uint32_t n_small;
-  uint32_t digit;
-  uint32_t k_rem;
-  uint32_t bin_count;
-  int32_t n_heavy;
-  int32_t heavy_set[SAI_MAX_SETS];
-  uint32_t heavy_count[SAI_MAX_SETS];
 };
 
-__device__ __forceinline__ uint32_t block_sum(uint32_t v, uint32_t* red, int tid) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  __syncthreads();
-  if ((tid & 63) == 0) red[tid >> 6] = v;
-  __syncthreads();
-  return red[0] + red[1] + red[2] + red[3];
+// The digits chosen so far, as the number they spell: prefix = floor(v * 256^level) for every value v still
+// on the path (a floor of a double: exact), scale = 256^level.
+struct Path {
+  double prefix;
+  double scale;
+};
+
+// digit `level` of v, or -1 when v left the chosen path at an earlier level.  v * scale and its multiple by
+// 256 are scalings by powers of two, the floors of doubles are doubles, and the difference is the digit
+// itself (0..255, or 256 for v = 1.0 at level 0): every step is exact.
+__device__ __forceinline__ int digit_on_path(double v, const Path& path) {
+  const double s = v * path.scale;
+  if (path.scale != 1.0 && floor(s) != path.prefix) return -1;  // at level 0 every value is on the path (1.0: digit 256)
+  return static_cast<int>(floor(s * static_cast<double>(1 << kDigitBits)) - path.prefix * static_cast<double>(1 << kDigitBits));
 }
 
-__device__ __forceinline__ double block_min(double v, double* red, int tid) {
+// A set's planes as a wave walks them when it needs every qualifying site: eight lanes per tile, each
+// owning eight sites (one byte of the tile's condition word), eight tiles per round -- a 2 000-site window
+// is five rounds, against 33 with lane = site.  on_byte(t, c, rank0, any_bits, inv_bits) is called by the
+// WHOLE wave once per round (c = 0 in lanes without a condition site): bit b of c has its frequency at
+// rank rank0 + popcount(any_bits below b) of tile t.  Bytes ascend with the lane, so (lane, bit) order
+// is site order.
+template <typename F>
+__device__ __forceinline__ void walk_bytes(const WinSrc& src, int ci, int ii, int lo, int hi, int lane, F&& on_byte) {
+  const int sub = lane & 7;
+  // lane = tile first: ONE load per plane brings 64 tiles' words (the window), the rounds below take
+  // theirs from the lanes that hold them -- no round waits for a load of its own
+  walk_tiles(lo, hi, lane, [&](int t, bool live, uint64_t mask) {
+    const uint64_t cw = live ? src.word(t, ci) & mask : 0ull;
+    const uint64_t aw = live ? src.word(t, kAny) : 0ull;
+    const uint64_t iw = (live && ii >= 0) ? src.word(t, ii) : 0ull;
+    const unsigned long long nonempty = __ballot(cw != 0ull);
+    if (nonempty == 0ull) return;  // no condition site among these 4 096: the usual case for a tight set
+    const int tb = t - lane;
+#pragma unroll 1
+    for (int r = 0; r < 8; ++r) {
+      if (((nonempty >> (8 * r)) & 0xFFull) == 0ull) continue;  // wave-uniform
+      const int from = 8 * r + (lane >> 3);
+      const uint64_t c64 = __shfl(cw, from, 64), a64 = __shfl(aw, from, 64), i64 = __shfl(iw, from, 64);
+      const uint32_t c = static_cast<uint32_t>(c64 >> (8 * sub)) & 0xFFu;
+      on_byte(tb + from, c, __popcll(a64 & ((1ull << (8 * sub)) - 1ull)), static_cast<uint32_t>(a64 >> (8 * sub)) & 0xFFu,
+              static_cast<uint32_t>(i64 >> (8 * sub)) & 0xFFu);
+    }
+  });
+}
+
+// How the passes of a heavy set see its values: the wave's list of LDS frequency slots when the build
+// pass could make one (the window's frequencies are in LDS and the set selects at most kListCap sites:
+// ten rounds of 64 for C5's 630), else the planes again.  use(e) runs per lane, possibly under a
+// divergent mask: no wave-wide operation inside.
+struct SetValues {
+  const WinSrc* src;
+  const uint16_t* list;  // slot of each qualifying site's frequency in WinLds::freq, bit 15 = inverted; or NULL
+  int ci, ii, lo, hi;
+  uint32_t n_c;
+};
+
+// the eight sites of a lane's byte: all frequencies first (independent reads), then fn(b, e) per condition bit
+template <typename F>
+__device__ __forceinline__ void for_byte_values(const WinSrc& src, int t, uint32_t c, int rank0, uint32_t ab, uint32_t iv, F&& fn) {
+  double v[8];
+#pragma unroll
+  for (int b = 0; b < 8; ++b) v[b] = ((c >> b) & 1u) ? src.freq(t, rank0 + __popc(ab & ((1u << b) - 1u))) : 0.0;
+#pragma unroll
+  for (int b = 0; b < 8; ++b)
+    if ((c >> b) & 1u) fn(b, ((iv >> b) & 1u) ? 1.0 - v[b] : v[b]);
+}
+
+constexpr int kListUnroll = 4;
+
+template <typename F>
+__device__ __forceinline__ void for_each_selected(const SetValues& sv, int lane, F&& use) {
+  if (sv.list) {
+    for (uint32_t i0 = 0; i0 < sv.n_c; i0 += 64 * kListUnroll) {  // four entries per lane in flight
+      uint32_t entry[kListUnroll];
+      double v[kListUnroll];
+#pragma unroll
+      for (int u = 0; u < kListUnroll; ++u) {
+        const uint32_t i = i0 + u * 64 + lane;
+        entry[u] = i < sv.n_c ? sv.list[i] : 0xFFFFFFFFu;
+      }
+#pragma unroll
+      for (int u = 0; u < kListUnroll; ++u) v[u] = entry[u] != 0xFFFFFFFFu ? sv.src->lds->freq[entry[u] & 0x7FFFu] : 0.0;
+#pragma unroll
+      for (int u = 0; u < kListUnroll; ++u)
+        if (entry[u] != 0xFFFFFFFFu) use((entry[u] & 0x8000u) ? 1.0 - v[u] : v[u]);
+    }
+  } else {
+    walk_bytes(*sv.src, sv.ci, sv.ii, sv.lo, sv.hi, lane, [&](int t, uint32_t c, int rank0, uint32_t ab, uint32_t iv) {
+      for_byte_values(*sv.src, t, c, rank0, ab, iv, [&](int, double e) { use(e); });
+    });
+  }
+}
+
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// first radix digit of a value in [0, 1] (digit_on_path at level 0)
+__device__ __forceinline__ int first_digit(double e) {
+  const int d = static_cast<int>(e * static_cast<double>(1 << kDigitBits));
+  return d > (1 << kDigitBits) ? (1 << kDigitBits) : d;
+}
+
+// The bin of the wave's histogram that holds rank k: {digit, rank inside the bin, members}.  Lane l owns
+// bins 5 l .. 5 l + 4; exclusive scan of the lanes' sums.
+struct BinOfRank {
+  int digit;
+  uint32_t rank_in_bin, members;
+};
+__device__ __forceinline__ BinOfRank bin_of_rank(const WaveLds& sh, uint32_t k, int lane) {
+  uint32_t h[5], mine_sum = 0;
+#pragma unroll
+  for (int j = 0; j < 5; ++j) {
+    h[j] = sh.hist[lane * 5 + j];
+    mine_sum += h[j];
+  }
+  uint32_t inc = mine_sum;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t t = __shfl_up(inc, o, 64);
+    if (lane >= o) inc += t;
+  }
+  uint32_t before = inc - mine_sum;
+  int my_digit = -1;
+  uint32_t my_rem = 0, my_count = 0;
+#pragma unroll
+  for (int j = 0; j < 5; ++j) {
+    if (h[j] != 0 && k >= before && k < before + h[j]) {  // exactly one bin of one lane
+      my_digit = lane * 5 + j;
+      my_rem = k - before;
+      my_count = h[j];
+    }
+    before += h[j];
+  }
+  const int owner = __ffsll(static_cast<long long>(__ballot(my_digit >= 0))) - 1;
+  return BinOfRank{__shfl(my_digit, owner, 64), static_cast<uint32_t>(__shfl(my_rem, owner, 64)),
+                   static_cast<uint32_t>(__shfl(my_count, owner, 64))};
+}
+
+// the values of ranks k0 and k1 among vals[0, n) (ties broken by slot: ranks are a permutation); a rank
+// >= n leaves its output untouched
+__device__ __forceinline__ void two_ranks(const double* vals, uint32_t n, uint32_t k0, uint32_t k1, int lane, double& x0, double& x1) {
+  for (uint32_t e0 = 0; e0 < n; e0 += 64) {
+    const uint32_t e = e0 + lane;
+    const bool act = e < n;
+    const double ve = act ? vals[e] : 0.0;
+    uint32_t rank = 0;
+    for (uint32_t j = 0; j < n; ++j) {
+      const double vj = vals[j];  // same address in every lane: LDS broadcast
+      rank += (vj < ve) || (vj == ve && j < e);
+    }
+    const unsigned long long h0 = __ballot(act && rank == k0);
+    const unsigned long long h1 = __ballot(act && rank == k1);
+    if (h0) x0 = __shfl(ve, __ffsll(static_cast<long long>(h0)) - 1, 64);
+    if (h1) x1 = __shfl(ve, __ffsll(static_cast<long long>(h1)) - 1, 64);
+  }
+}
+
+__device__ __forceinline__ double wave_min(double m) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
-    const double w = __shfl_xor(v, o, 64);
-    v = w < v ? w : v;
+    const double other = __shfl_xor(m, o, 64);
+    m = other < m ? other : m;
   }
-  __syncthreads();
-  if ((tid & 63) == 0) red[tid >> 6] = v;
-  __syncthreads();
-  double m = red[0];
-#pragma unroll
-  for (int k = 1; k < 4; ++k) m = red[k] < m ? red[k] : m;
   return m;
 }
 
-// digit `level` of v, or -1 when v left the chosen path at an earlier level
-__device__ __forceinline__ int digit_on_path(double v, int level, const int (&path)[kMaxLevels]) {
-  double f = v;
-  for (int l = 0;; ++l) {
-    const double t = f * 1024.0;
-    int d = static_cast<int>(t);
-    d = d > 1024 ? 1024 : d;
-    if (l == level) return d;
-    if (d != path[l]) return -1;
-    f = t - static_cast<double>(d);
-  }
-}
-
-// One set's planes as the workgroup walks them: eight threads per tile, each owning eight sites (one
-// byte of the tile's condition word), so a 2 000-site window keeps all 256 threads busy.
-struct SetPlanes {
-  int cond;  // word of this set's condition in a row
-  int inv;   // word of its inverted plane, or -1
-};
-constexpr int kSubs = 8;  // threads per tile
-
-// on_byte(tile, rank0, any_bits, cond_bits, inv_bits) for every byte of the window that holds a condition
-// site: bit b of the byte has its frequency at src.freq(tile, rank0 + popcount(any_bits below b))
-template <typename F>
-__device__ __forceinline__ void for_each_cond_byte(const WinSrc& src, const SetPlanes& sp, int lo, int hi, int tid, F&& on_byte) {
-  if (hi <= lo) return;
-  const int t0 = lo >> 6, t1 = (hi + kTile - 1) >> 6;
-  const int sub = tid % kSubs;
-  for (int t = t0 + tid / kSubs; t < t1; t += kWinThreads / kSubs) {
-    const uint32_t c = static_cast<uint32_t>((src.word(t, sp.cond) & range_mask(t, lo, hi)) >> (8 * sub)) & 0xFFu;
-    if (c == 0u) continue;
-    const uint64_t any = src.word(t, kAny);
-    on_byte(t, __popcll(any & ((1ull << (8 * sub)) - 1ull)), static_cast<uint32_t>(any >> (8 * sub)) & 0xFFu, c,
-            sp.inv >= 0 ? static_cast<uint32_t>(src.word(t, sp.inv) >> (8 * sub)) & 0xFFu : 0u);
-  }
-}
-
-// calls use(v) for every selected value of the window: from the compact copy in LDS, or through the
-// window's planes when the set selects more than kSelCap of them
-template <bool COMPACT, typename F>
-__device__ __forceinline__ void for_each_selected(const WinShared& sh, const WinSrc& src, const SetPlanes& sp, int lo,
-                                                  int hi, uint32_t n_sel, int tid, F&& use) {
-  if (COMPACT) {
-    for (uint32_t i = tid; i < n_sel; i += kWinThreads) use(sh.vals[i]);
-  } else {
-    for_each_cond_byte(src, sp, lo, hi, tid, [&](int t, int rank0, uint32_t ab, uint32_t c, uint32_t iv) {
-      while (c) {
-        const int b = __ffs(static_cast<int>(c)) - 1;
-        c &= c - 1u;
-        const double v = src.freq(t, rank0 + __popc(ab & ((1u << b) - 1u)));
-        use(((iv >> b) & 1u) ? 1.0 - v : v);
-      }
-    });
-  }
-}
-
-// k-th smallest (0-based) of the selected values
-template <bool COMPACT>
-__device__ double select_kth(WinShared& sh, const WinSrc& src, const SetPlanes& fl, int lo, int hi,
-                             uint32_t n_sel, uint32_t k, int tid) {
-  int path[kMaxLevels];
-#pragma unroll
-  for (int l = 0; l < kMaxLevels; ++l) path[l] = 0;
+// k-th smallest (0-based) of the set's qualifying values, by one wave
+__device__ __forceinline__ double wave_select_kth(WaveLds& sh, const SetValues& sv, uint32_t k, int lane) {
+  Path path{0.0, 1.0};
   for (int level = 0; level < kMaxLevels; ++level) {
-    for (int i = tid; i < kBins; i += kWinThreads) sh.hist[i] = 0;
-    __syncthreads();
-    for_each_selected<COMPACT>(sh, src, fl, lo, hi, n_sel, tid, [&](double v) {
-      const int d = digit_on_path(v, level, path);
+#pragma unroll
+    for (int j = 0; j < 5; ++j) sh.hist[j * 64 + lane] = 0u;  // 320 >= kBins
+    if (lane == 0) sh.n_small = 0u;
+    wave_lds_fence();
+    for_each_selected(sv, lane, [&](double e) {
+      const int d = digit_on_path(e, path);
       if (d >= 0) atomicAdd(&sh.hist[d], 1u);
     });
-    __syncthreads();
-    // the bin that holds rank k: every thread owns 5 consecutive bins (256 x 5 >= 1025), exclusive
-    // scan of the per-thread sums with shuffles inside each wave and wave totals through LDS
-    uint32_t h[5], mine = 0;
-#pragma unroll
-    for (int j = 0; j < 5; ++j) {
-      const int bin = tid * 5 + j;
-      h[j] = bin < kBins ? sh.hist[bin] : 0u;
-      mine += h[j];
-    }
-    uint32_t inc = mine;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const uint32_t t = __shfl_up(inc, o, 64);
-      if ((tid & 63) >= o) inc += t;
-    }
-    if ((tid & 63) == 63) sh.wave_tot[tid >> 6] = inc;
-    __syncthreads();
-    uint32_t before = inc - mine;
-    for (int wv = 0; wv < (tid >> 6); ++wv) before += sh.wave_tot[wv];
-#pragma unroll
-    for (int j = 0; j < 5; ++j) {
-      if (h[j] != 0 && k >= before && k < before + h[j]) {  // exactly one bin of one thread
-        sh.digit = static_cast<uint32_t>(tid * 5 + j);
-        sh.k_rem = k - before;
-        sh.bin_count = h[j];
-      }
-      before += h[j];
-    }
-    __syncthreads();
-    path[level] = static_cast<int>(sh.digit);
-    k = sh.k_rem;
-    const uint32_t members = sh.bin_count;
-    __syncthreads();
-    if (members <= kSmallBin || level == kMaxLevels - 1) {
-      // gather the bin (at the last level all its members are the same number) and rank directly
-      if (tid == 0) sh.n_small = 0;
-      __syncthreads();
-      for_each_selected<COMPACT>(sh, src, fl, lo, hi, n_sel, tid, [&](double v) {
-        if (digit_on_path(v, level, path) == path[level]) {  // on the chosen path through this level
+    wave_lds_fence();
+    const BinOfRank bin = bin_of_rank(sh, k, lane);
+    const int digit = bin.digit;
+    k = bin.rank_in_bin;
+    const uint32_t members = bin.members;
+    if (members <= kWaveCap || level == kMaxLevels - 1) {
+      // gather the bin (at the last level all its members are the same number) and rank directly; the order
+      // of the members does not matter: ties are broken by slot, whichever value ends up with rank k is the
+      // k-th smallest
+      for_each_selected(sv, lane, [&](double e) {
+        if (digit_on_path(e, path) == digit) {
           const uint32_t slot = atomicAdd(&sh.n_small, 1u);
-          if (slot < kSmallBin) sh.small[slot] = v;
+          if (slot < kWaveCap) sh.vals[slot] = e;
         }
       });
-      __syncthreads();
-      const uint32_t n = sh.n_small < kSmallBin ? sh.n_small : kSmallBin;
-      if (members > kSmallBin) {  // last level: all equal
-        const double same = sh.small[0];
-        __syncthreads();
-        return same;
-      }
-      // rank counting with ties broken by slot: ranks are a permutation of 0..n-1
-      double found = 0.0;
-      bool have = false;
-      for (uint32_t e = tid; e < n; e += kWinThreads) {
-        const double ve = sh.small[e];
-        uint32_t rank = 0;
-        for (uint32_t j = 0; j < n; ++j) {
-          const double vj = sh.small[j];
-          rank += (vj < ve) || (vj == ve && j < e);
-        }
-        if (rank == k) { found = ve; have = true; }
-      }
-      __syncthreads();
-      if (have) sh.small[0] = found;  // exactly one thread
-      __syncthreads();
-      const double res = sh.small[0];
-      __syncthreads();
-      return res;
+      wave_lds_fence();
+      if (members > kWaveCap) return sh.vals[0];  // last level: all equal
+      double found = 0.0, unused = 0.0;
+      two_ranks(sh.vals, members, k, k, lane, found, unused);
+      wave_lds_fence();
+      return found;
     }
+    path.prefix = path.prefix * static_cast<double>(1 << kDigitBits) + static_cast<double>(digit);
+    path.scale *= static_cast<double>(1 << kDigitBits);
   }
   return 0.0;  // not reached
 }
 
-// One set of the window with n_c > kWaveCap qualifying sites, by the whole workgroup: Q, the Q list's
-// size and U's count (the wave stopped looking at values when it handed the set over).
-__device__ void heavy_set(WinShared& sh, const WinArgs& a, const WinSrc& src, int set, int lo, int hi, uint32_t n_c,
-                          int64_t ridx, int tid) {
-  const SetPlanes fl{cond_word(set), inv_word(a.with_inv, a.n_sets, set)};
-  const bool compact = n_c <= kSelCap;
-  if (tid == 0) sh.n_stored = 0;
-  __syncthreads();
-  if (compact) {
-    // a thread's eight sites: all frequencies first (independent reads), then one reservation in LDS
-    for_each_cond_byte(src, fl, lo, hi, tid, [&](int t, int rank0, uint32_t ab, uint32_t c, uint32_t iv) {
-      double val[8];
-#pragma unroll
-      for (int b = 0; b < 8; ++b) val[b] = ((c >> b) & 1u) ? src.freq(t, rank0 + __popc(ab & ((1u << b) - 1u))) : 0.0;
-      uint32_t slot = atomicAdd(&sh.n_stored, static_cast<uint32_t>(__popc(c)));
-#pragma unroll
-      for (int b = 0; b < 8; ++b)
-        if ((c >> b) & 1u) sh.vals[slot++] = ((iv >> b) & 1u) ? 1.0 - val[b] : val[b];
-    });
-  }
-  __syncthreads();
-  const double v = static_cast<double>(n_c - 1) * a.quantile[set];
-  const bool take_max = v >= static_cast<double>(n_c - 1);
-  const double fl_v = floor(v);
-  const uint32_t k = take_max ? n_c - 1 : static_cast<uint32_t>(fl_v);
-  const double x0 = compact ? select_kth<true>(sh, src, fl, lo, hi, n_c, k, tid)
-                            : select_kth<false>(sh, src, fl, lo, hi, n_c, k, tid);
-  double q = x0;
-  if (!take_max) {
-    // the next order statistic: x0 again when more than k + 1 values are <= x0, else the smallest
-    // value above x0 -- one pass instead of a second selection
-    uint32_t c_le = 0;
-    double m_gt = std::numeric_limits<double>::infinity();
-    auto look = [&](double u) {
-      c_le += u <= x0 ? 1u : 0u;
-      if (u > x0 && u < m_gt) m_gt = u;
-    };
-    if (compact) for_each_selected<true>(sh, src, fl, lo, hi, n_c, tid, look);
-    else for_each_selected<false>(sh, src, fl, lo, hi, n_c, tid, look);
-    const uint32_t n_le = block_sum(c_le, sh.red, tid);
-    const double above = block_min(m_gt, sh.redf, tid);
-    const double x1 = n_le > k + 1 ? x0 : above;
-    q = numpy_lerp(x0, x1, v, fl_v);
-  }
-  const double x = a.x[set];
-  uint32_t c_q = 0, c_u = 0;
-  auto tally = [&](double u) {
-    c_q += u >= q ? 1u : 0u;
-    c_u += u > x ? 1u : 0u;
-  };
-  if (compact) for_each_selected<true>(sh, src, fl, lo, hi, n_c, tid, tally);
-  else for_each_selected<false>(sh, src, fl, lo, hi, n_c, tid, tally);
-  const uint32_t n_q = block_sum(c_q, sh.red, tid);
-  const uint32_t n_u = block_sum(c_u, sh.red, tid);
-  if (tid == 0) {
-    sai_window_record rec;
-    rec.n_sites = hi > lo ? hi - lo : 0;
-    rec.u_count = static_cast<int32_t>(n_u);
-    rec.n_cond = static_cast<int32_t>(n_c);
-    rec.n_cdd_q = static_cast<int32_t>(n_q);
-    rec.q = q;
-    a.records[ridx] = rec;
-  }
-  __syncthreads();
-}
-
-// One set of the window answered by one wave from the window's data: counts + order-preserving
-// compaction of the qualifying effective frequencies into the wave's LDS slice (U's tgt > x is taken
-// from the same values), then Q = numpy's `linear` quantile by rank counting.  Returns false -- with
-// n_c_out = the condition count -- when the set selects more than kWaveCap sites.
-__device__ __forceinline__ bool wave_set(const WinArgs& a, const WinSrc& src, double* vals, int set, int lo, int hi,
-                                         int lane, int64_t ridx, uint32_t& n_c_out) {
+// One set of one window answered by one wave.  Build pass: counts, the qualifying effective frequencies
+// into the wave's LDS slice (site order; U's tgt > x is taken from the same values), the histogram of
+// their first radix digit and -- when the window's frequencies are in LDS -- the list of their slots.
+// Then Q = numpy's `linear` quantile: by rank counting over the slice, or, above kWaveCap qualifying
+// sites, from the histogram: ONE more pass gathers the bin that holds the wanted rank (and the smallest
+// value above it), and the order statistics, Q and the size of the Q list follow from the bin's members
+// and the histogram's counts.  Only a bin with more than kWaveCap members goes through the level-by-level
+// select and its extra passes.
+__device__ __forceinline__ void wave_set(const WinArgs& a, const WinSrc& src, WaveLds& sh, uint16_t* list, int set, int lo,
+                                         int hi, int lane, int64_t ridx) {
   const int ci = cond_word(set), ii = inv_word(a.with_inv, a.n_sets, set);
-  const unsigned long long lt_mask = (1ull << lane) - 1ull;
   const double x = a.x[set];
-  uint32_t n_c = 0, n_u = 0;
-  walk_tiles(lo, hi, lane, [&](int t, bool live, uint64_t mask) {
-    const uint64_t c = live ? src.word(t, ci) & mask : 0ull;
-    const uint32_t mine = __popcll(c);
-    const unsigned long long nonempty = __ballot(mine != 0u);
-    if (nonempty == 0ull) return;  // no condition site among these 4 096: the usual case
-    if (n_c >= kWaveCap) {  // uniform: the set goes to the workgroup and only the count matters
-      uint32_t tot = mine;
+  double* vals = sh.vals;
+  const bool can_list = list != nullptr && src.freq_in_lds;
 #pragma unroll
-      for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o, 64);
-      n_c += tot;
-      return;
+  for (int j = 0; j < 5; ++j) sh.hist[j * 64 + lane] = 0u;  // 320 >= kBins
+  if (lane == 0) sh.n_small = 0u;
+  wave_lds_fence();
+  uint32_t n_c = 0, u_mine = 0;
+  walk_bytes(src, ci, ii, lo, hi, lane, [&](int t, uint32_t c, int rank0, uint32_t ab, uint32_t iv) {
+    const uint32_t cnt = __popc(c);
+    uint32_t inc = cnt;  // the lanes' bytes are in site order: an exclusive scan places every site
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t up = __shfl_up(inc, o, 64);
+      if (lane >= o) inc += up;
     }
-    const uint64_t iv = (c && ii >= 0) ? src.word(t, ii) : 0ull;
-    const uint64_t an = c ? src.word(t, kAny) : 0ull;
-    const int tb = t - lane;  // first tile of the chunk
-    for_nonempty_tiles(nonempty, [&](int n, const int (&tl)[kTileBatch]) {
-      uint64_t cw[kTileBatch], iw[kTileBatch], aw[kTileBatch];
-      double v[kTileBatch];
-#pragma unroll
-      for (int u = 0; u < kTileBatch; ++u) {
-        cw[u] = u < n ? read_lane64(c, tl[u]) : 0ull;
-        iw[u] = u < n ? read_lane64(iv, tl[u]) : 0ull;
-        aw[u] = u < n ? read_lane64(an, tl[u]) : 0ull;
-      }
-#pragma unroll
-      for (int u = 0; u < kTileBatch; ++u)
-        v[u] = ((cw[u] >> lane) & 1ull) ? src.freq(tb + tl[u], __popcll(aw[u] & lt_mask)) : 0.0;
-#pragma unroll
-      for (int u = 0; u < kTileBatch; ++u) {
-        const bool mine_c = (cw[u] >> lane) & 1ull;
-        const double e = ((iw[u] >> lane) & 1ull) ? 1.0 - v[u] : v[u];
-        const uint32_t slot = n_c + __popcll(cw[u] & lt_mask);  // tiles ascend, sites ascend inside a tile
-        if (mine_c && slot < kWaveCap) vals[slot] = e;
-        n_u += __popcll(__ballot(mine_c && e > x));
-        n_c += __popcll(cw[u]);
-      }
+    const uint32_t base = n_c + inc - cnt;
+    n_c += __shfl(inc, 63, 64);
+    const uint32_t slot0 = (can_list && c) ? src.lds->pre[t - src.t0] + rank0 : 0u;
+    for_byte_values(src, t, c, rank0, ab, iv, [&](int b, double e) {
+      const uint32_t below = (1u << b) - 1u;
+      const uint32_t slot = base + __popc(c & below);
+      if (slot < kWaveCap) vals[slot] = e;
+      if (can_list && slot < kListCap)
+        list[slot] = static_cast<uint16_t>((slot0 + __popc(ab & below)) | (((iv >> b) & 1u) ? 0x8000u : 0u));
+      atomicAdd(&sh.hist[first_digit(e)], 1u);
+      u_mine += e > x ? 1u : 0u;
     });
   });
-  n_c_out = n_c;
-  if (n_c > kWaveCap) return false;  // uniform
+  const uint32_t n_u = wave_sum(u_mine);
   double q = std::numeric_limits<double>::quiet_NaN();
   uint32_t n_q = 0;
   if (n_c > 0) {
@@ -606,27 +572,59 @@ __device__ __forceinline__ bool wave_set(const WinArgs& a, const WinSrc& src, do
     const bool take_max = v >= static_cast<double>(n_c - 1);  // at/after the last index: maximum
     const double fl_v = floor(v);
     const uint32_t k0 = take_max ? n_c - 1 : static_cast<uint32_t>(fl_v);
-    const uint32_t k1 = take_max ? n_c - 1 : k0 + 1;
-    double x0 = 0.0, x1 = 0.0;
-    // rank counting: rank(e) = #{j: v_j < v_e or (v_j == v_e and j < e)} is a permutation
-    for (uint32_t e0 = 0; e0 < n_c; e0 += 64) {
-      const uint32_t e = e0 + lane;
-      const bool act = e < n_c;
-      const double ve = act ? vals[e] : 0.0;
-      uint32_t rank = 0;
-      for (uint32_t j = 0; j < n_c; ++j) {
-        const double vj = vals[j];  // same address in every lane: LDS broadcast
-        rank += (vj < ve) || (vj == ve && j < e);
+    if (n_c <= kWaveCap) {
+      double x0 = 0.0, x1 = 0.0;
+      two_ranks(vals, n_c, k0, take_max ? k0 : k0 + 1, lane, x0, x1);
+      q = take_max ? x0 : numpy_lerp(x0, x1, v, fl_v);
+      for (uint32_t e0 = 0; e0 < n_c; e0 += 64) {
+        const uint32_t e = e0 + lane;
+        n_q += __popcll(__ballot(e < n_c && vals[e] >= q));
       }
-      const unsigned long long h0 = __ballot(act && rank == k0);
-      const unsigned long long h1 = __ballot(act && rank == k1);
-      if (h0) x0 = __shfl(ve, __ffsll(static_cast<long long>(h0)) - 1, 64);
-      if (h1) x1 = __shfl(ve, __ffsll(static_cast<long long>(h1)) - 1, 64);
-    }
-    q = take_max ? x0 : numpy_lerp(x0, x1, v, fl_v);
-    for (uint32_t e0 = 0; e0 < n_c; e0 += 64) {
-      const uint32_t e = e0 + lane;
-      n_q += __popcll(__ballot(e < n_c && vals[e] >= q));
+    } else {
+      const SetValues sv{&src, (can_list && n_c <= kListCap) ? list : nullptr, ci, ii, lo, hi, n_c};
+      const BinOfRank bin = bin_of_rank(sh, k0, lane);
+      if (bin.members <= kWaveCap) {
+        // gather the bin's members (any order) and find the smallest value of the bins above it
+        double next_mine = std::numeric_limits<double>::infinity();
+        for_each_selected(sv, lane, [&](double e) {
+          const int d = first_digit(e);
+          if (d == bin.digit) {
+            vals[atomicAdd(&sh.n_small, 1u)] = e;  // exactly bin.members of them
+          } else if (d > bin.digit && e < next_mine) {
+            next_mine = e;
+          }
+        });
+        const double next_bin = wave_min(next_mine);
+        wave_lds_fence();
+        double x0 = 0.0, x1 = next_bin;  // the next order statistic is the next bin's smallest when the bin ends at k0
+        two_ranks(vals, bin.members, bin.rank_in_bin, take_max ? bin.rank_in_bin : bin.rank_in_bin + 1, lane, x0, x1);
+        q = take_max ? x0 : numpy_lerp(x0, x1, v, fl_v);
+        // every value of a higher bin is >= x1 >= q; of the bin's own members those that reach q
+        n_q = n_c - (k0 - bin.rank_in_bin) - bin.members;
+        for (uint32_t e0 = 0; e0 < bin.members; e0 += 64) {
+          const uint32_t e = e0 + lane;
+          n_q += __popcll(__ballot(e < bin.members && vals[e] >= q));
+        }
+      } else {
+        const double x0 = wave_select_kth(sh, sv, k0, lane);
+        q = x0;
+        if (!take_max) {
+          // the next order statistic: x0 again when more than k0 + 1 values are <= x0, else the smallest
+          // value above x0 -- one pass instead of a second selection
+          uint32_t le_mine = 0;
+          double m_gt = std::numeric_limits<double>::infinity();
+          for_each_selected(sv, lane, [&](double e) {
+            le_mine += e <= x0 ? 1u : 0u;
+            if (e > x0 && e < m_gt) m_gt = e;
+          });
+          const uint32_t n_le = wave_sum(le_mine);
+          m_gt = wave_min(m_gt);
+          q = numpy_lerp(x0, n_le > k0 + 1 ? x0 : m_gt, v, fl_v);
+        }
+        uint32_t q_mine = 0;
+        for_each_selected(sv, lane, [&](double e) { q_mine += e >= q ? 1u : 0u; });
+        n_q = wave_sum(q_mine);
+      }
     }
     wave_lds_fence();  // the slice is reused by this wave's next set
   }
@@ -639,32 +637,41 @@ __device__ __forceinline__ bool wave_set(const WinArgs& a, const WinSrc& src, do
     rec.q = q;
     a.records[ridx] = rec;
   }
-  return true;
 }
 
+// SHARED: one workgroup per window; the window's data comes into LDS once and the four waves share the
+// sets (calls with >= kWinWaves sets: C5's sweep).  !SHARED: one WAVE per window, every word read where it
+// lies (one to three sets read a plane word once to three times; C2 / C3 / C4), and no workgroup barrier.
+template <bool SHARED>
+struct StatsLds {
+  WinLds win;
+  WaveLds wave[kWinWaves];
+  uint16_t list[kWinWaves][kListCap];
+};
+template <>
+struct StatsLds<false> {
+  WaveLds wave[kWinWaves];
+};
+
+template <bool SHARED>
 __global__ __launch_bounds__(kWinThreads) void window_stats_kernel(WinArgs a) {
-  __shared__ WinShared sh;
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int w = xcd_contiguous(blockIdx.x, gridDim.x);  // each XCD works on a contiguous run of (overlapping) windows
-  if (w >= a.n_windows) return;
+  __shared__ StatsLds<SHARED> sh;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);  // the compiler cannot see that it is uniform over the wave
+  // each XCD works on a contiguous run of (overlapping) windows
+  const int w = SHARED ? xcd_contiguous(blockIdx.x, gridDim.x) : xcd_contiguous(blockIdx.x, gridDim.x) * kWinWaves + wv;
+  if (w >= a.n_windows) return;  // SHARED: the whole workgroup; else the wave (which meets no barrier below)
   const int lo = clamp_site(a.lo[w], a.n_sites), hi = clamp_site(a.hi[w], a.n_sites);
-  if (tid == 0) sh.n_heavy = 0;
-  const WinSrc src = load_window(a, lo, hi, sh.win, tid, true);
-  __syncthreads();
-  for (int set = wv; set < a.n_sets; set += kWinWaves) {
-    uint32_t n_c = 0;
-    if (!wave_set(a, src, sh.vals + wv * kWaveCap, set, lo, hi, lane, static_cast<int64_t>(set) * a.n_windows + w, n_c) && lane == 0) {
-      const int slot = atomicAdd(&sh.n_heavy, 1);
-      sh.heavy_set[slot] = set;
-      sh.heavy_count[slot] = n_c;
-    }
+  WinSrc src;
+  uint16_t* list = nullptr;
+  if constexpr (SHARED) {
+    src = load_window(a, lo, hi, sh.win, tid, true);
+    list = sh.list[wv];
+  } else {
+    src = global_window(a, lo);
   }
-  __syncthreads();
-  const int n_heavy = sh.n_heavy;  // uniform
-  for (int h = 0; h < n_heavy; ++h) {
-    const int set = sh.heavy_set[h];
-    heavy_set(sh, a, src, set, lo, hi, sh.heavy_count[h], static_cast<int64_t>(set) * a.n_windows + w, tid);
-  }
+  for (int set = SHARED ? wv : 0; set < a.n_sets; set += SHARED ? kWinWaves : 1)
+    wave_set(a, src, sh.wave[wv], list, set, lo, hi, lane, static_cast<int64_t>(set) * a.n_windows + w);
 }
 
 // ---- CSR offsets ---------------------------------------------------------------------------
@@ -770,42 +777,63 @@ __global__ __launch_bounds__(kScanThreads) void window_scan_apply_kernel(WinArgs
 
 // ---- candidate lists -----------------------------------------------------------------------
 
-struct ListShared {
+template <bool SHARED>
+struct ListLds {
   WinLds win;
   int32_t any_list;
 };
+template <>
+struct ListLds<false> {
+  int32_t any_list;
+};
 
-// One workgroup per window: the window's rows and stored frequencies come into LDS once more, then
-// each wave writes the lists of its sets -- a tile's U sites are the condition bits whose effective
-// frequency exceeds x, its Q sites those whose frequency reaches q (a ballot each); each leaves at
-// `offset + done + popcount(word & lanes below)`, i.e. in ascending site order.
+// The candidate lists of the window's sets, in ascending site order: a tile's U sites are the condition
+// bits whose effective frequency exceeds x, its Q sites those whose frequency reaches q (a ballot each);
+// each leaves at `offset + done + popcount(word & lanes below)`.  SHARED / !SHARED as in window_stats.
+template <bool SHARED>
 __global__ __launch_bounds__(kWinThreads) void window_lists_kernel(WinArgs a) {
-  __shared__ ListShared sh;
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int w = xcd_contiguous(blockIdx.x, gridDim.x);
-  if (w >= a.n_windows) return;
-  // nothing to write for any set of this window (C3: most windows have no U candidate; a window without
-  // condition sites has no Q list either): leave before touching the planes
-  if (tid == 0) sh.any_list = 0;
-  __syncthreads();
-  if (tid < a.n_sets) {
-    const int64_t r = static_cast<int64_t>(tid) * a.n_windows + w;
-    const sai_window_record rec = a.records[r];
-    if ((rec.u_count > 0 && a.cdd_off[2 * r] >= 0 && a.cdd_u != nullptr) || (rec.n_cdd_q > 0 && a.cdd_off[2 * r + 1] >= 0 && a.cdd_q != nullptr))
-      sh.any_list = 1;
+  __shared__ ListLds<SHARED> sh;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);  // the compiler cannot see that it is uniform over the wave
+  const int w = SHARED ? xcd_contiguous(blockIdx.x, gridDim.x) : xcd_contiguous(blockIdx.x, gridDim.x) * kWinWaves + wv;
+  if constexpr (SHARED) {
+    if (w >= a.n_windows) return;
+    // nothing to write for any set of this window: leave before touching the planes
+    if (tid == 0) sh.any_list = 0;
+    __syncthreads();
+    if (tid < a.n_sets) {
+      const int64_t r = static_cast<int64_t>(tid) * a.n_windows + w;
+      const sai_window_record rec = a.records[r];
+      if ((rec.u_count > 0 && a.cdd_off[2 * r] >= 0 && a.cdd_u != nullptr) || (rec.n_cdd_q > 0 && a.cdd_off[2 * r + 1] >= 0 && a.cdd_q != nullptr))
+        sh.any_list = 1;
+    }
+    __syncthreads();
+    if (!sh.any_list) return;  // uniform
+  } else {
+    if (w >= a.n_windows) return;
   }
-  __syncthreads();
-  if (!sh.any_list) return;  // uniform
-  const int lo = clamp_site(a.lo[w], a.n_sites), hi = clamp_site(a.hi[w], a.n_sites);
-  const WinSrc src = load_window(a, lo, hi, sh.win, tid, true);
+  int lo = 0, hi = 0;
+  WinSrc src;
+  if constexpr (SHARED) {
+    lo = clamp_site(a.lo[w], a.n_sites);
+    hi = clamp_site(a.hi[w], a.n_sites);
+    src = load_window(a, lo, hi, sh.win, tid, true);
+  }
   const unsigned long long lt_mask = (1ull << lane) - 1ull;
-  for (int set = wv; set < a.n_sets; set += kWinWaves) {
+  for (int set = SHARED ? wv : 0; set < a.n_sets; set += SHARED ? kWinWaves : 1) {
     const int64_t ridx = static_cast<int64_t>(set) * a.n_windows + w;
     const sai_window_record rec = a.records[ridx];
     const long long off_u = a.cdd_off[2 * ridx + 0], off_q = a.cdd_off[2 * ridx + 1];
     const bool write_u = rec.u_count > 0 && off_u >= 0 && a.cdd_u != nullptr;
     const bool write_q = rec.n_cdd_q > 0 && off_q >= 0 && a.cdd_q != nullptr;
-    if (!write_u && !write_q) continue;
+    if (!write_u && !write_q) continue;  // C3: most windows have no U candidate, a window without condition sites no Q list
+    if constexpr (!SHARED) {
+      if (hi == 0 && lo == 0) {
+        lo = clamp_site(a.lo[w], a.n_sites);
+        hi = clamp_site(a.hi[w], a.n_sites);
+        src = global_window(a, lo);
+      }
+    }
     const int ci = cond_word(set), ii = inv_word(a.with_inv, a.n_sets, set);
     const double q = rec.q, x = a.x[set];
     uint32_t done_u = 0, done_q = 0;
@@ -931,8 +959,12 @@ int sai_window_stats(sai_ctx* ctx, int64_t n_sites, const double* tgt_freq, cons
     a.quantile[s] = sets_host[s].quantile;
     a.x[s] = sets_host[s].x;
   }
-  const dim3 win_grid(static_cast<unsigned>(n_windows));
-  hipLaunchKernelGGL(window_stats_kernel, win_grid, dim3(kWinThreads), 0, st, a);
+  // a call with at least kWinWaves sets shares a window's data between the waves of a workgroup; fewer sets:
+  // one wave per window, nothing staged
+  const bool shared = n_sets >= kWinWaves;
+  const dim3 win_grid(shared ? static_cast<unsigned>(n_windows) : static_cast<unsigned>((n_windows + kWinWaves - 1) / kWinWaves));
+  if (shared) hipLaunchKernelGGL(window_stats_kernel<true>, win_grid, dim3(kWinThreads), 0, st, a);
+  else hipLaunchKernelGGL(window_stats_kernel<false>, win_grid, dim3(kWinThreads), 0, st, a);
   if (int rc = check_launch("window_stats")) return rc;
   const int64_t n_rec = static_cast<int64_t>(n_sets) * n_windows;
   const unsigned scan_grid = static_cast<unsigned>((n_rec + kScanBlock - 1) / kScanBlock);
@@ -941,7 +973,8 @@ int sai_window_stats(sai_ctx* ctx, int64_t n_sites, const double* tgt_freq, cons
   if (int rc = check_launch("window_scan_partials")) return rc;
   hipLaunchKernelGGL(window_scan_apply_kernel, dim3(scan_grid), dim3(kScanThreads), 0, st, a, partials);
   if (int rc = check_launch("window_scan_apply")) return rc;
-  hipLaunchKernelGGL(window_lists_kernel, win_grid, dim3(kWinThreads), 0, st, a);
+  if (shared) hipLaunchKernelGGL(window_lists_kernel<true>, win_grid, dim3(kWinThreads), 0, st, a);
+  else hipLaunchKernelGGL(window_lists_kernel<false>, win_grid, dim3(kWinThreads), 0, st, a);
   return check_launch("window_lists");
 }
 
