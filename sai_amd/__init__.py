@@ -8,4 +8,4 @@ All statistics are computed by hand-written HIP kernels in ``libsaihip.so`` (C A
 ``include/saihip.h``); there is no CPU compute path in this package.
 """
 
-__version__ = "0.1.0"
+__version__ = "0.2.0"
