@@ -33,8 +33,11 @@ struct sai_bgzf_stream {
   std::string err;
   std::thread reader;
   // region seek through <vcf>.tbi: the reader starts at the member of the region's first record and
-  // ends with the member that holds the first record beyond it (-1: to the end of the file)
+  // slows down at the member that holds the first record of a later window (-1: no bound)
   int64_t file_begin = 0, file_stop = -1;
+  // the record index has seen a record beyond the region (or the next chromosome): set by the consumer,
+  // under `m`; past `file_stop` the reader goes on in small batches until then
+  bool consumer_done = false;
   int64_t first_text_skip = 0;  // text of the first member that precedes the region's first record
   bool nothing_to_read = false; // the index says the region holds no record
   // indexer (the consumer's thread)
@@ -59,21 +62,30 @@ int bgzf_reader_run(sai_bgzf_stream* st) {
   const size_t total = static_cast<size_t>(sb.st_size);
   size_t file_off = static_cast<size_t>(st->file_begin);
   if (st->nothing_to_read || file_off >= total) return SAI_OK;
-  bool region_end = false;
+  bool past_stop = false;
+  constexpr size_t kPastStopBytes = size_t(1) << 18;  // per batch beyond the index's bound
   WorkerPool readers(std::max(1, std::min(st->n_threads, 8)));
-  while (file_off < total && !region_end) {
+  while (file_off < total) {
     int b;
     {
       std::unique_lock<std::mutex> lk(st->m);
       b = static_cast<int>(st->produced % 2);
-      st->cv.wait(lk, [&] { return st->state[b] == 0 || st->cancel; });
-      if (st->cancel) return SAI_OK;
+      st->cv.wait(lk, [&] { return st->state[b] == 0 || st->cancel || st->consumer_done; });
+      if (st->cancel || st->consumer_done) return SAI_OK;
     }
     unsigned char* dst = st->bufs[b];
     size_t want = std::min(st->cap - 8, total - file_off);  // 8 bytes of zero padding behind the data
-    if (st->file_stop >= 0)  // a region: up to its last member (a member is < 64 KiB + header), not the whole buffer
-      want = std::min(want, static_cast<size_t>(st->file_stop) + (size_t(1) << 17) > file_off
-                                ? static_cast<size_t>(st->file_stop) + (size_t(1) << 17) - file_off : size_t(0));
+    if (st->file_stop >= 0) {
+      // A region.  The index only says where reading may SLOW DOWN, not where it ends: a linear-index entry
+      // is the first record that OVERLAPS a 16 kb window (REF length, INFO/END), so an indel or SV that
+      // starts before the region's end and reaches into the next window makes `file_stop` ITS member, with
+      // records of the region still behind it.  Up to that member in one piece (a member is < 64 KiB +
+      // header), beyond it a few members at a time until the record index reports a record past the end
+      // (`consumer_done`) -- what the host readers do (vcf_stream.cpp, vcf_ingest.cpp: seek to the start,
+      // stop at POS > end).
+      const size_t stop = static_cast<size_t>(st->file_stop);
+      want = std::min(want, past_stop || file_off >= stop ? kPastStopBytes : stop + (size_t(1) << 17) - file_off);
+    }
     if (want == 0) break;
     {
       // one thread copies ~3 GB/s out of the page cache, i.e. ~35 GB/s of text: not enough
@@ -117,10 +129,10 @@ int bgzf_reader_run(sai_bgzf_stream* st) {
       r.reserved = 0;
       mem.push_back(r);
       out_total += isize;
-      const bool last_of_region = st->file_stop >= 0 && file_off + off >= static_cast<size_t>(st->file_stop);
+      const bool at_stop = st->file_stop >= 0 && file_off + off >= static_cast<size_t>(st->file_stop);
       off += static_cast<size_t>(bsize);
-      if (last_of_region) {
-        region_end = true;
+      if (at_stop && !past_stop) {  // hand this batch over now: usually the index then says "done"
+        past_stop = true;
         break;
       }
     }
@@ -276,8 +288,9 @@ int sai_bgzf_stream_open(const char* path, const char* chrom, int64_t start, int
       // linear index, one entry per 16 kb window; utils.py:117-138 gets the same from scikit-allel) to the
       // member of the first record of a LATER window take the trip -- each worker of a sharded run reads
       // its own region (chunk_generator.py:130-142), not the file.  The record index filters by POS as
-      // always, so a coarse or stale bound costs bytes, never records: an entry equal to the window's
-      // own (an index that fills empty windows from the previous one) is not taken as the end.
+      // always and decides when the region is over (bgzf_reader_run reads on past the bound, a few members
+      // at a time, until it says so), so a coarse or stale bound costs bytes, never records: an entry equal
+      // to the window's own (an index that fills empty windows from the previous one) is not taken.
       TbiRef idx;
       if (load_tbi(path, chrom, idx)) {
         const uint64_t w0 = static_cast<uint64_t>(start > 0 ? start - 1 : 0) >> 14;
@@ -487,6 +500,13 @@ int sai_vcf_index_text(sai_bgzf_stream* st, const char* text_host, int64_t n_byt
         st->seen_chrom = st->seen_chrom || o.saw_chrom;
         if (o.beyond_stop || (st->seen_chrom && o.last_line_other)) st->done = true;
       }
+      if (st->done) {
+        {
+          std::lock_guard<std::mutex> lk(st->m);
+          st->consumer_done = true;
+        }
+        st->cv.notify_all();
+      }
     }
     *n_usable = static_cast<int64_t>(cut - text_host);
     *n_lines = static_cast<int64_t>(st->out.off.size());
@@ -537,6 +557,13 @@ int sai_vcf_index_heads(sai_bgzf_stream* st, const char* heads_host, int32_t hea
         st->out.gi.insert(st->out.gi.end(), o.gi.begin(), o.gi.end());
         st->seen_chrom = st->seen_chrom || o.saw_chrom;
         if (o.beyond_stop || (st->seen_chrom && o.last_line_other)) st->done = true;
+      }
+      if (st->done) {
+        {
+          std::lock_guard<std::mutex> lk(st->m);
+          st->consumer_done = true;
+        }
+        st->cv.notify_all();
       }
     }
     *n_lines_out = static_cast<int64_t>(st->out.off.size());

@@ -11,7 +11,7 @@ import os
 import numpy as np
 import pytest
 
-from test_ingest_native import write_tbi, write_vcf
+from test_ingest_native import write_bgzf, write_tbi, write_vcf
 
 
 def stream_batches(path, chrom, names, ploidies, start=None, end=None, anc=None, threads=3, cap=1 << 16):
@@ -386,3 +386,47 @@ def test_bgzf_stream_region_seek_through_the_tabix_index(indexed_bgzf, heads):
         assert READ_LOG[-1]["file_begin"] == 0 and READ_LOG[-1]["file_stop"] == -1
     finally:
         os.utime(str(path) + ".tbi", (fresh.st_atime, fresh.st_mtime))
+
+
+@pytest.mark.parametrize("heads", [False, True])
+def test_bgzf_region_with_a_long_ref_record_across_the_window_boundary(tmp_path, heads):
+    """a tabix linear-index entry is the first record that OVERLAPS a 16 kb window, so
+    a deletion that starts just before the region's end and reaches into the next window becomes that
+    window's entry, and its member the index's end bound -- with records of the region still behind it in
+    later members.  The reader must go on past the bound until the record index sees a record beyond the
+    region: same records as the host reader (which seeks to the start and stops at POS > end), and the
+    member cut in the middle of a line is never taken for a file without a final newline."""
+    from sai_amd.utils.native_vcf import load_dosage
+
+    rng = np.random.default_rng(77)
+    names = [f"s{i}" for i in range(12)]
+    lines = ["##fileformat=VCFv4.2", "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t" + "\t".join(names)]
+
+    def rec(pos, ref="A", alt="C"):
+        calls = ["|".join(str(int(rng.integers(0, 2))) for _ in range(2)) for _ in names]
+        lines.append("\t".join(["9", str(pos), ".", ref, alt, "50", "PASS", ".", "GT"] + calls))
+
+    for pos in range(15000, 16300, 13):
+        rec(pos)
+    rec(16300, ref="A" + "CGT" * 40, alt="A")  # 121 bases: reaches 16420, into the window that starts at 16385
+    behind = list(range(16301, 16384, 2))  # still in the first window, behind the deletion in the file
+    for pos in behind:
+        rec(pos)
+    for pos in range(16390, 250000, 23):  # the rest of the chromosome: a region is a small part of the file
+        rec(pos)
+    path = tmp_path / "del.vcf.gz"
+    write_bgzf(path, ("\n".join(lines) + "\n").encode(), rng, max_block=600)  # many members: the deletion's is not the last of the region
+    write_tbi(path)
+    pick, ploidies = [names[3], names[8]], [2, 2]
+    for start, end in ((15500, 16383), (16000, 16350), (15000, 16384), (16301, 16383)):
+        want = load_dosage(str(path), "9", pick, ploidies, start, end, None, 2)
+        for text_cap in (1 << 16, 1 << 20):
+            batches, sel, _ = bgzf_stream_batches(path, "9", pick, ploidies, start, end, text_cap=text_cap, heads=heads)
+            got_pos, got_dos = python_tokenize(batches, sel[0], ploidies)
+            assert got_pos.tolist() == want[0].tolist(), (start, end, text_cap)
+            assert np.array_equal(got_dos, want[1])
+            log = READ_LOG[-1]
+            assert 0 <= log["file_begin"] <= log["file_stop"] and log["comp_bytes"] < os.path.getsize(path) // 2, log
+    # what the bound alone would have kept: the sites behind the deletion are there
+    want = load_dosage(str(path), "9", pick, ploidies, 16000, 16383, None, 2)[0].tolist()
+    assert want[-len(behind) :] == behind
