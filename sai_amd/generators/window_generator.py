@@ -17,7 +17,7 @@ from typing import Any, Iterator, Optional
 import numpy as np
 
 from ..utils.genomic_dataclasses import ChromosomeData
-from ..utils.read_data import read_data
+from ..utils.read_data import read_dosage_data
 from ..utils.windows import split_genome
 from .data_generator import DataGenerator
 
@@ -80,7 +80,7 @@ class WindowGenerator(DataGenerator):
 
             results, pos_dev = read_data_device(Engine.get(), **kw)
         else:
-            results = read_data(**kw)
+            results = read_dosage_data(**kw)  # = read_data(..., is_phased=False, no filters): window_generator.py:105-120
         self._setup(
             chr_name, win_len, win_step, ploidy_config, results["ref"], results["tgt"], results["src"], start, end, num_src,
             results["outgroup"],

@@ -1,6 +1,9 @@
-"""Load the ref / tgt / src populations of one chromosome region (mirror of
-sai/utils/utils.py:215-356 ``read_data`` and :649-761 ``_load_population_data`` as used by
-WindowGenerator: unphased, no fixed-variant or missing-data filtering)."""
+"""Load the ref / tgt / src populations of one chromosome region (mirror of sai/utils/utils.py:215-356
+``read_data`` and :649-761 ``_load_population_data``).  ``read_data`` has the reference's signature and
+defaults; the combination WindowGenerator asks for (window_generator.py:105-120: unphased, no
+fixed-variant or missing-call filter) is served by the native tokenizers as int8 dosages
+(``read_dosage_data`` on the host, ``read_data_device`` in HBM), every other combination by the
+allele-level reader of ``geno.py``."""
 
 from __future__ import annotations
 
@@ -25,9 +28,51 @@ def read_data(
     anc_allele_file: Optional[str] = None,
     start: int = None,
     end: int = None,
+    is_phased: bool = True,
+    filter_ref: bool = True,
+    filter_tgt: bool = True,
+    filter_src: bool = False,
+    filter_out: bool = False,
+    filter_missing: bool = True,
     engine: str = "native",
 ) -> dict[str, tuple[Optional[dict[str, ChromosomeData]], Optional[dict[str, list[str]]]]]:
-    """{"ref": (data, samples), "tgt": ..., "src": ..., "outgroup": (data, samples) or (None, None)}.
+    """{"ref": (data, samples), "tgt": ..., "src": ..., "outgroup": ...} with the reference's options
+    (utils.py:215-356): ``is_phased`` = haplotype columns [sites][individuals * ploidy] instead of the
+    dosage [sites][individuals]; ``filter_<group>`` = drop the variants fixed in a population;
+    ``filter_missing`` = drop the sites where a sample of the population has a missing allele.  Blocks
+    carry REF / ALT.  All options off and unphased is the ``score`` path's request: it goes to the native
+    tokenizer (``read_dosage_data``: int8 dosages, REF / ALT not kept)."""
+    if not (is_phased or filter_ref or filter_tgt or filter_src or filter_out or filter_missing):
+        return read_dosage_data(vcf_file, chr_name, ploidy_config, ref_ind_file, tgt_ind_file, src_ind_file, out_ind_file,
+                                anc_allele_file, start, end, engine)  # fmt: skip
+    from .geno import load_population_data
+
+    results = {}
+    for group, ind_file, fixed in (("ref", ref_ind_file, filter_ref), ("tgt", tgt_ind_file, filter_tgt),
+                                   ("src", src_ind_file, filter_src), ("outgroup", out_ind_file, filter_out)):  # fmt: skip
+        if ind_file is None or (group == "outgroup" and group not in ploidy_config.root):  # utils.py:331-337
+            results[group] = (None, None)
+            continue
+        results[group] = load_population_data(vcf_file, str(chr_name), ind_file, anc_allele_file, start, end, is_phased, fixed,
+                                              filter_missing, ploidy_config, group)  # fmt: skip
+    return results
+
+
+def read_dosage_data(
+    vcf_file: str,
+    chr_name: str,
+    ploidy_config,
+    ref_ind_file: Optional[str],
+    tgt_ind_file: Optional[str],
+    src_ind_file: Optional[str],
+    out_ind_file: Optional[str] = None,
+    anc_allele_file: Optional[str] = None,
+    start: int = None,
+    end: int = None,
+    engine: str = "native",
+) -> dict[str, tuple[Optional[dict[str, ChromosomeData]], Optional[dict[str, list[str]]]]]:
+    """``read_data(..., is_phased=False, filter_*=False, filter_missing=False)``:
+    {"ref": (data, samples), "tgt": ..., "src": ..., "outgroup": (data, samples) or (None, None)}.
 
     ``data`` maps population -> ChromosomeData for the populations that have a ploidy entry
     (others are skipped with the reference's RuntimeWarning, utils.py:722-728); a population

@@ -186,7 +186,8 @@ def test_read_data_device_and_score_equal_the_host_path(eng, in_repo_root, tmp_p
     import os
 
     from sai_amd.sai import load_config, score
-    from sai_amd.utils.read_data import read_data, read_data_device
+    from sai_amd.utils.read_data import read_data_device
+    from sai_amd.utils.read_data import read_dosage_data as read_data
 
     if not os.path.exists(cfgfile):
         pytest.skip("fixture config not present")
@@ -219,7 +220,8 @@ def test_a_sample_in_populations_of_different_ploidy(eng, tmp_path):
     blocks as the host reader (which reads per population), also when a population's samples come from
     different passes; and `score` runs on it with either reader."""
     from sai_amd.configs import PloidyConfig
-    from sai_amd.utils.read_data import read_data, read_data_device
+    from sai_amd.utils.read_data import read_data_device
+    from sai_amd.utils.read_data import read_dosage_data as read_data
 
     rng = np.random.default_rng(77)
     vcf = tmp_path / "m.vcf.gz"

@@ -116,7 +116,7 @@ def test_native_equals_python_reader(tmp_path, gz, crlf):
 def test_native_on_reference_fixtures(in_repo_root):
     """The reference's own test VCFs through both engines of read_data."""
     from sai_amd.configs import PloidyConfig
-    from sai_amd.utils import read_data
+    from sai_amd.utils import read_dosage_data as read_data
 
     cases = [
         ("tests/data/example.vcf", "21", {"ref": {"AFR": 2}, "tgt": {"CHB": 2}, "src": {"Nean": 2}},
@@ -140,7 +140,7 @@ def test_native_on_reference_fixtures(in_repo_root):
 
 def test_native_errors(tmp_path, in_repo_root):
     from sai_amd.configs import PloidyConfig
-    from sai_amd.utils import read_data
+    from sai_amd.utils import read_dosage_data as read_data
     from sai_amd.utils.native_vcf import load_dosage, scan_first_last
 
     with pytest.raises(ValueError, match="samples not found"):
