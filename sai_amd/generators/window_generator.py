@@ -25,9 +25,9 @@ from .data_generator import DataGenerator
 class AlignedSites:
     """Row selection of one population combination (``WindowGenerator.aligned``)."""
 
-    __slots__ = ("keys", "pos_rows", "uniq", "rows", "file_order")
+    __slots__ = ("keys", "pos_rows", "uniq", "rows", "file_order", "segments")
 
-    def __init__(self, keys, pos_rows, uniq, rows, file_order=None):
+    def __init__(self, keys, pos_rows, uniq, rows, file_order=None, segments=None):
         self.keys = keys  # [(group, population)] in ref, tgt, sources, outgroup order
         self.pos_rows = pos_rows  # position of every selected row, non-decreasing
         self.uniq = uniq  # the unique common positions when rows repeat a position, else None
@@ -36,6 +36,11 @@ class AlignedSites:
         # gathered in position order (`rows`), and file_order[j] = index in the file of sorted row j -- the
         # reference's matrices keep the file order while its `pos` is sorted (window_generator.py:193-231)
         self.file_order = file_order
+        # populations whose position arrays do not ascend AND differ: the reference pairs, window by window, row k
+        # of one population's selection (file order) with row k of every other's and with the k-th smallest
+        # common position, so no single row order serves all windows -- the selected rows are the windows'
+        # own selections laid end to end: segments[w] = [lo, hi) of window w in `rows` / `pos_rows`
+        self.segments = segments
 
 
 class WindowGenerator(DataGenerator):
@@ -193,11 +198,10 @@ class WindowGenerator(DataGenerator):
             order = np.argsort(pos, kind="stable")
             out = AlignedSites(keys, pos[order], None, {k: order for k in keys}, file_order=order)
         else:
-            for b in blocks:
-                if b.POS.size > 1 and not np.all(b.POS[1:] >= b.POS[:-1]):
-                    # populations whose unsorted positions differ: the reference pairs row k of one matrix with
-                    # row k of the other per window; no batched form of that is offered
-                    raise NotImplementedError("populations with different unsorted position arrays")
+            if any(b.POS.size > 1 and not np.all(b.POS[1:] >= b.POS[:-1]) for b in blocks):
+                out = self._aligned_per_window(keys, blocks, tgt_pop)
+                cache[tuple(keys)] = out
+                return out
             common = np.unique(pos)
             for b in blocks[1:]:
                 common = np.intersect1d(common, b.POS)
@@ -215,6 +219,29 @@ class WindowGenerator(DataGenerator):
             out = AlignedSites(keys, row_pos[0], uniq, None if identity else dict(zip(keys, rows)))
         cache[tuple(keys)] = out
         return out
+
+    def _aligned_per_window(self, keys, blocks, tgt_pop) -> "AlignedSites":
+        """window_generator.py:173-231 taken literally, for position arrays that are unsorted and differ: per
+        window the common positions (sorted, unique) and, per population, the rows that carry them IN FILE
+        ORDER.  A position repeated inside a population has no batched form here."""
+        if any(np.unique(b.POS).size != b.POS.size for b in blocks):
+            raise NotImplementedError("populations with different unsorted position arrays that repeat a position")
+        common = np.unique(blocks[0].POS)
+        for b in blocks[1:]:
+            common = np.intersect1d(common, b.POS)
+        order = [np.argsort(b.POS, kind="stable") for b in blocks]
+        sorted_pos = [b.POS[o] for b, o in zip(blocks, order)]
+        rows, pos_parts, segments, at = [[] for _ in blocks], [], [], 0
+        for start, end in self.tgt_windows[tgt_pop]:
+            here = common[slice(*self.window_range(common, start, end))]
+            for k in range(len(blocks)):
+                rows[k].append(np.sort(order[k][np.searchsorted(sorted_pos[k], here)]))
+            pos_parts.append(here)
+            segments.append((at, at + here.size))
+            at += here.size
+        cat = lambda parts, dt: np.concatenate(parts).astype(dt, copy=False) if parts else np.zeros(0, dtype=dt)  # noqa: E731
+        return AlignedSites(keys, cat(pos_parts, blocks[0].POS.dtype), None, {k: cat(r, np.int64) for k, r in zip(keys, rows)},
+                            segments=segments)  # fmt: skip
 
     def common_positions(self, ref_pop, tgt_pop, src_comb, out_pop=None) -> np.ndarray:
         """Positions of the rows shared by the populations of one combination."""
@@ -272,8 +299,8 @@ class WindowGenerator(DataGenerator):
             for key in al.keys:
                 gt = group_data[key[0]][key[1]].GT
                 mats[key] = gt if al.rows is None else gt[al.rows[key]]
-            for start, end in self.tgt_windows[tgt_pop]:
-                lo, hi = self.window_range(al.pos_rows, start, end)
+            for wi, (start, end) in enumerate(self.tgt_windows[tgt_pop]):
+                lo, hi = al.segments[wi] if al.segments is not None else self.window_range(al.pos_rows, start, end)
                 if hi <= lo:  # window_generator.py:199-215
                     yield self._empty_item(ref_pop, tgt_pop, src_comb, out_pop, start, end)
                     continue

@@ -314,17 +314,20 @@ class FeaturePreprocessor(DataPreprocessor):
             pos_dev = pos_dev_cache[pid]
             uq_keys = [("ref", ref_pop), ("tgt", tgt_pop)] + [("src", s) for s in src_comb[:n_eff]]
             lo = hi = None
+            segs = al.segments  # one piece per window: populations with different unsorted position arrays
             if uq_names:
-                block = ResidentBlock([tiled[k] for k in uq_keys], ploidy[: 2 + n_eff], pos_dev)
+                block = ResidentBlock([tiled[k] for k in uq_keys], ploidy[: 2 + n_eff], pos_dev,
+                                      segments=None if segs is None else [tuple(map(int, sg)) for sg in segs])  # fmt: skip
                 # one scorer per (window grid, block length, number of sets) serves every combination of the
                 # region -- and the next call on the same generator: only its launch sequences are re-recorded
-                key = (tgt_pop, n_sites, len(sets))
+                key = (tgt_pop, n_sites, len(sets)) if segs is None else (tgt_pop, n_sites, len(sets), tuple(al.keys))
                 as_indices = al.uniq is not None or al.file_order is not None
                 scorer = scorers.get(key)
                 if scorer is None:
                     scorer = scorers[key] = ResidentScorer(eng, block, windows, sets, cap_u=1 << 16, cap_q=1 << 16,
                                                            counts_in=counts_of(uq_keys) if shared else None,
-                                                           lists_as_indices=as_indices, fetch_lists=1 << 16)  # fmt: skip
+                                                           lists_as_indices=as_indices, fetch_lists=1 << 16,
+                                                           window_segment=None if segs is None else np.arange(len(segs)))  # fmt: skip
                 else:
                     scorer.rebind(block, sets, counts_of(uq_keys) if shared else None, lists_as_indices=as_indices)
                 scorer.step()
@@ -335,6 +338,10 @@ class FeaturePreprocessor(DataPreprocessor):
                     cb.nsnps = _repeated_position_semantics(cb.uq, uq_names, lo.cpu().numpy(), win, al.uniq)
                 elif al.file_order is not None:
                     _file_order_semantics(cb.uq, uq_names, lo.cpu().numpy(), hi.cpu().numpy(), pos, al.file_order)
+            elif segs is not None:  # the windows' site ranges ARE the pieces
+                bounds = np.asarray(segs, dtype=np.int32).reshape(-1, 2)
+                lo, hi = (torch.from_numpy(np.ascontiguousarray(bounds[:, k])).to(eng.device) for k in (0, 1))
+                cb.nsnps = (bounds[:, 1] - bounds[:, 0]).astype(np.int32)
             else:
                 lo, hi = eng.window_bounds(pos_dev, win[:, 0], win[:, 1])
                 cb.nsnps = (hi - lo).cpu().numpy().astype(np.int32)

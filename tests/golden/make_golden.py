@@ -788,7 +788,8 @@ if __name__ == "__main__" and os.path.isdir(REF):
 
 SITESET_CASES = [("ragged", 1), ("ragged", 2), ("ragged", 3), ("dup_u", 4), ("dup_u", 5), ("dup_u", 6), ("dup_uq", 7),
                  ("dup_uq", 8), ("dup_uneven", 9), *[("dup_rare", s) for s in range(10, 18)],
-                 ("unsorted", 18), ("unsorted", 19), ("unsorted", 20)]
+                 ("unsorted", 18), ("unsorted", 19), ("unsorted", 20), ("unsorted_mixed", 21), ("unsorted_mixed", 22),
+                 ("unsorted_mixed", 23)]
 
 
 def make_sitesets():

@@ -90,6 +90,8 @@ def siteset_scenario(kind, seed):
           "unsorted"    all populations share one position array that is NOT ascending (blocks of an
                         unsorted VCF swapped): the reference's matrices keep the file order while its
                         `pos` is intersect1d's sorted array, so candidate positions come out permuted
+          "unsorted_mixed"  every population has its OWN file order (and lacks a few sites): row k of one
+                        population's window selection meets row k of another's and the k-th smallest position
     Returns dict(pos={group: {pop: int32}}, gts={group: {pop: int64}}, pl, stats, win, step, anc)."""
     rng = np.random.default_rng(seed)
     n_sites = int(rng.integers(300, 700))
@@ -119,8 +121,8 @@ def siteset_scenario(kind, seed):
         for name, ploidy in pl[grp].items():
             g = pop(sizes[name], ploidy, role)
             keep = np.ones(len(rows), bool)
-            if kind == "ragged":
-                drop_site = rng.random(n_sites) < 0.12
+            if kind in ("ragged", "unsorted_mixed"):
+                drop_site = rng.random(n_sites) < (0.12 if kind == "ragged" else 0.05)
                 keep = ~drop_site[rows]
             elif kind == "dup_uneven" and name != "T0":
                 keep = np.concatenate([[True], rows[1:] != rows[:-1]])  # only T0 keeps the second rows
@@ -131,6 +133,12 @@ def siteset_scenario(kind, seed):
                 cuts = np.sort(np.random.default_rng(seed + 1000).choice(np.arange(20, n_sites - 20), 6, replace=False))
                 parts = np.split(order, cuts)
                 order = np.concatenate([parts[i] for i in (0, 2, 1, 3, 5, 4, 6)])
+                pos[grp][name], gts[grp][name] = pos[grp][name][order], gts[grp][name][order]
+            if kind == "unsorted_mixed":  # a different swap of blocks of records in every population
+                n_rows = len(pos[grp][name])
+                own = np.random.default_rng(seed * 31 + len(pos) * 7 + len(pos[grp])).permutation(7)
+                cuts = np.sort(rng.choice(np.arange(20, n_rows - 20), 6, replace=False))
+                order = np.concatenate([np.split(np.arange(n_rows), cuts)[i] for i in own])
                 pos[grp][name], gts[grp][name] = pos[grp][name][order], gts[grp][name][order]
     uq = lambda tgt: {"ref": {"R": 0.3}, "tgt": dict(tgt), "src": {"S0": "=1", "S1": ">=0.5"}}  # noqa: E731
     stats = {"U": uq({"T0": 0.2, "T1": 0.0})}
