@@ -17,6 +17,8 @@
 #include <string>
 
 #include <cerrno>
+#include <pthread.h>
+#include <sys/stat.h>
 #include <sys/uio.h>
 #include <unistd.h>
 
@@ -241,6 +243,34 @@ int write_pieces(int fd, const std::string* const* piece, int n_pieces, int64_t*
   return SAI_OK;
 }
 
+// What sai_write_window_rows keeps between calls: the pieces' strings (a later call appends into memory
+// that is already mapped -- a fresh MB costs more in page faults than the formatting of its text) and the
+// mutex that makes concurrent callers take turns.  A fork() while another thread is inside would hand the
+// child a mutex that stays locked for ever: the child starts with a FRESH state (the old one is abandoned,
+// not destroyed -- its mutex may be held, its strings half written).
+struct WriterState {
+  std::mutex busy;
+  std::string piece[kTextThreads][1 + SAI_MAX_LOGS];
+};
+WriterState* g_writer = nullptr;
+void writer_reset_in_child() { g_writer = new (std::nothrow) WriterState; }
+WriterState* writer_state() {
+  static std::once_flag once;
+  std::call_once(once, [] {
+    g_writer = new WriterState;
+    pthread_atfork(nullptr, nullptr, writer_reset_in_child);
+  });
+  return g_writer;
+}
+constexpr size_t kKeepPieceBytes = size_t{1} << 20;  // larger pieces (a whole-genome call) are given back
+
+// size of a regular file behind fd, or -1 (a pipe, a terminal: nothing to roll back to)
+int64_t regular_file_size(int fd) {
+  struct stat sb;
+  if (fstat(fd, &sb) != 0 || !S_ISREG(sb.st_mode)) return -1;
+  return static_cast<int64_t>(sb.st_size);
+}
+
 template <typename F>
 int guarded_text(const char* what, F&& body) {
   try {
@@ -339,11 +369,10 @@ int sai_write_window_rows(const char* chr_name_host, const char* pop_columns_hos
     for (int32_t k = 0; bytes_out && k <= n_logs; ++k) bytes_out[k] = 0;
     const std::string chr(chr_name_host), pops(pop_columns_host);
     const ScoreRows score{chr, pops, windows_host, nsnps_host, n_cols, cols_host};
-    // the pieces' strings live as long as the library: a later call appends into memory that is already
-    // mapped (a fresh MB costs more in page faults than the formatting of its text)
-    static std::mutex busy;
-    static std::string piece[kTextThreads][1 + SAI_MAX_LOGS];
-    std::lock_guard<std::mutex> lk(busy);
+    WriterState* ws = writer_state();
+    if (!ws) return sai_set_error(SAI_ERR_HIP, "sai_write_window_rows: out of host memory");
+    std::lock_guard<std::mutex> lk(ws->busy);
+    auto& piece = ws->piece;
     int nt = static_cast<int>(std::min<int64_t>(kTextThreads, n_windows / kRowsPerPiece));
     if (nt < 1 || !text_pool().usable()) nt = 1;  // (a forked child: no worker threads)
     bool threw[kTextThreads] = {false};
@@ -369,6 +398,14 @@ int sai_write_window_rows(const char* chr_name_host, const char* pop_columns_hos
     int rc = SAI_OK;
     for (int t = 0; t < nt; ++t)
       if (threw[t]) rc = sai_set_error(SAI_ERR_HIP, "sai_write_window_rows: out of host memory");
+    // The three files of a run must agree on their last window: where each output ended before this call is
+    // remembered, and a failed or short write takes every output back there (regular files; a pipe keeps
+    // what it got).
+    int64_t before[1 + SAI_MAX_LOGS];
+    for (int32_t k = 0; k <= n_logs; ++k) {
+      const int fd = k == 0 ? tsv_fd : logs_host[k - 1].fd;
+      before[k] = fd >= 0 ? regular_file_size(fd) : -1;
+    }
     for (int32_t k = 0; rc == SAI_OK && k <= n_logs; ++k) {
       const int fd = k == 0 ? tsv_fd : logs_host[k - 1].fd;
       if (fd < 0) continue;
@@ -378,9 +415,17 @@ int sai_write_window_rows(const char* chr_name_host, const char* pop_columns_hos
       rc = write_pieces(fd, of, nt, &n);
       if (bytes_out) bytes_out[k] = n;
     }
+    if (rc != SAI_OK) {
+      for (int32_t k = 0; k <= n_logs; ++k) {
+        const int fd = k == 0 ? tsv_fd : logs_host[k - 1].fd;
+        if (fd >= 0 && before[k] >= 0 && regular_file_size(fd) > before[k] && ftruncate(fd, static_cast<off_t>(before[k])) == 0)
+          lseek(fd, 0, SEEK_END);
+        if (bytes_out) bytes_out[k] = 0;
+      }
+    }
     for (int t = 0; t < nt; ++t)
       for (int32_t k = 0; k <= n_logs; ++k)
-        if (piece[t][k].capacity() > (size_t{32} << 20)) std::string().swap(piece[t][k]);  // a whole-genome piece: give it back
+        if (piece[t][k].capacity() > kKeepPieceBytes) std::string().swap(piece[t][k]);
     return rc;
   });
 }

@@ -212,3 +212,98 @@ def test_writer_in_a_forked_child(tmp_path):
     assert os.WIFEXITED(status) and os.WEXITSTATUS(status) == 0
     for sfx in (".tsv", ".U.log", ".Q.log"):
         assert (tmp_path / f"child{sfx}").read_bytes() == (tmp_path / f"parent{sfx}").read_bytes()
+
+
+def test_a_failed_output_takes_the_others_back(tmp_path):
+    """the TSV and the logs of a run must agree on their last window.  The Q log's descriptor is
+    not open for writing: the call fails, and the TSV and the U log -- already written by then -- are cut
+    back to where they were before the call (earlier rows stay)."""
+    import os
+
+    from sai_amd import _ffi
+
+    lib = _ffi.load_host()
+    n_w = 400
+    batch = _random_batch(np.random.default_rng(5), n_w, 1, False, "int32")
+    cb, win, nsnps, cols, lists, _keep = _row_args(batch)
+    paths = [tmp_path / n for n in ("s.tsv", "s.U.log", "s.Q.log")]
+    for p in paths:
+        p.write_bytes(b"header of an earlier call\n")
+    fds = [os.open(paths[0], os.O_WRONLY | os.O_APPEND), os.open(paths[1], os.O_WRONLY | os.O_APPEND), os.open(paths[2], os.O_RDONLY)]
+    try:
+        logs = (_ffi.SaiLogRows * 2)(*[_ffi.SaiLogRows(c.ctypes.data, c.strides[0], o.ctypes.data, 1, a.ctypes.data, 4, fds[1 + k])
+                                       for k, (c, o, a) in enumerate(lists)])  # fmt: skip
+        nbytes = (C.c_int64 * 3)()
+        with pytest.raises(_ffi.SaiHipError, match="write to fd"):
+            _ffi.check(lib.sai_write_window_rows(b"chr7", b"a\tb\tc\tNA", n_w, win.ctypes.data_as(C.c_void_p), nsnps.ctypes.data_as(C.c_void_p), 2,
+                                                 cols, fds[0], 2, logs, nbytes), lib)  # fmt: skip
+        assert list(nbytes) == [0, 0, 0]
+        for p in paths:
+            assert p.read_bytes() == b"header of an earlier call\n"
+        os.close(fds[2])
+        fds[2] = os.open(paths[2], os.O_WRONLY | os.O_APPEND)  # the same call with a usable descriptor: appended behind the headers
+        logs[1].fd = fds[2]
+        _ffi.check(lib.sai_write_window_rows(b"chr7", b"a\tb\tc\tNA", n_w, win.ctypes.data_as(C.c_void_p), nsnps.ctypes.data_as(C.c_void_p), 2,
+                                             cols, fds[0], 2, logs, nbytes), lib)  # fmt: skip
+        for k, p in enumerate(paths):
+            body = p.read_bytes()
+            assert body.startswith(b"header of an earlier call\n") and len(body) == 26 + nbytes[k] and body.count(b"\n") == 1 + n_w
+    finally:
+        for fd in fds:
+            os.close(fd)
+
+
+def test_fork_while_another_thread_is_writing(tmp_path):
+    """a fork() while another thread is inside sai_write_window_rows hands the child a copy of the
+    writer's mutex in its locked state.  The child starts with a fresh writer state (pthread_atfork) and
+    writes the same bytes instead of waiting for ever."""
+    import os
+    import threading
+    import time
+
+    from sai_amd.configs import StatConfig
+    from sai_amd.preprocessors import FeaturePreprocessor
+
+    stats = {"U": {"ref": {"refA": 0.1}, "tgt": {"tgtB": 0.5}, "src": {"s0": "=1"}}, "Q": {"ref": {"refA": 0.1}, "tgt": {"tgtB": 0.9}, "src": {"s0": "=1"}}}
+    small = _random_batch(np.random.default_rng(11), 2000, 1, False, "int32")
+    big = _random_batch(np.random.default_rng(12), 400000, 1, False, "int32")
+    FeaturePreprocessor(str(tmp_path / "parent.tsv"), StatConfig(dict(stats))).write_batches([small])
+    stop = threading.Event()
+
+    def keep_writing():  # the library releases the GIL while it formats and writes
+        fp = FeaturePreprocessor(str(tmp_path / "busy.tsv"), StatConfig(dict(stats)))
+        while not stop.is_set():
+            fp.write_batches([big])
+            for sfx in (".tsv", ".U.log", ".Q.log"):
+                os.truncate(tmp_path / f"busy{sfx}", 0)
+
+    th = threading.Thread(target=keep_writing)
+    th.start()
+    try:
+        hung = 0
+        for attempt in range(6):
+            time.sleep(0.05 + 0.03 * attempt)  # most forks land while the other thread holds the writer
+            pid = os.fork()
+            if pid == 0:
+                try:
+                    FeaturePreprocessor(str(tmp_path / f"child{attempt}.tsv"), StatConfig(dict(stats))).write_batches([small])
+                    os._exit(0)
+                except BaseException:
+                    os._exit(1)
+            for _ in range(300):
+                done, status = os.waitpid(pid, os.WNOHANG)
+                if done:
+                    break
+                time.sleep(0.1)
+            else:
+                os.kill(pid, 9)
+                os.waitpid(pid, 0)
+                hung += 1
+                continue
+            assert os.WIFEXITED(status) and os.WEXITSTATUS(status) == 0
+            for sfx in (".tsv", ".U.log", ".Q.log"):
+                assert (tmp_path / f"child{attempt}{sfx}").read_bytes() == (tmp_path / f"parent{sfx}").read_bytes()
+        assert hung == 0, f"{hung} forked children hung in sai_write_window_rows"
+    finally:
+        stop.set()
+        th.join()
