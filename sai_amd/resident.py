@@ -232,7 +232,14 @@ class ResidentScorer:
             raise ValueError("rebind needs a block of the same number of sites and as many parameter sets")
         if (block.segments is None) != (self.block.segments is None) or (block.segments is not None and block.segments != self.block.segments):
             raise ValueError("rebind needs the same chromosome pieces")
+        signature = self._binding_signature(block, sets, counts_in, lists_as_indices)
+        if signature == getattr(self, "_bound", None):
+            # the very same buffers and parameters as the launch sequences in hand were recorded for (the same
+            # region scored again): nothing to wait for, nothing to record
+            self.block = block
+            return
         self._sync()  # nothing of the old block may still be in flight
+        self._bound = signature
         self.block, self.sets = block, list(sets)
         self.have_counts = counts_in is not None
         self.fused = self.n_sets <= _ffi.SAI_FUSED_SETS and not self.have_counts
@@ -244,6 +251,18 @@ class ResidentScorer:
         self.list_pos = None if lists_as_indices else block.pos
         self._build_pass_plans()
         self._build_stage_plans()
+
+    @staticmethod
+    def _binding_signature(block, sets, counts_in, lists_as_indices):
+        """What the prepared launch sequences depend on: where the blocks and positions lie, the ploidies, the
+        parameter sets byte for byte, the counts handed in, positions or indices in the lists."""
+        import ctypes as C
+
+        return (
+            tuple((p.tiles.data_ptr(), p.n_sites, p.n_ind) for p in block.pops), tuple(block.ploidies), block.pos.data_ptr(),
+            tuple(bytes(C.string_at(C.addressof(ps), C.sizeof(ps))) for ps in sets),
+            None if counts_in is None else counts_in.data_ptr(), bool(lists_as_indices),
+        )  # fmt: skip
 
     # A step's launches are recorded once per buffer set as prepared sequences (Engine.plan): the
     # host then pays for two C calls per step instead of nine with freshly marshalled arguments.
