@@ -98,8 +98,9 @@ inline unsigned stream_grid(const sai_ctx* ctx, int64_t n_tiles, int waves_per_c
 //    against 4.47-4.57, packed2 0.79-0.82 against 0.85;
 //  * a short pass (C2: 15 625 tiles, under four per wave at 16) needs its waves for the ramp and the
 //    tail: 16 (0.088 ms per step against 0.109 at 8).
+constexpr int kLeanSets = 4;  // from this many parameter sets on the int8 pass runs its 64-register form (site_pass.hip)
 inline int site_pass_waves_per_cu(const sai_ctx* ctx, int64_t n_tiles, int32_t n_sets) {
-  if (n_sets >= 4) return 12;
+  if (n_sets >= kLeanSets) return 12;
   return n_tiles >= static_cast<int64_t>(ctx->n_cu) * 8 * 32 ? 8 : kStreamWavesPerCu;
 }
 

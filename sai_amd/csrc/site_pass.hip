@@ -66,8 +66,13 @@ static_assert(sizeof(CountsArgs) + sizeof(FusedArgs) <= 4096, "kernel arguments 
 // The second launch bound keeps the usual form at 5 waves per SIMD (<= 96 VGPRs): four resident waves of
 // more than that leave the windows stage's waves no room next to the pass, and the pipelined step loses
 // what the overlap gives (measured at 99 VGPRs: C5 3.63 -> 3.79 ms per step).
-template <bool MULTI, bool FUSED>
-__global__ __launch_bounds__(64, MULTI ? 4 : 5) void site_counts_kernel(CountsArgs a, FusedArgs fa) {
+// LEAN: the same kernel held to 64 registers (a few values of the tile's tail spill to scratch).  Alone it
+// is the slower one -- C3: 3.04-3.10 against 2.93 ms -- but a pass with many parameter sets runs next to a
+// windows stage that is worth registers: four LEAN waves per SIMD leave half of the register file to the
+// stage's waves, and C5's pipelined step takes 3.15-3.19 ms with it at 16 waves per CU against 3.20-3.26
+// with three 80-register waves (12 per CU) and 3.42-3.44 with four (profiles/r04_waves_per_cu.txt).
+template <bool MULTI, bool FUSED, bool LEAN = false>
+__global__ __launch_bounds__(64, MULTI ? 4 : (LEAN ? 8 : 5)) void site_counts_kernel(CountsArgs a, FusedArgs fa) {
   // FUSED: the butterfly leaves lane l with site (l%4)*16 + l/4 of the tile; each lane parks those
   // {alt_sum, n_called} per population in LDS AT ITS SITE'S INDEX, and once all populations of the
   // tile are done lane l takes site l back and evaluates the parameter sets for it -- lanes in site
@@ -184,10 +189,12 @@ static int launch_site_counts(sai_ctx* ctx, int64_t n_sites, int32_t n_pops, con
   fa.planes = planes;
   fa.plane_stride = plane_stride;
   for (int s = 0; s < n_sets; ++s) fa.sets[s] = sets_host[s];
-  const dim3 grid(stream_grid(ctx, a.n_tiles, site_pass_waves_per_cu(ctx, a.n_tiles, n_sets)));
+  const bool lean = !multi && n_sets >= kLeanSets;
+  const dim3 grid(stream_grid(ctx, a.n_tiles, lean ? kStreamWavesPerCu : site_pass_waves_per_cu(ctx, a.n_tiles, n_sets)));
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (n_sets > 0) {
     if (multi) hipLaunchKernelGGL((site_counts_kernel<true, true>), grid, dim3(64), 0, st, a, fa);
+    else if (lean) hipLaunchKernelGGL((site_counts_kernel<false, true, true>), grid, dim3(64), 0, st, a, fa);
     else hipLaunchKernelGGL((site_counts_kernel<false, true>), grid, dim3(64), 0, st, a, fa);
   } else {
     if (multi) hipLaunchKernelGGL((site_counts_kernel<true, false>), grid, dim3(64), 0, st, a, fa);

@@ -43,11 +43,20 @@ __device__ __forceinline__ int64_t group_search(const int32_t* __restrict__ pos,
   return a;
 }
 
-constexpr int kBoundsGroup = 8;  // lanes per window
+constexpr int kBoundsGroup = 8;      // lanes per search, many windows
+constexpr int kBoundsWideGroup = 32;  // lanes per search, few windows: both searches of a window side by side in one wave
+constexpr int kBoundsWideMax = 32768;
 
 // lo = first site with pos >= start, hi = first site with pos > end, both searched inside the
 // window's segment [seg_lo[w], seg_hi[w]) of the block (the whole block when seg_lo is NULL): a
 // block that holds several chromosomes back to back has positions that ascend only per segment.
+// PAIR = false: G lanes per window, lo then hi (hi from lo onward).  PAIR = true: 2 G lanes per window,
+// one group per bound at the same time -- with G = 32 a wave per window and 4 dependent loads for 10^6
+// sites instead of 14.  Stand-alone the narrow form is the faster one (fewer probes: the texture path
+// bounds the kernel, 14 against 33 us for 10^4 windows), but the pipelined scorer runs this kernel under
+// the next step's genotype stream, where every dependent load takes microseconds and the chain of the
+// windows stage has to fit under a SHORT pass (C2: 75 us): there the wide form is used.
+template <int G, bool PAIR>
 __global__ __launch_bounds__(256) void window_bounds_kernel(const int32_t* __restrict__ pos,
                                                              int64_t n_sites, int32_t n_windows,
                                                              const int64_t* __restrict__ ws,
@@ -57,18 +66,25 @@ __global__ __launch_bounds__(256) void window_bounds_kernel(const int32_t* __res
                                                              int32_t* __restrict__ lo,
                                                              int32_t* __restrict__ hi) {
   const int lane = threadIdx.x & 63;
-  const int w = (blockIdx.x * 256 + threadIdx.x) / kBoundsGroup;
+  const int slot = (blockIdx.x * 256 + threadIdx.x) / G;  // one search group
+  const int w = PAIR ? slot >> 1 : slot;
+  const bool upper = PAIR && (slot & 1);  // this group looks for hi
   const bool live = w < n_windows;  // dead groups search an empty range: no loads, no stores
   int64_t a = 0, b = live ? n_sites : 0;
   if (live && seg_lo) {  // clamped into the block, so a bad segment can never turn into a wild load
     a = min(max(static_cast<int64_t>(seg_lo[w]), int64_t{0}), n_sites);
     b = min(max(static_cast<int64_t>(seg_hi[w]), a), n_sites);
   }
-  const int64_t first = group_search<kBoundsGroup>(pos, a, b, live ? ws[w] : 0, false, lane);
-  const int64_t last = group_search<kBoundsGroup>(pos, first, live ? b : first, live ? we[w] : 0, true, lane);
-  if (live && lane % kBoundsGroup == 0) {
-    lo[w] = static_cast<int32_t>(first);
-    hi[w] = static_cast<int32_t>(last);
+  if (PAIR) {
+    const int64_t at = group_search<G>(pos, a, b, live ? (upper ? we[w] : ws[w]) : 0, upper, lane);
+    if (live && lane % G == 0) (upper ? hi : lo)[w] = static_cast<int32_t>(at);
+  } else {
+    const int64_t first = group_search<G>(pos, a, b, live ? ws[w] : 0, false, lane);
+    const int64_t last = group_search<G>(pos, first, live ? b : first, live ? we[w] : 0, true, lane);
+    if (live && lane % G == 0) {
+      lo[w] = static_cast<int32_t>(first);
+      hi[w] = static_cast<int32_t>(last);
+    }
   }
 }
 
@@ -900,9 +916,19 @@ static int launch_window_bounds(sai_ctx* ctx, const int32_t* pos, int64_t n_site
   if (n_sites < 0 || n_sites >= 0x7FFFFFFFll || n_windows < 0) return fail(SAI_ERR_ARG, "size out of range");
   if (n_windows == 0) return SAI_OK;
   if ((n_sites > 0 && !pos) || !win_start || !win_end || !lo || !hi) return fail(SAI_ERR_ARG, "NULL buffer");
-  const unsigned grid = static_cast<unsigned>((static_cast<int64_t>(n_windows) * kBoundsGroup + 255) / 256);
-  hipLaunchKernelGGL(window_bounds_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), pos, n_sites,
-                     n_windows, win_start, win_end, seg_lo, seg_hi, lo, hi);
+  static const int wide_max = [] {  // SAI_BOUNDS_WIDE_MAX: tuning knob for sweeps
+    const char* e = std::getenv("SAI_BOUNDS_WIDE_MAX");
+    return e ? std::atoi(e) : kBoundsWideMax;
+  }();
+  if (n_windows <= wide_max) {
+    const unsigned grid = static_cast<unsigned>((static_cast<int64_t>(n_windows) * 2 * kBoundsWideGroup + 255) / 256);
+    hipLaunchKernelGGL((window_bounds_kernel<kBoundsWideGroup, true>), dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       pos, n_sites, n_windows, win_start, win_end, seg_lo, seg_hi, lo, hi);
+  } else {
+    const unsigned grid = static_cast<unsigned>((static_cast<int64_t>(n_windows) * kBoundsGroup + 255) / 256);
+    hipLaunchKernelGGL((window_bounds_kernel<kBoundsGroup, false>), dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       pos, n_sites, n_windows, win_start, win_end, seg_lo, seg_hi, lo, hi);
+  }
   return check_launch("window_bounds");
 }
 

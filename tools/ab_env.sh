@@ -2,7 +2,7 @@
 # A/B on one box: bench.py runs of the given workloads under each value of an environment knob.
 # Usage: bash tools/ab_env.sh VAR "v1 v2 ..." "wl1 wl2 ..." [extra bench flags]  -> one line per run
 VAR=$1; VALS=$2; WLS=$3; shift; shift; shift
-for rep in 1 2; do
+for rep in $(seq 1 ${REPS:-2}); do
 for v in $VALS; do
   for wl in $WLS; do
     env $VAR=$v python bench.py --workload $wl --steps 40 --cpu-sites 0 --score-path off --traffic off "$@" 2>/dev/null | python -c "

@@ -3,7 +3,7 @@
 # Usage: bash tools/ab_lib.sh "variant1 variant2 ... (cur = the tree's own)" "waves..." "workloads..." [bench flags]
 VARS=$1; WAVES=$2; WLS=$3; shift; shift; shift
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
-for rep in 1 2; do
+for rep in $(seq 1 ${REPS:-2}); do
 for v in $VARS; do
   LIB=$ROOT/sai_amd/lib/ab/$v/libsaihip.so; [ "$v" = cur ] && LIB=$ROOT/sai_amd/lib/libsaihip.so
   for wv in $WAVES; do
