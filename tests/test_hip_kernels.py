@@ -216,6 +216,47 @@ def test_quantile_beyond_lds_capacity(eng):
             assert res.u_list(0, wi).tolist() == eu["cdd_pos"].tolist()
 
 
+def test_shared_form_beyond_its_lds_capacities(eng):
+    """window_stats / window_lists with >= 4 sets (one workgroup per window, the window's rows and stored
+    frequencies in LDS): windows that fit, windows whose stored frequencies exceed the 1 024 kept in LDS
+    (rows in LDS, frequencies read where they lie), windows of more than 128 tiles or 1 024 row words (all
+    from global memory), light and heavy sets side by side, with and without inverted planes -- every
+    record and both lists equal the per-window oracle."""
+    from oracle import sai_oracle as O
+    from sai_amd import _ffi
+
+    rng = np.random.default_rng(41)
+    n_sites = 12000
+    pos = np.cumsum(rng.integers(1, 9, n_sites)).astype(np.int64)
+    p = rng.random(n_sites) ** 2
+    ref = rng.binomial(2, (p * 0.05)[:, None], size=(n_sites, 20)).astype(np.int64)
+    tgt = rng.binomial(2, p[:, None], size=(n_sites, 31)).astype(np.int64)
+    tgt[rng.random(tgt.shape) < 0.03] = -2
+    s1 = rng.integers(0, 3, size=(n_sites, 1)).astype(np.int64)
+    s2 = rng.integers(0, 3, size=(n_sites, 1)).astype(np.int64)
+    ends = [int(pos[-1]), int(pos[9000]), int(pos[5000]), int(pos[1500]), int(pos[700]), int(pos[63]), int(pos[5])]
+    starts = [1, int(pos[100]), 1, int(pos[300]), 1, 1, 1]
+    for anc in (True, False):
+        specs = [dict(w=1.0, x=0.4, quantile=0.95, y_list=[(">=", 0.0), (">=", 0.0)], anc=anc),  # nearly every site
+                 dict(w=0.2, x=0.5, quantile=0.5, y_list=[("=", 1.0), (">=", 0.5)], anc=anc),
+                 dict(w=0.05, x=0.1, quantile=0.0, y_list=[("=", 0.0), ("=", 0.0)], anc=anc),
+                 dict(w=1.0, x=0.9, quantile=1.0, y_list=[("<=", 0.5), (">", 0.0)], anc=anc),
+                 dict(w=0.5, x=0.3, quantile=0.777, y_list=[(">=", 0.5), ("<", 1.0)], anc=anc)]
+        sets = [_ffi.make_params(s["w"], s["x"], s["quantile"], s["y_list"], s["anc"]) for s in specs]
+        res, lo, hi = _window_pass(eng, [ref, tgt, s1, s2], [2, 2, 2, 2], sets, pos, np.array(starts), np.array(ends))
+        assert (hi - lo).max() > 128 * 64 and res.records[0]["n_cond"].max() > 1024 and res.records[0]["n_cond"].min() <= 6
+        for si, s in enumerate(specs):
+            for wi, (ws, we) in enumerate(zip(starts, ends)):
+                m = (pos >= ws) & (pos <= we)
+                kw = dict(ref_gts=ref[m], tgt_gts=tgt[m], src_gts_list=[s1[m], s2[m]], ref_ploidy=2, tgt_ploidy=2,
+                          src_ploidy_list=[2, 2], pos=pos[m], w=s["w"], y_list=s["y_list"], anc_allele_available=anc)  # fmt: skip
+                eq, eu = O.q_stat(quantile=s["quantile"], **kw), O.u_stat(x=s["x"], **kw)
+                rec = res.records[si, wi]
+                assert rec["n_sites"] == int(m.sum()) and rec["u_count"] == eu["value"], (anc, si, wi)
+                assert same_f64(rec["q"], eq["value"]), (anc, si, wi, rec["q"], eq["value"])
+                assert res.q_list(si, wi).tolist() == eq["cdd_pos"].tolist() and res.u_list(si, wi).tolist() == eu["cdd_pos"].tolist()
+
+
 def test_synth_device_equals_host(eng):
     import ctypes as C
 
