@@ -92,12 +92,12 @@ __global__ __launch_bounds__(256) void window_bounds_kernel(const int32_t* __res
 // window statistics.  Four launches, no atomics on shared words (a returning atomic on one
 // address saturates at ~90 per microsecond, which at one reservation per window was 85 % of the
 // first single-kernel version), and every window's data is read ONCE per kernel:
-//   window_stats   one WORKGROUP per window, all sets of the call: the window's plane rows and stored
-//                  target frequencies are brought into LDS once; each of the four waves then answers
-//                  sets (U count, condition count, Q, Q-list size) from LDS, and sets with more than
-//                  kWaveCap qualifying sites are finished by the whole workgroup (radix select)
+//   window_stats   >= 4 sets: one WORKGROUP per window -- the window's plane rows and stored target
+//                  frequencies are brought into LDS once, each of the four waves then answers sets (U
+//                  count, condition count, Q, Q-list size) from LDS on its own; fewer sets: one WAVE per
+//                  window, every word read where it lies.  No workgroup barrier after the fill.
 //   window_scan    exclusive prefix sums of the list sizes -> CSR offsets + totals (two launches)
-//   window_lists   one workgroup per window again: candidate lists in ascending site order
+//   window_lists   the same two forms: candidate lists in ascending site order
 // Round 3 ran one wavefront per (window, set) and a second workgroup kernel for the heavy pairs, all
 // reading global memory: C5's 18 sets x 2x window overlap x 64-byte lines re-read ~190 MB of planes
 // and frequencies as 1.36 GB per step (profiles/r03g_c5_pmc_summary.csv), under the next step's
@@ -128,8 +128,7 @@ struct WinArgs {
 
 constexpr int kWinThreads = 256;
 constexpr int kWinWaves = kWinThreads / 64;
-constexpr int kWaveCap = 256;       // qualifying sites a wave ranks directly; more -> the workgroup's radix select
-constexpr int kSelCap = kWinWaves * kWaveCap;  // values the radix select keeps in LDS (the waves' slices, 8 KiB); beyond: re-read
+constexpr int kWaveCap = 256;  // qualifying sites a wave ranks directly; more -> digit histogram + one gathered bin
 // Words of a tile's row (saihip.h): 0 = "any" (sites whose frequency is stored), 1 + s = condition of
 // set s, 1 + n + s = inverted for set s (present only with a.with_inv).
 constexpr int kAny = 0;
