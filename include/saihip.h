@@ -63,7 +63,7 @@
 extern "C" {
 #endif
 
-#define SAI_ABI_VERSION 14
+#define SAI_ABI_VERSION 15
 #define SAI_TILE_SITES 64
 #define SAI_MAX_SRC 6   /* source populations per call */
 #define SAI_MAX_SETS 20 /* parameter sets per call: 1 + 2 * 20 plane words of a tile = one wave store (C5's 18 sets fit) */
@@ -269,6 +269,23 @@ int sai_plan_add_window_stats(sai_plan* plan, int64_t n_sites, const double* tgt
                               int32_t* cdd_q, int64_t cap_q, int64_t* cdd_total);
 /* hipMemcpyAsync of n_bytes from device memory to (pinned) host memory: the records of a step */
 int sai_plan_add_copy_to_host(sai_plan* plan, void* dst_host, const void* src, int64_t n_bytes);
+
+/* Events carried BY a launch.  Between two consecutive site passes of one queue every marker a caller records
+ * (the end of a pass for timing, the hand-over the host waits for before it enqueues the windows stage, the
+ * start of the next pass) is a packet of its own that the queue works off before the next dispatch: ~10 us
+ * for three of them, an eighth of a short pass (C2: 75 us; nothing in the reference corresponds -- its
+ * statistics run where the data is, sai.py:146-151).  A launch can carry its events in its own dispatch
+ * packet instead (hipExtLaunchKernelGGL): `start` is stamped when the kernel begins, `stop` when it ends,
+ * and no packet stands between this pass and the next.  sai_plan_set_pass_events attaches two such events
+ * (either may be NULL) to the site pass of a plan (sai_plan_add_site_pass / _site_counts): every
+ * sai_plan_run from then on stamps them; the caller waits for `stop` (sai_event_synchronize / _query) and
+ * reads the pass's duration with sai_event_elapsed_ms.  Events belong to the ctx's device. */
+int sai_event_create(sai_ctx* ctx, void** event_out);
+int sai_event_destroy(void* event);
+int sai_event_synchronize(void* event);
+int sai_event_query(void* event, int32_t* done_out);
+int sai_event_elapsed_ms(void* start_event, void* stop_event, float* ms_out);
+int sai_plan_set_pass_events(sai_plan* plan, void* start_event, void* stop_event);
 
 /* ---- ABBA-BABA family: fd, df, Danc, Dplus --------------------- */
 

@@ -22,7 +22,7 @@ SAI_PLANES_PER_SET = 3
 SAI_ERR_ARG = -1
 SAI_ERR_UNSUPPORTED = -4  # enum sai_status
 FREQ_MODES = {"dense": 0, "candidates": 1}  # enum sai_freq_mode
-SAI_ABI_VERSION = 14
+SAI_ABI_VERSION = 15
 
 OPS = {"=": 0, "<": 1, ">": 2, "<=": 3, ">=": 4}
 
@@ -108,6 +108,12 @@ SIGNATURES = {
     "sai_plan_create": (C.c_int, [_p, C.POINTER(_p)]),
     "sai_plan_destroy": (C.c_int, [_p]),
     "sai_plan_run": (C.c_int, [_p, _p]),
+    "sai_plan_set_pass_events": (C.c_int, [_p, _p, _p]),
+    "sai_event_create": (C.c_int, [_p, C.POINTER(_p)]),
+    "sai_event_destroy": (C.c_int, [_p]),
+    "sai_event_synchronize": (C.c_int, [_p]),
+    "sai_event_query": (C.c_int, [_p, C.POINTER(_i32)]),
+    "sai_event_elapsed_ms": (C.c_int, [_p, _p, C.POINTER(C.c_float)]),
     "sai_plan_add_site_counts": (C.c_int, [_p, _i64, _i32, C.POINTER(SaiPop), _p]),
     "sai_plan_add_site_pass": (
         C.c_int,

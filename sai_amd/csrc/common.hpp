@@ -2,6 +2,7 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <cmath>
 #include <cstdarg>
@@ -43,7 +44,20 @@ struct sai_ctx {
   size_t sw_dev_cap;
   void* sw_host;  // pinned
   size_t sw_host_cap;
+  // events the NEXT site-pass launch of this ctx carries in its dispatch packet (sai_plan_set_pass_events);
+  // taken -- and cleared -- by that launch
+  hipEvent_t next_start;
+  hipEvent_t next_stop;
 };
+
+// launch a streaming site-pass kernel, with the ctx's pending events in the dispatch packet when there are any
+template <typename K, typename... Args>
+inline void launch_pass(sai_ctx* ctx, K kernel, dim3 grid, dim3 block, hipStream_t st, Args... args) {
+  hipEvent_t start = ctx->next_start, stop = ctx->next_stop;
+  ctx->next_start = ctx->next_stop = nullptr;
+  if (start || stop) hipExtLaunchKernelGGL(kernel, grid, block, 0, st, start, stop, 0, args...);
+  else hipLaunchKernelGGL(kernel, grid, block, 0, st, args...);
+}
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));

@@ -107,11 +107,46 @@ int sai_ctx_create(int device, sai_ctx** ctx_out) {
   c->probe_partials = nullptr;
   c->sw_dev = c->sw_host = nullptr;
   c->sw_dev_cap = c->sw_host_cap = 0;
+  c->next_start = c->next_stop = nullptr;
   if (hipMalloc(&c->probe_partials, sizeof(uint32_t) * c->n_cu * kProbeWavesPerCu) != hipSuccess) {
     delete c;
     return fail(SAI_ERR_HIP, "hipMalloc of the context scratch failed");
   }
   *ctx_out = c;
+  return SAI_OK;
+}
+
+int sai_event_create(sai_ctx* ctx, void** event_out) {
+  if (int rc = enter(ctx)) return rc;
+  if (!event_out) return fail(SAI_ERR_ARG, "event_out is NULL");
+  hipEvent_t e = nullptr;
+  SAI_HIP(hipEventCreate(&e));
+  *event_out = e;
+  return SAI_OK;
+}
+
+int sai_event_destroy(void* event) {
+  if (event) SAI_HIP(hipEventDestroy(static_cast<hipEvent_t>(event)));
+  return SAI_OK;
+}
+
+int sai_event_synchronize(void* event) {
+  if (!event) return fail(SAI_ERR_ARG, "event is NULL");
+  SAI_HIP(hipEventSynchronize(static_cast<hipEvent_t>(event)));
+  return SAI_OK;
+}
+
+int sai_event_query(void* event, int32_t* done_out) {
+  if (!event || !done_out) return fail(SAI_ERR_ARG, "NULL argument");
+  const hipError_t e = hipEventQuery(static_cast<hipEvent_t>(event));
+  if (e != hipSuccess && e != hipErrorNotReady) return fail(SAI_ERR_HIP, "hipEventQuery failed: %s", hipGetErrorString(e));
+  *done_out = e == hipSuccess ? 1 : 0;
+  return SAI_OK;
+}
+
+int sai_event_elapsed_ms(void* start_event, void* stop_event, float* ms_out) {
+  if (!start_event || !stop_event || !ms_out) return fail(SAI_ERR_ARG, "NULL argument");
+  SAI_HIP(hipEventElapsedTime(ms_out, static_cast<hipEvent_t>(start_event), static_cast<hipEvent_t>(stop_event)));
   return SAI_OK;
 }
 

@@ -15,6 +15,7 @@
 struct sai_plan {
   sai_ctx* ctx;
   std::vector<std::function<int(void*)>> ops;  // each enqueues on the stream it is handed
+  hipEvent_t pass_start = nullptr, pass_stop = nullptr;  // carried by the plan's site pass (sai_plan_set_pass_events)
 };
 
 namespace {
@@ -45,7 +46,7 @@ extern "C" {
 int sai_plan_create(sai_ctx* ctx, sai_plan** plan_out) {
   if (int rc = enter(ctx)) return rc;
   if (!plan_out) return fail(SAI_ERR_ARG, "plan_out is NULL");
-  sai_plan* p = new (std::nothrow) sai_plan{ctx, {}};
+  sai_plan* p = new (std::nothrow) sai_plan{ctx, {}, nullptr, nullptr};
   if (!p) return fail(SAI_ERR_HIP, "out of host memory");
   *plan_out = p;
   return SAI_OK;
@@ -67,7 +68,13 @@ int sai_plan_add_site_counts(sai_plan* plan, int64_t n_sites, int32_t n_pops, co
   return guarded_add(plan, [&] {
     auto pv = copy_pops(n_pops, pops);
     sai_ctx* ctx = plan->ctx;
-    return [=](void* st) { return sai_site_counts(ctx, n_sites, n_pops, pv.data(), counts, st); };
+    return [=](void* st) {
+      ctx->next_start = plan->pass_start;
+      ctx->next_stop = plan->pass_stop;
+      const int rc = sai_site_counts(ctx, n_sites, n_pops, pv.data(), counts, st);
+      ctx->next_start = ctx->next_stop = nullptr;  // also when the call returned before its launch
+      return rc;
+    };
   });
 }
 
@@ -80,10 +87,14 @@ int sai_plan_add_site_pass(sai_plan* plan, int64_t n_sites, int32_t n_pops, cons
     sai_ctx* ctx = plan->ctx;
     return [=](void* st) {
       const sai_params* s = sv.empty() ? nullptr : sv.data();
-      return packed2 ? sai_site_pass_packed2(ctx, n_sites, n_pops, pv.data(), counts, n_sets, s, freq_mode, tgt_freq, planes,
-                                             plane_stride, st)
-                     : sai_site_pass(ctx, n_sites, n_pops, pv.data(), counts, n_sets, s, freq_mode, tgt_freq, planes,
-                                     plane_stride, st);
+      ctx->next_start = plan->pass_start;
+      ctx->next_stop = plan->pass_stop;
+      const int rc = packed2 ? sai_site_pass_packed2(ctx, n_sites, n_pops, pv.data(), counts, n_sets, s, freq_mode, tgt_freq,
+                                                     planes, plane_stride, st)
+                             : sai_site_pass(ctx, n_sites, n_pops, pv.data(), counts, n_sets, s, freq_mode, tgt_freq, planes,
+                                             plane_stride, st);
+      ctx->next_start = ctx->next_stop = nullptr;  // also when the call returned before its launch
+      return rc;
     };
   });
 }
@@ -128,6 +139,13 @@ int sai_plan_add_window_stats(sai_plan* plan, int64_t n_sites, const double* tgt
                               n_windows, lo, hi, pos, records, cdd_off, cdd_u, cap_u, cdd_q, cap_q, cdd_total, st);
     };
   });
+}
+
+int sai_plan_set_pass_events(sai_plan* plan, void* start_event, void* stop_event) {
+  if (!plan) return fail(SAI_ERR_ARG, "plan is NULL");
+  plan->pass_start = static_cast<hipEvent_t>(start_event);
+  plan->pass_stop = static_cast<hipEvent_t>(stop_event);
+  return SAI_OK;
 }
 
 int sai_plan_add_copy_to_host(sai_plan* plan, void* dst_host, const void* src, int64_t n_bytes) {

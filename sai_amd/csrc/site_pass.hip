@@ -193,12 +193,12 @@ static int launch_site_counts(sai_ctx* ctx, int64_t n_sites, int32_t n_pops, con
   const dim3 grid(stream_grid(ctx, a.n_tiles, lean ? kStreamWavesPerCu : site_pass_waves_per_cu(ctx, a.n_tiles, n_sets)));
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (n_sets > 0) {
-    if (multi) hipLaunchKernelGGL((site_counts_kernel<true, true>), grid, dim3(64), 0, st, a, fa);
-    else if (lean) hipLaunchKernelGGL((site_counts_kernel<false, true, true>), grid, dim3(64), 0, st, a, fa);
-    else hipLaunchKernelGGL((site_counts_kernel<false, true>), grid, dim3(64), 0, st, a, fa);
+    if (multi) launch_pass(ctx, site_counts_kernel<true, true>, grid, dim3(64), st, a, fa);
+    else if (lean) launch_pass(ctx, site_counts_kernel<false, true, true>, grid, dim3(64), st, a, fa);
+    else launch_pass(ctx, site_counts_kernel<false, true>, grid, dim3(64), st, a, fa);
   } else {
-    if (multi) hipLaunchKernelGGL((site_counts_kernel<true, false>), grid, dim3(64), 0, st, a, fa);
-    else hipLaunchKernelGGL((site_counts_kernel<false, false>), grid, dim3(64), 0, st, a, fa);
+    if (multi) launch_pass(ctx, site_counts_kernel<true, false>, grid, dim3(64), st, a, fa);
+    else launch_pass(ctx, site_counts_kernel<false, false>, grid, dim3(64), st, a, fa);
   }
   return check_launch("site_counts");
 }

@@ -121,6 +121,45 @@ class WindowResults:
         return self.cdd_q[o : o + int(self.records[s, w]["n_cdd_q"])]
 
 
+class LaunchEvent:
+    """A HIP event that a site-pass launch carries in its own dispatch packet (saihip.h,
+    sai_plan_set_pass_events): no marker packet between two consecutive passes of a queue.  The part of
+    torch.cuda.Event's interface the scorer and the bench use."""
+
+    __slots__ = ("_lib", "_h")
+
+    def __init__(self, eng: "Engine"):
+        self._lib = eng.lib
+        h = C.c_void_p()
+        _ffi.check(eng.lib.sai_event_create(eng.ctx, C.byref(h)))
+        self._h = h
+
+    @property
+    def handle(self) -> C.c_void_p:
+        return self._h
+
+    def synchronize(self) -> None:
+        _ffi.check(self._lib.sai_event_synchronize(self._h))
+
+    def query(self) -> bool:
+        done = C.c_int32()
+        _ffi.check(self._lib.sai_event_query(self._h, C.byref(done)))
+        return bool(done.value)
+
+    def elapsed_time(self, end: "LaunchEvent") -> float:
+        ms = C.c_float()
+        _ffi.check(self._lib.sai_event_elapsed_ms(self._h, end._h, C.byref(ms)))
+        return float(ms.value)
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                self._lib.sai_event_destroy(self._h)
+                self._h = None
+        except Exception:  # interpreter shutdown
+            pass
+
+
 class Plan:
     """A prepared launch sequence (saihip.h, sai_plan_*): the engine calls of a step recorded once
     with all their arguments, replayed by ONE C call on the current stream.  The tensors whose
@@ -150,6 +189,12 @@ class Plan:
         rc = self._run(self._h, self.eng._stream())
         if rc:
             _ffi.check(rc)
+
+    def set_pass_events(self, start: "Optional[LaunchEvent]", stop: "Optional[LaunchEvent]") -> None:
+        """The events every later ``run`` stamps in the dispatch packet of this plan's site pass."""
+        self._events = (start, stop)  # kept alive
+        _ffi.check(self.eng.lib.sai_plan_set_pass_events(self._h, start.handle if start is not None else None,
+                                                         stop.handle if stop is not None else None))  # fmt: skip
 
     def _pops(self, pops, ploidies, packed: bool):
         arr = (_ffi.SaiPop * len(pops))()

@@ -193,7 +193,10 @@ class ResidentScorer:
         self._tgt_freq = [torch.full((n,), float("nan"), dtype=torch.float64, device=dev) for _ in range(n_buf)]
         self._flags = [eng.alloc_planes(n, n_s) for _ in range(n_buf)]  # flag planes [tiles][3 * sets]
         self.side = torch.cuda.Stream(device=dev, priority=-1) if self.overlap else None  # small kernels first
-        self._site_done = [torch.cuda.Event() for _ in range(n_buf)]
+        self._plain_done = [torch.cuda.Event() for _ in range(n_buf)]
+        self._site_done = list(self._plain_done)  # per buffer set: what the host waits for before the windows stage
+        # the hand-over (and, in timed steps, both ends) of a fused pass ride in its own dispatch packet
+        self._carried = [None] * n_buf  # per buffer set: the LaunchEvent pair its plan carries at the moment
         self._win_done = [torch.cuda.Event() for _ in range(n_buf)]  # after the windows stage that last read buffer b
         self._win_used = [False] * n_buf
         self._pending = None  # (buffer set, step index) whose windows stage has not been enqueued yet
@@ -268,6 +271,7 @@ class ResidentScorer:
     # host then pays for two C calls per step instead of nine with freshly marshalled arguments.
     def _build_pass_plans(self) -> None:
         eng, blk = self.eng, self.block
+        self._carried = [None] * len(self._tgt_freq)  # new plans carry nothing yet
         self._count_plans, self._flag_plans = [], []
         for tgt_freq, planes in zip(self._tgt_freq, self._flags):
             out = (tgt_freq, planes)
@@ -406,16 +410,34 @@ class ResidentScorer:
         main = torch.cuda.current_stream(eng.device)
         if self.overlap and self._win_used[b]:
             self._wait(self._win_done[b], "windows stage")  # the stage that last read buffer set b (2 steps ago)
-        if time_counts:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-        if self._count_plans[b] is not None:
-            self._count_plans[b].run()  # the genotype stream: site_counts, fused with the per-site decision when it can be
-        if time_counts:
-            e1.record()
-            self.count_events.append((e0, e1))
-        if self._flag_plans[b] is not None:
-            self._flag_plans[b].run()
+        # Pipelined form, fused pass: the events ride in the pass's own dispatch packet (saihip.h,
+        # sai_plan_set_pass_events) -- between two consecutive passes of the queue there is then NO marker packet
+        # (end of pass k, hand-over, start of pass k + 1 were three: ~10 us of a 75-us pass).  A timed step gets a
+        # pair of its own (its duration is read after the run); an untimed one reuses its buffer set's pair.
+        carried = self.overlap and self._flag_plans[b] is None and self._count_plans[b] is not None
+        if carried:
+            from .engine import LaunchEvent
+
+            if time_counts or self._carried[b] is None or self._carried[b][2]:
+                pair = (LaunchEvent(eng), LaunchEvent(eng), time_counts)
+                self._count_plans[b].set_pass_events(pair[0], pair[1])
+                self._carried[b] = pair
+            pair = self._carried[b]
+            self._count_plans[b].run()
+            if time_counts:
+                self.count_events.append((pair[0], pair[1]))
+            self._site_done[b] = pair[1]
+        else:
+            if time_counts:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            if self._count_plans[b] is not None:
+                self._count_plans[b].run()  # the genotype stream: site_counts, fused with the per-site decision when it can be
+            if time_counts:
+                e1.record()
+                self.count_events.append((e0, e1))
+            if self._flag_plans[b] is not None:
+                self._flag_plans[b].run()
         index = self._k
         self._k += 1
         if not self.overlap:
@@ -423,7 +445,9 @@ class ResidentScorer:
             if self.after_stage is not None:
                 self.after_stage(index)
             return
-        self._site_done[b].record(main)
+        if not carried:
+            self._site_done[b] = self._plain_done[b]
+            self._plain_done[b].record(main)
         main.query()                 # submit the site pass before the host starts waiting
         self._launch_pending()       # the previous step's stage runs under this site pass
         self._pending = (b, index)

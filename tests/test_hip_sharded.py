@@ -396,6 +396,44 @@ def test_bench_default_line_has_the_contract_fields():
     assert sp["item_protocol"]["same_bytes_as_native"] is True
 
 
+def test_launch_carried_events_time_the_pass_and_hand_it_over(eng):
+    """sai_plan_set_pass_events: the site pass of a plan stamps its two events in its own dispatch packet.  The
+    pipelined scorer uses them as the hand-over to the windows stage and -- in timed steps -- as the pass's
+    duration: as many pairs as timed steps, every duration positive and below the wall time of the run, the
+    results those of the scorer without the pipeline."""
+    import time
+
+    import torch
+
+    from sai_amd.engine import LaunchEvent
+
+    wl = small_job("c2", sites=400_000, chroms=1)
+    got = run_rank(eng, wl, 0, 1, overlap=False, through_row=False)[0]
+    from sai_amd.resident import ResidentScorer
+    from sai_amd.sharding import build_synth_shard
+
+    block, lay, _ = build_synth_shard(eng, wl, 0, 1)
+    scorer = ResidentScorer(eng, block, [(s, e) for _, s, e in lay.windows], wl.params(), cap_u=1 << 20, cap_q=1 << 20, overlap=True,
+                            window_segment=lay.window_segment)  # fmt: skip
+    for _ in range(2):
+        scorer.step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(7):
+        scorer.step(time_counts=True)
+    for _ in range(2):
+        scorer.step()  # untimed steps after timed ones must not re-stamp the timed pairs
+    res = scorer.results()
+    wall_ms = (time.perf_counter() - t0) * 1e3
+    assert len(scorer.count_events) == 7 and all(isinstance(a, LaunchEvent) and isinstance(b, LaunchEvent) for a, b in scorer.count_events)
+    ms = [a.elapsed_time(b) for a, b in scorer.count_events]
+    assert all(0.0 < m < wall_ms for m in ms) and sum(ms) < wall_ms, (ms, wall_ms)
+    assert all(b.query() for _, b in scorer.count_events)
+    assert res.records.tobytes() == got.records.tobytes() and res.cdd_q.tobytes() == got.cdd_q.tobytes()
+    ev = LaunchEvent(eng)  # never stamped: a query says "done" (nothing pending), elapsed_time between unstamped events is an error
+    assert ev.query() is True
+
+
 # ---- the product entry point over several worker processes (VERDICT r3 #1) ----------------------------
 
 
