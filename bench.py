@@ -318,6 +318,11 @@ def score_path_rate(eng, wl, block, lay, repeats: int = 3) -> dict:
         for _ in range(repeats + 1):
             write_headers(out, stats, ploidies)
             write_headers(out_items, stats, ploidies)
+            # The item route of the repeat before kept the host busy -- and the GPU idle -- for ~80 ms; a device
+            # that idle has clocked its memory down, and the first pass after it ran 0.4 ms slower than the same
+            # pass in a loop (3.87 against 3.38 ms for the call).  `score` never meets the GPU that cold (the
+            # ingest runs right before), so the timed call follows an untimed one.
+            fp.score_windows(wg)
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             t0 = time.perf_counter()
@@ -362,7 +367,8 @@ def score_path_rate(eng, wl, block, lay, repeats: int = 3) -> dict:
         },
         "what": "FeaturePreprocessor.score_windows + write_batches on the resident block = what `score` runs after the "
         "ingest (U and Q as two statistics, one fused pass, TSV + .U.log + .Q.log); item_protocol = the same batch "
-        "through items_from_batch + process_items; best of %d" % repeats,
+        "through items_from_batch + process_items; best of %d, each right after an untimed call of the same (the device has "
+        "idled through the item route of the repeat before)" % repeats,
     }
 
 

@@ -61,7 +61,7 @@ def main() -> None:
         for _ in range(10):
             once()
         pr.disable()
-        pstats.Stats(pr).sort_stats("cumulative").print_stats(45)
+        pstats.Stats(pr).sort_stats("tottime").print_stats(25)
 
 
 if __name__ == "__main__":
