@@ -570,3 +570,65 @@ def test_window_batch_bytes_round_trip_and_single_chunk_order(tmp_path):
     assert sorted((it["tgt_pop"], it["start"], it["U"]) for it in merged) == sorted((it["tgt_pop"], it["start"], it["U"]) for it in per_chunk)
     for it in merged:
         assert isinstance(it["U"], int) and len(it["cdd_pos"]["U"]) == it["U"] or it["nsnps"] == 0
+
+
+def test_value_radix_digits_are_an_exact_monotone_code():
+    """The arithmetic of the windows stage's radix select on the VALUE (sai_amd/csrc/windows.hip,
+    digit_on_path): digit l of v in [0, 1] is floor(v * 256^(l+1)) - 256 * floor(v * 256^l) -- scalings by
+    powers of two and floors, so every step is exact in binary floating point -- and a value is on the
+    chosen path iff floor(v * 256^l) equals the prefix the earlier digits spell.  Restated in numpy float64
+    (the same IEEE operations) and driven like the kernel: histogram per level, the bin of the wanted rank,
+    descend until the bin holds few values, rank those directly.  The selected order statistic must be
+    np.sort's for tie-heavy inputs, neighbours one ulp apart, exact 0.0 / 1.0, subnormal-small values, and
+    fifteen levels must separate any two distinct doubles."""
+    rng = np.random.default_rng(2024)
+
+    def digit(v, prefix, scale):
+        s = v * scale
+        on = np.ones(v.shape, bool) if scale == 1.0 else np.floor(s) == prefix
+        d = np.floor(s * 256.0) - prefix * 256.0
+        return np.where(on, d, -1.0).astype(np.int64)
+
+    def select(vals, k, small=4):
+        prefix, scale = 0.0, 1.0
+        for level in range(15):
+            d = digit(vals, prefix, scale)
+            assert d.max() <= (256 if level == 0 else 255) and (d[d >= 0] >= 0).all()
+            hist = np.bincount(d[d >= 0], minlength=257)
+            before = np.concatenate([[0], np.cumsum(hist)])
+            b = int(np.searchsorted(before, k, side="right") - 1)
+            k -= int(before[b])
+            members = vals[d == b]
+            if len(members) <= small or level == 14:
+                if len(members) > small:
+                    assert np.all(members == members[0])  # the last level leaves only equal numbers in a bin
+                    return members[0]
+                return np.sort(members)[k]
+            prefix, scale = prefix * 256.0 + b, scale * 256.0
+        raise AssertionError("not reached")
+
+    base = rng.random(300)
+    ulp = np.nextafter(base[:40], 2.0)
+    cases = [
+        np.concatenate([base, ulp, np.nextafter(ulp, 2.0)]),  # neighbours one and two ulps apart
+        np.concatenate([np.zeros(200), np.ones(150), rng.integers(0, 2001, 400) / 2000.0]),  # frequencies k / 2000 with heavy ties
+        np.concatenate([rng.integers(0, 1398, 500) / 1398.0, [5e-324, 1e-310, 2.0**-55, 1.0 - 2.0**-53, 1.0]]),
+        np.full(100, 1.0 / 3.0),
+        np.array([0.0, 1.0]),
+    ]
+    for vals in cases:
+        order = np.sort(vals)
+        for k in sorted({0, 1, len(vals) // 3, len(vals) // 2, int(0.95 * (len(vals) - 1)), len(vals) - 2, len(vals) - 1} & set(range(len(vals)))):
+            got = select(vals, k)
+            assert got.tobytes() == order[k].tobytes(), (k, got, order[k])
+    # the code is monotone: comparing digit strings compares the values
+    v = np.sort(np.concatenate([rng.random(2000), ulp, [0.0, 1.0]]))
+    codes = []
+    for x in v:
+        prefix, scale, ds = 0.0, 1.0, []
+        for level in range(15):
+            d = int(digit(np.array([x]), prefix, scale)[0])
+            ds.append(d)
+            prefix, scale = prefix * 256.0 + d, scale * 256.0
+        codes.append(tuple(ds))
+    assert codes == sorted(codes) and len(set(codes)) == len(set(v.tolist()))
