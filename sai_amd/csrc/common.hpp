@@ -101,21 +101,28 @@ inline unsigned stream_grid(const sai_ctx* ctx, int64_t n_tiles, int waves_per_c
   return static_cast<unsigned>(n_tiles < max_grid ? n_tiles : max_grid);
 }
 
-// Waves per CU of the int8 / packed2 site pass (profiles/r04_waves_per_cu.txt, same-box sweeps):
+// Waves per CU of the int8 / packed2 site pass (profiles/r04_waves_per_cu.txt, profiles/r04_shape_sweep.txt:
+// same-box sweeps).  The pass is HBM-bound from 8 waves per CU on when its populations are wide, so the grid
+// is chosen for what runs NEXT to it (the windows stage of the step before, on a second stream) and for the
+// pass's own tail:
 //  * with many parameter sets (C5's 18) the pass alone is fastest at 16 (3.23 ms; 12: 3.28; 8: 3.89 -- every
 //    tile ends in the sets' evaluation, during which a wave loads nothing), but the PIPELINED step, with the
-//    previous step's windows stage next to it, is fastest at 12: 3.31 against 3.56 ms (13: 3.33, 14: 3.45,
-//    11: 3.38) whatever the stage's kernels look like -- three pass waves per SIMD leave the stage's waves
-//    registers and issue slots that a fourth takes away;
-//  * with one to three sets a long pass is a little faster at 8 -- two waves per SIMD, multiples of four
-//    only: 9 and 10 are slower than either -- C3 2.924 against 2.966 ms, three chromosomes of C4 4.37
-//    against 4.47-4.57, packed2 0.79-0.82 against 0.85;
+//    previous step's windows stage next to it, is fastest when the stage's waves find registers: the int8
+//    pass then runs its 64-register form at 16 (site_pass.hip), the packed2 pass 12 waves of its one form;
+//  * with one to three sets, WIDE populations (>= 2 000 individuals per site in at most three populations:
+//    C3, C4) and a long pass, 8 -- two waves per SIMD, multiples of four only: 9 and 10 are slower than
+//    either -- is a little faster: C3 2.924 against 2.966 ms, 2000 / 2000 / 2 individuals 2.99 against 3.06,
+//    three chromosomes of C4 4.37 against 4.47-4.57, packed2 0.79-0.82 against 0.85.  Narrower populations
+//    need their waves (a population's rows are over before a wave has many loads in flight, and every
+//    population boundary drains them): 250 / 250 / 2 is 7 % slower at 8, 100 / 100 / 1 / 1 26 %; a fourth
+//    population (two sources) makes 8 and 16 equal at best;
 //  * a short pass (C2: 15 625 tiles, under four per wave at 16) needs its waves for the ramp and the
 //    tail: 16 (0.088 ms per step against 0.109 at 8).
 constexpr int kLeanSets = 4;  // from this many parameter sets on the int8 pass runs its 64-register form (site_pass.hip)
-inline int site_pass_waves_per_cu(const sai_ctx* ctx, int64_t n_tiles, int32_t n_sets) {
+inline int site_pass_waves_per_cu(const sai_ctx* ctx, int64_t n_tiles, int32_t n_sets, int32_t n_pops, int64_t individuals) {
   if (n_sets >= kLeanSets) return 12;
-  return n_tiles >= static_cast<int64_t>(ctx->n_cu) * 8 * 32 ? 8 : kStreamWavesPerCu;
+  const bool wide = individuals >= 2000 && n_pops <= 3;
+  return wide && n_tiles >= static_cast<int64_t>(ctx->n_cu) * 8 * 32 ? 8 : kStreamWavesPerCu;
 }
 
 // XCD-aware block order: consecutive workgroup ids go round-robin over the 8 XCDs; give each XCD a

@@ -228,7 +228,9 @@ int sai_site_pass_packed2(sai_ctx* ctx, int64_t n_sites, int32_t n_pops, const s
   fa.planes = planes;
   fa.plane_stride = plane_stride;
   for (int s = 0; s < n_sets; ++s) fa.sets[s] = sets_host[s];
-  const dim3 grid(stream_grid(ctx, a.n_tiles, site_pass_waves_per_cu(ctx, a.n_tiles, n_sets)));
+  int64_t individuals = 0;
+  for (int p = 0; p < n_pops; ++p) individuals += pops[p].n_ind;
+  const dim3 grid(stream_grid(ctx, a.n_tiles, site_pass_waves_per_cu(ctx, a.n_tiles, n_sets, n_pops, individuals)));
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (n_sets > 0) launch_pass(ctx, site_counts_packed2_kernel<true>, grid, dim3(64), st, a, fa);
   else launch_pass(ctx, site_counts_packed2_kernel<false>, grid, dim3(64), st, a, fa);

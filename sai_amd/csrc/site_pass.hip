@@ -190,7 +190,9 @@ static int launch_site_counts(sai_ctx* ctx, int64_t n_sites, int32_t n_pops, con
   fa.plane_stride = plane_stride;
   for (int s = 0; s < n_sets; ++s) fa.sets[s] = sets_host[s];
   const bool lean = !multi && n_sets >= kLeanSets;
-  const dim3 grid(stream_grid(ctx, a.n_tiles, lean ? kStreamWavesPerCu : site_pass_waves_per_cu(ctx, a.n_tiles, n_sets)));
+  int64_t individuals = 0;
+  for (int p = 0; p < n_pops; ++p) individuals += pops[p].n_ind;
+  const dim3 grid(stream_grid(ctx, a.n_tiles, lean ? kStreamWavesPerCu : site_pass_waves_per_cu(ctx, a.n_tiles, n_sets, n_pops, individuals)));
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (n_sets > 0) {
     if (multi) launch_pass(ctx, site_counts_kernel<true, true>, grid, dim3(64), st, a, fa);
