@@ -38,7 +38,6 @@ struct sai_bgzf_stream {
   // the record index has seen a record beyond the region (or the next chromosome): set by the consumer,
   // under `m`; past `file_stop` the reader goes on in small batches until then
   bool consumer_done = false;
-  int64_t indexed = 0;  // batches the record index has been through (under `m`)
   int64_t first_text_skip = 0;  // text of the first member that precedes the region's first record
   bool nothing_to_read = false; // the index says the region holds no record
   // indexer (the consumer's thread)
@@ -73,14 +72,6 @@ int bgzf_reader_run(sai_bgzf_stream* st) {
       b = static_cast<int>(st->produced % 2);
       st->cv.wait(lk, [&] { return st->state[b] == 0 || st->cancel || st->consumer_done; });
       if (st->cancel || st->consumer_done) return SAI_OK;
-      if (past_stop) {
-        // beyond the index's bound nothing is read ahead: usually the batch that reached the bound already holds
-        // a record past the region and the index says "done" -- wait for its verdict on what was handed over
-        // (bounded: a consumer that indexes less often than once per batch only loses the time-out)
-        st->cv.wait_for(lk, std::chrono::milliseconds(200),
-                        [&] { return st->indexed >= st->produced || st->cancel || st->consumer_done; });
-        if (st->cancel || st->consumer_done) return SAI_OK;
-      }
     }
     unsigned char* dst = st->bufs[b];
     size_t want = std::min(st->cap - 8, total - file_off);  // 8 bytes of zero padding behind the data
@@ -517,11 +508,6 @@ int sai_vcf_index_text(sai_bgzf_stream* st, const char* text_host, int64_t n_byt
         st->cv.notify_all();
       }
     }
-    {
-      std::lock_guard<std::mutex> lk(st->m);
-      ++st->indexed;
-    }
-    st->cv.notify_all();
     *n_usable = static_cast<int64_t>(cut - text_host);
     *n_lines = static_cast<int64_t>(st->out.off.size());
     *line_off_host = st->out.off.data();
@@ -580,11 +566,6 @@ int sai_vcf_index_heads(sai_bgzf_stream* st, const char* heads_host, int32_t hea
         st->cv.notify_all();
       }
     }
-    {
-      std::lock_guard<std::mutex> lk(st->m);
-      ++st->indexed;
-    }
-    st->cv.notify_all();
     *n_lines_out = static_cast<int64_t>(st->out.off.size());
     *line_off_host = st->out.off.data();
     *line_len_host = st->out.len.data();
