@@ -77,7 +77,14 @@ __global__ __launch_bounds__(256) void window_bounds_kernel(const int32_t* __res
   }
   if (PAIR) {
     const int64_t at = group_search<G>(pos, a, b, live ? (upper ? we[w] : ws[w]) : 0, upper, lane);
-    if (live && lane % G == 0) (upper ? hi : lo)[w] = static_cast<int32_t>(at);
+    // hi is never below lo (a window whose end lies before its start is empty), as in the form that searches
+    // hi from lo onward: the window's two groups sit side by side in the wave
+    const int base = lane - lane % (2 * G);
+    const int64_t first = __shfl(at, base, 64), last = __shfl(at, base + G, 64);
+    if (live && lane == base) {
+      lo[w] = static_cast<int32_t>(first);
+      hi[w] = static_cast<int32_t>(last > first ? last : first);
+    }
   } else {
     const int64_t first = group_search<G>(pos, a, b, live ? ws[w] : 0, false, lane);
     const int64_t last = group_search<G>(pos, first, live ? b : first, live ? we[w] : 0, true, lane);

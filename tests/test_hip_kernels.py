@@ -696,6 +696,45 @@ def test_window_bounds_equals_searchsorted(eng, n_sites):
     assert np.array_equal(lo.cpu().numpy(), want_lo) and np.array_equal(hi.cpu().numpy(), want_hi)
 
 
+def test_window_bounds_forms_agree_also_on_windows_that_end_before_they_start(eng):
+    """Both forms of window_bounds -- 32 lanes per bound side by side (up to 32 768 windows), 8 lanes per window
+    lo then hi (more; forced here with SAI_BOUNDS_WIDE_MAX=0 in a child process, the knob is read once) --
+    against numpy, with many windows whose end lies before their start inside dense positions: hi is never
+    below lo."""
+    import subprocess
+    import sys
+
+    import torch
+
+    from conftest import ROOT
+
+    rng = np.random.default_rng(12)
+    n_sites = 50_000
+    pos = (np.cumsum(rng.integers(0, 3, n_sites)) + 3).astype(np.int32)  # dense, with ties
+    starts = rng.integers(0, int(pos[-1]) + 5, 3000).astype(np.int64)
+    ends = starts + rng.integers(-40, 60, 3000)
+    want_lo = np.searchsorted(pos, starts, side="left")
+    want_hi = np.maximum(np.searchsorted(pos, ends, side="right"), want_lo)
+    assert (np.searchsorted(pos, ends, side="right") < want_lo).sum() > 300  # the case is there
+    lo, hi = eng.window_bounds(torch.as_tensor(pos).to(eng.device), starts, ends)
+    assert np.array_equal(lo.cpu().numpy(), want_lo) and np.array_equal(hi.cpu().numpy(), want_hi)
+    code = (
+        "import sys, numpy as np, torch; sys.path.insert(0, %r)\n"
+        "from sai_amd.engine import Engine\n"
+        "d = np.load(sys.argv[1]); eng = Engine.get(0)\n"
+        "lo, hi = eng.window_bounds(torch.as_tensor(d['pos']).to(eng.device), d['starts'], d['ends'])\n"
+        "assert np.array_equal(lo.cpu().numpy(), d['lo']) and np.array_equal(hi.cpu().numpy(), d['hi']); print('narrow ok')\n" % str(ROOT)
+    )
+    import tempfile
+
+    with tempfile.TemporaryDirectory() as td:
+        f = td + "/case.npz"
+        np.savez(f, pos=pos, starts=starts, ends=ends, lo=want_lo, hi=want_hi)
+        res = subprocess.run([sys.executable, "-c", code, f], env={**__import__("os").environ, "SAI_BOUNDS_WIDE_MAX": "0"},
+                             capture_output=True, text=True, timeout=600)  # fmt: skip
+    assert res.returncode == 0 and "narrow ok" in res.stdout, res.stderr[-2000:]
+
+
 # ---- np.sum's order in parallel (fourpop.hip: wave_numpy_sum) -------------------------------
 
 
