@@ -48,7 +48,8 @@ def filter_geno_data(data: ChromosomeData, index: Union[np.ndarray, Sequence[boo
     """The rows ``index`` keeps (boolean mask or integer indices) of every field (utils.py:189-212)."""
     index = np.asarray(index)
     gt = np.asarray(data.GT)
-    return ChromosomeData(POS=np.asarray(data.POS)[index], REF=np.asarray(data.REF)[index], ALT=np.asarray(data.ALT)[index],
+    rows = lambda column: None if column is None else np.asarray(column)[index]  # noqa: E731 -- blocks of the native ingest carry no REF / ALT
+    return ChromosomeData(POS=np.asarray(data.POS)[index], REF=rows(data.REF), ALT=rows(data.ALT),
                           GT=np.compress(index, gt, axis=0) if index.dtype == bool else gt[index])  # fmt: skip
 
 

@@ -26,6 +26,11 @@ def test_filter_geno_data_keeps_the_indexed_rows_of_every_field():
     assert got.ALT.tolist() == case["expect"]["ALT"] and list(got.GT.shape) == case["expect"]["GT_shape"]
     by_number = filter_geno_data(block(case), np.flatnonzero(case["index"]))  # "boolean or integer array"
     assert by_number.POS.tolist() == got.POS.tolist() and np.array_equal(by_number.GT, got.GT)
+    from sai_amd.utils import ChromosomeData
+
+    bare = ChromosomeData(POS=np.array(case["POS"]), REF=None, ALT=None, GT=np.array(case["GT"], dtype=np.int8).sum(axis=2))
+    kept = filter_geno_data(bare, np.array(case["index"]))  # a dosage block of the native ingest: no REF / ALT to filter
+    assert kept.REF is None and kept.ALT is None and kept.POS.tolist() == case["expect"]["POS"] and kept.GT.shape == (3, 2)
 
 
 def test_filter_fixed_variants_drops_all_hom_ref_and_all_hom_alt_sites():
