@@ -5,9 +5,11 @@ the array scikit-allel's ``GenotypeArray`` wraps), and the filters the reference
 Nothing on the ``score`` path comes through here: ``WindowGenerator`` asks ``read_data`` for unphased
 dosages without filters (window_generator.py:105-120), which the native tokenizers serve
 (``read_data.read_dosage_data`` / ``read_data_device``).  This module is for plug-in authors who use the
-reference's reader options -- phased haplotype columns, fixed-variant and missing-call filters -- and
-reads through the package's Python statement of the VCF rules (``vcf.read_region``; host side, sized for
-such use)."""
+reference's reader options -- phased haplotype columns, fixed-variant and missing-call filters.  The calls
+come from the native tokenizer all the same (``allele_calls``: the dosage of a call's first k alleles is what
+``sai_vcf_load`` returns at ploidy k, so allele k is the difference of two reads); REF / ALT are the fixed
+columns of the text, read without looking at a sample column.  The package's Python statement of the VCF
+rules (``vcf.read_region``) is the cross-check (``engine="python"``)."""
 
 from __future__ import annotations
 
@@ -18,7 +20,7 @@ import numpy as np
 
 from .genomic_dataclasses import ChromosomeData
 from .samples import parse_ind_file
-from .vcf import _alleles, read_anc_allele, read_region
+from .vcf import _alleles, read_anc_allele, read_region, read_site_columns
 
 
 # -- what the reference asks of allel.GenotypeArray, on the plain [sites][individuals][ploidy] array ------
@@ -108,8 +110,48 @@ def check_anc_allele(data: ChromosomeData, anc_allele: dict, c: str) -> Chromoso
     return data
 
 
+def allele_calls(vcf: str, chr_name: str, samples: Sequence[str], ploidy: int, start=None, end=None, engine: str = "native"):
+    """(POS int32 [n], REF [n], ALT [n], calls int8 [n][len(samples)][ploidy]) of one region, unpolarised.
+
+    ``engine="native"``: ``sai_vcf_load`` read at ploidy 1, 2, ..., ``ploidy`` -- it sums a call's first k alleles
+    (missing = -1, a call shorter than k padded with -1, longer ones cut: ``numbers={"GT": ploidy}``,
+    utils.py:123-138), so allele k = dosage_k - dosage_(k-1), exactly; one multithreaded pass over the file
+    per allele.  ``engine="python"``: the readable statement of the same rules, call by call."""
+    samples = list(samples)
+    if engine == "python":
+        records = read_region(vcf, chr_name, samples, start, end)
+        cache: dict = {}
+        calls = np.empty((len(records), len(samples), ploidy), dtype=np.int8)
+        for i, row in enumerate(records.gt):
+            for j, call in enumerate(row):
+                alleles = cache.get(call)
+                if alleles is None:
+                    alleles = cache[call] = _alleles(call, ploidy)
+                calls[i, j] = alleles
+        return records.pos, records.ref, records.alt, calls
+    import os
+
+    from .native_vcf import load_dosage
+
+    if not os.path.exists(vcf):
+        raise ValueError(f"cannot open VCF {vcf}")
+    pos, before, calls = None, None, None
+    for k in range(1, ploidy + 1):
+        pos_k, dosage, _, _ = load_dosage(vcf, chr_name, samples, [k] * len(samples), start, end, None)
+        if calls is None:
+            pos, calls = pos_k, np.empty((len(pos_k), len(samples), ploidy), dtype=np.int8)
+            before = np.zeros(dosage.shape, dtype=np.int16)
+        now = dosage.astype(np.int16)
+        calls[:, :, k - 1] = now - before
+        before = now
+    pos_text, ref, alt = read_site_columns(vcf, chr_name, start, end)
+    if not np.array_equal(pos_text, pos):
+        raise ValueError(f"{vcf}: the tokenizer and the fixed-column reader disagree about the records of {chr_name}")
+    return pos, ref, alt, calls
+
+
 def read_geno_data(vcf: str, ind_samples: dict, chr_name: str, ploidy: int = 2, start: int = None, end: int = None,
-                   anc_allele_file: Optional[str] = None, filter_missing: bool = True) -> Optional[dict]:  # fmt: skip
+                   anc_allele_file: Optional[str] = None, filter_missing: bool = True, engine: str = "native") -> Optional[dict]:  # fmt: skip
     """{population: ChromosomeData} of one chromosome (region) with per-allele calls (utils.py:78-186):
     first ALT allele only (``alt_number=1``), calls padded with -1 / cut to ``ploidy``
     (``numbers={"GT": ploidy}``); ``filter_missing`` drops the sites where a sample of the population has
@@ -119,26 +161,16 @@ def read_geno_data(vcf: str, ind_samples: dict, chr_name: str, ploidy: int = 2, 
     region = f"{chr_name}" if start is None and end is None else f"{chr_name}:{start}-{end}"
     all_samples = [s for names in ind_samples.values() for s in names]
     try:
-        records = read_region(vcf, chr_name, all_samples, start, end)
-    except FileNotFoundError as e:
-        raise ValueError(f"Failed to read VCF file {vcf} from {region}: {e}") from e
+        pos, ref_list, alt_list, gt = allele_calls(vcf, chr_name, all_samples, ploidy, start, end, engine)
     except Exception as e:  # noqa: BLE001 -- utils.py:139-140
         raise ValueError(f"Failed to read VCF file {vcf} from {region}: {e}") from e
-    if len(records) == 0:
+    if len(pos) == 0:
         return None
-    cache: dict = {}
-    gt = np.empty((len(records), len(all_samples), ploidy), dtype=np.int8)
-    for i, row in enumerate(records.gt):
-        for j, call in enumerate(row):
-            alleles = cache.get(call)
-            if alleles is None:
-                alleles = cache[call] = _alleles(call, ploidy)
-            gt[i, j] = alleles
-    ref, alt = np.array(records.ref, dtype=object).astype(str), np.array(records.alt, dtype=object).astype(str)
+    ref, alt = np.array(ref_list, dtype=object).astype(str), np.array(alt_list, dtype=object).astype(str)
     anc_alleles = read_anc_allele(anc_allele_file, chr_name, start, end) if anc_allele_file else None
     out, column = {}, {s: j for j, s in enumerate(all_samples)}
     for population, names in ind_samples.items():
-        block = ChromosomeData(POS=records.pos.copy(), REF=ref.copy(), ALT=alt.copy(), GT=gt[:, [column[s] for s in names]])
+        block = ChromosomeData(POS=pos.copy(), REF=ref.copy(), ALT=alt.copy(), GT=gt[:, [column[s] for s in names]])
         missing = calls_missing(block.GT).sum(axis=1) != 0
         if filter_missing and missing.any():
             block = filter_geno_data(block, ~missing)
@@ -149,7 +181,7 @@ def read_geno_data(vcf: str, ind_samples: dict, chr_name: str, ploidy: int = 2, 
 
 
 def load_population_data(vcf_file, chr_name, sample_file, anc_allele_file, start, end, is_phased, filter_flag, filter_missing,
-                         ploidy_config, group):  # fmt: skip
+                         ploidy_config, group, engine: str = "native"):  # fmt: skip
     """(data, samples) of one group (utils.py:649-761): every population of the sample file that has a
     ploidy entry is read at ITS ploidy, optionally stripped of its fixed variants, then reshaped."""
     if sample_file is None:
@@ -168,7 +200,8 @@ def load_population_data(vcf_file, chr_name, sample_file, anc_allele_file, start
             continue
         try:
             blocks = read_geno_data(vcf=vcf_file, ind_samples={population: names}, chr_name=chr_name, start=start, end=end,
-                                    anc_allele_file=anc_allele_file, filter_missing=filter_missing, ploidy=group_ploidies[population])  # fmt: skip
+                                    anc_allele_file=anc_allele_file, filter_missing=filter_missing, ploidy=group_ploidies[population],
+                                    engine=engine)  # fmt: skip
         except Exception as e:  # noqa: BLE001 -- utils.py:735-738
             raise ValueError(f"Failed to read VCF data for {sample_file}, population '{population}': {e}")
         if blocks is None:

@@ -3,7 +3,7 @@
 defaults; the combination WindowGenerator asks for (window_generator.py:105-120: unphased, no
 fixed-variant or missing-call filter) is served by the native tokenizers as int8 dosages
 (``read_dosage_data`` on the host, ``read_data_device`` in HBM), every other combination by the
-allele-level reader of ``geno.py``."""
+allele-level reader of ``geno.py`` (calls from the same native tokenizer, allele by allele)."""
 
 from __future__ import annotations
 
@@ -54,7 +54,7 @@ def read_data(
             results[group] = (None, None)
             continue
         results[group] = load_population_data(vcf_file, str(chr_name), ind_file, anc_allele_file, start, end, is_phased, fixed,
-                                              filter_missing, ploidy_config, group)  # fmt: skip
+                                              filter_missing, ploidy_config, group, engine)  # fmt: skip
     return results
 
 

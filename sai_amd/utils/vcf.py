@@ -115,6 +115,27 @@ def read_region(
     return VcfRegion(list(samples), np.array(pos, dtype=np.int32), ref, alt, gts)
 
 
+def read_site_columns(vcf_file: str, chr_name: str, start: Optional[int] = None, end: Optional[int] = None):
+    """(POS int32, REF, first ALT) of the records of ``chr_name`` with start <= POS <= end: the fixed columns only,
+    no sample column is looked at (the allele-level reader takes the calls from the native tokenizer)."""
+    chr_name = str(chr_name)
+    pos, ref, alt = [], [], []
+    with _open_text(vcf_file) as f:
+        for line in f:
+            if line.startswith("#"):
+                continue
+            fields = line.split("\t", 5)
+            if fields[0] != chr_name:
+                continue
+            p = int(fields[1])
+            if (start is not None and p < start) or (end is not None and p > end):
+                continue
+            pos.append(p)
+            ref.append(fields[3])
+            alt.append(fields[4].split(",")[0])
+    return np.array(pos, dtype=np.int32), ref, alt
+
+
 def _alleles(gt: str, ploidy: int) -> list[int]:
     """Allele indices of one call, -1 for '.', padded with -1 / cut to ``ploidy``."""
     parts = gt.replace("|", "/").split("/")

@@ -182,3 +182,49 @@ def test_the_options_compose_and_the_unfiltered_unphased_form_is_the_native_toke
         only = read_data(**{**files, "ploidy_config": PloidyConfig({"ref": {"ref1": 2}, "tgt": {"tgt1": 4}, "src": {"src1": 4, "src2": 4}})},
                          anc_allele_file=None)  # fmt: skip
     assert list(only["tgt"][0]) == ["tgt1"]
+
+
+@pytest.mark.parametrize("gz", [False, True, "bgzf"])
+def test_allele_calls_from_the_native_tokenizer_equal_the_readable_reader(tmp_path, gz):
+    """The allele-level reader takes its calls from the native tokenizer (allele k = dosage of the first k
+    alleles minus the dosage of the first k - 1: one ``sai_vcf_load`` pass per allele) and only REF / ALT from
+    the text.  On deliberately awkward files -- GT not first in FORMAT, missing and half-missing calls, '/' and
+    '|', multi-allelic ALT and allele index 2, calls shorter and longer than the ploidy asked for, plain / gzip
+    / bgzip, regions -- every call, position and allele string equals the package's Python statement of the
+    rules, and so do the blocks of ``read_geno_data`` / ``read_data`` built on it."""
+    from test_ingest_native import write_vcf
+
+    from sai_amd.configs import PloidyConfig
+    from sai_amd.utils import read_data, read_geno_data
+    from sai_amd.utils.geno import allele_calls
+
+    rng = np.random.default_rng(7)
+    path = tmp_path / ("a.vcf.gz" if gz else "a.vcf")
+    names = write_vcf(path, rng, 260, 14, gz=gz)
+    pick = [names[i] for i in (9, 2, 13, 0, 5)]
+    for chrom, region in (("7", (None, None)), ("21", (300, 9000)), ("22", (1, 40))):
+        for ploidy in (1, 2, 3, 4):
+            a = allele_calls(str(path), chrom, pick, ploidy, *region, engine="native")
+            b = allele_calls(str(path), chrom, pick, ploidy, *region, engine="python")
+            assert a[0].tolist() == b[0].tolist() and list(a[1]) == list(b[1]) and list(a[2]) == list(b[2])
+            assert a[3].dtype == np.int8 and np.array_equal(a[3], b[3]), (chrom, region, ploidy)
+    full = allele_calls(str(path), "7", pick, 4)[3]
+    assert full.min() == -1 and full.max() == 2 and len(full) == 260  # missing alleles and a second alternate allele are in the data
+    for missing in (True, False):
+        x = read_geno_data(str(path), {"p": pick[:3], "q": pick[3:]}, "7", ploidy=2, filter_missing=missing)
+        y = read_geno_data(str(path), {"p": pick[:3], "q": pick[3:]}, "7", ploidy=2, filter_missing=missing, engine="python")
+        for pop in ("p", "q"):
+            assert x[pop].POS.tolist() == y[pop].POS.tolist() and np.array_equal(x[pop].GT, y[pop].GT)
+            assert x[pop].REF.tolist() == y[pop].REF.tolist() and x[pop].ALT.tolist() == y[pop].ALT.tolist()
+    ind = tmp_path / "ind.list"
+    ind.write_text("".join(f"A\t{n}\n" for n in pick[:3]) + "".join(f"B\t{n}\n" for n in pick[3:]))
+    pc = PloidyConfig({"ref": {"A": 2}, "tgt": {"B": 4}, "src": {"A": 1}})
+    kw = dict(vcf_file=str(path), chr_name="21", ploidy_config=pc, ref_ind_file=str(ind), tgt_ind_file=str(ind), src_ind_file=str(ind),
+              out_ind_file=None, anc_allele_file=None, filter_missing=False)  # fmt: skip
+    import warnings
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", RuntimeWarning)  # populations of the list without a ploidy entry are skipped, as in the reference
+        n_, p_ = read_data(**kw), read_data(**kw, engine="python")
+    for group, pop, width in (("ref", "A", 6), ("tgt", "B", 8), ("src", "A", 3)):
+        assert n_[group][0][pop].GT.shape[1] == width and np.array_equal(n_[group][0][pop].GT, p_[group][0][pop].GT)
