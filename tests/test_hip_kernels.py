@@ -462,6 +462,97 @@ def test_randomized_windows_against_oracle(eng):
                 assert res.q_list(si, wi).tolist() == np.asarray(eq["cdd_pos"]).astype(np.int64).tolist()
 
 
+def test_randomized_stage_shapes_against_oracle(eng):
+    """Fuzz of the windows stage's forms and capacities: 1-24 parameter sets (wave form below four, one
+    workgroup per window from four on, a second call beyond 20), windows of one site up to thousands (rows
+    and stored frequencies inside and beyond what a workgroup keeps in LDS), few individuals (hundreds of
+    equal frequencies around the quantile: rank counting, the digit histogram's gather pass and the
+    level-by-level select all occur), with and without inverted planes; every record and both lists
+    against the per-window oracle."""
+    from oracle import sai_oracle as O
+    from sai_amd import _ffi
+
+    rng = np.random.default_rng(4242)
+    ops = ["=", "<", ">", "<=", ">="]
+    seen_heavy = seen_shared = 0
+    for trial in range(int(os.environ.get("SAI_FUZZ_SHAPES", "24"))):  # 6000 were run once on the GPU box
+        n_sites = int(rng.choice([int(rng.integers(1, 300)), int(rng.integers(300, 3000)), int(rng.integers(3000, 14000))]))
+        n_src = int(rng.integers(1, 3))
+        sizes = [int(rng.integers(1, 30)), int(rng.choice([1, 3, 17, 60, 200]))] + [int(rng.integers(1, 3)) for _ in range(n_src)]
+        pl = [int(rng.integers(1, 5)) for _ in range(2 + n_src)]
+        p = rng.random(n_sites) ** float(rng.choice([1, 2, 4]))
+        mats = []
+        for k, (n, ploidy) in enumerate(zip(sizes, pl)):
+            scale = float(rng.choice([0.02, 0.3, 1.0])) if k == 0 else 1.0  # a rare reference makes "ref < w" common
+            g = rng.binomial(ploidy, np.broadcast_to((p * scale)[:, None], (n_sites, n))).astype(np.int64)
+            if k >= 2 and rng.random() < 0.7:
+                g[rng.random(n_sites) < 0.5] = ploidy * int(rng.integers(0, 2))
+            g[rng.random(g.shape) < float(rng.choice([0.0, 0.02, 0.3]))] = -ploidy
+            mats.append(g)
+        pos = np.cumsum(rng.integers(1, int(rng.choice([2, 9, 60])) + 1, n_sites)).astype(np.int64)
+        n_win = int(rng.integers(1, 25))
+        a = rng.integers(0, n_sites, n_win)
+        width = np.minimum(rng.choice([1, 40, 300, 2200, 9000], n_win) * (0.2 + rng.random(n_win)), n_sites).astype(np.int64)
+        b = np.minimum(a + width, n_sites - 1)
+        ws, we = pos[a] - rng.integers(0, 2, n_win), pos[b] + rng.integers(0, 2, n_win)
+        n_sets = int(rng.choice([1, 2, 3, 4, 5, 9, 18, 20, 24]))
+        anc_mode = int(rng.integers(0, 3))  # all polarised, none, mixed
+        specs = [dict(w=float(rng.choice([0.05, 0.3, 1.0, 1.0])), x=float(rng.choice([0.0, 0.3, 0.9])),
+                      quantile=float(rng.choice([0.0, 0.5, 0.95, 1.0, rng.random()])),
+                      y_list=[(str(rng.choice(ops)), float(rng.choice([0.0, 0.5, 1.0]))) for _ in range(n_src)],
+                      anc=(True, False, bool(rng.random() < 0.5))[anc_mode]) for _ in range(n_sets)]  # fmt: skip
+        sets = [_ffi.make_params(s["w"], s["x"], s["quantile"], s["y_list"], s["anc"]) for s in specs]
+        if n_sets <= _ffi.SAI_MAX_SETS:
+            res, lo, hi = _window_pass(eng, mats, pl, sets, pos, ws, we)
+            get = lambda si: (res, si)  # noqa: E731
+        else:  # more sets than one call takes: the callers split them (ResidentScorer does the same)
+            m = _ffi.SAI_MAX_SETS
+            parts = [_window_pass(eng, mats, pl, sets[i : i + m], pos, ws, we)[0] for i in range(0, n_sets, m)]
+            get = lambda si: (parts[si // m], si % m)  # noqa: E731
+        seen_shared += n_sets >= 4
+        if trial % 2 == 0:
+            # the same job through a ResidentScorer (fused pass up to 20 sets, set chunks beyond; plain and
+            # pipelined steps): the very records and lists of the two-kernel route above
+            import torch
+
+            from sai_amd.resident import ResidentBlock, ResidentScorer
+
+            block = ResidentBlock([eng.tile(g) for g in mats], pl, torch.as_tensor(pos.astype(np.int32)).to(eng.device))
+            scorer = ResidentScorer(eng, block, list(zip(ws.tolist(), we.tolist())), sets, cap_u=1 << 10, cap_q=1 << 10,
+                                    overlap=trial % 4 == 0)  # fmt: skip
+            for _ in range(1 + trial % 3):
+                scorer.step()
+            got = scorer.results(grow=True)
+            for si in range(n_sets):
+                r, ri = get(si)
+                for f in ("n_sites", "n_cond", "u_count", "n_cdd_q"):
+                    assert got.records[si][f].tolist() == r.records[ri][f].tolist(), (trial, si, f)
+                assert got.records[si]["q"].tobytes() == r.records[ri]["q"].tobytes(), (trial, si)
+                for wi in range(n_win):
+                    assert got.u_list(si, wi).tolist() == r.u_list(ri, wi).tolist(), (trial, si, wi)
+                    assert got.q_list(si, wi).tolist() == r.q_list(ri, wi).tolist(), (trial, si, wi)
+            scorer.close()
+        for si, s in enumerate(specs):
+            r, ri = get(si)
+            for wi in range(n_win):
+                msk = (pos >= ws[wi]) & (pos <= we[wi])
+                rec = r.records[ri, wi]
+                assert rec["n_sites"] == int(msk.sum()), (trial, si, wi)
+                if not msk.any():
+                    assert rec["u_count"] == 0 and np.isnan(rec["q"])
+                    continue
+                kw = dict(ref_gts=mats[0][msk], tgt_gts=mats[1][msk], src_gts_list=[g[msk] for g in mats[2:]], ref_ploidy=pl[0],
+                          tgt_ploidy=pl[1], src_ploidy_list=pl[2:], pos=pos[msk], w=s["w"], y_list=s["y_list"],
+                          anc_allele_available=s["anc"])  # fmt: skip
+                eu, eq = O.u_stat(x=s["x"], **kw), O.q_stat(quantile=s["quantile"], **kw)
+                seen_heavy += rec["n_cond"] > 256
+                assert rec["u_count"] == eu["value"], (trial, si, wi)
+                assert r.u_list(ri, wi).tolist() == eu["cdd_pos"].tolist(), (trial, si, wi)
+                assert same_f64(rec["q"], eq["value"]), (trial, si, wi, rec["q"], eq["value"])
+                assert r.q_list(ri, wi).tolist() == np.asarray(eq["cdd_pos"]).astype(np.int64).tolist(), (trial, si, wi)
+    assert seen_heavy > 0 and seen_shared > 0
+
+
 @pytest.mark.parametrize("n_sets,polarised", [(20, "none"), (20, "all"), (27, "first chunk only"), (27, "second chunk only"), (45, "mixed")])
 def test_rows_of_many_sets_and_both_polarity_modes(eng, n_sets, polarised):
     """A full row (20 sets: 1 + 20 condition words, + 20 inverted words when a set lacks ancestral alleles)
