@@ -119,8 +119,16 @@ inline unsigned stream_grid(const sai_ctx* ctx, int64_t n_tiles, int waves_per_c
 //  * a short pass (C2: 15 625 tiles, under four per wave at 16) needs its waves for the ramp and the
 //    tail: 16 (0.088 ms per step against 0.109 at 8).
 constexpr int kLeanSets = 4;  // from this many parameter sets on the int8 pass runs its 64-register form (site_pass.hip)
+inline int lean_sets() {
+  static const int n = [] {  // SAI_LEAN_SETS: tuning knob for sweeps (1 = always the 64-register form, 99 = never)
+    const char* e = std::getenv("SAI_LEAN_SETS");
+    const int v = e ? std::atoi(e) : 0;
+    return v > 0 ? v : kLeanSets;
+  }();
+  return n;
+}
 inline int site_pass_waves_per_cu(const sai_ctx* ctx, int64_t n_tiles, int32_t n_sets, int32_t n_pops, int64_t individuals) {
-  if (n_sets >= kLeanSets) return 12;
+  if (n_sets >= lean_sets()) return 12;
   const bool wide = individuals >= 2000 && n_pops <= 3;
   return wide && n_tiles >= static_cast<int64_t>(ctx->n_cu) * 8 * 32 ? 8 : kStreamWavesPerCu;
 }

@@ -66,11 +66,13 @@ static_assert(sizeof(CountsArgs) + sizeof(FusedArgs) <= 4096, "kernel arguments 
 // The second launch bound keeps the usual form at 5 waves per SIMD (<= 96 VGPRs): four resident waves of
 // more than that leave the windows stage's waves no room next to the pass, and the pipelined step loses
 // what the overlap gives (measured at 99 VGPRs: C5 3.63 -> 3.79 ms per step).
-// LEAN: the same kernel held to 64 registers (a few values of the tile's tail spill to scratch).  Alone it
-// is the slower one -- C3: 3.04-3.10 against 2.93 ms -- but a pass with many parameter sets runs next to a
-// windows stage that is worth registers: four LEAN waves per SIMD leave half of the register file to the
-// stage's waves, and C5's pipelined step takes 3.15-3.19 ms with it at 16 waves per CU against 3.20-3.26
-// with three 80-register waves (12 per CU) and 3.42-3.44 with four (profiles/r04_waves_per_cu.txt).
+// LEAN: the same kernel held to 64 registers.  A pass with many parameter sets runs next to a windows stage
+// that is worth registers: four LEAN waves per SIMD leave half of the register file to the stage's waves,
+// and C5's pipelined step takes 3.15-3.19 ms with it at 16 waves per CU against 3.20-3.26 with three
+// 80-register waves (12 per CU) and 3.42-3.44 with four (profiles/r04_waves_per_cu.txt).  (Its first build
+// spilled five lane-derived loop invariants and was 4-5 % slower than the 80-register form when alone -- a
+// reload is a memory round trip behind the streaming loads; with the lane index re-taken per tile nothing
+// spills and the two forms are level alone: profiles/r04_lean_no_spill.txt.)
 template <bool MULTI, bool FUSED, bool LEAN = false>
 __global__ __launch_bounds__(64, MULTI ? 4 : (LEAN ? 8 : 5)) void site_counts_kernel(CountsArgs a, FusedArgs fa) {
   // FUSED: the butterfly leaves lane l with site (l%4)*16 + l/4 of the tile; each lane parks those
@@ -78,9 +80,13 @@ __global__ __launch_bounds__(64, MULTI ? 4 : (LEAN ? 8 : 5)) void site_counts_ke
   // tile are done lane l takes site l back and evaluates the parameter sets for it -- lanes in site
   // order, so the ballots per set are the tile's flag planes and the candidates' tgt_freq leave packed
   __shared__ uint2 stash[FUSED ? kMaxPops : 1][FUSED ? 64 : 1];
-  const int lane = threadIdx.x;
-  const int r = lane >> 2;
   for (int64_t tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
+    // LEAN: the lane index is taken anew per tile, so that nothing derived from it (lane masks, shuffle
+    // addresses, per-lane base offsets) lives across tiles -- hoisted, those values were what spilled, and
+    // each reload is a memory round trip behind the chip's streaming loads
+    int lane = threadIdx.x;
+    if (LEAN) asm volatile("" : "+v"(lane));
+    const int r = lane >> 2;
     for (int p = 0; p < a.n_pops; ++p) {
       const int n_ind = a.pop[p].n_ind;
       const u32x4* base =
@@ -189,7 +195,7 @@ static int launch_site_counts(sai_ctx* ctx, int64_t n_sites, int32_t n_pops, con
   fa.planes = planes;
   fa.plane_stride = plane_stride;
   for (int s = 0; s < n_sets; ++s) fa.sets[s] = sets_host[s];
-  const bool lean = !multi && n_sets >= kLeanSets;
+  const bool lean = !multi && n_sets >= lean_sets();
   int64_t individuals = 0;
   for (int p = 0; p < n_pops; ++p) individuals += pops[p].n_ind;
   const dim3 grid(stream_grid(ctx, a.n_tiles, lean ? kStreamWavesPerCu : site_pass_waves_per_cu(ctx, a.n_tiles, n_sets, n_pops, individuals)));
