@@ -216,6 +216,42 @@ def test_quantile_beyond_lds_capacity(eng):
             assert res.u_list(0, wi).tolist() == eu["cdd_pos"].tolist()
 
 
+def test_windows_of_a_million_sites(eng):
+    """Windows far beyond anything a wave keeps: 1.2 million sites in one window, a third of them qualifying,
+    47 distinct frequencies (tens of thousands of ties per value, so the digit histogram's bins are huge and
+    the level-by-level select runs to the bottom), next to a window of three sites and an empty one; wave
+    form (one set) and workgroup form (five sets)."""
+    from oracle import sai_oracle as O
+    from sai_amd import _ffi
+
+    rng = np.random.default_rng(12)
+    n_sites = 1_200_000
+    ref = (rng.random((n_sites, 3)) < 0.15).astype(np.int64)
+    tgt = rng.integers(0, 3, size=(n_sites, 23)).astype(np.int64)
+    tgt[rng.random(tgt.shape) < 0.02] = -2
+    src = np.full((n_sites, 1), 2, dtype=np.int64)
+    src[rng.random(n_sites) < 0.3] = 0
+    pos = np.cumsum(rng.integers(1, 4, n_sites)).astype(np.int64)
+    starts = np.array([1, int(pos[500_000]), int(pos[7]), int(pos[-1]) + 5])
+    ends = np.array([int(pos[-1]), int(pos[900_000]), int(pos[9]), int(pos[-1]) + 50])
+    specs = [dict(w=0.5, x=0.5, quantile=q, y_list=[("=", 1.0)], anc=True) for q in (0.95, 0.0, 0.5, 1.0, 0.123456)]
+    for group in (specs[:1], specs):
+        sets = [_ffi.make_params(s["w"], s["x"], s["quantile"], s["y_list"], s["anc"]) for s in group]
+        res, lo, hi = _window_pass(eng, [ref, tgt, src], [1, 2, 2], sets, pos, starts, ends)
+        assert (hi - lo).tolist() == [n_sites, 400_001, 3, 0]
+        for si, s in enumerate(group):
+            for wi in range(3):
+                m = (pos >= starts[wi]) & (pos <= ends[wi])
+                kw = dict(ref_gts=ref[m], tgt_gts=tgt[m], src_gts_list=[src[m]], ref_ploidy=1, tgt_ploidy=2, src_ploidy_list=[2],
+                          pos=pos[m], w=s["w"], y_list=s["y_list"], anc_allele_available=True)  # fmt: skip
+                eq, eu = O.q_stat(quantile=s["quantile"], **kw), O.u_stat(x=s["x"], **kw)
+                rec = res.records[si, wi]
+                assert rec["u_count"] == eu["value"] and same_f64(rec["q"], eq["value"]), (si, wi, rec["q"], eq["value"])
+                assert np.array_equal(res.u_list(si, wi), eu["cdd_pos"]) and np.array_equal(res.q_list(si, wi), eq["cdd_pos"])
+            assert res.records[si, 3]["n_sites"] == 0 and np.isnan(res.records[si, 3]["q"])
+        assert res.records[0, 0]["n_cond"] > 300_000
+
+
 def test_shared_form_beyond_its_lds_capacities(eng):
     """window_stats / window_lists with >= 4 sets (one workgroup per window, the window's rows and stored
     frequencies in LDS): windows that fit, windows whose stored frequencies exceed the 1 024 kept in LDS
