@@ -815,22 +815,36 @@ class Engine:
             )
         )  # fmt: skip
 
-    def alloc_window_bufs(self, n_sets, n_windows, cap_u, cap_q):
+    def alloc_window_bufs(self, n_sets, n_windows, cap_u, cap_q, joined: bool = False):
         """(records, offsets, cdd_u, cdd_q, totals, head): records, offsets and totals are views of
-        the one contiguous byte buffer ``head``, so a single copy brings them to the host."""
+        the one contiguous byte buffer ``head``, so a single copy brings them to the host.  ``joined``: the
+        two candidate lists lie right behind ``head`` in the same allocation (a seventh entry is the whole of
+        it): ONE copy then brings records and lists -- every copy of the runtime's starts ~12 us after the
+        kernel before it has ended (profiles/r04_score_windows_call.txt)."""
         torch = _torch()
         n_rec = n_sets * n_windows
         rec_bytes, off_bytes = n_rec * RECORD_DTYPE.itemsize, n_rec * 16  # 24 B records keep 8-byte alignment
         tot_bytes = 8 * int(self.lib.sai_window_total_words(n_sets, n_windows))  # 2 totals + the scan's scratch
-        head = self._empty((rec_bytes + off_bytes + tot_bytes,), torch.uint8)
-        return (
+        head_bytes = rec_bytes + off_bytes + tot_bytes
+        cap_u, cap_q = max(int(cap_u), 1), max(int(cap_q), 1)
+        if joined:
+            whole = self._empty((head_bytes + 4 * (cap_u + cap_q),), torch.uint8)
+            head = whole[:head_bytes]
+            cdd_u = whole[head_bytes : head_bytes + 4 * cap_u].view(torch.int32)
+            cdd_q = whole[head_bytes + 4 * cap_u :].view(torch.int32)
+        else:
+            whole = None
+            head = self._empty((head_bytes,), torch.uint8)
+            cdd_u, cdd_q = self._empty((cap_u,), torch.int32), self._empty((cap_q,), torch.int32)
+        bufs = (
             head[:rec_bytes],
             head[rec_bytes : rec_bytes + off_bytes].view(torch.int64),
-            self._empty((max(int(cap_u), 1),), torch.int32),
-            self._empty((max(int(cap_q), 1),), torch.int32),
+            cdd_u,
+            cdd_q,
             head[rec_bytes + off_bytes :].view(torch.int64),
             head,
         )
+        return bufs + (whole,) if joined else bufs
 
     def window_stats(self, tgt_freq, planes, sets, lo, hi, pos=None, cap_hint=1 << 16) -> WindowResults:
         """Records and candidate lists of every (set, window), copied to the host."""

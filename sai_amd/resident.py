@@ -30,6 +30,7 @@ from .utils.windows import split_genome
 # belonged to the stream-side-wait arrangement it had at the time and does not reproduce.)
 _WAIT_MODE = __import__("os").environ.get("SAI_AMD_WAIT", "sync")
 WAIT_DEADLINE_S = float(__import__("os").environ.get("SAI_AMD_WAIT_DEADLINE_S", "300"))
+_JOIN_COPY = __import__("os").environ.get("SAI_AMD_JOIN_COPY", "1") != "0"  # 0: records and list heads as three copies (A/B runs)
 
 
 @dataclass
@@ -86,18 +87,27 @@ class _SetChunk:
         import torch
 
         self.s0, self.s1 = s0, s1
-        self.bufs = eng.alloc_window_bufs(s1 - s0, n_windows, cap_u, cap_q)
+        # the whole of both lists is fetched with the records (the product path: lists no longer than they are
+        # fetched): records and lists lie in one allocation and travel as ONE copy
+        self.joined = _JOIN_COPY and 0 < max(int(cap_u), 1) <= int(fetch_lists) and 0 < max(int(cap_q), 1) <= int(fetch_lists)
+        self.bufs = eng.alloc_window_bufs(s1 - s0, n_windows, cap_u, cap_q, joined=self.joined)
+        self.dev_whole = self.bufs[6] if self.joined else None
+        head_bytes = self.bufs[5].numel()
         # pinned mirror of the records | offsets | totals buffer: one copy per step
-        self._eng, self._pinned = eng, eng.pinned_acquire(self.bufs[5].numel())
+        self._eng, self._pinned = eng, eng.pinned_acquire(self.dev_whole.numel() if self.joined else head_bytes)
         # ... and, when asked for, of the first `fetch_lists` entries of both candidate lists: their sizes
         # are known only from the totals, so the lists would otherwise cost a second round trip
         self.n_fetch = (min(int(fetch_lists), self.bufs[2].numel()), min(int(fetch_lists), self.bufs[3].numel()))
-        self._pinned_lists = eng.pinned_acquire(4 * sum(self.n_fetch)) if sum(self.n_fetch) else None
-        self.host_lists = None
-        if self._pinned_lists is not None:
+        self._pinned_lists = eng.pinned_acquire(4 * sum(self.n_fetch)) if sum(self.n_fetch) and not self.joined else None
+        self.host_lists = self.host_whole = None
+        if self.joined:
+            self.host_whole = self._pinned[: self.dev_whole.numel()]
+            flat = self.host_whole[head_bytes:].view(torch.int32)
+            self.host_lists = (flat[: self.n_fetch[0]], flat[self.n_fetch[0] :])
+        elif self._pinned_lists is not None:
             flat = self._pinned_lists[: 4 * sum(self.n_fetch)].view(torch.int32)
             self.host_lists = (flat[: self.n_fetch[0]], flat[self.n_fetch[0] :])
-        self.host_head = self._pinned[: self.bufs[5].numel()]
+        self.host_head = self._pinned[:head_bytes]
         rec_bytes = (s1 - s0) * n_windows * RECORD_DTYPE.itemsize
         self.rec_bytes = rec_bytes
         self.host_records = self.host_head[:rec_bytes]
@@ -109,7 +119,9 @@ class _SetChunk:
         """Hand the pinned mirror back to the engine's pool (the chunk must not be used afterwards)."""
         if self._pinned is not None:
             buf, self._pinned = self._pinned, None
-            self.host_head = self.host_records = self.host_offsets = self.host_totals = None
+            self.host_head = self.host_records = self.host_offsets = self.host_totals = self.host_whole = None
+            if self.joined:
+                self.host_lists = None
             self._eng.pinned_release(buf, streams)
         if self._pinned_lists is not None:
             buf, self._pinned_lists, self.host_lists = self._pinned_lists, None, None
@@ -304,6 +316,9 @@ class ResidentScorer:
             for ch in self.chunks:
                 sp.add_window_stats(tgt_freq, planes[:, PLANES * ch.s0 : PLANES * ch.s1], self.sets[ch.s0 : ch.s1], self.lo,
                                     self.hi, self.list_pos, ch.bufs)  # fmt: skip
+                if ch.joined:
+                    sp.add_copy_to_host(ch.host_whole, ch.dev_whole)
+                    continue
                 sp.add_copy_to_host(ch.host_head, ch.bufs[5])
                 if ch.host_lists is not None:
                     for host, dev, n in zip(ch.host_lists, ch.bufs[2:4], ch.n_fetch):
