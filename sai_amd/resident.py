@@ -1,7 +1,8 @@
 """A chromosome block resident in HBM and its repeated scoring (the path ``score``, bench.py and the
 multi-GPU driver all run): buffers are allocated once, one ``step()`` enqueues the whole hot path --
 site_counts (+ fused per-site decision) -> window_bounds -> window_stats -> async copy of the records
-to pinned host memory -- on the current HIP stream without any host synchronisation.
+to pinned host memory -- without any host synchronisation: the genotype stream on the current HIP stream,
+what follows it on the scorer's second stream, behind a stream-side wait (``results()`` waits for both).
 
 A block may hold several chromosome *pieces* back to back (a rank's share of a whole-genome window
 list, sai_amd.sharding): positions then ascend only inside a piece, every window names the piece
@@ -204,7 +205,12 @@ class ResidentScorer:
         # the fused pass writes tgt_freq only at candidate sites (all the windows stage reads)
         self._tgt_freq = [torch.full((n,), float("nan"), dtype=torch.float64, device=dev) for _ in range(n_buf)]
         self._flags = [eng.alloc_planes(n, n_s) for _ in range(n_buf)]  # flag planes [tiles][3 * sets]
-        self.side = torch.cuda.Stream(device=dev, priority=-1) if self.overlap else None  # small kernels first
+        # the windows stage always runs on a second stream.  Pipelined form: under the next site pass.  Plain
+        # form: a kernel queued BEHIND a running site pass on the pass's own stream slows the pass down (C3, one
+        # box: 2.92 ms with nothing or only a copy behind it, 3.09 with window_bounds, 3.10 with the whole stage;
+        # profiles/r04_lone_pass.txt), so the stage waits for the pass on its own stream instead: a lone
+        # step + results takes 3.02 instead of 3.19 ms
+        self.side = torch.cuda.Stream(device=dev, priority=-1)  # small kernels first
         self._plain_done = [torch.cuda.Event() for _ in range(n_buf)]
         self._site_done = list(self._plain_done)  # per buffer set: what the host waits for before the windows stage
         # the hand-over (and, in timed steps, both ends) of a fused pass ride in its own dispatch packet
@@ -367,7 +373,7 @@ class ResidentScorer:
 
         import torch
 
-        return torch.cuda.stream(self.side) if self.overlap else contextlib.nullcontext()
+        return torch.cuda.stream(self.side)
 
     def _wait(self, event, what: str) -> None:
         """Wait for an event on the host (see _WAIT_MODE).  The polling form spins for the first
@@ -423,6 +429,8 @@ class ResidentScorer:
         eng = self.eng
         b = self._k % len(self._flags)
         main = torch.cuda.current_stream(eng.device)
+        if not self.overlap and self._win_used[b]:
+            main.wait_event(self._win_done[b])  # the stage of the step before reads the one buffer set this pass writes
         if self.overlap and self._win_used[b]:
             self._wait(self._win_done[b], "windows stage")  # the stage that last read buffer set b (2 steps ago)
         # Pipelined form, fused pass: the events ride in the pass's own dispatch packet (saihip.h,
@@ -451,14 +459,23 @@ class ResidentScorer:
             if time_counts:
                 e1.record()
                 self.count_events.append((e0, e1))
-            if self._flag_plans[b] is not None:
+            if self._flag_plans[b] is not None and self.overlap:
                 self._flag_plans[b].run()
         index = self._k
         self._k += 1
         if not self.overlap:
-            self._stage_plans[b].run()
-            if self.after_stage is not None:
-                self.after_stage(index)
+            # plain form: whatever follows the genotype stream is enqueued on the second stream, behind a
+            # stream-side wait for the pass (nothing but markers stands behind the pass on its own stream)
+            self._plain_done[b].record(main)
+            self.side.wait_event(self._plain_done[b])
+            with torch.cuda.stream(self.side):
+                if self._flag_plans[b] is not None:
+                    self._flag_plans[b].run()
+                self._stage_plans[b].run()
+                if self.after_stage is not None:
+                    self.after_stage(index)
+                self._win_done[b].record(self.side)
+                self._win_used[b] = True
             return
         if not carried:
             self._site_done[b] = self._plain_done[b]

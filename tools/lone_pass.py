@@ -1,0 +1,54 @@
+"""What a kernel queued behind a running site pass costs the pass (C3 block, the plain scorer's own plans): nothing,
+a tiny kernel, window_bounds, the copy, the whole stage on the pass's stream, the stage on a second stream.  GPU box only."""
+import sys, time
+from pathlib import Path
+ROOT = Path(__file__).resolve().parents[1]
+sys.path.insert(0, str(ROOT))
+import torch
+import bench
+from sai_amd.engine import Engine
+from sai_amd.resident import ResidentScorer
+from sai_amd.sharding import build_synth_shard
+
+wl = bench.make_workload("c3", 0, 0, "strong", 1)
+eng = Engine.get(0)
+block, lay, _ = build_synth_shard(eng, wl, 0, 1)
+windows = [(s, e) for _, s, e in lay.windows]
+sets = wl.params()
+plain = ResidentScorer(eng, block, windows, sets, overlap=False, cap_u=1 << 16, cap_q=1 << 16, fetch_lists=1 << 16)
+plain.step(); plain.results()
+cp, sp = plain._count_plans[0], plain._stage_plans[0]
+ch = plain.chunks[0]
+bounds = eng.plan(); bounds.add_window_bounds(block.pos, plain.win_start, plain.win_end, None, None, plain.lo, plain.hi)
+copy = eng.plan(); copy.add_copy_to_host(ch.host_whole if ch.joined else ch.host_head, ch.dev_whole if ch.joined else ch.bufs[5])
+side = torch.cuda.Stream()
+small = torch.zeros(1024, device=eng.device)
+
+def run(label, after):
+    ds, ws = [], []
+    for _ in range(8):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        e0.record(); cp.run(); e1.record(); after(e1); torch.cuda.synchronize()
+        ws.append(1e3 * (time.perf_counter() - t0)); ds.append(e0.elapsed_time(e1))
+    print(f"{label:60s} pass {sum(ds[2:])/6:.4f} ms (min {min(ds[2:]):.4f}), wall {sum(ws[2:])/6:.3f} ms")
+
+def on_side(e1):
+    e1.synchronize()
+    with torch.cuda.stream(side):
+        sp.run()
+    side.synchronize()
+
+def on_side_stream_wait(e1):
+    side.wait_event(e1)
+    with torch.cuda.stream(side):
+        sp.run()
+
+for rnd in range(2):
+    run("nothing behind the pass", lambda e: None)
+    run("a tiny torch kernel behind it", lambda e: small.add_(1.0))
+    run("window_bounds behind it", lambda e: bounds.run())
+    run("the copy of the records behind it", lambda e: copy.run())
+    run("the whole stage behind it (same stream)", lambda e: sp.run())
+    run("the stage on a second stream after a host wait", on_side)
+    run("the stage on a second stream behind a stream-side wait", on_side_stream_wait)
