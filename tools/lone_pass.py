@@ -44,8 +44,16 @@ def on_side_stream_wait(e1):
     with torch.cuda.stream(side):
         sp.run()
 
+import torch as _t
+other_out = (_t.full((block.n_sites,), float("nan"), dtype=_t.float64, device=eng.device), eng.alloc_planes(block.n_sites, len(sets)))
+other = eng.plan(); other.add_site_pass(block.pops, block.ploidies, sets, other_out, counts=None, freq_mode="candidates")
+stats_only = eng.plan()
+stats_only.add_window_stats(plain._tgt_freq[0], plain._flags[0][:, : 3 * len(sets)], sets, plain.lo, plain.hi, plain.list_pos, ch.bufs)
+
 for rnd in range(2):
     run("nothing behind the pass", lambda e: None)
+    run("another site pass behind it (other output buffers)", lambda e: other.run())
+    run("window_stats + scan + lists behind it (no bounds)", lambda e: stats_only.run())
     run("a tiny torch kernel behind it", lambda e: small.add_(1.0))
     run("window_bounds behind it", lambda e: bounds.run())
     run("the copy of the records behind it", lambda e: copy.run())
