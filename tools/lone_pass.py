@@ -50,7 +50,21 @@ other = eng.plan(); other.add_site_pass(block.pops, block.ploidies, sets, other_
 stats_only = eng.plan()
 stats_only.add_window_stats(plain._tgt_freq[0], plain._flags[0][:, : 3 * len(sets)], sets, plain.lo, plain.hi, plain.list_pos, ch.bufs)
 
+big = _t.zeros(32 << 20, device=eng.device)
+counts = _t.zeros((len(block.pops), block.n_sites, 2), dtype=_t.int32, device=eng.device)
+flags_out = (_t.full((block.n_sites,), float("nan"), dtype=_t.float64, device=eng.device), eng.alloc_planes(block.n_sites, len(sets)))
+flags = eng.plan(); flags.add_site_flags(counts, block.ploidies, sets, flags_out)
+probe_buf = _t.zeros(1 << 20, dtype=_t.int32, device=eng.device)
+probe_out = _t.zeros((1,), dtype=_t.int32, device=eng.device)
+from sai_amd import _ffi as _f
+
 for rnd in range(2):
+    run("a tiny torch kernel, then window_bounds behind it", lambda e: (small.add_(1.0), bounds.run()))
+    run("a tiny torch kernel, then the whole stage behind it", lambda e: (small.add_(1.0), sp.run()))
+    run("an event record, then window_bounds behind it", lambda e: (_t.cuda.Event().record(), bounds.run()))
+    run("a torch elementwise kernel over 128 MB behind it", lambda e: big.add_(1.0))
+    run("site_flags (one wave per tile, 4 per workgroup) behind it", lambda e: flags.run())
+    run("the stream-read probe over 4 MB behind it", lambda e: _f.check(eng.lib.sai_probe_stream_read(eng.ctx, eng._ptr(probe_buf), 4 << 20, eng._ptr(probe_out), eng._stream())))
     run("nothing behind the pass", lambda e: None)
     run("another site pass behind it (other output buffers)", lambda e: other.run())
     run("window_stats + scan + lists behind it (no bounds)", lambda e: stats_only.run())
