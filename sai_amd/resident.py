@@ -359,10 +359,12 @@ class ResidentScorer:
 
     def flag_bytes(self):
         """The most recent step's decisions as one byte per set and site (Engine.flag_bytes)."""
+        self._sync()  # the per-site arrays may have been written on the second stream (site_flags of a pass that is not the fused one)
         return self.eng.flag_bytes(self.flags, self.block.n_sites, self.sets, self.tgt_freq)
 
     def site_tgt_freq(self):
         """The most recent step's target frequencies per site (Engine.site_tgt_freq): NaN where none was stored."""
+        self._sync()
         return self.eng.site_tgt_freq(self.flags, self.tgt_freq, self.block.n_sites)
 
     def window_stream(self):
