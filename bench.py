@@ -3,6 +3,7 @@
 
     python bench.py                      # N = 1: BASELINE.json configs[2] (C3), the metric's configuration
     python bench.py --workload c2|c4|c5  # the other configs (C4 on one GPU holds 220 GB)
+    python bench.py --workload c2x22     # 22 chromosomes of C2's size as ONE block of 22 pieces
     python bench.py --gpus N             # N > 1: configs[3] (C4) over N GPUs; starts its own ranks (a child
                                          # torch.distributed.run on 127.0.0.1) and relays rank 0's line
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
@@ -13,6 +14,7 @@ in place in HBM by the counter-based generator, so a shard holds exactly the byt
 holds at those sites):
 
   c2  1e6 sites, 200 ref / 200 tgt / 2 src diploids, 50 kb windows every 10 kb, U
+  c2x22  22 chromosomes of c2's size, resident as one block of 22 pieces: one pass, one windows stage per step
   c3  1e7 sites, 1,000 / 1,000 / 2, 50 kb every 25 kb, U + Q95            (default for --gpus 1)
   c4  22 chromosomes x 5e6 sites, same populations and windows as c3       (default for --gpus N>1)
   c5  1e7 sites, two source populations of 1 diploid, Q95 sweep over 18 (op, y1, y2) sets
@@ -70,6 +72,13 @@ def make_workload(name: str, sites=None, chroms=None, scaling: str = "strong", w
         wl = SynthWorkload("c2", SEED0 + 2, [1], int(1e6), 200, 200, [2], 50000, 10000, [dict(UQ)],
                            description="synthetic chr: 1e6 sites, 200 ref/200 tgt/2 src diploids, 50kb/10kb windows, U stat "
                            "(BASELINE.json configs[1])")  # fmt: skip
+    elif name == "c2x22":
+        # small chromosomes the way a real run meets them: 22 of C2's size resident as ONE block of 22 pieces
+        # (sharding.build_synth_shard), one site pass and one windows stage per step -- the ramp and the tail
+        # of a launch are paid once per 8.8 GB, not once per 0.4 GB
+        wl = SynthWorkload("c2x22", SEED0 + 2, list(range(1, 23)), int(1e6), 200, 200, [2], 50000, 10000, [dict(UQ)],
+                           description="22 synthetic chromosomes of C2's size (1e6 sites, 200 ref/200 tgt/2 src diploids, 50kb/10kb "
+                           "windows, U stat) as ONE multi-piece block: what BASELINE.json configs[1] looks like inside a whole-genome run")  # fmt: skip
     elif name == "c3":
         wl = SynthWorkload("c3", SEED0 + 3, [1], int(1e7), 1000, 1000, [2], 50000, 25000, [dict(UQ)],
                            description="synthetic chr: 1e7 sites, 1000 ref/1000 tgt/2 src diploids, 50kb/25kb windows, U+Q95 "
@@ -233,17 +242,35 @@ def cpu_baseline(wl, n_sites: int, workers: int, runs: int = 3, min_run_s: float
 # ------------------------------------------------------------------------------------------
 
 
-def run_passes(scorer, gather, row_of, steps: int, warmup: int, gather_mode: str, fence, new_ring=None) -> dict:
+def run_passes(scorer, gather, row_of, steps: int, warmup: int, gather_mode: str, fence, new_ring=None, new_event=None) -> dict:
     """W untimed + K timed passes of ``scorer`` with the per-pass gather of its row.
 
     ``scorer`` = a ResidentScorer (or None on a rank without windows); ``gather`` = a RowGather;
     ``row_of(k)`` = the uint8 tensor pass k's row is packed into; ``fence()`` = barrier +
-    synchronize on both sides of the timed region.  Returns the wall time and what rank 0 received
-    last (a list of per-rank rows)."""
+    synchronize on both sides of the timed region; ``new_event()`` = an event of the device's current
+    stream with ``record()`` / ``elapsed_time()`` (None: host clock only).  Returns the wall time, what
+    rank 0 received last (a list of per-rank rows) and what every per-pass gather of the timed passes took:
+    ``gather_host_ms`` (the call, on the host) and ``gather_events`` (an event pair around it on the stream
+    it was issued on) -- so that ONE record of a multi-GPU run says whether a step that is too long spent
+    its time in the collective."""
     layout = gather.layouts[gather.rank]
     dist_on = gather.on
-    got = {"rows": None}
+    got = {"rows": None, "timed": False}
     queue: list[int] = []
+    gather_host_ms: list = []
+    gather_events: list = []
+
+    def gather_row(k: int) -> None:
+        pair = (new_event(), new_event()) if (got["timed"] and new_event is not None) else None
+        if pair:
+            pair[0].record()
+        t0 = time.perf_counter()
+        got["rows"] = gather.gather(row_of(k))
+        if got["timed"]:
+            gather_host_ms.append((time.perf_counter() - t0) * 1e3)
+        if pair:
+            pair[1].record()
+            gather_events.append(pair)
 
     def on_stage(_index: int) -> None:  # on the stream the windows stage ran on, right after it
         k = queue.pop(0)
@@ -251,12 +278,12 @@ def run_passes(scorer, gather, row_of, steps: int, warmup: int, gather_mode: str
             return
         scorer.pack_row(row_of(k), layout)
         if gather_mode == "step":
-            got["rows"] = gather.gather(row_of(k))
+            gather_row(k)
 
     def one_pass(k: int, timed: bool) -> None:
         if scorer is None:  # a rank without windows still takes part in every collective
             if dist_on and gather_mode == "step":
-                got["rows"] = gather.gather(row_of(k))
+                gather_row(k)
             return
         queue.append(k)
         scorer.step(time_counts=timed)
@@ -273,12 +300,13 @@ def run_passes(scorer, gather, row_of, steps: int, warmup: int, gather_mode: str
         one_pass(k, False)
     finish(max(warmup, 1) if warmup else 0)  # also sets up RCCL's channels outside the timed region
     fence()
+    got["timed"] = True
     t0 = time.perf_counter()
     for k in range(steps):
         one_pass(k, True)
     finish(steps)
     fence()
-    return {"dt": time.perf_counter() - t0, "rows": got["rows"]}
+    return {"dt": time.perf_counter() - t0, "rows": got["rows"], "gather_host_ms": gather_host_ms, "gather_events": gather_events}
 
 
 # ------------------------------------------------------------------------------------------
@@ -477,23 +505,51 @@ def one_gpu_base(wl, args) -> dict:
     return rec
 
 
-def per_rank_figures(dist_on: bool, cdev, dt: float, steps: int, site_ms: list, n_windows: int, n_sites: int,
-                     t_setup: float) -> list:  # fmt: skip
-    """One entry per rank, all_gathered after the timed region (outside it): the rank's own wall time
-    per step, its site-pass average (HIP events), its windows and sites -- a straggler or a slow gather
-    shows in ONE record of the scaling run."""
+RANK_RECORD_BYTES = 1024
+
+
+def per_rank_figures(dist_on: bool, cdev, mine: dict) -> list:
+    """One record per rank, all_gathered after the timed region (outside it) as JSON in fixed-size byte
+    rows: the rank's own wall time per step, its site-pass average (HIP events), what its per-pass gather
+    took, its windows and sites, and WHERE it ran -- host, local rank, device index, PCI bus id, UUID -- so
+    that ONE record of the scaling run shows a straggler, a slow gather, or two ranks on one device."""
     import torch
     import torch.distributed as dist
 
-    mine = [dt / max(steps, 1) * 1e3, sum(site_ms) / len(site_ms) if site_ms else 0.0, float(n_windows), float(n_sites), t_setup]
-    rows = [mine]
-    if dist_on:
-        t = torch.tensor(mine, dtype=torch.float64, device=cdev)
-        every = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
-        dist.all_gather(every, t)
-        rows = [e.cpu().tolist() for e in every]
-    return [{"rank": r, "ms_per_step_wall": round(v[0], 4), "site_pass_avg_ms": round(v[1], 4), "windows": int(v[2]),
-             "sites": int(v[3]), "setup_s": round(v[4], 2)} for r, v in enumerate(rows)]  # fmt: skip
+    if not dist_on:
+        return [mine]
+    raw = json.dumps(mine).encode()
+    if len(raw) > RANK_RECORD_BYTES:
+        raise ValueError("per-rank record too long")
+    row = torch.zeros((RANK_RECORD_BYTES,), dtype=torch.uint8)
+    row[: len(raw)] = torch.frombuffer(bytearray(raw), dtype=torch.uint8)
+    row = row.to(cdev)
+    every = [torch.zeros_like(row) for _ in range(dist.get_world_size())]
+    dist.all_gather(every, row)
+    return [json.loads(bytes(e.cpu().tolist()).rstrip(b"\0").decode()) for e in every]
+
+
+def collective_record(backend: str, per_rank: list, backend_seen=None, world_seen=None) -> dict:
+    """What the job's process group is, as seen from inside it, and whether its ranks sit on distinct devices."""
+    import torch
+    import torch.distributed as dist
+
+    rec = {
+        "backend": backend_seen if backend_seen is not None else dist.get_backend(),
+        "backend_requested": backend,
+        "world_size_seen_by_group": world_seen if world_seen is not None else dist.get_world_size(),
+        "rccl_version": None,
+        "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY"),
+        "hosts": sorted({r.get("hostname") for r in per_rank}),
+    }
+    try:
+        rec["rccl_version"] = ".".join(map(str, torch.cuda.nccl.version()))
+    except Exception as exc:  # noqa: BLE001 - a CPU build of torch, a rehearsal without the library
+        rec["rccl_version"] = f"unavailable ({type(exc).__name__})"
+    where = [(r.get("hostname"), r.get("pci_bus_id") or r.get("uuid")) for r in per_rank]
+    rec["devices"] = [f"{h}:{d}" for h, d in where]
+    rec["distinct_devices"] = len(set(where)) == len(where) and all(d for _, d in where)
+    return rec
 
 
 def static_traffic(wl, args, world: int, sites_rank0: int):
@@ -577,6 +633,15 @@ class HipDevice:
             scorer.step()
         return block, lay, win_counts, scorer
 
+    def identity(self) -> dict:
+        return self.eng.identity()
+
+    def new_event(self):
+        import torch
+
+        ev = torch.cuda.Event(enable_timing=True)
+        return ev
+
     def synchronize(self) -> None:
         import torch
 
@@ -620,11 +685,15 @@ def main(argv=None, device=None) -> None:
     result_out = os.fdopen(os.dup(1), "w")
     os.dup2(2, 1)
     argv = sys.argv[1:] if argv is None else list(argv)
+    # the host driver of this pool only supports dmabuf IPC; without this RCCL's communicator set-up fails with
+    # `hipIpcGetMemHandle: invalid argument`.  Set here, before anything has initialised HIP, so that ranks started
+    # by ANY launcher have it -- the repo's own launcher sets it for its children too (sai_amd/launcher.py)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", choices=["auto", "c2", "c3", "c4", "c5"], default="auto",
+    ap.add_argument("--workload", choices=["auto", "c2", "c2x22", "c3", "c4", "c5"], default="auto",
                     help="auto = c3 on one GPU (the configuration the metric is quoted on), c4 on several; "
                     "`--workload c4` on one GPU runs the N > 1 job itself (220 GB resident), so ONE job can be used for every N")
     ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
@@ -752,11 +821,28 @@ def main(argv=None, device=None) -> None:
             dist.barrier()
         device.synchronize()
 
-    out = run_passes(scorer, gather, row_of, args.steps, args.warmup, args.gather, fence, gather_ring)
+    out = run_passes(scorer, gather, row_of, args.steps, args.warmup, args.gather, fence, gather_ring,
+                     getattr(device, "new_event", None))  # fmt: skip
     dt = out["dt"]
-    rank_figures = per_rank_figures(dist_on, cdev, dt, args.steps, device.site_pass_ms(scorer) if scorer is not None else [],
-                                    scorer.n_windows if scorer is not None else 0,
-                                    block.n_real_sites if block is not None else 0, t_setup)  # fmt: skip
+    import socket
+
+    site_ms = device.site_pass_ms(scorer) if scorer is not None else []
+    on_stream = [a.elapsed_time(b) for a, b in out["gather_events"]]
+    avg = lambda xs: round(sum(xs) / len(xs), 4) if xs else None  # noqa: E731
+    mine = {"rank": rank, "local_rank": int(os.environ.get("LOCAL_RANK", 0)), "hostname": socket.gethostname(),
+            "ms_per_step_wall": round(dt / max(args.steps, 1) * 1e3, 4), "site_pass_avg_ms": avg(site_ms) or 0.0,
+            "gather_avg_ms_on_stream": avg(on_stream), "gather_max_ms_on_stream": round(max(on_stream), 4) if on_stream else None,
+            "gather_avg_ms_host_call": avg(out["gather_host_ms"]), "gathers_timed": len(out["gather_host_ms"]),
+            "windows": scorer.n_windows if scorer is not None else 0,
+            "sites": block.n_real_sites if block is not None else 0, "setup_s": round(t_setup, 2),
+            **(device.identity() if hasattr(device, "identity") else {})}  # fmt: skip
+    rank_figures = per_rank_figures(dist_on, cdev, mine)
+    collective = collective_record(backend, rank_figures) if dist_on else None
+    if collective is not None and collective["backend"] == "nccl" and not collective["distinct_devices"]:
+        # every rank holds the same records: all leave, with a message from rank 0, and no line is printed
+        if rank == 0:
+            print(f"bench.py: {world} RCCL rank(s) but not as many distinct devices: {collective['devices']}", file=sys.stderr, flush=True)
+        sys.exit(3)
     if dist_on:
         tmax = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -852,6 +938,7 @@ def main(argv=None, device=None) -> None:
                 "gather": args.gather if dist_on else None,
                 "gather_row_bytes": gather.sizes if dist_on else None,
                 "gather_check": gather_check if dist_on else None,
+                "collective": collective,
                 "one_gpu_base": one_gpu_base(wl, args) if world > 1 else None,
                 "per_rank": rank_figures,
                 "source_digest": source_digest(),

@@ -63,7 +63,7 @@
 extern "C" {
 #endif
 
-#define SAI_ABI_VERSION 15
+#define SAI_ABI_VERSION 16
 #define SAI_TILE_SITES 64
 #define SAI_MAX_SRC 6   /* source populations per call */
 #define SAI_MAX_SETS 20 /* parameter sets per call: 1 + 2 * 20 plane words of a tile = one wave store (C5's 18 sets fit) */
@@ -121,6 +121,13 @@ int sai_abi_version(void);            /* SAI_ABI_VERSION the library was built w
 const char* sai_build_arch(void);     /* "gfx950" */
 const char* sai_last_error(void);     /* thread-local, never NULL */
 int sai_device_count(int* count_out); /* visible HIP devices */
+
+/* Which physical GPU a HIP device index of this process is: its PCI bus id ("0000:05:00.0", at least 16
+ * bytes of room) and, when uuid_hex_out is not NULL, its 16-byte UUID as 32 hex digits (33 bytes of room).
+ * No reference counterpart: a job of one worker process per GPU (the MI355X form of mp_pool.py:45-73) reports
+ * them per rank, so that its record shows N ranks on N distinct devices. */
+int sai_device_identity(int device, char* bus_id_out, int32_t bus_id_capacity, char* uuid_hex_out,
+                        int32_t uuid_capacity);
 
 int sai_ctx_create(int device, sai_ctx** ctx_out);
 int sai_ctx_destroy(sai_ctx* ctx);
@@ -334,6 +341,30 @@ int sai_site_absdiff(sai_ctx* ctx, int64_t n_sites, const sai_pop* pop, const sa
 int sai_window_dd(sai_ctx* ctx, int64_t n_sites, int32_t n_src_ind, const uint32_t* ad_ref,
                   int32_t n_ref_ind, const uint32_t* ad_tgt, int32_t n_tgt_ind, int32_t n_windows,
                   const int32_t* lo, const int32_t* hi, double* scratch, double* dd, void* stream);
+
+/* The same terms from the site pass itself: sai_site_pass with DD riding along, so that the genotypes of
+ * ref and tgt are read ONCE for the counts, the per-site decision and DD (the stand-alone form above streams a
+ * population again per two source individuals).  dd->first_pop .. first_pop + n_pops - 1 name the source
+ * populations of `pops` whose individuals are DD's sources (all of them together at most SAI_DD_FUSED_ROWS
+ * rows); dd->absdiff receives [2][n_rows][n_sites] uint32: [0] against pops[0] (ref), [1] against pops[1]
+ * (tgt), row r = the r-th individual of those populations in order -- the slices sai_window_dd takes.
+ * n_sets == 0 asks for the counts (and DD) only: every population behind tgt is then just counted (an
+ * outgroup may ride along); with parameter sets they are the sources of the decision, as in sai_site_pass.
+ * counts / tgt_freq / planes as in sai_site_pass.  SAI_ERR_UNSUPPORTED -- more source individuals -- tells the
+ * caller to take sai_site_pass + sai_site_absdiff. */
+#define SAI_DD_FUSED_ROWS 4
+typedef struct sai_dd_rows {
+  int32_t first_pop;
+  int32_t n_pops;
+  uint32_t* absdiff;
+} sai_dd_rows;
+int sai_site_pass_dd(sai_ctx* ctx, int64_t n_sites, int32_t n_pops, const sai_pop* pops, uint32_t* counts,
+                     int32_t n_sets, const sai_params* sets_host, int32_t freq_mode, double* tgt_freq,
+                     uint64_t* planes, int64_t plane_stride, const sai_dd_rows* dd, void* stream);
+/* as a step of a prepared launch sequence (sai_plan_add_site_pass) */
+int sai_plan_add_site_pass_dd(sai_plan* plan, int64_t n_sites, int32_t n_pops, const sai_pop* pops, uint32_t* counts,
+                              int32_t n_sets, const sai_params* sets_host, int32_t freq_mode, double* tgt_freq,
+                              uint64_t* planes, int64_t plane_stride, const sai_dd_rows* dd);
 
 /* ---- packed2: optional 2-bit layout ----------------------------- */
 

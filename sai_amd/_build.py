@@ -17,7 +17,7 @@ CSRC = PKG / "csrc"
 # the public header: include/ at the repository root, or the copy an installed package carries
 INCLUDE = ROOT / "include" if (ROOT / "include" / "saihip.h").exists() else PKG / "include"
 HOST_UNITS = ["host_core.cpp", "vcf_ingest.cpp", "vcf_stream.cpp", "bgzf_stream.cpp", "narrow.cpp", "text_out.cpp"]  # plain C++: also built alone under the sanitizers
-UNITS = ["core.hip", "site_pass.hip", "packed2.hip", "windows.hip", "single_window.hip", "plan.hip", "fourpop.hip", "dd.hip", "synth.hip", "tokenize.hip", "inflate.hip", "lines.hip", *HOST_UNITS]
+UNITS = ["core.hip", "site_pass.hip", "site_pass_dd.hip", "packed2.hip", "windows.hip", "single_window.hip", "plan.hip", "fourpop.hip", "dd.hip", "synth.hip", "tokenize.hip", "inflate.hip", "lines.hip", *HOST_UNITS]
 LIB = PKG / "lib" / "libsaihip.so"
 SAN_LIB = LIB.parent / "libsaihost_san.so"
 OBJ = LIB.parent / "obj"
@@ -65,25 +65,46 @@ def _link(cmd_without_output: list, target: Path) -> None:
             tmp.unlink()
 
 
+def shipped_library_is_current() -> bool:
+    """An INSTALLED package (pip / a wheel) carries libsaihip.so and the sources but no object directory: every
+    unit would look stale, and a rebuild would need hipcc and a writable site-packages -- neither is a given
+    where the package was merely installed.  Such a library is taken as it is when it loads with the ABI this
+    package expects; a source tree (lib/obj exists) is always checked unit by unit."""
+    if OBJ.exists() or not LIB.exists():
+        return False
+    try:
+        from . import _ffi
+
+        _ffi.load()
+        return True
+    except Exception:  # noqa: BLE001 - anything wrong with it: let the build say what
+        return False
+
+
 def build(force: bool = False, sanitize: bool = False) -> None:
     """Compile every translation unit for gfx950 (in parallel, only the stale ones), link them
     in-tree into libsaihip.so and import the package.  Safe to call from several processes at once
     (the ranks of a torchrun job): they serialise on a file lock and the later ones find the tree
     current.  ``sanitize=True`` additionally builds the host-only part (the VCF / BED reader, the
     int8 narrowing, the host generator) with g++ -fsanitize=address,undefined into
-    libsaihost_san.so for the CPU test suite (tests/test_sanitizer_build.py)."""
+    libsaihost_san.so for the CPU test suite (tests/test_sanitizer_build.py).  The compilers are looked
+    for only when something has to be compiled; the library an installed package ships is not rebuilt
+    (``shipped_library_is_current``)."""
     from concurrent.futures import ThreadPoolExecutor
 
+    if not force and not sanitize and shipped_library_is_current():
+        return
     OBJ.mkdir(parents=True, exist_ok=True)
     with open(LIB.parent / ".build.lock", "w") as lock:
         fcntl.flock(lock, fcntl.LOCK_EX)
         headers = [INCLUDE / "saihip.h", *sorted(CSRC.glob("*.hpp"))]
-        hipcc = _hipcc()
-        gxx = shutil.which("g++") or "g++"
+        hipcc = gxx = None
         jobs = []
         for unit in UNITS:
             src, obj = CSRC / unit, OBJ / (Path(unit).stem + ".o")
             if force or _stale(obj, [src, *headers]):
+                hipcc = hipcc or _hipcc()  # only now: a current tree builds nothing and needs no compiler
+                gxx = gxx or shutil.which("g++") or "g++"
                 if unit in HOST_UNITS:  # plain C++, the same sources the sanitizer build compiles
                     jobs.append([gxx, *HOST_FLAGS, f"-I{INCLUDE}", "-c", str(src), "-o", str(obj)])
                 else:
@@ -93,11 +114,11 @@ def build(force: bool = False, sanitize: bool = False) -> None:
                 list(pool.map(_run, jobs))
         objs = [OBJ / (Path(u).stem + ".o") for u in UNITS]
         if force or _stale(LIB, objs):
-            _link([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *map(str, objs), "-lz", "-lpthread", "-ldl"], LIB)
+            _link([hipcc or _hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", *map(str, objs), "-lz", "-lpthread", "-ldl"], LIB)
         if sanitize:
             srcs = [CSRC / u for u in HOST_UNITS]
             if force or _stale(SAN_LIB, [*srcs, *headers]):
-                _link([gxx, *SAN_FLAGS, f"-I{INCLUDE}", "-shared", *map(str, srcs), "-lz", "-lpthread", "-ldl"], SAN_LIB)
+                _link([gxx or shutil.which("g++") or "g++", *SAN_FLAGS, f"-I{INCLUDE}", "-shared", *map(str, srcs), "-lz", "-lpthread", "-ldl"], SAN_LIB)
     if str(ROOT) not in sys.path:
         sys.path.insert(0, str(ROOT))
     import sai_amd  # noqa: F401

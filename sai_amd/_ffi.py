@@ -19,10 +19,13 @@ SAI_MAX_SRC = 6
 SAI_MAX_SETS = 20
 SAI_FUSED_SETS = SAI_MAX_SETS
 SAI_PLANES_PER_SET = 3
+SAI_DD_FUSED_ROWS = 4  # source individuals whose DD terms can ride along the site pass
 SAI_ERR_ARG = -1
+SAI_ERR_HIP = -2
+SAI_ERR_NO_DEVICE = -3
 SAI_ERR_UNSUPPORTED = -4  # enum sai_status
 FREQ_MODES = {"dense": 0, "candidates": 1}  # enum sai_freq_mode
-SAI_ABI_VERSION = 15
+SAI_ABI_VERSION = 16
 
 OPS = {"=": 0, "<": 1, ">": 2, "<=": 3, ">=": 4}
 
@@ -50,6 +53,10 @@ class SaiParams(C.Structure):
         ("y", C.c_double * SAI_MAX_SRC),
         ("one_minus_y", C.c_double * SAI_MAX_SRC),
     ]
+
+
+class SaiDdRows(C.Structure):
+    _fields_ = [("first_pop", C.c_int32), ("n_pops", C.c_int32), ("absdiff", C.c_void_p)]
 
 
 class SaiTextColumn(C.Structure):
@@ -84,6 +91,7 @@ SIGNATURES = {
     "sai_build_arch": (C.c_char_p, []),
     "sai_last_error": (C.c_char_p, []),
     "sai_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "sai_device_identity": (C.c_int, [C.c_int, C.c_char_p, _i32, C.c_char_p, _i32]),
     "sai_ctx_create": (C.c_int, [C.c_int, C.POINTER(_p)]),
     "sai_ctx_destroy": (C.c_int, [_p]),
     "sai_tiled_bytes": (_i64, [_i64, _i32]),
@@ -93,6 +101,14 @@ SIGNATURES = {
     "sai_site_pass": (
         C.c_int,
         [_p, _i64, _i32, C.POINTER(SaiPop), _p, _i32, C.POINTER(SaiParams), _i32, _p, _p, _i64, _p],
+    ),
+    "sai_site_pass_dd": (
+        C.c_int,
+        [_p, _i64, _i32, C.POINTER(SaiPop), _p, _i32, C.POINTER(SaiParams), _i32, _p, _p, _i64, C.POINTER(SaiDdRows), _p],
+    ),
+    "sai_plan_add_site_pass_dd": (
+        C.c_int,
+        [_p, _i64, _i32, C.POINTER(SaiPop), _p, _i32, C.POINTER(SaiParams), _i32, _p, _p, _i64, C.POINTER(SaiDdRows)],
     ),
     "sai_site_flags": (
         C.c_int,

@@ -101,14 +101,14 @@ inline unsigned stream_grid(const sai_ctx* ctx, int64_t n_tiles, int waves_per_c
   return static_cast<unsigned>(n_tiles < max_grid ? n_tiles : max_grid);
 }
 
-// Waves per CU of the int8 / packed2 site pass (profiles/r04_waves_per_cu.txt, profiles/r04_shape_sweep.txt:
-// same-box sweeps).  The pass is HBM-bound from 8 waves per CU on when its populations are wide, so the grid
-// is chosen for what runs NEXT to it (the windows stage of the step before, on a second stream) and for the
-// pass's own tail:
-//  * with many parameter sets (C5's 18) the pass alone is fastest at 16 (3.23 ms; 12: 3.28; 8: 3.89 -- every
-//    tile ends in the sets' evaluation, during which a wave loads nothing), but the PIPELINED step, with the
-//    previous step's windows stage next to it, is fastest when the stage's waves find registers: the int8
-//    pass then runs its 64-register form at 16 (site_pass.hip), the packed2 pass 12 waves of its one form;
+// Waves per CU of the int8 / packed2 site pass (same-box sweeps: profiles/r04_waves_per_cu.txt,
+// profiles/r04_shape_sweep.txt, profiles/r05_c5_grid.txt).  The pass is HBM-bound from 8 waves per CU on when its
+// populations are wide, so the grid is chosen for what runs NEXT to it (the windows stage of the step before, on
+// a second stream) and for the pass's own tail:
+//  * with many parameter sets (C5's 18) every tile ends in the sets' evaluation, during which a wave loads
+//    nothing, and the stage next to the pass is a large one: 12 waves per CU -- three per SIMD, which leaves the
+//    stage's waves half of the register file.  C5 pipelined, one box: 3.09 ms per step at 12, 3.41-3.46 at 16
+//    (round 4's 64-register form at 16 with the set-by-set decision: 3.15);
 //  * with one to three sets, WIDE populations (>= 2 000 individuals per site in at most three populations:
 //    C3, C4) and a long pass, 8 -- two waves per SIMD, multiples of four only: 9 and 10 are slower than
 //    either -- is a little faster: C3 2.924 against 2.966 ms, 2000 / 2000 / 2 individuals 2.99 against 3.06,
@@ -118,20 +118,26 @@ inline unsigned stream_grid(const sai_ctx* ctx, int64_t n_tiles, int waves_per_c
 //    population (two sources) makes 8 and 16 equal at best;
 //  * a short pass (C2: 15 625 tiles, under four per wave at 16) needs its waves for the ramp and the
 //    tail: 16 (0.088 ms per step against 0.109 at 8).
-constexpr int kLeanSets = 4;  // from this many parameter sets on the int8 pass runs its 64-register form (site_pass.hip)
-inline int lean_sets() {
-  static const int n = [] {  // SAI_LEAN_SETS: tuning knob for sweeps (1 = always the 64-register form, 99 = never)
-    const char* e = std::getenv("SAI_LEAN_SETS");
+constexpr int kManySets = 4;  // from this many parameter sets on the pass takes 12 waves per CU
+inline int many_sets() {
+  static const int n = [] {  // SAI_MANY_SETS: tuning knob for sweeps (99 = never)
+    const char* e = std::getenv("SAI_MANY_SETS");
     const int v = e ? std::atoi(e) : 0;
-    return v > 0 ? v : kLeanSets;
+    return v > 0 ? v : kManySets;
   }();
   return n;
 }
 inline int site_pass_waves_per_cu(const sai_ctx* ctx, int64_t n_tiles, int32_t n_sets, int32_t n_pops, int64_t individuals) {
-  if (n_sets >= lean_sets()) return 12;
+  if (n_sets >= many_sets()) return 12;
   const bool wide = individuals >= 2000 && n_pops <= 3;
   return wide && n_tiles >= static_cast<int64_t>(ctx->n_cu) * 8 * 32 ? 8 : kStreamWavesPerCu;
 }
+
+// The site pass with DD's terms riding along (site_pass_dd.hip) is built for three waves per SIMD (one or two
+// source individuals) or two (three or four), and takes them: unlike the plain pass it has arithmetic to hide
+// behind its loads (C3 shape, two source individuals: 3.26 ms at 12 waves per CU, 3.45 at 8; three source
+// individuals at a grid their registers do not hold at once: 4.02 against 3.67 -- profiles/r05_dd_pass.txt).
+inline int dd_pass_waves_per_cu(const sai_ctx*, int64_t, int64_t, int n_rows) { return n_rows > 2 ? 8 : 12; }
 
 // XCD-aware block order: consecutive workgroup ids go round-robin over the 8 XCDs; give each XCD a
 // contiguous run of (overlapping) windows so their shared sites stay in one L2.

@@ -87,6 +87,21 @@ int sai_device_count(int* count_out) {
   return SAI_OK;
 }
 
+int sai_device_identity(int device, char* bus_id_out, int32_t bus_id_capacity, char* uuid_hex_out, int32_t uuid_capacity) {
+  if (!bus_id_out || bus_id_capacity < 16) return fail(SAI_ERR_ARG, "bus_id_out needs room for 16 bytes");
+  if (uuid_hex_out && uuid_capacity < 33) return fail(SAI_ERR_ARG, "uuid_hex_out needs room for 33 bytes");
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n)
+    return fail(SAI_ERR_NO_DEVICE, "device %d is not one of the %d visible HIP devices", device, n);
+  SAI_HIP(hipDeviceGetPCIBusId(bus_id_out, bus_id_capacity, device));
+  if (uuid_hex_out) {
+    hipUUID id;
+    SAI_HIP(hipDeviceGetUuid(&id, device));
+    for (int i = 0; i < 16; ++i) std::snprintf(uuid_hex_out + 2 * i, 3, "%02x", static_cast<unsigned>(static_cast<unsigned char>(id.bytes[i])));
+  }
+  return SAI_OK;
+}
+
 int sai_ctx_create(int device, sai_ctx** ctx_out) {
   if (!ctx_out) return fail(SAI_ERR_ARG, "ctx_out is NULL");
   *ctx_out = nullptr;

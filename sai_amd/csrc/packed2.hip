@@ -103,6 +103,12 @@ template <bool FUSED>
 __global__ __launch_bounds__(64) void site_counts_packed2_kernel(PackedArgs a, FusedArgs fa) {
   // indexed per-lane storage only: entry [p][lane] is written and read by the same lane
   __shared__ uint2 stash[kMaxPops][64];
+  __shared__ uint32_t table_words[FUSED ? sizeof(PredTable) / 4 : 1];
+  PredTable* table = reinterpret_cast<PredTable*>(table_words);
+  if (FUSED) {
+    stage_pred_table(fa.es, table);
+    wave_lds_fence();
+  }
   const int lane = threadIdx.x;
   for (int64_t tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
     const int64_t site = tile * kTile + lane;
@@ -147,7 +153,7 @@ __global__ __launch_bounds__(64) void site_counts_packed2_kernel(PackedArgs a, F
     }
     if (FUSED)  // lane = site inside the tile already: the ballots of eval_site are the tile's flag planes
       eval_site(
-          a.n_pops, fa.ploidy, [&](int p) { return stash[p][lane]; }, fa.n_sets, fa.sets, tile, lane, site < a.n_sites,
+          a.n_pops, fa.ploidy, [&](int p) { return stash[p][lane]; }, fa.n_sets, fa.es, table, tile, lane, site < a.n_sites,
           a.n_sites, fa.tgt_freq, fa.planes, fa.plane_stride, nullptr, fa.sparse_freq != 0, fa.with_inv != 0);
   }
 }
@@ -227,7 +233,7 @@ int sai_site_pass_packed2(sai_ctx* ctx, int64_t n_sites, int32_t n_pops, const s
   fa.tgt_freq = tgt_freq;
   fa.planes = planes;
   fa.plane_stride = plane_stride;
-  for (int s = 0; s < n_sets; ++s) fa.sets[s] = sets_host[s];
+  if (n_sets > 0) fill_eval_sets(fa.es, n_sets, sets_host, n_pops - 2);
   int64_t individuals = 0;
   for (int p = 0; p < n_pops; ++p) individuals += pops[p].n_ind;
   const dim3 grid(stream_grid(ctx, a.n_tiles, site_pass_waves_per_cu(ctx, a.n_tiles, n_sets, n_pops, individuals)));

@@ -35,6 +35,20 @@ std::vector<sai_params> copy_sets(int32_t n_sets, const sai_params* sets) {
   return (n_sets > 0 && sets) ? std::vector<sai_params>(sets, sets + n_sets) : std::vector<sai_params>();
 }
 
+// After a site-pass call of a plan: the events the plan carries have been taken by the launch -- or, when the
+// call returned without launching (no sites) or failed, they are still pending: they are then recorded on the
+// stream as ordinary markers, so that a caller waiting for `stop` waits for the work before it on the stream
+// instead of finding an event that was never recorded (which reads as done at once).
+int finish_pass(sai_ctx* ctx, int rc, void* st) {
+  hipEvent_t start = ctx->next_start, stop = ctx->next_stop;
+  ctx->next_start = ctx->next_stop = nullptr;
+  if (rc == SAI_OK) {
+    if (start) SAI_HIP(hipEventRecord(start, static_cast<hipStream_t>(st)));
+    if (stop) SAI_HIP(hipEventRecord(stop, static_cast<hipStream_t>(st)));
+  }
+  return rc;
+}
+
 std::vector<sai_pop> copy_pops(int32_t n_pops, const sai_pop* pops) {
   return (n_pops > 0 && pops) ? std::vector<sai_pop>(pops, pops + n_pops) : std::vector<sai_pop>();
 }
@@ -72,8 +86,7 @@ int sai_plan_add_site_counts(sai_plan* plan, int64_t n_sites, int32_t n_pops, co
       ctx->next_start = plan->pass_start;
       ctx->next_stop = plan->pass_stop;
       const int rc = sai_site_counts(ctx, n_sites, n_pops, pv.data(), counts, st);
-      ctx->next_start = ctx->next_stop = nullptr;  // also when the call returned before its launch
-      return rc;
+      return finish_pass(ctx, rc, st);
     };
   });
 }
@@ -93,8 +106,26 @@ int sai_plan_add_site_pass(sai_plan* plan, int64_t n_sites, int32_t n_pops, cons
                                                      planes, plane_stride, st)
                              : sai_site_pass(ctx, n_sites, n_pops, pv.data(), counts, n_sets, s, freq_mode, tgt_freq, planes,
                                              plane_stride, st);
-      ctx->next_start = ctx->next_stop = nullptr;  // also when the call returned before its launch
-      return rc;
+      return finish_pass(ctx, rc, st);
+    };
+  });
+}
+
+int sai_plan_add_site_pass_dd(sai_plan* plan, int64_t n_sites, int32_t n_pops, const sai_pop* pops, uint32_t* counts,
+                              int32_t n_sets, const sai_params* sets_host, int32_t freq_mode, double* tgt_freq,
+                              uint64_t* planes, int64_t plane_stride, const sai_dd_rows* dd) {
+  if (!dd) return fail(SAI_ERR_ARG, "dd is NULL");
+  return guarded_add(plan, [&] {
+    auto pv = copy_pops(n_pops, pops);
+    auto sv = copy_sets(n_sets, sets_host);
+    const sai_dd_rows rows = *dd;
+    sai_ctx* ctx = plan->ctx;
+    return [=](void* st) {
+      ctx->next_start = plan->pass_start;
+      ctx->next_stop = plan->pass_stop;
+      const int rc = sai_site_pass_dd(ctx, n_sites, n_pops, pv.data(), counts, n_sets, sv.empty() ? nullptr : sv.data(),
+                                      freq_mode, tgt_freq, planes, plane_stride, &rows, st);
+      return finish_pass(ctx, rc, st);
     };
   });
 }

@@ -33,11 +33,152 @@ __device__ __forceinline__ bool cmp_op(int op, double f, double y) {
 // this one writes 2.6 + 2.5 there and 0.25 + 0.06 for one set.
 constexpr int kPlanesPerSet = SAI_PLANES_PER_SET;  // row words RESERVED per set (1 + 2 n <= 3 n are used)
 
+// ------------------------------------------------------------------------------------------
+// Predicate table.  A call's parameter sets repeat the same comparisons: C5's 18 sets hold 6 distinct
+// (source, operator, y) and one w, yet the set-by-set form below evaluates 72 source comparisons per site,
+// each behind a scalar load and a five-way branch on the operator (a quarter of a C5 tile's time went there,
+// during which the wave loads nothing).  The host therefore lists every DISTINCT comparison of a call once --
+// (value slot, operator, threshold) with slot p = frequency of population p and slot kMaxPops = 1 - ref_freq,
+// the reference frequency of an inverted site (stat_utils.py:159) -- sorted by slot, at most 32 of them; a
+// site evaluates each into one bit of a 32-bit word, and a set is then the test "all bits of a mask are up":
+//   cond        = the set's y comparisons and ref_freq < w                       (stat_utils.py:141-144, 166)
+//   mirror      = its 1 - y comparisons                                           (stat_utils.py:148-152)
+//   mirror_cond = mirror and 1 - ref_freq < w   (an inverted site is tested on 1 - ref_freq, :156-166)
+// The arithmetic per comparison is the reference's: one f64 compare of the same two doubles.
+// ------------------------------------------------------------------------------------------
+constexpr int kMaxPreds = 32;  // with the masks below the table stays under 1 KiB of LDS next to the 4 KiB of parked counts
+constexpr int kMirrorRefSlot = kMaxPops;
+
+struct PredEntry {
+  double value;
+  int32_t op_bits;  // 1: f < value, 2: f == value, 4: f > value (<= is 3, >= is 6)
+  int32_t slot;
+};
+
+struct SetMasks {
+  uint32_t cond, mirror, mirror_cond;
+  int32_t anc;  // anc_allele_available: mirror / mirror_cond are not looked at
+};
+
+struct PredTable {
+  int32_t n_preds;
+  uint8_t slot_end[kMaxPops + 2];  // the comparisons of slot s are [slot_end[s - 1], slot_end[s])
+  uint8_t pad[2];
+  PredEntry preds[kMaxPreds];
+  SetMasks sets[SAI_MAX_SETS];
+};
+
+// What the per-site decision is handed: the table (use_table) or, for a call with more than 32 distinct
+// comparisons, the parameter sets themselves.
+struct EvalSets {
+  int32_t use_table;
+  int32_t pad;
+  union {
+    sai_params sets[SAI_MAX_SETS];
+    PredTable table;
+  };
+};
+static_assert(sizeof(PredTable) <= sizeof(sai_params) * SAI_MAX_SETS, "the table rides in the sets' kernel-argument space");
+
+inline int op_bits_of(int op) {
+  switch (op) {
+    case SAI_OP_EQ: return 2;
+    case SAI_OP_LT: return 1;
+    case SAI_OP_GT: return 4;
+    case SAI_OP_LE: return 3;
+    default: return 6;
+  }
+}
+
+// host: the call's parameter sets as kernel arguments (n_src = source populations of the call)
+inline void fill_eval_sets(EvalSets& es, int32_t n_sets, const sai_params* sets, int32_t n_src) {
+  std::memset(&es, 0, sizeof(es));
+  struct Raw { int slot, op_bits; double value; };
+  Raw raw[SAI_MAX_SETS * (2 * SAI_MAX_SRC + 2)];
+  int n_raw = 0;
+  bool fits = !std::getenv("SAI_NO_PRED_TABLE");  // test knob: the set-by-set form for every call
+  auto index_of = [&](int slot, int op_bits, double value) {
+    for (int i = 0; i < n_raw; ++i)
+      if (raw[i].slot == slot && raw[i].op_bits == op_bits && std::memcmp(&raw[i].value, &value, sizeof(double)) == 0) return i;
+    raw[n_raw] = Raw{slot, op_bits, value};
+    return n_raw++;
+  };
+  for (int s = 0; s < n_sets; ++s) {
+    const sai_params& ps = sets[s];
+    for (int k = 0; k < n_src && k < SAI_MAX_SRC; ++k) {
+      index_of(2 + k, op_bits_of(ps.op[k]), ps.y[k]);
+      if (!ps.anc_allele_available) index_of(2 + k, op_bits_of(ps.op[k]), ps.one_minus_y[k]);
+    }
+    index_of(0, 1, ps.w);
+    if (!ps.anc_allele_available) index_of(kMirrorRefSlot, 1, ps.w);
+  }
+  fits = fits && n_raw <= kMaxPreds;
+  if (!fits) {
+    for (int s = 0; s < n_sets; ++s) es.sets[s] = sets[s];
+    return;
+  }
+  es.use_table = 1;
+  PredTable& t = es.table;
+  // bit numbers in slot order
+  int bit_of[SAI_MAX_SETS * (2 * SAI_MAX_SRC + 2)];
+  int n = 0;
+  for (int slot = 0; slot <= kMirrorRefSlot; ++slot) {
+    for (int i = 0; i < n_raw; ++i)
+      if (raw[i].slot == slot) {
+        bit_of[i] = n;
+        t.preds[n].value = raw[i].value;
+        t.preds[n].op_bits = raw[i].op_bits;
+        t.preds[n].slot = slot;
+        ++n;
+      }
+    t.slot_end[slot] = static_cast<uint8_t>(n);
+  }
+  t.n_preds = n;
+  auto bit = [&](int slot, int op_bits, double value) { return uint32_t{1} << bit_of[index_of(slot, op_bits, value)]; };
+  for (int s = 0; s < n_sets; ++s) {
+    const sai_params& ps = sets[s];
+    SetMasks& m = t.sets[s];
+    m.anc = ps.anc_allele_available != 0;
+    m.cond = bit(0, 1, ps.w);
+    for (int k = 0; k < n_src && k < SAI_MAX_SRC; ++k) m.cond |= bit(2 + k, op_bits_of(ps.op[k]), ps.y[k]);
+    if (!m.anc) {
+      for (int k = 0; k < n_src && k < SAI_MAX_SRC; ++k) m.mirror |= bit(2 + k, op_bits_of(ps.op[k]), ps.one_minus_y[k]);
+      m.mirror_cond = m.mirror | bit(kMirrorRefSlot, 1, ps.w);
+    }
+  }
+}
+
+// `value` (wave-uniform) into lane `lane` (wave-uniform) of `row`, the other lanes as they were: v_writelane_b32
+// (this compiler offers no builtin for it; the lane select travels in M0 -- an instruction reads one SGPR only)
+__device__ __forceinline__ uint32_t write_lane(uint32_t value, int lane, uint32_t row) {
+  const uint32_t v = __builtin_amdgcn_readfirstlane(value);  // uniform already; this pins it to an SGPR
+  const int l = __builtin_amdgcn_readfirstlane(lane);
+  asm("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(row) : "s"(v), "s"(l) : "m0");
+  return row;
+}
+
+// a value every lane holds alike, as a scalar
+__device__ __forceinline__ double uniform_f64(double x) {
+  const uint64_t u = __builtin_bit_cast(uint64_t, x);
+  const uint32_t lo = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(u));
+  const uint32_t hi = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(u >> 32));
+  return __builtin_bit_cast(double, (static_cast<uint64_t>(hi) << 32) | lo);
+}
+
+// The workgroup's copy of the table: called by every thread of the workgroup before the first eval_site,
+// followed by a workgroup barrier (a wave barrier for single-wave workgroups).
+__device__ __forceinline__ void stage_pred_table(const EvalSets& es, PredTable* lds_table) {
+  if (!es.use_table) return;
+  const uint32_t* src = reinterpret_cast<const uint32_t*>(&es.table);
+  uint32_t* dst = reinterpret_cast<uint32_t*>(lds_table);
+  for (int i = threadIdx.x; i < static_cast<int>(sizeof(PredTable) / 4); i += blockDim.x) dst[i] = src[i];
+}
+
 // get(p) -> uint2 {alt_sum, n_called} of population p at this lane's site (site = tile * 64 + lane;
 // `live` = the site exists).  Must be called by the whole wavefront.
 template <typename GetCounts>
 __device__ __forceinline__ void eval_site(int n_pops, const int32_t* ploidy, GetCounts get, int n_sets,
-                                          const sai_params* sets, int64_t tile, int lane, bool live, int64_t n_sites,
+                                          const EvalSets& es, const PredTable* lds_table, int64_t tile, int lane, bool live, int64_t n_sites,
                                           double* tgt_freq, uint64_t* planes, int64_t plane_stride, double* adj_freq,
                                           bool sparse_freq, bool with_inv) {
   const int64_t site = tile * kTile + lane;
@@ -57,39 +198,96 @@ __device__ __forceinline__ void eval_site(int n_pops, const int32_t* ploidy, Get
     }
   }
   const int n_src = n_pops - 2;
-  uint64_t row_word = 0;  // lane k ends up with word k of the tile's row
+  // lane k ends up with word k of the tile's row: a ballot is wave-uniform, v_writelane drops it into its lane
+  uint32_t row_lo = 0, row_hi = 0;
   uint64_t any = sparse_freq ? 0ull : ~0ull;
-  for (int s = 0; s < n_sets; ++s) {
-    const sai_params& ps = sets[s];
-    bool hit_y = true, hit_m = true;
-#pragma unroll
-    for (int k = 0; k < SAI_MAX_SRC; ++k) {
-      if (k < n_src) {
-        hit_y = hit_y && cmp_op(ps.op[k], f[2 + k], ps.y[k]);
-        hit_m = hit_m && cmp_op(ps.op[k], f[2 + k], ps.one_minus_y[k]);
-      }
-    }
-    const bool anc = ps.anc_allele_available != 0;
-    const bool inverted = !anc && hit_m && valid;
-    const bool hit = anc ? hit_y : (hit_y || hit_m);
-    const double rf = inverted ? 1.0 - f[0] : f[0];
-    const bool cond = valid && hit && (rf < ps.w);
+  // what a set leaves behind, whichever way its decision was taken
+  auto emit = [&](int s, bool cond, bool inverted) {
     const uint64_t bc = __ballot(cond);
     any |= bc;
-    row_word = lane == 1 + s ? bc : row_word;
+    row_lo = write_lane(static_cast<uint32_t>(bc), 1 + s, row_lo);
+    row_hi = write_lane(static_cast<uint32_t>(bc >> 32), 1 + s, row_hi);
     if (with_inv) {  // uniform
       const uint64_t bi = __ballot(inverted);
-      row_word = lane == 1 + n_sets + s ? bi : row_word;
+      row_lo = write_lane(static_cast<uint32_t>(bi), 1 + n_sets + s, row_lo);
+      row_hi = write_lane(static_cast<uint32_t>(bi >> 32), 1 + n_sets + s, row_hi);
     }
     if (adj_freq && live) {
-      adj_freq[(static_cast<int64_t>(s) * 2 + 0) * n_sites + site] = rf;
+      adj_freq[(static_cast<int64_t>(s) * 2 + 0) * n_sites + site] = inverted ? 1.0 - f[0] : f[0];
       adj_freq[(static_cast<int64_t>(s) * 2 + 1) * n_sites + site] = inverted ? 1.0 - f[1] : f[1];
     }
+  };
+  if (es.use_table) {  // uniform
+    // The table is read from the workgroup's LDS copy (stage_pred_table), not from the kernel arguments: next to
+    // the windows stage of the step before, a scalar load per comparison and set -- each waited for -- made a
+    // C5 pass 8 % slower than the set-by-set form, alone 2 % faster (profiles/r05_eval_cost.txt); LDS answers in
+    // the same time whatever else the chip is doing.  Every lane reads the same address; the values are made
+    // wave-uniform again with v_readfirstlane so that compares take them as scalars and branches stay scalar.
+    const PredTable& t = *lds_table;
+    uint32_t miss = ~0u;  // bit i DOWN = comparison i holds at this site
+    const int n_preds = __builtin_amdgcn_readfirstlane(t.n_preds);
+    PredEntry e = t.preds[0];
+    int cur_slot = -1;
+    double v = 0.0;
+    for (int i = 0; i < n_preds; ++i) {
+      const PredEntry next = t.preds[i + 1 < n_preds ? i + 1 : i];  // fetched while entry i is evaluated
+      const int slot = __builtin_amdgcn_readfirstlane(e.slot);
+      const int ob = __builtin_amdgcn_readfirstlane(e.op_bits);
+      const double y = uniform_f64(e.value);
+      if (slot != cur_slot) {  // uniform: the comparisons come sorted by value slot
+        cur_slot = slot;
+        v = 1.0 - f[0];
+#pragma unroll
+        for (int p = 0; p < kMaxPops; ++p) v = cur_slot == p ? f[p] : v;
+      }
+      bool holds;  // one compare per comparison, chosen by a scalar branch; its lane mask selects the bit
+      switch (ob) {
+        case 2: holds = v == y; break;
+        case 1: holds = v < y; break;
+        case 4: holds = v > y; break;
+        case 3: holds = v <= y; break;
+        default: holds = v >= y; break;
+      }
+      miss &= holds ? ~(1u << i) : ~0u;
+      e = next;
+    }
+    SetMasks m = t.sets[0];
+    for (int s = 0; s < n_sets; ++s) {
+      const SetMasks next = t.sets[s + 1 < n_sets ? s + 1 : s];
+      const uint32_t cond_mask = __builtin_amdgcn_readfirstlane(m.cond);
+      if (__builtin_amdgcn_readfirstlane(m.anc)) {
+        emit(s, valid && (miss & cond_mask) == 0u, false);
+      } else {
+        const bool mirrored = (miss & __builtin_amdgcn_readfirstlane(m.mirror)) == 0u;
+        const bool mirror_cond = (miss & __builtin_amdgcn_readfirstlane(m.mirror_cond)) == 0u;
+        emit(s, valid && (mirror_cond | (!mirrored & ((miss & cond_mask) == 0u))), mirrored && valid);
+      }
+      m = next;
+    }
+  } else {
+    for (int s = 0; s < n_sets; ++s) {
+      const sai_params& ps = es.sets[s];
+      bool hit_y = true, hit_m = true;
+#pragma unroll
+      for (int k = 0; k < SAI_MAX_SRC; ++k) {
+        if (k < n_src) {
+          hit_y = hit_y && cmp_op(ps.op[k], f[2 + k], ps.y[k]);
+          hit_m = hit_m && cmp_op(ps.op[k], f[2 + k], ps.one_minus_y[k]);
+        }
+      }
+      const bool anc = ps.anc_allele_available != 0;
+      const bool inverted = !anc && hit_m && valid;
+      const bool hit = anc ? hit_y : (hit_y || hit_m);
+      const double rf = inverted ? 1.0 - f[0] : f[0];
+      emit(s, valid && hit && (rf < ps.w), inverted);
+    }
   }
-  row_word = lane == 0 ? any : row_word;
+  row_lo = write_lane(static_cast<uint32_t>(any), 0, row_lo);
+  row_hi = write_lane(static_cast<uint32_t>(any >> 32), 0, row_hi);
   // non-temporal stores: measured on MI355X, plain stores in the middle of the genotype stream cost
   // twice as much of the pass as streaming ones
-  if (lane < 1 + (with_inv ? 2 : 1) * n_sets) __builtin_nontemporal_store(row_word, planes + tile * plane_stride + lane);
+  if (lane < 1 + (with_inv ? 2 : 1) * n_sets)
+    __builtin_nontemporal_store((static_cast<uint64_t>(row_hi) << 32) | row_lo, planes + tile * plane_stride + lane);
   // The windows stage reads tgt_freq only where a set's condition bit is up (about 1 site in 1000; one in
   // three for C5's loosest sets), and dense f64 stores in the middle of the genotype stream cost ~10 % of
   // the pass: SAI_FREQ_CANDIDATES stores those sites' values only, packed at the start of the tile's slots.
@@ -105,17 +303,18 @@ __device__ __forceinline__ void wave_lds_fence() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// parameter sets the fused tail of site_counts carries in its kernel arguments (20 x 152 B + the
-// rest stay below the 4 KiB kernarg segment)
+// parameter sets the fused tail of site_counts carries in its kernel arguments (20 x 152 B, or the
+// predicate table in their place, + the rest stay below the 4 KiB kernarg segment)
 constexpr int kFusedSets = SAI_FUSED_SETS;
 
 struct FusedArgs {
   int32_t n_sets;  // 0 = plain site_counts
   int16_t sparse_freq;
   int16_t with_inv;  // some set lacks ancestral alleles: the rows carry inverted words
+  int32_t pad;
   int32_t ploidy[kMaxPops];
   double* tgt_freq;
   uint64_t* planes;
   int64_t plane_stride;  // words per tile row
-  sai_params sets[kFusedSets];
+  EvalSets es;
 };

@@ -16,19 +16,22 @@ struct FlagArgs {
   uint64_t* planes;
   int64_t plane_stride;
   double* adj_freq;
-  sai_params sets[SAI_MAX_SETS];
+  EvalSets es;
 };
 static_assert(sizeof(FlagArgs) <= 4096, "kernel arguments exceed the kernarg segment");
 
 // one wavefront per tile (four per workgroup): lane = site inside the tile
 __global__ __launch_bounds__(256) void site_flags_kernel(FlagArgs a) {
+  __shared__ PredTable table;
+  stage_pred_table(a.es, &table);
+  __syncthreads();
   const int64_t site = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
   if ((site & ~int64_t{63}) >= a.n_sites) return;  // whole wavefronts beyond the last tile: there is no row for them
   const bool live = site < a.n_sites;              // the last tile's spare lanes vote 0
   eval_site(
       a.n_pops, a.ploidy,
       [&](int p) { return live ? a.counts[static_cast<int64_t>(p) * a.n_sites + site] : make_uint2(0u, 0u); }, a.n_sets,
-      a.sets, site >> 6, static_cast<int>(threadIdx.x & 63), live, a.n_sites, a.tgt_freq, a.planes, a.plane_stride,
+      a.es, &table, site >> 6, static_cast<int>(threadIdx.x & 63), live, a.n_sites, a.tgt_freq, a.planes, a.plane_stride,
       a.adj_freq, false, a.with_inv != 0);
 }
 
@@ -45,19 +48,6 @@ __global__ __launch_bounds__(256) void site_flags_kernel(FlagArgs a) {
 // flight per wave and 4 waves per SIMD hide HBM latency.
 // ------------------------------------------------------------------------------------------
 
-struct PopArg {
-  const int8_t* tiles;
-  int32_t n_ind;
-  int32_t pad;
-};
-
-struct CountsArgs {
-  int64_t n_sites;
-  int64_t n_tiles;
-  int32_t n_pops;
-  PopArg pop[kMaxPops];
-  uint2* counts;
-};
 static_assert(sizeof(CountsArgs) + sizeof(FusedArgs) <= 4096, "kernel arguments exceed the kernarg segment");
 
 // MULTI: some population has more than 16 * kChunkIters individuals, so the packed fields are
@@ -66,26 +56,25 @@ static_assert(sizeof(CountsArgs) + sizeof(FusedArgs) <= 4096, "kernel arguments 
 // The second launch bound keeps the usual form at 5 waves per SIMD (<= 96 VGPRs): four resident waves of
 // more than that leave the windows stage's waves no room next to the pass, and the pipelined step loses
 // what the overlap gives (measured at 99 VGPRs: C5 3.63 -> 3.79 ms per step).
-// LEAN: the same kernel held to 64 registers.  A pass with many parameter sets runs next to a windows stage
-// that is worth registers: four LEAN waves per SIMD leave half of the register file to the stage's waves,
-// and C5's pipelined step takes 3.15-3.19 ms with it at 16 waves per CU against 3.20-3.26 with three
-// 80-register waves (12 per CU) and 3.42-3.44 with four (profiles/r04_waves_per_cu.txt).  (Its first build
-// spilled five lane-derived loop invariants and was 4-5 % slower than the 80-register form when alone -- a
-// reload is a memory round trip behind the streaming loads; with the lane index re-taken per tile nothing
-// spills and the two forms are level alone: profiles/r04_lean_no_spill.txt.)
-template <bool MULTI, bool FUSED, bool LEAN = false>
-__global__ __launch_bounds__(64, MULTI ? 4 : (LEAN ? 8 : 5)) void site_counts_kernel(CountsArgs a, FusedArgs fa) {
+// (Round 4 also had a 64-register form for passes with many parameter sets, at 16 waves per CU.  With the
+// predicate table of site_eval.hpp the per-site decision no longer decides the grid: the usual form at 12
+// waves per CU gives C5's pipelined step 3.09 ms where that form gave 3.15 with the set-by-set decision and
+// 3.41 with the table -- profiles/r05_c5_grid.txt -- and the form is gone.)
+template <bool MULTI, bool FUSED>
+__global__ __launch_bounds__(64, MULTI ? 4 : 5) void site_counts_kernel(CountsArgs a, FusedArgs fa) {
   // FUSED: the butterfly leaves lane l with site (l%4)*16 + l/4 of the tile; each lane parks those
   // {alt_sum, n_called} per population in LDS AT ITS SITE'S INDEX, and once all populations of the
   // tile are done lane l takes site l back and evaluates the parameter sets for it -- lanes in site
   // order, so the ballots per set are the tile's flag planes and the candidates' tgt_freq leave packed
   __shared__ uint2 stash[FUSED ? kMaxPops : 1][FUSED ? 64 : 1];
+  __shared__ uint32_t table_words[FUSED ? sizeof(PredTable) / 4 : 1];
+  PredTable* table = reinterpret_cast<PredTable*>(table_words);
+  if (FUSED) {
+    stage_pred_table(fa.es, table);
+    wave_lds_fence();
+  }
   for (int64_t tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
-    // LEAN: the lane index is taken anew per tile, so that nothing derived from it (lane masks, shuffle
-    // addresses, per-lane base offsets) lives across tiles -- hoisted, those values were what spilled, and
-    // each reload is a memory round trip behind the chip's streaming loads
-    int lane = threadIdx.x;
-    if (LEAN) asm volatile("" : "+v"(lane));
+    const int lane = threadIdx.x;
     const int r = lane >> 2;
     for (int p = 0; p < a.n_pops; ++p) {
       const int n_ind = a.pop[p].n_ind;
@@ -126,7 +115,7 @@ __global__ __launch_bounds__(64, MULTI ? 4 : (LEAN ? 8 : 5)) void site_counts_ke
     if (FUSED) {
       wave_lds_fence();
       eval_site(
-          a.n_pops, fa.ploidy, [&](int p) { return stash[p][lane]; }, fa.n_sets, fa.sets, tile, lane,
+          a.n_pops, fa.ploidy, [&](int p) { return stash[p][lane]; }, fa.n_sets, fa.es, table, tile, lane,
           tile * kTile + lane < a.n_sites, a.n_sites, fa.tgt_freq, fa.planes, fa.plane_stride, nullptr,
           fa.sparse_freq != 0, fa.with_inv != 0);
       wave_lds_fence();  // the next tile's counts must not overtake these reads
@@ -194,15 +183,13 @@ static int launch_site_counts(sai_ctx* ctx, int64_t n_sites, int32_t n_pops, con
   fa.tgt_freq = tgt_freq;
   fa.planes = planes;
   fa.plane_stride = plane_stride;
-  for (int s = 0; s < n_sets; ++s) fa.sets[s] = sets_host[s];
-  const bool lean = !multi && n_sets >= lean_sets();
+  if (n_sets > 0) fill_eval_sets(fa.es, n_sets, sets_host, n_pops - 2);
   int64_t individuals = 0;
   for (int p = 0; p < n_pops; ++p) individuals += pops[p].n_ind;
-  const dim3 grid(stream_grid(ctx, a.n_tiles, lean ? kStreamWavesPerCu : site_pass_waves_per_cu(ctx, a.n_tiles, n_sets, n_pops, individuals)));
+  const dim3 grid(stream_grid(ctx, a.n_tiles, site_pass_waves_per_cu(ctx, a.n_tiles, n_sets, n_pops, individuals)));
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (n_sets > 0) {
     if (multi) launch_pass(ctx, site_counts_kernel<true, true>, grid, dim3(64), st, a, fa);
-    else if (lean) launch_pass(ctx, site_counts_kernel<false, true, true>, grid, dim3(64), st, a, fa);
     else launch_pass(ctx, site_counts_kernel<false, true>, grid, dim3(64), st, a, fa);
   } else {
     if (multi) launch_pass(ctx, site_counts_kernel<true, false>, grid, dim3(64), st, a, fa);
@@ -269,7 +256,7 @@ int sai_site_flags(sai_ctx* ctx, int64_t n_sites, int32_t n_pops, const int32_t*
   a.planes = planes;
   a.plane_stride = plane_stride;
   a.adj_freq = adj_freq;
-  for (int s = 0; s < n_sets; ++s) a.sets[s] = sets_host[s];
+  fill_eval_sets(a.es, n_sets, sets_host, n_pops - 2);
   const unsigned grid = static_cast<unsigned>((n_sites + 255) / 256);
   hipLaunchKernelGGL(site_flags_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), a);
   return check_launch("site_flags");

@@ -4,6 +4,20 @@
 
 #include "common.hpp"
 
+// kernel arguments of the int8 site pass (site_pass.hip, site_pass_dd.hip)
+struct PopArg {
+  const int8_t* tiles;
+  int32_t n_ind;
+  int32_t pad;
+};
+
+struct CountsArgs {
+  int64_t n_sites;
+  int64_t n_tiles;
+  int32_t n_pops;
+  PopArg pop[kMaxPops];
+  uint2* counts;
+};
 __device__ __forceinline__ void store_counts_nt(uint2* dst, uint2 v) {
   __builtin_nontemporal_store(u32x2{v.x, v.y}, reinterpret_cast<u32x2*>(dst));
 }

@@ -39,6 +39,10 @@ def init_process_group(backend: Optional[str] = None, force: bool = False) -> tu
 
     global _STATUS_GROUP
     rank, local_rank, world = env_rank_world()
+    # the host driver of the MI355X pool only supports dmabuf IPC (RCCL's set-up fails with `hipIpcGetMemHandle:
+    # invalid argument` otherwise): the rank launcher sets this for its children, a rank started by any other
+    # launcher gets it here -- read when HIP initialises, i.e. it must be in place before the first GPU call
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if (world > 1 or force) and not dist.is_initialized():
         if backend is None:  # SAI_AMD_DIST_BACKEND=gloo: several ranks on one GPU (tests, rehearsals)
             backend = os.environ.get("SAI_AMD_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")

@@ -211,12 +211,27 @@ class Plan:
         self._keep.append(counts)
         _ffi.check(e.lib.sai_plan_add_site_counts(self._h, pops[0].n_sites, len(pops), self._pops(pops, None, False), e._ptr(counts)))
 
-    def add_site_pass(self, pops, ploidies, sets, out, counts=None, freq_mode="dense", packed2=False) -> None:
-        """``Engine.site_pass`` / ``site_pass_packed2`` (``packed2=True``; ``sets == []`` = counts only)."""
+    def add_site_pass(self, pops, ploidies, sets, out, counts=None, freq_mode="dense", packed2=False, dd=None) -> None:
+        """``Engine.site_pass`` / ``site_pass_packed2`` (``packed2=True``; ``sets == []`` = counts only);
+        ``dd = (first source population, number of them, int32 tensor [2][rows][n_sites])``: DD's per-site
+        terms ride along (``Engine.site_pass_dd``)."""
         e = self.eng
         n_sites = pops[0].n_sites
         pl_ptr, pl_stride = e._planes_arg(out[1], len(sets), n_sites) if sets else (None, PLANES * len(sets))
         self._keep.extend([t for t in (out or ()) if t is not None] + ([counts] if counts is not None else []))
+        if dd is not None:
+            if packed2:
+                raise ValueError("DD rides along the int8 pass only")
+            rows = e._dd_rows(pops, dd)
+            self._keep.append(dd[2])
+            _ffi.check(
+                e.lib.sai_plan_add_site_pass_dd(
+                    self._h, n_sites, len(pops), self._pops(pops, ploidies, False), e._ptr(counts) if counts is not None else None,
+                    len(sets), e._params_array(sets) if sets else None, _ffi.FREQ_MODES[freq_mode],
+                    e._ptr(out[0]) if sets else None, pl_ptr, pl_stride, C.byref(rows),
+                )
+            )  # fmt: skip
+            return
         _ffi.check(
             e.lib.sai_plan_add_site_pass(
                 self._h, n_sites, len(pops), self._pops(pops, ploidies, packed2), e._ptr(counts) if counts is not None else None,
@@ -299,8 +314,10 @@ class Engine:
         _ffi.check(self.lib.sai_ctx_create(self.device_index, C.byref(ctx)))
         self.ctx = ctx
         self._tile_cache = None  # {id(matrix): (matrix, TiledPop)} while an upload_scope is open
+        self._window_scope = None  # {"hints": ..., "results": ...} of the open upload_scope (stats/_window.py)
         self._scope_depth = 0
         self._staging = None  # pinned int8 buffer the host matrices are narrowed into
+        self._staging_busy = None  # event behind the last H2D copies out of it
         self._pinned_free: dict[int, list] = {}  # capacity -> [(pinned uint8 tensor, [events])]
 
     def close(self) -> None:
@@ -311,6 +328,14 @@ class Engine:
             Engine._cache.pop(self.device_index, None)
 
     # -- helpers ---------------------------------------------------------------------------
+
+    def identity(self) -> dict:
+        """Which physical GPU this engine computes on: device index, PCI bus id, UUID, name -- what a
+        multi-GPU record carries per rank (sai_device_identity)."""
+        bus, uuid = C.create_string_buffer(32), C.create_string_buffer(40)
+        _ffi.check(self.lib.sai_device_identity(self.device_index, bus, 32, uuid, 40))
+        return {"device_index": self.device_index, "pci_bus_id": bus.value.decode(), "uuid": uuid.value.decode(),
+                "name": _torch().cuda.get_device_name(self.device_index)}  # fmt: skip
 
     def _stream(self):
         return C.c_void_p(_torch().cuda.current_stream(self.device).cuda_stream)
@@ -383,17 +408,20 @@ class Engine:
 
     # -- layout ----------------------------------------------------------------------------
 
-    def upload_scope(self):
+    def upload_scope(self, hints=None):
         """Context manager: inside it, a host matrix handed to ``tile`` more than once (the same
         object: FeaturePreprocessor.run passes one window's matrices to every configured statistic)
         is narrowed, uploaded and re-tiled ONCE.  The caller promises not to modify the matrices
-        while the scope is open; nothing is remembered after it closes."""
+        while the scope is open; nothing is remembered after it closes.  ``hints`` = {(ploidies, w, y_list,
+        anc): {"x": ..., "quantile": ...}}: which U and Q thresholds of the window belong to one parameter set,
+        so that the two statistics share ONE device call (stats/_window.py)."""
         import contextlib
 
         @contextlib.contextmanager
         def scope():
             if self._scope_depth == 0:
                 self._tile_cache = {}
+                self._window_scope = {"hints": dict(hints or {}), "results": {}}
             self._scope_depth += 1
             try:
                 yield self
@@ -401,8 +429,12 @@ class Engine:
                 self._scope_depth -= 1
                 if self._scope_depth == 0:
                     self._tile_cache = None
+                    self._window_scope = None
 
         return scope()
+
+    def window_scope(self):
+        return self._window_scope
 
     def _stage_host(self, g: np.ndarray, offset: int):
         """Narrow a host matrix to int8 [sites][individuals] straight into the engine's pinned
@@ -453,6 +485,12 @@ class Engine:
         if not host:
             return out
         total = sum(int(g.size) for _, g in host)
+        # the staging buffer must not be rewritten before the copies of the call before have left it: an event
+        # behind them is waited for HERE -- by then it has long passed -- instead of a stream synchronisation at
+        # the end of every call (one host wait less per window of the per-window route)
+        if self._staging_busy is not None:
+            self._staging_busy.synchronize()
+            self._staging_busy = None
         if self._staging is None or self._staging.numel() < total:
             self._staging = torch.empty((max(int(total * 1.25), 1 << 20),), dtype=torch.int8).pin_memory()
         offset, staged = 0, False
@@ -468,7 +506,8 @@ class Engine:
             if cache is not None:
                 cache[id(mats[i])] = (mats[i], out[i])  # holding the matrix keeps its id from being reused
         if staged:
-            torch.cuda.current_stream(self.device).synchronize()
+            self._staging_busy = torch.cuda.Event()
+            self._staging_busy.record(torch.cuda.current_stream(self.device))
         return out
 
     def tile_columns(self, block, cols: Sequence[int]) -> TiledPop:
@@ -644,6 +683,52 @@ class Engine:
             )
         )  # fmt: skip
         return out
+
+    @staticmethod
+    def dd_rides_along(pops: Sequence[TiledPop], first: int, n_src_pops: int) -> bool:
+        """Whether ``site_pass_dd`` serves these populations: at most SAI_DD_FUSED_ROWS source individuals in all."""
+        rows = sum(p.n_ind for p in pops[first : first + n_src_pops])
+        return 1 <= rows <= _ffi.SAI_DD_FUSED_ROWS
+
+    def _dd_rows(self, pops, dd) -> "_ffi.SaiDdRows":
+        first, n_src_pops, out = dd
+        rows = sum(p.n_ind for p in pops[first : first + n_src_pops])
+        if tuple(out.shape) != (2, rows, pops[0].n_sites) or out.element_size() != 4 or not out.is_contiguous():
+            raise ValueError(f"DD terms go to a contiguous int32 tensor [2][{rows}][{pops[0].n_sites}]")
+        r = _ffi.SaiDdRows()
+        r.first_pop, r.n_pops, r.absdiff = int(first), int(n_src_pops), out.data_ptr() if out.numel() else 0
+        return r
+
+    def site_pass_dd(self, pops: Sequence[TiledPop], ploidies: Sequence[int], sets: Sequence[_ffi.SaiParams], first_src: int,
+                     n_src_pops: int, out=None, counts=None, freq_mode: str = "dense", absdiff=None):
+        """``site_pass`` with DD's per-site terms riding along (sai_site_pass_dd): returns (out, absdiff) with
+        absdiff = int32 [2][rows][n_sites] -- [0] against ``pops[0]``, [1] against ``pops[1]``, row = the
+        individuals of ``pops[first_src : first_src + n_src_pops]`` in order.  ``sets == []``: counts (``counts``
+        must be given) and DD only; the populations behind tgt are then merely counted."""
+        torch = _torch()
+        n_sites = pops[0].n_sites
+        if any(p.n_sites != n_sites for p in pops):
+            raise ValueError("all populations of one call must cover the same sites")
+        arr = (_ffi.SaiPop * len(pops))()
+        for i, p in enumerate(pops):
+            arr[i].tiles = p.tiles.data_ptr() if p.tiles.numel() else 0
+            arr[i].n_ind = p.n_ind
+            arr[i].ploidy = int(ploidies[i]) if ploidies is not None else 1
+        if out is None and sets:
+            out = self._pass_out(n_sites, len(sets), freq_mode)
+        rows = sum(p.n_ind for p in pops[first_src : first_src + n_src_pops])
+        if absdiff is None:
+            absdiff = self._empty((2, rows, n_sites), torch.int32)
+        dd = self._dd_rows(pops, (first_src, n_src_pops, absdiff))
+        pl_ptr, pl_stride = self._planes_arg(out[1], len(sets), n_sites) if sets else (None, PLANES * len(sets))
+        _ffi.check(
+            self.lib.sai_site_pass_dd(
+                self.ctx, n_sites, len(pops), arr, self._ptr(counts) if counts is not None else None, len(sets),
+                self._params_array(sets) if sets else None, _ffi.FREQ_MODES[freq_mode], self._ptr(out[0]) if sets else None,
+                pl_ptr, pl_stride, C.byref(dd), self._stream(),
+            )
+        )  # fmt: skip
+        return out, absdiff
 
     def pack2(self, pop: TiledPop) -> PackedPop:
         """Re-encode a tiled int8 block (dosages 0..2, negative = missing) as packed2.  Raises if a

@@ -13,7 +13,6 @@ library context -- and the child is started with ``subprocess``, never exec'd ov
 from __future__ import annotations
 
 import os
-import socket
 import subprocess
 import sys
 from pathlib import Path
@@ -59,20 +58,17 @@ def chunks_per_worker() -> int:
     return n
 
 
-def free_port() -> int:
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        return s.getsockname()[1]
-
-
 def rank_command(n_ranks: int, argv: Sequence[str], module: Optional[str] = None, script: Optional[str] = None,
                  port: Optional[int] = None) -> list:  # fmt: skip
-    """The child job's command line: ``-m module`` or a script path, followed by ``argv``."""
+    """The child job's command line: ``-m module`` or a script path, followed by ``argv``.  Without a ``port``
+    the job is a stand-alone one on 127.0.0.1: torchrun's own store binds a free port itself, so two launches at
+    the same moment cannot be handed the same port (probing for a free one and closing the probe could)."""
     if (module is None) == (script is None):
         raise ValueError("exactly one of module / script names what the ranks run")
     target = ["-m", module] if module is not None else [str(script)]
-    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={int(n_ranks)}",
-            "--master-addr", "127.0.0.1", "--master-port", str(port or free_port()), *target, *map(str, argv)]  # fmt: skip
+    where = ["--master-addr", "127.0.0.1", "--master-port", str(port)] if port else ["--standalone", "--local-addr", "127.0.0.1"]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={int(n_ranks)}", *where, *target,
+            *map(str, argv)]  # fmt: skip
 
 
 def launch_ranks(n_ranks: int, argv: Sequence[str], module: Optional[str] = None, script: Optional[str] = None,

@@ -10,7 +10,20 @@ from ..sai import score
 from .argument_validation import existed_file, positive_int
 
 
+def resolve_workers(args: argparse.Namespace) -> int:
+    """``--num-workers``, else $SAI_AMD_GPUS, else 1 (the reference's CLI, score_parser.py:64).  The environment is
+    read when `score` runs, not while the parser is built: a malformed value is `sai score`'s usage error only,
+    never a traceback from `sai --help` or another sub-command."""
+    if args.num_workers is None:
+        try:
+            args.num_workers = workers_from_env()
+        except ValueError:
+            args.score_parser.error("SAI_AMD_GPUS must be a positive integer")
+    return args.num_workers
+
+
 def _run_score(args: argparse.Namespace) -> None:
+    resolve_workers(args)
     score(
         vcf_file=args.vcf,
         chr_name=args.chr_name,
@@ -41,6 +54,6 @@ def add_score_parser(subparsers) -> None:
                         "settings, and population group file paths.")  # fmt: skip
     # not a flag of the reference, whose CLI passes num_workers=1 (score_parser.py:64): the number of GPUs,
     # one worker process each (sai.py:42); the default, 1, is the reference's behaviour
-    parser.add_argument("--num-workers", dest="num_workers", type=positive_int, default=workers_from_env(),
+    parser.add_argument("--num-workers", dest="num_workers", type=positive_int, default=None,
                         help="Number of GPUs to use, one worker process per GPU. Default: $SAI_AMD_GPUS, else 1.")  # fmt: skip
-    parser.set_defaults(runner=_run_score)
+    parser.set_defaults(runner=_run_score, score_parser=parser)

@@ -186,8 +186,20 @@ class FeaturePreprocessor(DataPreprocessor):
             return [item]
         from ..engine import Engine
 
-        # one upload of the window's matrices serves every configured statistic
-        with Engine.get().upload_scope():
+        # one upload of the window's matrices serves every configured statistic, and U and Q of one parameter set
+        # are one device call (a record carries both): the scope is told which thresholds go together
+        hints = {}
+        try:
+            pl = (ploidy_config.get_ploidy("ref", ref_pop), ploidy_config.get_ploidy("tgt", tgt_pop), *ploidy_config.get_ploidy("src"))
+            for name in names:
+                if name in _HIP_STATS:
+                    kw = self._stat_kwargs(name, ref_pop, tgt_pop)
+                    key = (tuple(int(p) for p in pl[: 2 + len(src_gts_list)]), float(kw["w"]),
+                           tuple((op, float(y)) for op, y in kw["y_list"]), bool(kw["anc_allele_available"]))  # fmt: skip
+                    hints.setdefault(key, {})["x" if name == "U" else "quantile"] = float(kw["x"] if name == "U" else kw["quantile"])
+        except (KeyError, TypeError, ValueError):  # whatever is wrong with the configuration is the statistics' to report
+            hints = {}
+        with Engine.get().upload_scope(hints):
             self._run_statistics(item, names, ref_pop, tgt_pop, pos, ref_gts, tgt_gts, src_gts_list, out_gts, out_pop,
                                  ploidy_config)  # fmt: skip
         return [item]
@@ -315,6 +327,25 @@ class FeaturePreprocessor(DataPreprocessor):
             uq_keys = [("ref", ref_pop), ("tgt", tgt_pop)] + [("src", s) for s in src_comb[:n_eff]]
             lo = hi = None
             segs = al.segments  # one piece per window: populations with different unsorted position arrays
+            # DD's per-site terms ride along a pass over ref and tgt that is needed anyway (Engine.site_pass_dd):
+            # the scorer's fused pass, or the counts pass of the combination's blocks -- the genotypes are then
+            # read once, not once more per two source individuals (dd_statistic.py:60-77)
+            dd_keys = [("ref", ref_pop), ("tgt", tgt_pop)] + [("src", s) for s in src_comb]
+            dd_terms = None
+            dd_along = want_dd and eng.dd_rides_along([tiled[k] for k in dd_keys], 2, len(src_comb))
+            if dd_along:
+                rows = sum(tiled[k].n_ind for k in dd_keys[2:])
+                dd_terms = torch.empty((2, rows, n_sites), dtype=torch.int32, device=eng.device)
+            dd_in_scorer = dd_along and bool(uq_names) and not shared and n_eff == len(src_comb)
+            if dd_along and not dd_in_scorer:
+                keys = list(dd_keys)
+                if four_names and out_pop is not None:
+                    keys.append(("outgroup", out_pop))
+                c = torch.empty((len(keys), n_sites, 2), dtype=torch.int32, device=eng.device) if shared else None
+                eng.site_pass_dd([tiled[k] for k in keys], None, [], 2, len(src_comb), counts=c, absdiff=dd_terms)
+                if shared:
+                    for j, k in enumerate(keys):
+                        counts_rows.setdefault(k, c[j])
             if uq_names:
                 block = ResidentBlock([tiled[k] for k in uq_keys], ploidy[: 2 + n_eff], pos_dev,
                                       segments=None if segs is None else [tuple(map(int, sg)) for sg in segs])  # fmt: skip
@@ -322,14 +353,17 @@ class FeaturePreprocessor(DataPreprocessor):
                 # region -- and the next call on the same generator: only its launch sequences are re-recorded
                 key = (tgt_pop, n_sites, len(sets)) if segs is None else (tgt_pop, n_sites, len(sets), tuple(al.keys))
                 as_indices = al.uniq is not None or al.file_order is not None
+                dd_arg = (2, len(src_comb), dd_terms) if dd_in_scorer else None
                 scorer = scorers.get(key)
                 if scorer is None:
                     scorer = scorers[key] = ResidentScorer(eng, block, windows, sets, cap_u=1 << 16, cap_q=1 << 16,
                                                            counts_in=counts_of(uq_keys) if shared else None,
                                                            lists_as_indices=as_indices, fetch_lists=1 << 16,
-                                                           window_segment=None if segs is None else np.arange(len(segs)))  # fmt: skip
+                                                           window_segment=None if segs is None else np.arange(len(segs)),
+                                                           dd_out=dd_arg)  # fmt: skip
                 else:
-                    scorer.rebind(block, sets, counts_of(uq_keys) if shared else None, lists_as_indices=as_indices)
+                    scorer.rebind(block, sets, counts_of(uq_keys) if shared else None, lists_as_indices=as_indices,
+                                  dd_out=dd_arg)  # fmt: skip
                 scorer.step()
                 cb.uq = _rows_per_statistic(scorer.results(grow=True), set_of)
                 lo, hi = scorer.lo, scorer.hi
@@ -359,7 +393,16 @@ class FeaturePreprocessor(DataPreprocessor):
                     _check_ploidy(p)
                 freqs = eng.site_freqs(counts_of(keys), pl4)
                 cb.four = eng.window_fourpop(freqs, len(src_comb), out_pop is not None, lo, hi).cpu().numpy()
-            if want_dd:  # per source population: two streaming passes per pair of its individuals
+            if dd_terms is not None:  # the terms came with the pass: only the window sums are left
+                ref_t, tgt_t = tiled[("ref", ref_pop)], tiled[("tgt", tgt_pop)]
+                cols, row = [], 0
+                for s in src_comb:
+                    n = tiled[("src", s)].n_ind
+                    cols.append(eng.window_dd(dd_terms[0, row : row + n], ref_t.n_ind, dd_terms[1, row : row + n], tgt_t.n_ind,
+                                              lo, hi).cpu().numpy())  # fmt: skip
+                    row += n
+                cb.dd = np.stack(cols, axis=1)
+            elif want_dd:  # more source individuals than ride along: two streaming passes per pair of them
                 ref_t, tgt_t = tiled[("ref", ref_pop)], tiled[("tgt", tgt_pop)]
                 cb.dd = np.stack(
                     [

@@ -133,7 +133,7 @@ class ResidentScorer:
     def __init__(self, eng: Engine, block: ResidentBlock, windows: Sequence[tuple], sets: Sequence[_ffi.SaiParams],
                  cap_u: int = 1 << 20, cap_q: int = 1 << 20, layout: str = "int8", overlap: bool = False,
                  window_segment: Optional[Sequence[int]] = None, counts_out=None, counts_in=None,
-                 lists_as_indices: bool = False, fetch_lists: int = 0):  # fmt: skip
+                 lists_as_indices: bool = False, fetch_lists: int = 0, dd_out=None):  # fmt: skip
         """``windows`` = inclusive ``(start, end)`` position pairs; for a block of several pieces
         ``window_segment[w]`` is the index into ``block.segments`` of the piece window w lies in.
 
@@ -152,7 +152,10 @@ class ResidentScorer:
         genotype byte is read.  ``lists_as_indices``: the candidate lists hold block-relative
         site indices instead of positions.  ``fetch_lists`` = n: every step also copies the first n
         entries of both candidate lists to pinned host memory with the records, and ``results()`` needs
-        no second round trip when the lists are that short (the product path; bench.py's steps gather rows)."""
+        no second round trip when the lists are that short (the product path; bench.py's steps gather rows).
+        ``dd_out`` = (index of the first source population, number of them, int32 device tensor [2][rows][n_sites]):
+        DD's per-site terms of those populations' individuals ride along the fused pass (``Engine.site_pass_dd``;
+        the caller has asked ``Engine.dd_rides_along``)."""
         import torch
 
         self.fetch_lists = int(fetch_lists)
@@ -192,6 +195,9 @@ class ResidentScorer:
             raise ValueError("counts_in excludes counts_out and the packed2 layout")
         self.have_counts = counts_in is not None
         self.fused = n_s <= _ffi.SAI_FUSED_SETS and not self.have_counts
+        if dd_out is not None and (not self.fused or layout != "int8"):
+            raise ValueError("DD rides along the fused int8 pass only")
+        self.dd_out = dd_out
         self.counts_out = counts_out
         self.counts = counts_in if self.have_counts else counts_out
         if self.counts is None and not self.fused:
@@ -240,7 +246,7 @@ class ResidentScorer:
         self._build_stage_plans()
 
     def rebind(self, block: ResidentBlock, sets: Sequence[_ffi.SaiParams], counts_in=None,
-               lists_as_indices: bool = False) -> None:
+               lists_as_indices: bool = False, dd_out=None) -> None:
         """Point this scorer at another block over the SAME sites and windows -- the next population
         combination of a region, or the same one again -- and other parameter sets of the same number:
         the per-site arrays, the window arrays on the device, the candidate buffers and their pinned
@@ -253,7 +259,9 @@ class ResidentScorer:
             raise ValueError("rebind needs a block of the same number of sites and as many parameter sets")
         if (block.segments is None) != (self.block.segments is None) or (block.segments is not None and block.segments != self.block.segments):
             raise ValueError("rebind needs the same chromosome pieces")
-        signature = self._binding_signature(block, sets, counts_in, lists_as_indices)
+        if dd_out is not None and (counts_in is not None or self.n_sets > _ffi.SAI_FUSED_SETS):
+            raise ValueError("DD rides along the fused int8 pass only")
+        signature = self._binding_signature(block, sets, counts_in, lists_as_indices, dd_out)
         if signature == getattr(self, "_bound", None):
             # the very same buffers and parameters as the launch sequences in hand were recorded for (the same
             # region scored again): nothing to wait for, nothing to record
@@ -264,6 +272,7 @@ class ResidentScorer:
         self.block, self.sets = block, list(sets)
         self.have_counts = counts_in is not None
         self.fused = self.n_sets <= _ffi.SAI_FUSED_SETS and not self.have_counts
+        self.dd_out = dd_out
         self.counts = counts_in
         if self.counts is None and not self.fused:
             import torch
@@ -274,15 +283,16 @@ class ResidentScorer:
         self._build_stage_plans()
 
     @staticmethod
-    def _binding_signature(block, sets, counts_in, lists_as_indices):
+    def _binding_signature(block, sets, counts_in, lists_as_indices, dd_out=None):
         """What the prepared launch sequences depend on: where the blocks and positions lie, the ploidies, the
-        parameter sets byte for byte, the counts handed in, positions or indices in the lists."""
+        parameter sets byte for byte, the counts handed in, positions or indices in the lists, where DD's terms go."""
         import ctypes as C
 
         return (
             tuple((p.tiles.data_ptr(), p.n_sites, p.n_ind) for p in block.pops), tuple(block.ploidies), block.pos.data_ptr(),
             tuple(bytes(C.string_at(C.addressof(ps), C.sizeof(ps))) for ps in sets),
             None if counts_in is None else counts_in.data_ptr(), bool(lists_as_indices),
+            None if dd_out is None else (dd_out[0], dd_out[1], dd_out[2].data_ptr()),
         )  # fmt: skip
 
     # A step's launches are recorded once per buffer set as prepared sequences (Engine.plan): the
@@ -303,7 +313,8 @@ class ResidentScorer:
                     cp.add_site_pass(self.packed, blk.ploidies, [], None, counts=self.counts, packed2=True)
             elif self.fused:
                 cp = eng.plan()
-                cp.add_site_pass(blk.pops, blk.ploidies, self.sets, out, counts=self.counts_out, freq_mode="candidates")
+                cp.add_site_pass(blk.pops, blk.ploidies, self.sets, out, counts=self.counts_out, freq_mode="candidates",
+                                 dd=self.dd_out)  # fmt: skip
             elif not self.have_counts:
                 cp = eng.plan()
                 cp.add_site_counts(blk.pops, self.counts)

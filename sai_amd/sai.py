@@ -94,10 +94,30 @@ def _reads_in_one_pass(vcf_file: str) -> bool:
         return False
 
 
+def _is_device_failure(exc: BaseException) -> bool:
+    """A HIP call, the device or its memory failed -- anywhere in the exception's chain (the readers wrap what
+    they meet in the reference's ``ValueError("Failed to read VCF file ...")``, utils.py:139-140)."""
+    from . import _ffi
+
+    seen = set()
+    while exc is not None and id(exc) not in seen:
+        seen.add(id(exc))
+        if isinstance(exc, _ffi.SaiHipError) and exc.status in (_ffi.SAI_ERR_HIP, _ffi.SAI_ERR_NO_DEVICE):
+            return True
+        if isinstance(exc, MemoryError) or type(exc).__name__ in ("OutOfMemoryError", "AcceleratorError"):
+            return True
+        if isinstance(exc, RuntimeError) and not isinstance(exc, _ffi.SaiHipError) and ("HIP error" in str(exc) or "hip" in str(exc)[:200].lower()):
+            return True
+        exc = exc.__cause__ or exc.__context__
+    return False
+
+
 def _scan_while_reading(driver: ChunkPreprocessor, vcf_file: str, chr_name: str):
     """((first, last) of the scan, what ``ChunkPreprocessor.preload`` read meanwhile or None).  The scan's
     answer decides: a chromosome it does not find is reported as ``ChunkGenerator`` reports it, and a
-    read that failed is left to be repeated -- and to fail with its own message -- in the usual order."""
+    read that failed over the FILE (a malformed line, an unknown sample, no ancestral allele ...) is left to be
+    repeated -- and to fail with its own message -- in the usual order.  A failure of the device is not: it is
+    raised here, by the call that met it, not after a second full read."""
     from concurrent.futures import ThreadPoolExecutor
 
     from .utils.native_vcf import scan_first_last
@@ -106,10 +126,43 @@ def _scan_while_reading(driver: ChunkPreprocessor, vcf_file: str, chr_name: str)
         scan = pool.submit(scan_first_last, vcf_file, chr_name)  # host threads inside libsaihip; the GIL is released
         try:
             preloaded = driver.preload(chr_name)
-        except Exception:  # noqa: BLE001 -- repeated by run_compact without the preload
+        except Exception as exc:  # noqa: BLE001 -- a file-level error: repeated by run_compact without the preload
+            if _is_device_failure(exc):
+                scan.result()
+                raise
             preloaded = None
         span = scan.result()
     return span, preloaded
+
+
+def chunks_for_memory(vcf_file: str) -> int:
+    """How many ChunkGenerator chunks a one-process `score` cuts the chromosome into so that a chunk's genotypes
+    fit the GPU: 1 (the reference's one-process form, sai.py:86-93 with one worker) unless the file promises more
+    int8 genotype bytes than the budget -- then ceil(bytes / budget), the grain the sharded route already uses
+    (chunk_generator.py:111-142), chunk after chunk through the same GPU, the output files byte-identical.
+    The estimate is the file's: a genotype is about four bytes of VCF text ("0|1" + tab; bgzip shrinks genotype
+    text about twelvefold), of which one int8 dosage stays resident -- besides the reader's staging and the tiled
+    copy per population, hence a budget of a quarter of the free HBM.  ``SAI_AMD_HBM_BUDGET_BYTES`` overrides it."""
+    try:
+        size = os.path.getsize(vcf_file)
+    except OSError:
+        return 1
+    resident = size * 3 if str(vcf_file).endswith((".gz", ".bgz")) else size // 4
+    raw = os.environ.get("SAI_AMD_HBM_BUDGET_BYTES", "")
+    if raw:
+        budget = int(raw)
+        if budget < 1:
+            raise ValueError("SAI_AMD_HBM_BUDGET_BYTES must be a positive integer")
+    else:
+        try:
+            import torch
+
+            if not torch.cuda.is_available():
+                return 1
+            budget = torch.cuda.mem_get_info()[0] // 4
+        except (ImportError, RuntimeError):
+            return 1
+    return max(1, -(-resident // max(budget, 1)))
 
 
 def _score_over_ranks(vcf_file, chr_name, win_len, win_step, anc_allele_file, output_file, config) -> None:
@@ -167,10 +220,11 @@ def score(vcf_file: str, chr_name: str, win_len: int, win_step: int, anc_allele_
     require_polarised_input(cfg.statistics, anc_allele_file)
     driver = chunk_preprocessor_for(cfg, vcf_file, win_len, win_step, output_file, anc_allele_file)
     span, preloaded = None, None
-    if _reads_in_one_pass(vcf_file):
+    n_chunks = chunks_for_memory(vcf_file)  # 1 unless the chromosome's genotypes would not fit the GPU at once
+    if n_chunks == 1 and _reads_in_one_pass(vcf_file):
         span, preloaded = _scan_while_reading(driver, vcf_file, str(chr_name))
-    chunks = ChunkGenerator(vcf_file=vcf_file, chr_name=chr_name, window_size=win_len, step_size=win_step, num_chunks=1,
-                            span=span)  # fmt: skip
+    chunks = ChunkGenerator(vcf_file=vcf_file, chr_name=chr_name, window_size=win_len, step_size=win_step,
+                            num_chunks=n_chunks, span=span)  # fmt: skip
     write_headers(output_file, cfg.statistics, cfg.ploidies)
     # numeric batches -> text, natively; the item-dictionary route (driver.run + process_items)
     # writes the same bytes and stays what plug-ins and the sharded executors use

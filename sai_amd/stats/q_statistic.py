@@ -24,7 +24,7 @@ class QStatistic(GenericStatistic):
             raise ValueError(f"Missing required argument(s): {', '.join(missing)}")
         pos = kwargs["pos"]
         rec, _, idx_q = run_single_window(
-            self, kwargs["w"], 0.0, kwargs["quantile"], kwargs["y_list"], kwargs["anc_allele_available"]
+            self, kwargs["w"], None, kwargs["quantile"], kwargs["y_list"], kwargs["anc_allele_available"]
         )
         if len(pos) != int(rec["n_sites"]):
             # the reference's `pos[condition]` (q_statistic.py:93) with a boolean mask over the matrix rows:

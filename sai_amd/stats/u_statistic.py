@@ -22,7 +22,7 @@ class UStatistic(GenericStatistic):
             raise ValueError(f"Missing required argument(s): {', '.join(missing)}")
         pos = kwargs["pos"]
         rec, idx_u, _ = run_single_window(
-            self, kwargs["w"], kwargs["x"], 0.5, kwargs["y_list"], kwargs["anc_allele_available"]
+            self, kwargs["w"], kwargs["x"], None, kwargs["y_list"], kwargs["anc_allele_available"]
         )
         # u_statistic.py:94-99: positions of the counted sites, count as a Python int
         return {"name": self.STAT_NAME, "value": int(rec["u_count"]), "cdd_pos": pos[idx_u]}

@@ -306,6 +306,9 @@ class OracleDevice:
     def synchronize(self):
         pass
 
+    def identity(self):
+        return {"device_index": None, "pci_bus_id": f"cpu-double:{os.getpid()}", "uuid": "", "name": "oracle double"}
+
     def empty_rows(self, n_rows, row_bytes):
         import torch
 
@@ -334,6 +337,7 @@ def _bench_main_worker(rank, world, port, out_dir, argv):
     sys.path.insert(0, str(ROOT / "tests"))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
                       SAI_BENCH_BACKEND="gloo")  # fmt: skip
+    os.environ.pop("HSA_ENABLE_IPC_MODE_LEGACY", None)  # a foreign launcher's environment: bench.main must set it itself
     fd = os.open(os.path.join(out_dir, f"stdout{rank}.txt"), os.O_WRONLY | os.O_CREAT | os.O_TRUNC)
     os.dup2(fd, 1)
     import bench
@@ -365,6 +369,15 @@ def test_the_two_rank_line_is_complete(tmp_path):
     assert ranks[0]["windows"] == cfg["windows_rank0"] and ranks[0]["sites"] == cfg["sites_rank0"]
     assert all(r["ms_per_step_wall"] > 0 and r["site_pass_avg_ms"] == 1.0 and r["sites"] > 0 for r in ranks)
     assert max(r["ms_per_step_wall"] for r in ranks) <= line["ms_per_step"] * 1.0001 + 1e-3
+    # WHERE every rank ran and what its per-pass gather took: the record of the one-shot 8-GPU run
+    # must show by itself that the group saw N ranks on N distinct devices, and attribute a slow step
+    assert [r["local_rank"] for r in ranks] == [0, 1] and all(r["hostname"] for r in ranks)
+    assert len({r["pci_bus_id"] for r in ranks}) == 2 and all(r["pci_bus_id"].startswith("cpu-double:") for r in ranks)
+    assert all(r["gathers_timed"] == 2 and r["gather_avg_ms_host_call"] > 0 for r in ranks)  # --steps 2, one gather per pass
+    assert all(r["gather_avg_ms_on_stream"] is None for r in ranks)  # the double has no stream events
+    coll = cfg["collective"]
+    assert coll["backend"] == "gloo" and coll["backend_requested"] == "gloo" and coll["world_size_seen_by_group"] == 2
+    assert coll["distinct_devices"] is True and len(coll["devices"]) == 2 and coll["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
     base = cfg["one_gpu_base"]
     assert base["workload_id"] == "c4" and base["command"] == "python bench.py --workload c4" and "note" in base
     assert "2 rank(s) match" in cfg["gather_check"] and len(cfg["source_digest"]) == 16
@@ -373,6 +386,35 @@ def test_the_two_rank_line_is_complete(tmp_path):
     cb = line["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] == 2 and cb["value"] > 0 and "before it joined the process group" in cb["sample"]
     assert cfg["u_sum"] > 0 and cfg["q_finite"] > 0
+
+
+def test_three_ranks_report_where_they_ran(tmp_path):
+    import json
+
+    import torch.multiprocessing as mp
+
+    argv = ["--gpus", "3", "--workload", "c4", "--sites", "2600", "--chroms", "4", "--steps", "1", "--warmup", "1", "--cpu-sites", "0",
+            "--gather", "end"]  # fmt: skip
+    mp.spawn(_bench_main_worker, args=(3, _free_port(), str(tmp_path), argv), nprocs=3, join=True)
+    (text,) = [ln for ln in (tmp_path / "stdout0.txt").read_text().splitlines() if ln.startswith("{")]
+    cfg = json.loads(text)["config"]
+    assert [r["rank"] for r in cfg["per_rank"]] == [0, 1, 2] and cfg["collective"]["world_size_seen_by_group"] == 3
+    assert cfg["collective"]["distinct_devices"] and all(r["gathers_timed"] == 0 for r in cfg["per_rank"])  # one gather at the end
+
+
+def test_ranks_that_share_a_device_are_told_apart_from_ranks_that_do_not():
+    """collective_record: N RCCL ranks must sit on N distinct (host, PCI bus id) pairs -- the rehearsal shape (every
+    rank on device 0) or a rank without an identity reads as NOT distinct, which ends an RCCL run with exit code 3."""
+    import bench
+
+    ranks = [{"hostname": "n0", "pci_bus_id": f"0000:{i:02x}:00.0"} for i in range(8)]
+    ok = bench.collective_record("nccl", ranks, backend_seen="nccl", world_seen=8)
+    assert ok["distinct_devices"] and ok["world_size_seen_by_group"] == 8 and ok["hosts"] == ["n0"] and len(ok["devices"]) == 8
+    same = bench.collective_record("nccl", ranks[:3] + [dict(ranks[0])], backend_seen="nccl", world_seen=4)
+    assert not same["distinct_devices"]
+    two_hosts = bench.collective_record("nccl", [ranks[0], {"hostname": "n1", "pci_bus_id": ranks[0]["pci_bus_id"]}], backend_seen="nccl", world_seen=2)
+    assert two_hosts["distinct_devices"]
+    assert not bench.collective_record("nccl", [ranks[0], {"hostname": "n0"}], backend_seen="nccl", world_seen=2)["distinct_devices"]
 
 
 def test_static_traffic_and_one_gpu_base_of_the_full_size_job(monkeypatch):

@@ -175,6 +175,42 @@ def test_score_reads_a_plain_file_once(in_repo_root, tmp_path, monkeypatch):
               output_file=str(tmp_path / "none.tsv"), config="tests/data/test.uq.config.yaml", num_workers=1)  # fmt: skip
 
 
+def test_score_cuts_a_chromosome_that_does_not_fit_into_chunks(in_repo_root, tmp_path, monkeypatch):
+    """One process, a chromosome whose genotypes exceed the HBM budget (here an artificially small one): the
+    chromosome goes through the GPU chunk after chunk (chunk_generator.py:111-142's ranges) and the three files
+    are the one-chunk files byte for byte (VERDICT r4 #8b).  (With an ancestral-allele file a chunk whose region holds
+    none of its entries ends the run, as a worker of the reference does: utils.py:480-487.)"""
+    from sai_amd.preprocessors import ChunkPreprocessor
+    from sai_amd.sai import chunks_for_memory, score
+
+    calls = []
+    real = ChunkPreprocessor.run_compact
+
+    def spy(self, chr_name, start, end, preloaded=None):
+        calls.append((start, end))
+        return real(self, chr_name, start, end, preloaded=preloaded)
+
+    monkeypatch.setattr(ChunkPreprocessor, "run_compact", spy)
+    for vcf, anc, tag, small in (("tests/data/test.data.vcf", None, "five", 300), ("tests/data/test.data.vcf", None, "two", 700)):
+        outs = []
+        for budget in (None, small):
+            if budget is None:
+                monkeypatch.delenv("SAI_AMD_HBM_BUDGET_BYTES", raising=False)
+            else:
+                monkeypatch.setenv("SAI_AMD_HBM_BUDGET_BYTES", str(budget))
+            n_before = len(calls)
+            out = tmp_path / f"{tag}_{budget}.tsv"
+            score(vcf_file=vcf, chr_name="21", win_len=10000, win_step=5000, anc_allele_file=anc, output_file=str(out),
+                  config="tests/data/test.uq.config.yaml", num_workers=1)  # fmt: skip
+            outs.append(([out.read_bytes(), out.with_suffix(".U.log").read_bytes(), out.with_suffix(".Q.log").read_bytes()],
+                         len(calls) - n_before))  # fmt: skip
+        assert outs[0][0] == outs[1][0] and outs[0][0][0].count(b"\n") > 3, tag
+        assert outs[0][1] == 1 and outs[1][1] == chunks_for_memory(vcf) >= 2, (tag, outs[0][1], outs[1][1])
+    monkeypatch.setenv("SAI_AMD_HBM_BUDGET_BYTES", "0")
+    with pytest.raises(ValueError, match="SAI_AMD_HBM_BUDGET_BYTES"):
+        chunks_for_memory("tests/data/test.data.vcf")
+
+
 def test_score_mixed_ploidy_with_anc_alleles(in_repo_root, tmp_path):
     """tests/test_sai.py:127-151: gz VCF, tetraploid targets/sources, two sources, polarised:
     U of the two rows = 0 and 1 (the df columns of that test are outside this path)."""
@@ -322,6 +358,66 @@ def test_site_absdiff_exact_at_extremes(_gpu):
         got = eng.site_absdiff(eng.tile(g), eng.tile(s)).cpu().numpy()
         exp = np.abs(s.astype(np.int64).T[:, :, None] - g.astype(np.int64)[None, :, :]).sum(axis=2)
         assert np.array_equal(got, exp)
+
+
+@pytest.mark.parametrize("n_src_inds", [(1,), (2,), (1, 2), (3,), (2, 2), (1, 1, 1, 1)])
+@pytest.mark.parametrize("fused", [True, False])
+def test_site_pass_dd_equals_pass_plus_absdiff(_gpu, n_src_inds, fused):
+    """DD's per-site terms riding along the site pass (sai_site_pass_dd): the same counts, planes and stored
+    frequencies as the plain pass and the same integers as sai_site_absdiff -- raw int8 values over the whole
+    range, partial row groups, a site count that is no multiple of 64, an outgroup behind the sources."""
+    import torch
+
+    from sai_amd import _ffi
+    from sai_amd.engine import Engine
+
+    eng = Engine.get(0)
+    rng = np.random.default_rng(100 + sum(n_src_inds) + 7 * len(n_src_inds) + fused)
+    for n_sites, n_ref, n_tgt in ((200, 37, 16), (1000, 250, 1), (64, 4100, 5), (130, 64, 63)):
+        mats = [rng.integers(-128, 128, size=(n_sites, n)).astype(np.int8) for n in (n_ref, n_tgt, *n_src_inds)]
+        if n_sites == 1000:  # realistic dosages with missing calls: the decision has something to decide
+            mats = [np.where(rng.random(m.shape) < 0.02, -2, rng.integers(0, 3, size=m.shape)).astype(np.int8) for m in mats]
+        if not fused:
+            mats.append(rng.integers(-2, 3, size=(n_sites, 4)).astype(np.int8))  # an outgroup is just counted
+        pops = eng.tile_many(mats)
+        ploidy = [2] * len(pops)
+        n_src = len(n_src_inds)
+        sets = [_ffi.make_params(0.3, 0.5, 0.9, [(">=", 0.5)] * n_src, anc) for anc in (True, False)] if fused else []
+        counts = torch.zeros((len(pops), n_sites, 2), dtype=torch.int32, device=eng.device)
+        out, ad = eng.site_pass_dd(pops, ploidy, sets, 2, n_src, counts=counts, freq_mode="candidates")
+        assert torch.equal(counts, eng.site_counts(pops))
+        if fused:
+            ref_out = eng.site_pass(pops, ploidy, sets, freq_mode="candidates")
+            assert torch.equal(out[1], ref_out[1])
+            assert torch.equal(eng.site_tgt_freq(out[1], out[0], n_sites).nan_to_num(-1.0),
+                               eng.site_tgt_freq(ref_out[1], ref_out[0], n_sites).nan_to_num(-1.0))
+        row = 0
+        for k, n in enumerate(n_src_inds):
+            for which in (0, 1):
+                assert torch.equal(ad[which, row : row + n], eng.site_absdiff(pops[which], pops[2 + k]))
+            row += n
+        exp = np.abs(mats[2].astype(np.int64).T[:, :, None] - mats[0].astype(np.int64)[None, :, :]).sum(axis=2)
+        assert np.array_equal(ad[0, : n_src_inds[0]].cpu().numpy(), exp)
+
+
+def test_site_pass_dd_says_when_it_cannot(_gpu):
+    import torch
+
+    from sai_amd import _ffi
+    from sai_amd.engine import Engine
+
+    eng = Engine.get(0)
+    rng = np.random.default_rng(3)
+    mats = [rng.integers(0, 3, size=(100, n)).astype(np.int8) for n in (20, 20, 5)]
+    pops = eng.tile_many(mats)
+    counts = torch.zeros((3, 100, 2), dtype=torch.int32, device=eng.device)
+    assert not eng.dd_rides_along(pops, 2, 1)
+    with pytest.raises(_ffi.SaiHipError) as exc:  # five source individuals
+        eng.site_pass_dd(pops, [2, 2, 2], [], 2, 1, counts=counts)
+    assert exc.value.status == _ffi.SAI_ERR_UNSUPPORTED
+    with pytest.raises(_ffi.SaiHipError) as exc:  # the rows of DD are source populations of the call
+        eng.site_pass_dd(pops, [2, 2, 2], [], 1, 1, counts=counts)
+    assert exc.value.status == _ffi.SAI_ERR_ARG
 
 
 # ---- sharded score: two ranks (both on this box's one GPU, gloo for the final gather) ---------

@@ -32,7 +32,7 @@ def eng():
 def small_job(name, sites=60_000, chroms=5):
     import bench
 
-    wl = bench.make_workload(name, sites=sites, chroms=chroms if name == "c4" else 0)
+    wl = bench.make_workload(name, sites=sites, chroms=chroms if name in ("c4", "c2x22") else 0)
     wl.n_ref, wl.n_tgt = 130, 70
     wl.missing_per_million = 2000
     for s in wl.specs:
@@ -96,13 +96,17 @@ def test_merged_shards_equal_the_one_gpu_job(eng, name, world):
         assert n_pieces >= world + len(wl.chroms) - 1  # ranks really span chromosome boundaries
 
 
-def test_multi_piece_block_equals_per_chromosome_blocks(eng):
+@pytest.mark.parametrize("name,sites,chroms", [("c4", 50_000, 4), ("c2x22", 20_000, 22)])
+def test_multi_piece_block_equals_per_chromosome_blocks(eng, name, sites, chroms):
     """The one-rank block of a 4-chromosome job (4 segments, one site pass, one windows stage)
-    against four single-chromosome scorers on separately generated blocks."""
+    against four single-chromosome scorers on separately generated blocks; and the 22-piece block of
+    `bench.py --workload c2x22` (C2's populations and window grid) against 22 single-chromosome runs."""
     from sai_amd.resident import ResidentScorer, default_windows, synth_block
 
-    wl = small_job("c4", sites=50_000, chroms=4)
+    wl = small_job(name, sites=sites, chroms=chroms)
+    assert len(wl.chroms) == chroms
     one, lay, counts = run_rank(eng, wl, 0, 1, through_row=False)
+    assert len(lay.pieces) == chroms
     g = 0
     for chrom, n_w in zip(wl.chroms, counts):
         block = synth_block(eng, wl.seed, chrom, wl.n_sites, wl.n_ref, wl.n_tgt, wl.src_sizes,
@@ -375,6 +379,14 @@ def test_bench_one_rank_on_real_rccl():
     assert 0 < r0["site_pass_avg_ms"] <= r0["ms_per_step_wall"] * 1.05 and abs(r0["site_pass_avg_ms"] - rccl["roofline"]["avg_launch_ms"]) < 1e-3
     assert rccl["config"]["gather"] == "step" and rccl["config"]["gather_row_bytes"][0] > 24 * one["config"]["windows_total"]
     assert "1 rank(s) match" in rccl["config"]["gather_check"]
+    # the record proves by itself what the group was and where the rank ran: RCCL, the world size the
+    # group saw, the device's PCI bus id / UUID, and what every per-pass gather took on the stream it was issued on
+    coll = rccl["config"]["collective"]
+    assert coll["backend"] == "nccl" and coll["world_size_seen_by_group"] == 1 and coll["distinct_devices"] is True
+    assert coll["rccl_version"] and coll["rccl_version"][0].isdigit() and coll["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    assert r0["device_index"] == 0 and len(r0["pci_bus_id"].split(":")) == 3 and len(r0["uuid"]) == 32 and r0["hostname"]
+    assert r0["gathers_timed"] == 3 and 0 < r0["gather_avg_ms_on_stream"] <= r0["gather_max_ms_on_stream"] < r0["ms_per_step_wall"] * 3
+    assert one["config"]["collective"] is None and one["config"]["per_rank"][0]["pci_bus_id"] == r0["pci_bus_id"]
 
 
 def test_bench_default_line_has_the_contract_fields():

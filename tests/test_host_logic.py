@@ -632,3 +632,47 @@ def test_value_radix_digits_are_an_exact_monotone_code():
             prefix, scale = prefix * 256.0 + d, scale * 256.0
         codes.append(tuple(ds))
     assert codes == sorted(codes) and len(set(codes)) == len(set(v.tolist()))
+
+
+def test_per_window_route_says_once_what_it_costs(monkeypatch):
+    """After 64 one-window statistic calls in a process ONE warning names the batched route;
+    the counter is the module's, so the classes and FeaturePreprocessor.run share it."""
+    import warnings
+
+    from sai_amd.stats import _window
+
+    monkeypatch.setattr(_window, "_calls", 0)
+    with warnings.catch_warnings(record=True) as seen:
+        warnings.simplefilter("always")
+        for _ in range(3 * _window.PER_WINDOW_WARN_AFTER):
+            _window.note_per_window_call()
+    mine = [w for w in seen if issubclass(w.category, _window.PerWindowRouteWarning)]
+    assert len(mine) == 1
+    text = str(mine[0].message)
+    assert "ChunkPreprocessor.run" in text and "score_windows" in text and "PCIe" in text
+
+
+def test_scan_while_reading_lets_device_failures_through(monkeypatch, tmp_path):
+    """`score`'s preload under the chromosome scan (sai.py): a file-level error is repeated later by the usual
+    read and fails there with its own message; a failure of the device is raised by the call that met it, also
+    when the reader has wrapped it in the reference's ValueError (VERDICT r4 #8c)."""
+    from sai_amd import _ffi, sai
+
+    monkeypatch.setattr("sai_amd.utils.native_vcf.scan_first_last", lambda vcf, chrom: (10, 20))
+
+    class Driver:
+        def __init__(self, exc):
+            self.exc = exc
+
+        def preload(self, chr_name):
+            raise self.exc
+
+    assert sai._scan_while_reading(Driver(ValueError("Failed to read VCF file x from 1: bad genotype")), "x.vcf", "1") == ((10, 20), None)
+    hip = _ffi.SaiHipError(_ffi.SAI_ERR_HIP, "hipMemcpyAsync failed: an illegal memory access was encountered")
+    wrapped = ValueError("Failed to read VCF file x from 1: libsaihip error -2")
+    wrapped.__cause__ = hip
+    for exc in (hip, wrapped, MemoryError("out of memory")):
+        with pytest.raises(type(exc)):
+            sai._scan_while_reading(Driver(exc), "x.vcf", "1")
+    refused = _ffi.SaiHipError(_ffi.SAI_ERR_UNSUPPORTED, "dosage outside int8")  # the library's own refusal: a file-level error
+    assert sai._scan_while_reading(Driver(refused), "x.vcf", "1") == ((10, 20), None)

@@ -81,3 +81,23 @@ def test_install_builds_the_library_and_the_sai_command_prints_the_reference_fla
     assert res.returncode == 0 and res.stdout.strip() == str(__import__("sai_amd._ffi", fromlist=["x"]).SAI_ABI_VERSION), res.stderr[-2000:]
     res = subprocess.run([sys.executable, str(script), "--version"], cwd=str(tmp_path), env=env, capture_output=True, text=True, timeout=300)
     assert res.returncode == 0 and res.stdout.strip() == _project()["project"]["version"]
+
+    # the multi-worker route from the INSTALLED tree, on a machine without hipcc and with a read-only package
+    # directory: the launcher's "build once" must take the shipped library as it is, not look for a
+    # compiler and recompile every unit into site-packages because the wheel has no object directory
+    rank = tmp_path / "rank.py"
+    rank.write_text("import os, torch.distributed as dist\ndist.init_process_group('gloo')\n"
+                    "print('rank', dist.get_rank(), flush=True)\ndist.destroy_process_group()\n")
+    code = ("import sai_amd._build as b, sai_amd.launcher as L, sys; assert b.shipped_library_is_current(); "
+            f"sys.exit(L.launch_ranks(2, [], script={str(rank)!r}))")
+    no_hipcc = {**env, "PATH": "/usr/bin:/bin", "HIPCC": "/nonexistent/hipcc"}
+    lib_dir = target / "sai_amd" / "lib"
+    before = sorted(f.name for f in lib_dir.iterdir())
+    os.chmod(lib_dir, 0o555)
+    try:
+        res = subprocess.run([sys.executable, "-c", code], cwd=str(tmp_path), env=no_hipcc, capture_output=True, text=True, timeout=300)
+    finally:
+        os.chmod(lib_dir, 0o755)
+    assert res.returncode == 0, res.stderr[-2000:]
+    assert sorted(ln for ln in res.stdout.splitlines() if ln.startswith("rank")) == ["rank 0", "rank 1"]
+    assert sorted(f.name for f in lib_dir.iterdir()) == before  # nothing was written next to the library

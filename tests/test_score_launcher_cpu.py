@@ -80,6 +80,8 @@ def test_launch_ranks_refuses_inside_a_rank_and_bad_counts(monkeypatch):
     cmd = launcher.rank_command(3, ["score", "--vcf", "x"], module="sai_amd", port=1234)
     assert cmd[1:] == ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=3", "--master-addr", "127.0.0.1",
                        "--master-port", "1234", "-m", "sai_amd", "score", "--vcf", "x"]  # fmt: skip
+    alone = launcher.rank_command(2, ["x"], script="s.py")  # no port: torchrun's own store picks a free one
+    assert alone[1:] == ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--standalone", "--local-addr", "127.0.0.1", "s.py", "x"]
     monkeypatch.setenv("SAI_AMD_GPUS", "4")
     assert launcher.workers_from_env() == 4
     monkeypatch.setenv("SAI_AMD_GPUS", "0")
@@ -129,13 +131,23 @@ def test_cli_has_the_flag_and_the_reference_default(monkeypatch):
 
     base = ["score", "--vcf", str(ROOT / "tests/data/test.data.vcf"), "--chr-name", "21", "--output", "o.tsv", "--config",
             str(ROOT / "tests/data/test.uq.config.yaml")]  # fmt: skip
+    from sai_amd.parsers.score_parser import resolve_workers
+
     monkeypatch.delenv("SAI_AMD_GPUS", raising=False)
-    assert _sai_cli_parser().parse_args(base).num_workers == 1  # score_parser.py:64
-    assert _sai_cli_parser().parse_args([*base, "--num-workers", "8"]).num_workers == 8
+    assert resolve_workers(_sai_cli_parser().parse_args(base)) == 1  # score_parser.py:64
+    assert resolve_workers(_sai_cli_parser().parse_args([*base, "--num-workers", "8"])) == 8
     monkeypatch.setenv("SAI_AMD_GPUS", "2")
-    assert _sai_cli_parser().parse_args(base).num_workers == 2
+    assert resolve_workers(_sai_cli_parser().parse_args(base)) == 2
     with pytest.raises(SystemExit):
         _sai_cli_parser().parse_args([*base, "--num-workers", "0"])
+    # a malformed variable is `score`'s usage error when it runs; the parser, --help and `outlier` never see it
+    monkeypatch.setenv("SAI_AMD_GPUS", "many")
+    args = _sai_cli_parser().parse_args(base)
+    with pytest.raises(SystemExit) as exc:
+        resolve_workers(args)
+    assert exc.value.code == 2
+    assert _sai_cli_parser().parse_args(["outlier", "--score", str(ROOT / "tests/data/test.data.vcf"), "--output-prefix", "x",
+                                         "--quantile", "0.9"]).runner is not None  # fmt: skip
 
 
 def test_plain_cli_with_two_workers_and_no_gpu_fails_loudly(tmp_path):

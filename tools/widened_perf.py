@@ -43,3 +43,24 @@ print(f"site_absdiff ref x 2 src individuals: {mn:.3f} ms  {n_sites * 1002 / mn 
 ad_tgt = eng.site_absdiff(pops[1], pops[2])
 mn, md = timeit(lambda: eng.window_dd(ad_ref, 1000, ad_tgt, 1000, lo, hi))
 print(f"window_dd: {mn:.3f} ms")
+# DD riding along the site pass (round 5): the counts of all four populations and DD's terms of the two source
+# individuals from ONE read of ref and tgt; and the fused U / Q pass with them
+import os
+from sai_amd import _ffi
+ad = torch.empty((2, 2, n_sites), dtype=torch.int32, device=eng.device)
+mn, md = timeit(lambda: eng.site_pass_dd(pops, None, [], 2, 1, counts=counts, absdiff=ad))
+print(f"site_pass_dd counts + DD terms (4 pops, 2 source individuals): {mn:.3f} ms  {nbytes / mn / 1e6:.0f} GB/s")
+assert torch.equal(ad[0], ad_ref) and torch.equal(ad[1], ad_tgt)
+sets = [_ffi.make_params(0.01, 0.5, 0.95, [("=", 1.0)], True)]
+out = eng.site_pass(pops[:3], [2, 2, 2], sets, freq_mode="candidates")
+nb3 = n_sites * sum(sizes[:3])
+mn, md = timeit(lambda: eng.site_pass(pops[:3], [2, 2, 2], sets, out=out, freq_mode="candidates"))
+print(f"site_pass U/Q (3 pops): {mn:.3f} ms  {nb3 / mn / 1e6:.0f} GB/s")
+mn, md = timeit(lambda: eng.site_pass_dd(pops[:3], [2, 2, 2], sets, 2, 1, out=out, freq_mode="candidates", absdiff=ad))
+print(f"site_pass_dd U/Q + DD terms (3 pops): {mn:.3f} ms  {nb3 / mn / 1e6:.0f} GB/s")
+for ns in (1, 3, 4):
+    src = eng.synth_population(seed, 1, 0, n_sites, 2, ns)
+    adk = torch.empty((2, ns, n_sites), dtype=torch.int32, device=eng.device)
+    pk = [pops[0], pops[1], src]
+    mn, md = timeit(lambda: eng.site_pass_dd(pk, [2, 2, 2], sets, 2, 1, out=out, freq_mode="candidates", absdiff=adk))
+    print(f"site_pass_dd U/Q + DD terms, {ns} source individual(s): {mn:.3f} ms  {n_sites * (2000 + ns) / mn / 1e6:.0f} GB/s")
