@@ -337,53 +337,62 @@ def score_path_rate(eng, wl, block, lay, repeats: int = 3) -> dict:
         str(wl.chroms[0]), pos_host, block.pos[:n], {"ref": _trim(block.pops[0], n)}, {"tgt": _trim(block.pops[1], n)},
         {nm: _trim(p, n) for nm, p in zip(src_names, block.pops[2:])}, wl.win_len, wl.win_step, ploidies,
     )  # fmt: skip
-    times, spans = [], []
+    times, plain = [], []
     with tempfile.TemporaryDirectory() as tmp:
         out, out_items = os.path.join(tmp, "scores.tsv"), os.path.join(tmp, "items.tsv")
         fp = FeaturePreprocessor(out, stats, anc_allele_available=s0["anc"])
         fp_items = FeaturePreprocessor(out_items, stats, anc_allele_available=s0["anc"])
         n_rows = 0
         for _ in range(repeats + 1):
-            write_headers(out, stats, ploidies)
-            write_headers(out_items, stats, ploidies)
             # The item route of the repeat before kept the host busy -- and the GPU idle -- for ~80 ms; a device
             # that idle has clocked its memory down, and the first pass after it ran 0.4 ms slower than the same
-            # pass in a loop (3.87 against 3.38 ms for the call).  `score` never meets the GPU that cold (the
-            # ingest runs right before), so the timed call follows an untimed one.
-            fp.score_windows(wg)
+            # pass in a loop.  `score` never meets the GPU that cold (the ingest runs right before), so every timed
+            # call follows an untimed one of the same kind.
+            write_headers(out, stats, ploidies)
+            fp.score_and_write(wg)
             torch.cuda.synchronize()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            write_headers(out, stats, ploidies)
             t0 = time.perf_counter()
-            e0.record()
-            batch = fp.score_windows(wg)
-            e1.record()
+            fp.score_and_write(wg)  # what `score` runs after the ingest: rows written while later windows are scored
             t1 = time.perf_counter()
-            e1.synchronize()
-            spans.append(e0.elapsed_time(e1))
-            fp.write_batches([batch])  # what `score` does: text straight from the numeric batch
+            # the same work as two calls, nothing overlapped (round 4's form), for comparison
+            write_headers(out_items, stats, ploidies)
+            fp_items.score_windows(wg)
+            torch.cuda.synchronize()
             t2 = time.perf_counter()
-            items = fp_items.items_from_batch(batch)  # the reference's item protocol, for comparison
+            batch = fp_items.score_windows(wg)
             t3 = time.perf_counter()
-            fp_items.process_items(items)
+            fp_items.write_batches([batch])
             t4 = time.perf_counter()
-            times.append((t2 - t0, t1 - t0, t2 - t1, t3 - t2, t4 - t3))
+            plain.append((t4 - t2, t3 - t2, t4 - t3))
+            same_plain = all(open(out + sfx, "rb").read() == open(out_items + sfx, "rb").read() for sfx in ("",)) and all(
+                open(os.path.join(tmp, f"scores.{k}.log"), "rb").read() == open(os.path.join(tmp, f"items.{k}.log"), "rb").read()
+                for k in ("U", "Q"))  # fmt: skip
+            write_headers(out_items, stats, ploidies)
+            t5 = time.perf_counter()
+            items = fp_items.items_from_batch(batch)  # the reference's item protocol, for comparison
+            t6 = time.perf_counter()
+            fp_items.process_items(items)
+            t7 = time.perf_counter()
+            times.append((t1 - t0, t6 - t5, t7 - t6))
             n_rows = len(items)
-        same = all(open(out + sfx, "rb").read() == open(out_items + sfx, "rb").read() for sfx in ("",))
+        same = same_plain and all(open(out + sfx, "rb").read() == open(out_items + sfx, "rb").read() for sfx in ("",))
         same = same and all(
             open(os.path.join(tmp, f"scores.{k}.log"), "rb").read() == open(os.path.join(tmp, f"items.{k}.log"), "rb").read()
             for k in ("U", "Q")
         )
         text_bytes = sum(os.path.getsize(os.path.join(tmp, f)) for f in os.listdir(tmp) if f.startswith("scores"))
-    total, gpu, write, build, items_write = min(times[1:])
+    total, build, items_write = min(times[1:])
+    two_calls, gpu, write = min(plain[1:])
     return {
         "value": round(n_rows / total, 1),
         "unit": "windows/s",
         "windows": n_rows,
         "ms_total": round(total * 1e3, 2),
+        "parts": FeaturePreprocessor.PARTS,
+        # the same work as score_windows + write_batches, one after the other (round 4's product path)
+        "ms_as_two_calls": round(two_calls * 1e3, 2),
         "ms_gpu_score_windows": round(gpu * 1e3, 2),
-        # the same call between two HIP events on the launch stream: the pass + the windows stage + the copies of the
-        # records and lists, one after the other (one call cannot hide its own stage); the rest is the host
-        "ms_score_windows_on_the_gpu": round(min(spans[1:]), 2),
         "ms_native_text": round(write * 1e3, 2),
         "host_us_per_window": round(write / max(n_rows, 1) * 1e6, 3),
         "output_bytes": text_bytes,
@@ -393,10 +402,11 @@ def score_path_rate(eng, wl, block, lay, repeats: int = 3) -> dict:
             "windows_per_s": round(n_rows / (gpu + build + items_write), 1),
             "same_bytes_as_native": bool(same),
         },
-        "what": "FeaturePreprocessor.score_windows + write_batches on the resident block = what `score` runs after the "
-        "ingest (U and Q as two statistics, one fused pass, TSV + .U.log + .Q.log); item_protocol = the same batch "
-        "through items_from_batch + process_items; best of %d, each right after an untimed call of the same (the device has "
-        "idled through the item route of the repeat before)" % repeats,
+        "what": "FeaturePreprocessor.score_and_write on the resident block = what `score` runs after the ingest (U and Q as two "
+        "statistics, one fused pass per window range, TSV + .U.log + .Q.log written while the later ranges are scored); "
+        "ms_as_two_calls = score_windows + write_batches one after the other; item_protocol = the same batch through "
+        "items_from_batch + process_items; best of %d, each right after an untimed call of the same (the device has idled through "
+        "the item route of the repeat before)" % repeats,
     }
 
 
@@ -658,7 +668,7 @@ class HipDevice:
         return torch.cuda.stream(torch.cuda.current_stream())
 
     def site_pass_ms(self, scorer) -> list:
-        return [a.elapsed_time(b) for a, b in scorer.count_events]
+        return scorer.site_pass_ms()
 
     def genotype_bytes(self, block, layout: str) -> int:
         return block.genotype_bytes if layout == "int8" else block.packed2_bytes
@@ -967,6 +977,8 @@ def main(argv=None, device=None) -> None:
                 "whole_path_gbps_this_rank": round(path_bytes / (dt / args.steps) / 1e9, 1),
             },
             "cpu_baseline": cpu,
+            # the product entry point on the same block (score_path.value): what a caller of `score` gets per second
+            "product_windows_per_s": score_path.get("value") if isinstance(score_path, dict) else None,
             "score_path": score_path,
         }
         reduced = bool(args.sites or args.chroms)

@@ -273,7 +273,7 @@ class WindowGenerator(DataGenerator):
         return torch.as_tensor(np.ascontiguousarray(pos, dtype=np.int32)).to(eng.device)
 
     def __getstate__(self):  # device handles never travel with a pickled generator
-        return {k: v for k, v in self.__dict__.items() if k not in ("_device_blocks", "_device_pos", "_aligned", "_scorers", "_win_arrays")}
+        return {k: v for k, v in self.__dict__.items() if k not in ("_device_blocks", "_device_pos", "_aligned", "_scorers", "_win_arrays", "_part_plans")}
 
     @staticmethod
     def window_range(pos: np.ndarray, start: int, end: int) -> tuple[int, int]:

@@ -69,10 +69,18 @@ class ChunkPreprocessor(DataPreprocessor):
                     span = (lo, hi) if span is None else (min(span[0], lo), max(span[1], hi))
         return results, pos_dev, span
 
+    def run_and_write(self, chr_name: str, start: int, end: int, preloaded=None) -> None:
+        """``write_results([run_compact(...)])`` for the ONE chunk of a one-process run, the writing overlapped
+        with the scoring (``FeaturePreprocessor.score_and_write``): same files."""
+        self.feature_preprocessor.score_and_write(self._window_generator(chr_name, start, end, preloaded))
+
     def run_compact(self, chr_name: str, start: int, end: int, preloaded=None):
         """The same work unit in numeric form (a ``WindowBatch``): what a rank of a sharded run
         computes and sends to rank 0, where ``unpack_results`` turns the batches into items."""
-        window_generator = WindowGenerator(
+        return self.feature_preprocessor.score_windows(self._window_generator(chr_name, start, end, preloaded))
+
+    def _window_generator(self, chr_name: str, start: int, end: int, preloaded=None):
+        return WindowGenerator(
             preloaded=preloaded,
             vcf_file=self.vcf_file,
             chr_name=chr_name,
@@ -89,7 +97,6 @@ class ChunkPreprocessor(DataPreprocessor):
             num_src=self.num_src,
             resident=os.environ.get("SAI_AMD_INGEST", "device") != "host",
         )
-        return self.feature_preprocessor.score_windows(window_generator)
 
     # transport hooks of sai_amd.distributed.run_sharded / sai_amd.multiprocessing.mp_pool
     @staticmethod

@@ -230,13 +230,33 @@ class FeaturePreprocessor(DataPreprocessor):
         """Items for every (population combination, window) of a WindowGenerator, in its order."""
         return self.items_from_batch(self.score_windows(wg))
 
-    def score_windows(self, wg) -> WindowBatch:
+    def score_and_write(self, wg) -> None:
+        """``write_batches([score_windows(wg)])`` for the ONE chunk of a run, with the two overlapped: a large region
+        whose combination is served by the fused pass alone is scored in ``PARTS`` contiguous window ranges -- each
+        over its own tile range of the resident blocks, the passes queued back to back -- and the rows of a part
+        are formatted and written while the GPU streams the following parts (the reference writes as its workers
+        deliver, sai.py:146-151, feature_preprocessor.py:193-258).  Same bytes as the two calls."""
+        files = self._open_outputs()
+        try:
+            self.score_windows(wg, sink=lambda cb: self._write_combo(files, wg.chr_name, cb))
+        finally:
+            for fh in files:
+                fh.close()
+
+    PARTS = 3  # window ranges a large region is scored in when its rows are written as they arrive (3: 3.58 ms for C3 on one box, 4: 3.70-3.97, 6: 4.18, one: 4.08-4.12 -- profiles/r05_score_parts.txt)
+    PART_MIN_WINDOWS = 2048
+
+    def score_windows(self, wg, sink=None) -> WindowBatch:
         """The GPU part of ``run_windows``: every population block of the region is uploaded once
         and U / Q are answered by a ``ResidentScorer`` -- the fused site pass (genotypes streamed
         once, per-site decision in the same launch, tgt_freq only at candidate sites) followed by
         the windows stage -- i.e. by the very path bench.py times.  When several population
         combinations share blocks, or the ABBA-BABA family needs the per-population counts anyway,
-        each block is reduced once (site_counts) and the combinations start from those counts."""
+        each block is reduced once (site_counts) and the combinations start from those counts.
+
+        ``sink(ComboBatch)``: called with every combination's results as soon as they are on the host -- a large
+        one in several parts, each a ComboBatch over a contiguous range of its windows (``score_and_write``); the
+        returned batch then lists the parts as they were handed over."""
         names = self._active_stats()
         uq_names = [n for n in names if n in _HIP_STATS]
         four_names = [n for n in names if n in _FOURPOP]
@@ -247,6 +267,8 @@ class FeaturePreprocessor(DataPreprocessor):
             for ref_pop, tgt_pop, src_comb, out_pop in combos:
                 win = np.asarray(wg.tgt_windows[tgt_pop], dtype=np.int64).reshape(-1, 2)
                 batch.combos.append(ComboBatch(ref_pop, tgt_pop, tuple(src_comb), out_pop, win, np.zeros(len(win), np.int32)))
+                if sink is not None:
+                    sink(batch.combos[-1])
             return batch
 
         import torch
@@ -317,9 +339,16 @@ class FeaturePreprocessor(DataPreprocessor):
             n_sites = int(pos.size)
             cb = ComboBatch(ref_pop, tgt_pop, tuple(src_comb), out_pop, win, np.zeros(len(win), np.int32), list(uq_names),
                             pos_dtype=np.dtype(pos.dtype).name)  # fmt: skip
-            batch.combos.append(cb)
             if not (names and len(win) and n_sites):
+                batch.combos.append(cb)
+                if sink is not None:
+                    sink(cb)
                 continue
+            if (sink is not None and uq_names and not shared and not four_names and not want_dd and al.segments is None
+                    and al.uniq is None and al.file_order is None and len(win) >= self.PART_MIN_WINDOWS):  # fmt: skip
+                self._score_in_parts(eng, wg, cb, al, tiled, ploidy, n_eff, sets, set_of, sink, batch)
+                continue
+            batch.combos.append(cb)
             pid = id(pos)
             if pid not in pos_dev_cache:
                 pos_dev_cache[pid] = wg.device_positions(eng, pos)
@@ -412,7 +441,67 @@ class FeaturePreprocessor(DataPreprocessor):
                     ],
                     axis=1,
                 )  # fmt: skip
+            if sink is not None:
+                sink(cb)
         return batch
+
+    def _score_in_parts(self, eng, wg, cb, al, tiled, ploidy, n_eff, sets, set_of, sink, batch) -> None:
+        """One combination of a large region as ``PARTS`` contiguous window ranges.  A part needs the sites from
+        its first window's start to its last window's end: the tiles that hold them are a contiguous slice of
+        every population's tiled block (a tile is ``n_ind * 64`` bytes), so each part is a scorer of its own over
+        views -- nothing is copied, the halo between neighbouring parts (a window length of sites) is read twice.
+        All passes are enqueued first; the parts' results are then taken in order, each as soon as ITS windows
+        stage has delivered, and handed to ``sink`` while the later passes still stream."""
+        from .. import _ffi
+        from ..engine import TiledPop
+        from ..resident import ResidentBlock, ResidentScorer
+        from ..utils.windows import split_index_ranges
+
+        pos, win = al.pos_rows, cb.windows
+        n_sites, tile = int(pos.size), _ffi.SAI_TILE_SITES
+        keys = [("ref", cb.ref_pop), ("tgt", cb.tgt_pop)] + [("src", s) for s in cb.src_comb[:n_eff]]
+        # the parts of a (generator, combination, parameter sets) are laid out once: a later call on the same
+        # generator -- the same region scored again -- finds its scorers bound and only enqueues their passes
+        plans = wg.__dict__.setdefault("_part_plans", {})
+        plan_key = (cb.tgt_pop, cb.ref_pop, tuple(cb.src_comb), self.PARTS)
+        signature = ResidentScorer._binding_signature(ResidentBlock([tiled[k] for k in keys], ploidy[: 2 + n_eff], wg.device_positions(eng, pos)),
+                                                      sets, None, False)  # fmt: skip
+        plan = plans.get(plan_key)
+        if plan is None or plan[0] != signature:
+            pos_dev = wg.device_positions(eng, pos)
+            scorers = wg.__dict__.setdefault("_scorers", {})
+            # the last part is the smallest: its rows are written after the GPU has finished
+            n_w = len(win)
+            cuts = [0] + [int(round(n_w * f)) for f in np.cumsum([1.0 / (self.PARTS - 0.4)] * (self.PARTS - 1))] + [n_w]
+            ranges = [(a, b) for a, b in zip(cuts, cuts[1:]) if b > a] if self.PARTS > 1 else split_index_ranges(n_w, 1)
+            built = []
+            for k, (w0, w1) in enumerate(ranges):
+                # needles in the positions' own dtype: numpy would otherwise convert the whole array for every search
+                info = np.iinfo(pos.dtype)
+                first, last = (pos.dtype.type(min(max(int(v), info.min), info.max)) for v in (win[w0, 0], win[w1 - 1, 1]))
+                s_lo, s_hi = int(np.searchsorted(pos, first, "left")), int(np.searchsorted(pos, last, "right"))
+                t0, t1 = s_lo // tile, max(-(-s_hi // tile), s_lo // tile + 1)
+                a, b = t0 * tile, min(t1 * tile, n_sites)
+                pops = [TiledPop(tiled[key].tiles[t0 * tiled[key].n_ind * tile : t1 * tiled[key].n_ind * tile], b - a, tiled[key].n_ind)
+                        for key in keys]  # fmt: skip
+                block = ResidentBlock(pops, ploidy[: 2 + n_eff], pos_dev[a:b])
+                key = (cb.tgt_pop, n_sites, len(sets), "part", k, self.PARTS)
+                scorer = scorers.get(key)
+                if scorer is None or scorer.block.n_sites != block.n_sites or scorer.n_windows != w1 - w0:
+                    scorer = scorers[key] = ResidentScorer(eng, block, win[w0:w1], sets, cap_u=1 << 16, cap_q=1 << 16, fetch_lists=1 << 16)
+                else:
+                    scorer.rebind(block, sets)
+                built.append((scorer, w0, w1))
+            plan = plans[plan_key] = (signature, built)
+        running = plan[1]
+        for scorer, _, _ in running:
+            scorer.step()
+        for scorer, w0, w1 in running:
+            part = ComboBatch(cb.ref_pop, cb.tgt_pop, cb.src_comb, cb.out_pop, win[w0:w1], None, list(cb.uq_names), pos_dtype=cb.pos_dtype)
+            part.uq = _rows_per_statistic(scorer.results(grow=True), set_of)
+            part.nsnps = part.uq.records[0]["n_sites"].astype(np.int32)
+            batch.combos.append(part)
+            sink(part)
 
     def items_from_batch(self, batch: WindowBatch, combos=None) -> list[dict[str, Any]]:
         """The reference's item dictionaries (feature_preprocessor.py:113-191) of a batch, in
@@ -472,76 +561,91 @@ class FeaturePreprocessor(DataPreprocessor):
 
     # -- output ----------------------------------------------------------------------------
 
-    def write_batches(self, batches) -> None:
-        """``process_items(items_from_batches(batches))`` without the items: the TSV and log rows are
-        formatted natively (libsaihip ``sai_format_score_rows`` / ``sai_format_log_rows``) straight
-        from the records, the CSR candidate lists and the f64 blocks -- same bytes, same order
-        (combination-major, the chunks' windows in chunk order), about a fifth of the host time."""
+    def _open_outputs(self) -> list:
+        """The TSV and the .U.log / .Q.log files, opened for appending.  Unbuffered: the library writes to the
+        descriptors itself (one fan-out formats a piece of every file, writev() in window order), nothing of the
+        text passes through Python."""
+        files = [open(self.output_file, "ab", buffering=0)]
+        try:
+            for key in _HIP_STATS:
+                if key in self.stat_config.root:
+                    files.append(open(Path(self.output_file).with_suffix(f".{key}.log"), "ab", buffering=0))
+        except BaseException:
+            for fh in files:
+                fh.close()
+            raise
+        return files
+
+    def _write_combo(self, files, chr_name, cb) -> None:
+        """The rows of one ComboBatch (a combination, or a window range of one) behind what the files hold."""
         import ctypes as C
 
         from .. import _ffi
 
         lib = _ffi.load_host()
-        batches = list(batches)
-        if not batches:
-            return
         names = self._active_stats()
-        n_combos = len(batches[0].combos)
-        if any(len(b.combos) != n_combos for b in batches):
-            raise ValueError("chunks disagree about the population combinations")
+        log_keys = [key for key in _HIP_STATS if key in self.stat_config.root]
         keep = []  # arrays the column descriptors point into
 
         def column(arr, kind):
             keep.append(arr)
             return _ffi.SaiTextColumn(arr.ctypes.data, arr.strides[0] if arr.ndim else 0, kind, 0)
 
-        log_keys = [key for key in _HIP_STATS if key in self.stat_config.root]
-        # unbuffered: the library writes to the descriptors itself (one fan-out formats a piece of every file,
-        # writev() in window order), nothing of the text passes through Python
-        files = [open(self.output_file, "ab", buffering=0)]
+        n_w = int(cb.windows.shape[0])
+        win = np.ascontiguousarray(cb.windows, dtype=np.int64)
+        nsnps = np.ascontiguousarray(cb.nsnps, dtype=np.int32)
+        n_src = len(cb.src_comb)
+        zeros = np.zeros(max(n_w, 1), dtype=np.float64)
+        cols = []
+        for name in names:
+            if name in _HIP_STATS:
+                if cb.uq is None:
+                    cols.append(column(zeros, 1))
+                    continue
+                si = cb.uq_names.index(name)
+                rec = cb.uq.records[si]
+                cols.append(column(rec["u_count"], 0) if name == "U" else column(rec["q"], 1))
+            elif name == "DD":
+                for s_i in range(max(n_src, 1)):
+                    cols.append(column(zeros if cb.dd is None else cb.dd[:, s_i], 1))
+            else:
+                for s_i in range(max(n_src, 1)):
+                    cols.append(column(zeros if cb.four is None else cb.four[:, s_i, _FOURPOP.index(name)], 1))
+        arr = (_ffi.SaiTextColumn * max(len(cols), 1))(*cols)
+        pops = f"{cb.ref_pop}\t{cb.tgt_pop}\t{','.join(cb.src_comb)}\t{'NA' if cb.out_pop is None else cb.out_pop}"
+        logs = (_ffi.SaiLogRows * max(len(log_keys), 1))()
+        for i, key in enumerate(log_keys):
+            if cb.uq is None or key not in cb.uq_names:
+                counts, offs, lists = np.zeros(max(n_w, 1), dtype=np.int32), np.zeros(max(n_w, 1), dtype=np.int64), None
+            else:
+                si = cb.uq_names.index(key)
+                counts = cb.uq.records[si]["u_count" if key == "U" else "n_cdd_q"]
+                offs = np.ascontiguousarray(cb.uq.offsets[si, :, 0 if key == "U" else 1])
+                lists = np.ascontiguousarray(cb.uq.cdd_u if key == "U" else cb.uq.cdd_q)
+            keep.extend([counts, offs, lists])
+            logs[i] = _ffi.SaiLogRows(counts.ctypes.data, counts.strides[0], offs.ctypes.data, 1,
+                                      None if lists is None or lists.size == 0 else lists.ctypes.data,
+                                      4 if lists is None else lists.dtype.itemsize, files[1 + i].fileno())  # fmt: skip
+        _ffi.check(lib.sai_write_window_rows(str(chr_name).encode(), pops.encode(), n_w, win.ctypes.data_as(C.c_void_p),
+                                             nsnps.ctypes.data_as(C.c_void_p), len(cols), arr, files[0].fileno(),
+                                             len(log_keys), logs, None), lib)  # fmt: skip
+
+    def write_batches(self, batches) -> None:
+        """``process_items(items_from_batches(batches))`` without the items: the TSV and log rows are
+        formatted natively (libsaihip ``sai_write_window_rows``) straight from the records, the CSR candidate
+        lists and the f64 blocks -- same bytes, same order (combination-major, the chunks' windows in chunk
+        order), about a fifth of the host time."""
+        batches = list(batches)
+        if not batches:
+            return
+        n_combos = len(batches[0].combos)
+        if any(len(b.combos) != n_combos for b in batches):
+            raise ValueError("chunks disagree about the population combinations")
+        files = self._open_outputs()
         try:
-            files += [open(Path(self.output_file).with_suffix(f".{key}.log"), "ab", buffering=0) for key in log_keys]
             for k in range(n_combos):
                 for b in batches:
-                    cb = b.combos[k]
-                    n_w = int(cb.windows.shape[0])
-                    win = np.ascontiguousarray(cb.windows, dtype=np.int64)
-                    nsnps = np.ascontiguousarray(cb.nsnps, dtype=np.int32)
-                    n_src = len(cb.src_comb)
-                    zeros = np.zeros(max(n_w, 1), dtype=np.float64)
-                    cols = []
-                    for name in names:
-                        if name in _HIP_STATS:
-                            if cb.uq is None:
-                                cols.append(column(zeros, 1))
-                                continue
-                            si = cb.uq_names.index(name)
-                            rec = cb.uq.records[si]
-                            cols.append(column(rec["u_count"], 0) if name == "U" else column(rec["q"], 1))
-                        elif name == "DD":
-                            for s_i in range(max(n_src, 1)):
-                                cols.append(column(zeros if cb.dd is None else cb.dd[:, s_i], 1))
-                        else:
-                            for s_i in range(max(n_src, 1)):
-                                cols.append(column(zeros if cb.four is None else cb.four[:, s_i, _FOURPOP.index(name)], 1))
-                    arr = (_ffi.SaiTextColumn * max(len(cols), 1))(*cols)
-                    pops = f"{cb.ref_pop}\t{cb.tgt_pop}\t{','.join(cb.src_comb)}\t{'NA' if cb.out_pop is None else cb.out_pop}"
-                    logs = (_ffi.SaiLogRows * max(len(log_keys), 1))()
-                    for i, key in enumerate(log_keys):
-                        if cb.uq is None or key not in cb.uq_names:
-                            counts, offs, lists = np.zeros(max(n_w, 1), dtype=np.int32), np.zeros(max(n_w, 1), dtype=np.int64), None
-                        else:
-                            si = cb.uq_names.index(key)
-                            counts = cb.uq.records[si]["u_count" if key == "U" else "n_cdd_q"]
-                            offs = np.ascontiguousarray(cb.uq.offsets[si, :, 0 if key == "U" else 1])
-                            lists = np.ascontiguousarray(cb.uq.cdd_u if key == "U" else cb.uq.cdd_q)
-                        keep.extend([counts, offs, lists])
-                        logs[i] = _ffi.SaiLogRows(counts.ctypes.data, counts.strides[0], offs.ctypes.data, 1,
-                                                  None if lists is None or lists.size == 0 else lists.ctypes.data,
-                                                  4 if lists is None else lists.dtype.itemsize, files[1 + i].fileno())  # fmt: skip
-                    _ffi.check(lib.sai_write_window_rows(str(b.chr_name).encode(), pops.encode(), n_w, win.ctypes.data_as(C.c_void_p),
-                                                         nsnps.ctypes.data_as(C.c_void_p), len(cols), arr, files[0].fileno(),
-                                                         len(log_keys), logs, None), lib)  # fmt: skip
+                    self._write_combo(files, b.chr_name, b.combos[k])
         finally:
             for f in files:
                 f.close()

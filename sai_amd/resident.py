@@ -230,7 +230,11 @@ class ResidentScorer:
         self.hi = torch.empty((n_w,), dtype=torch.int32, device=dev)
         self._alloc_chunks(cap_u, cap_q)
         self._build_pass_plans()
-        self.count_events: list = []  # (start, end) torch events around site_counts, when requested
+        # timed site passes (``step(time_counts=True)``): their durations in ms.  The event pairs behind them are a
+        # small ring per buffer set -- a pair is read and reused once its pass has certainly ended -- not a list that
+        # grows with every timed step; ``close()`` releases them
+        self._pass_ms: list = []
+        self._timing: list = [[] for _ in range(n_buf)]  # per buffer set: [start, stop, in_flight] entries
 
     def _alloc_chunks(self, cap_u: int, cap_q: int) -> None:
         m = _ffi.SAI_MAX_SETS
@@ -348,9 +352,42 @@ class ResidentScorer:
             ch.release((self.side,) if getattr(self, "side", None) is not None else ())
         self.chunks = []
 
+    def site_pass_ms(self) -> list:
+        """Durations (ms) of the timed site passes so far, in step order; waits for the ones still in flight."""
+        for ring in self._timing:
+            for pair in ring:
+                if pair[2]:
+                    pair[1].synchronize()
+        self._drain_timing()
+        return list(self._pass_ms)
+
+    def _drain_timing(self, b=None) -> None:
+        rings = self._timing if b is None else [self._timing[b]]
+        done = []
+        for ring in rings:
+            for pair in ring:
+                if pair[2] and pair[1].query():
+                    done.append((pair[2], pair[0].elapsed_time(pair[1])))
+                    pair[2] = 0
+        self._pass_ms.extend(ms for _, ms in sorted(done))
+
+    def _timing_pair(self, b: int, make):
+        """A free (start, stop) pair of buffer set b's ring, marked in flight with the step's ordinal."""
+        self._drain_timing(b)
+        ring = self._timing[b]
+        pair = next((p for p in ring if not p[2]), None)
+        if pair is None:
+            pair = [make(), make(), 0]
+            ring.append(pair)
+        pair[2] = self._k + 1
+        return pair
+
     def close(self) -> None:
-        """Return the pinned host mirrors to the engine (also done when the scorer is collected)."""
+        """Return the pinned host mirrors to the engine and release the timing events (also done when the scorer
+        is collected)."""
         self._release_chunks()
+        self._timing = [[] for _ in self._timing]
+        self._carried = [None] * len(self._carried)
 
     def __del__(self):
         try:
@@ -454,24 +491,26 @@ class ResidentScorer:
         if carried:
             from .engine import LaunchEvent
 
-            if time_counts or self._carried[b] is None or self._carried[b][2]:
-                pair = (LaunchEvent(eng), LaunchEvent(eng), time_counts)
+            if time_counts:  # a pair of the ring: its pass of three steps ago (the same buffer set) has ended
+                slot = self._timing_pair(b, lambda: LaunchEvent(eng))
+                pair = (slot[0], slot[1], True)
+                self._count_plans[b].set_pass_events(pair[0], pair[1])
+                self._carried[b] = pair
+            elif self._carried[b] is None or self._carried[b][2]:
+                pair = (LaunchEvent(eng), LaunchEvent(eng), False)
                 self._count_plans[b].set_pass_events(pair[0], pair[1])
                 self._carried[b] = pair
             pair = self._carried[b]
             self._count_plans[b].run()
-            if time_counts:
-                self.count_events.append((pair[0], pair[1]))
             self._site_done[b] = pair[1]
         else:
             if time_counts:
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0, e1, _ = self._timing_pair(b, lambda: torch.cuda.Event(enable_timing=True))
                 e0.record()
             if self._count_plans[b] is not None:
                 self._count_plans[b].run()  # the genotype stream: site_counts, fused with the per-site decision when it can be
             if time_counts:
                 e1.record()
-                self.count_events.append((e0, e1))
             if self._flag_plans[b] is not None and self.overlap:
                 self._flag_plans[b].run()
         index = self._k
@@ -507,9 +546,20 @@ class ResidentScorer:
         if self.side is not None:
             self.side.synchronize()
 
+    def _wait_last_stage(self) -> None:
+        """Wait until the last step's records and lists are on the host.  The plain form waits for the event
+        behind ITS OWN windows stage (pass, stage and copies are ordered before it), not for the streams: several
+        scorers whose passes queue on one stream -- the parts of a region, FeaturePreprocessor.score_and_write --
+        hand their results over one after the other while the later passes still run."""
+        b = (self._k - 1) % len(self._flags)
+        if not self.overlap and self._k > 0 and self._win_used[b]:
+            self._win_done[b].synchronize()
+            return
+        self._sync()
+
     def list_totals(self) -> list[tuple[int, int]]:
         """(entries of all U lists, entries of all Q lists) per set chunk, of the last step."""
-        self._sync()
+        self._wait_last_stage()
         return [tuple(int(v) for v in ch.host_totals.tolist()) for ch in self.chunks]
 
     def results(self, grow: bool = False) -> WindowResults:
@@ -524,8 +574,10 @@ class ResidentScorer:
                     f"candidate buffers too small (need {need_u}/{need_q}); rebuild the scorer with larger cap_u/cap_q"
                 )
             self._alloc_chunks(max(need_u, self.cap_u), max(need_q, self.cap_q))
+            b = (self._k - 1) % len(self._flags)
             with self.window_stream():
-                self._stage_plans[(self._k - 1) % len(self._flags)].run()
+                self._stage_plans[b].run()
+                self._win_done[b].record(self.side)
             totals = self.list_totals()
         recs, offs, us, qs = [], [], [], []
         base_u = base_q = 0

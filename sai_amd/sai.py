@@ -228,11 +228,13 @@ def score(vcf_file: str, chr_name: str, win_len: int, win_step: int, anc_allele_
     write_headers(output_file, cfg.statistics, cfg.ploidies)
     # numeric batches -> text, natively; the item-dictionary route (driver.run + process_items)
     # writes the same bytes and stays what plug-ins and the sharded executors use
-    batches = []
-    for chunk in chunks.get():
+    tasks = list(chunks.get())
+    if len(tasks) == 1:  # the usual run: the rows of the first windows are written while the GPU scores the later ones
+        chunk = tasks[0]
         fits = preloaded is not None and (preloaded[2] is None or (chunk["start"] <= preloaded[2][0] and preloaded[2][1] <= chunk["end"]))
-        batches.append(driver.run_compact(**chunk, preloaded=preloaded[:2] if fits else None))
-    driver.write_results(batches)
+        driver.run_and_write(**chunk, preloaded=preloaded[:2] if fits else None)
+    else:  # chunk after chunk through the GPU; the files are combination-major, so the rows wait for the last chunk
+        driver.write_results([driver.run_compact(**chunk) for chunk in tasks])
     if os.environ.get("SAI_AMD_KEEP_INGEST_BUFFERS", "1") == "0":
         # the readers' staging (about 650 MB of HBM + 125 MB pinned for a large bgzip file) is kept for the
         # next call by default -- allocating and page-locking it costs more than a small `score`

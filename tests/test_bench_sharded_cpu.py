@@ -61,7 +61,6 @@ class OracleScorer:
                 mats.append(m.astype(np.int64))
             self.pieces.append((all_pos[pc.chrom_index][a : a + n], mats))
         self.after_stage = None
-        self.count_events = []
         self._res = None
         self._k = 0
 

@@ -431,16 +431,20 @@ def test_launch_carried_events_time_the_pass_and_hand_it_over(eng):
         scorer.step()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(7):
+    for _ in range(25):
         scorer.step(time_counts=True)
     for _ in range(2):
         scorer.step()  # untimed steps after timed ones must not re-stamp the timed pairs
     res = scorer.results()
     wall_ms = (time.perf_counter() - t0) * 1e3
-    assert len(scorer.count_events) == 7 and all(isinstance(a, LaunchEvent) and isinstance(b, LaunchEvent) for a, b in scorer.count_events)
-    ms = [a.elapsed_time(b) for a, b in scorer.count_events]
-    assert all(0.0 < m < wall_ms for m in ms) and sum(ms) < wall_ms, (ms, wall_ms)
-    assert all(b.query() for _, b in scorer.count_events)
+    ms = scorer.site_pass_ms()
+    assert len(ms) == 25 and all(0.0 < m < wall_ms for m in ms) and sum(ms) < wall_ms, (ms, wall_ms)
+    # the pairs behind the durations are a ring per buffer set, read and reused, not one pair per timed step
+    pairs = [p for ring in scorer._timing for p in ring]
+    assert len(pairs) <= 9 and all(isinstance(a, LaunchEvent) and isinstance(b, LaunchEvent) and not busy for a, b, busy in pairs)
+    assert scorer.site_pass_ms() == ms
+    scorer.close()
+    assert not any(scorer._timing)
     assert res.records.tobytes() == got.records.tobytes() and res.cdd_q.tobytes() == got.cdd_q.tobytes()
     ev = LaunchEvent(eng)  # never stamped: a query says "done" (nothing pending), elapsed_time between unstamped events is an error
     assert ev.query() is True

@@ -24,7 +24,7 @@ for _ in range(steps):
     sc.step(time_counts=True)
 sc.flush(); torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / steps * 1e3
-ms = [a.elapsed_time(b) for a, b in sc.count_events]
+ms = sc.site_pass_ms()
 gb = block.genotype_bytes / 1e9
 print(f"waves={os.environ.get('SAI_STREAM_WAVES_PER_CU', 'rule')} {n_ref}/{n_tgt}/{'+'.join(map(str, src))} x {n_sites} sites, {n_sets} sets, {len(windows)} windows: "
       f"step {dt:.4f} ms, site pass {sum(ms) / len(ms):.4f} ms = {gb / (sum(ms) / len(ms)) * 1e3 / 8000:.3f} of peak ({gb:.2f} GB)")
