@@ -572,6 +572,9 @@ def static_traffic(wl, args, world: int, sites_rank0: int):
     key = wl.name + ("" if args.layout == "int8" else f":{args.layout}") + ("" if args.anc == "true" else ":noanc")
     if key not in rec:
         return None, None
+    if rec[key].get("source_digest") != source_digest():  # counters of another tree are not this tree's traffic
+        return None, (f"profiles/traffic.json[{key}] was measured on other sources ({rec[key].get('source_digest')} != {source_digest()}): "
+                      "not handed out")  # fmt: skip
     whole = rec[key].get("site_counts_hbm_bytes_per_launch")
     src = f"profiles/traffic.json[{key}] ({rec[key].get('source', 'rocprofv3 --pmc passes of this command')}); not measured in this run"
     if world == 1 or whole is None:

@@ -65,7 +65,9 @@ extern "C" {
 
 #define SAI_ABI_VERSION 16
 #define SAI_TILE_SITES 64
-#define SAI_MAX_SRC 6   /* source populations per call */
+#define SAI_MAX_SRC 14  /* source populations of a parameter set (the reference loops over any number, stat_utils.py:114-119) */
+#define SAI_FUSED_SRC 6 /* source populations a streaming pass takes per call (sai_site_counts, sai_site_pass, ...): more of
+                           them go through sai_site_counts in groups + sai_site_flags, which takes 2 + SAI_MAX_SRC populations */
 #define SAI_MAX_SETS 20 /* parameter sets per call: 1 + 2 * 20 plane words of a tile = one wave store (C5's 18 sets fit) */
 #define SAI_FUSED_SETS SAI_MAX_SETS /* parameter sets the fused site pass carries */
 #define SAI_PLANES_PER_SET 3 /* words of a tile row reserved per set (1 + 2 n <= 3 n are used) */
@@ -179,7 +181,8 @@ int sai_site_pass(sai_ctx* ctx, int64_t n_sites, int32_t n_pops, const sai_pop* 
  * target frequency (NaN when nothing is called), written for every site (SAI_FREQ_DENSE: "any" all
  * ones); the decisions go to the flag planes described at the top of this header (condition, site
  * inverted).  U's final test (u_statistic.py:92) is sai_window_stats'.
- * ploidy[p] pairs with population p of sai_site_counts.  adj_freq may be NULL; otherwise it
+ * ploidy[p] pairs with population p of sai_site_counts; up to 2 + SAI_MAX_SRC populations (counts of more than
+ * 2 + SAI_FUSED_SRC come from several sai_site_counts calls into one tensor).  adj_freq may be NULL; otherwise it
  * receives compute_matching_loci's returned (possibly inverted) frequencies:
  * adj_freq[(set * 2 + 0) * n_sites + site] = ref_freq, [(set * 2 + 1) * n_sites + site] = tgt_freq. */
 int sai_site_flags(sai_ctx* ctx, int64_t n_sites, int32_t n_pops, const int32_t* ploidy_host,

@@ -15,7 +15,8 @@ LIB_NAME = "libsaihip.so"
 LIB_PATH = Path(__file__).resolve().parent / "lib" / LIB_NAME
 
 SAI_TILE_SITES = 64
-SAI_MAX_SRC = 6
+SAI_MAX_SRC = 14  # source populations of a parameter set
+SAI_FUSED_SRC = 6  # ... of which a streaming pass takes this many per call (more: counts in groups + site_flags)
 SAI_MAX_SETS = 20
 SAI_FUSED_SETS = SAI_MAX_SETS
 SAI_PLANES_PER_SET = 3

@@ -28,7 +28,8 @@ extern "C" int sai_set_error(int code, const char* fmt, ...);
   } while (0)
 
 constexpr int kTile = SAI_TILE_SITES;
-constexpr int kMaxPops = 2 + SAI_MAX_SRC;
+constexpr int kMaxPops = 2 + SAI_FUSED_SRC;  // populations of a streaming pass
+constexpr int kBigPops = 2 + SAI_MAX_SRC;    // populations of the stand-alone per-site decision (sai_site_flags)
 constexpr int kProbeWavesPerCu = 32;
 // Grid of the streaming passes: 16 single-wave workgroups per CU = 4 waves per SIMD, enough to
 // saturate HBM (measured flat from 8 to 611 per CU) while leaving registers and LDS on every SIMD

@@ -332,7 +332,7 @@ int sai_window_fourpop(sai_ctx* ctx, int64_t n_sites, int32_t n_src, int32_t has
                        void* stream) {
   if (int rc = enter(ctx)) return rc;
   if (n_sites < 0 || n_sites >= 0x7FFFFFFFll || n_windows < 0) return fail(SAI_ERR_ARG, "size out of range");
-  if (n_src < 1 || n_src > SAI_MAX_SRC) return fail(SAI_ERR_ARG, "n_src must be 1..%d", SAI_MAX_SRC);
+  if (n_src < 1 || n_src > SAI_FUSED_SRC) return fail(SAI_ERR_ARG, "n_src must be 1..%d", SAI_FUSED_SRC);
   if (n_windows == 0) return SAI_OK;
   if ((n_sites > 0 && !freqs) || !lo || !hi || !sums || !stats) return fail(SAI_ERR_ARG, "NULL buffer");
   PatternArgs a;

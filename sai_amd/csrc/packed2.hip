@@ -152,7 +152,7 @@ __global__ __launch_bounds__(64) void site_counts_packed2_kernel(PackedArgs a, F
       if (FUSED) stash[p][lane] = cnt;
     }
     if (FUSED)  // lane = site inside the tile already: the ballots of eval_site are the tile's flag planes
-      eval_site(
+      eval_site<kMaxPops>(
           a.n_pops, fa.ploidy, [&](int p) { return stash[p][lane]; }, fa.n_sets, fa.es, table, tile, lane, site < a.n_sites,
           a.n_sites, fa.tgt_freq, fa.planes, fa.plane_stride, nullptr, fa.sparse_freq != 0, fa.with_inv != 0);
   }

@@ -38,7 +38,7 @@ constexpr int kPlanesPerSet = SAI_PLANES_PER_SET;  // row words RESERVED per set
 // (source, operator, y) and one w, yet the set-by-set form below evaluates 72 source comparisons per site,
 // each behind a scalar load and a five-way branch on the operator (a quarter of a C5 tile's time went there,
 // during which the wave loads nothing).  The host therefore lists every DISTINCT comparison of a call once --
-// (value slot, operator, threshold) with slot p = frequency of population p and slot kMaxPops = 1 - ref_freq,
+// (value slot, operator, threshold) with slot p = frequency of population p and slot kBigPops = 1 - ref_freq,
 // the reference frequency of an inverted site (stat_utils.py:159) -- sorted by slot, at most 32 of them; a
 // site evaluates each into one bit of a 32-bit word, and a set is then the test "all bits of a mask are up":
 //   cond        = the set's y comparisons and ref_freq < w                       (stat_utils.py:141-144, 166)
@@ -47,7 +47,7 @@ constexpr int kPlanesPerSet = SAI_PLANES_PER_SET;  // row words RESERVED per set
 // The arithmetic per comparison is the reference's: one f64 compare of the same two doubles.
 // ------------------------------------------------------------------------------------------
 constexpr int kMaxPreds = 32;  // with the masks below the table stays under 1 KiB of LDS next to the 4 KiB of parked counts
-constexpr int kMirrorRefSlot = kMaxPops;
+constexpr int kMirrorRefSlot = kBigPops;  // any slot beyond a kernel's populations reads as 1 - ref_freq
 
 struct PredEntry {
   double value;
@@ -62,10 +62,22 @@ struct SetMasks {
 
 struct PredTable {
   int32_t n_preds;
-  uint8_t slot_end[kMaxPops + 2];  // the comparisons of slot s are [slot_end[s - 1], slot_end[s])
+  uint8_t slot_end[kBigPops + 2];  // the comparisons of slot s are [slot_end[s - 1], slot_end[s])
   uint8_t pad[2];
   PredEntry preds[kMaxPreds];
   SetMasks sets[SAI_MAX_SETS];
+};
+
+// A parameter set as the set-by-set form of the decision reads it: the fields of sai_params that
+// compute_matching_loci looks at, for the at most SAI_FUSED_SRC sources of a streaming pass (twenty whole
+// sai_params would not fit the kernel arguments).
+struct DevSet {
+  double w;
+  int32_t anc;
+  int32_t op[SAI_FUSED_SRC];
+  int32_t pad;
+  double y[SAI_FUSED_SRC];
+  double one_minus_y[SAI_FUSED_SRC];
 };
 
 // What the per-site decision is handed: the table (use_table) or, for a call with more than 32 distinct
@@ -74,11 +86,10 @@ struct EvalSets {
   int32_t use_table;
   int32_t pad;
   union {
-    sai_params sets[SAI_MAX_SETS];
+    DevSet sets[SAI_MAX_SETS];
     PredTable table;
   };
 };
-static_assert(sizeof(PredTable) <= sizeof(sai_params) * SAI_MAX_SETS, "the table rides in the sets' kernel-argument space");
 
 inline int op_bits_of(int op) {
   switch (op) {
@@ -90,8 +101,10 @@ inline int op_bits_of(int op) {
   }
 }
 
-// host: the call's parameter sets as kernel arguments (n_src = source populations of the call)
-inline void fill_eval_sets(EvalSets& es, int32_t n_sets, const sai_params* sets, int32_t n_src) {
+// host: the call's parameter sets as kernel arguments (n_src = source populations of the call).  Returns
+// whether the table holds them; when it does not, the sets themselves are handed over -- unless `table_only`
+// (the kernel for more than SAI_FUSED_SRC sources has no set-by-set form: its caller takes fewer sets per launch).
+inline bool fill_eval_sets(EvalSets& es, int32_t n_sets, const sai_params* sets, int32_t n_src, bool table_only = false) {
   std::memset(&es, 0, sizeof(es));
   struct Raw { int slot, op_bits; double value; };
   Raw raw[SAI_MAX_SETS * (2 * SAI_MAX_SRC + 2)];
@@ -112,10 +125,20 @@ inline void fill_eval_sets(EvalSets& es, int32_t n_sets, const sai_params* sets,
     index_of(0, 1, ps.w);
     if (!ps.anc_allele_available) index_of(kMirrorRefSlot, 1, ps.w);
   }
-  fits = fits && n_raw <= kMaxPreds;
+  fits = (fits || table_only) && n_raw <= kMaxPreds;
   if (!fits) {
-    for (int s = 0; s < n_sets; ++s) es.sets[s] = sets[s];
-    return;
+    if (table_only) return false;
+    for (int s = 0; s < n_sets; ++s) {
+      DevSet& d = es.sets[s];
+      d.w = sets[s].w;
+      d.anc = sets[s].anc_allele_available != 0;
+      for (int k = 0; k < SAI_FUSED_SRC; ++k) {
+        d.op[k] = sets[s].op[k];
+        d.y[k] = sets[s].y[k];
+        d.one_minus_y[k] = sets[s].one_minus_y[k];
+      }
+    }
+    return false;
   }
   es.use_table = 1;
   PredTable& t = es.table;
@@ -146,6 +169,7 @@ inline void fill_eval_sets(EvalSets& es, int32_t n_sets, const sai_params* sets,
       m.mirror_cond = m.mirror | bit(kMirrorRefSlot, 1, ps.w);
     }
   }
+  return true;
 }
 
 // `value` (wave-uniform) into lane `lane` (wave-uniform) of `row`, the other lanes as they were: v_writelane_b32
@@ -175,17 +199,21 @@ __device__ __forceinline__ void stage_pred_table(const EvalSets& es, PredTable* 
 }
 
 // get(p) -> uint2 {alt_sum, n_called} of population p at this lane's site (site = tile * 64 + lane;
-// `live` = the site exists).  Must be called by the whole wavefront.
-template <typename GetCounts>
+// `live` = the site exists).  Must be called by the whole wavefront.  MAXP = populations the kernel is built
+// for.  `set0` / `n_row_sets`: the call evaluates sets set0 .. set0 + n_sets - 1 of a row that holds n_row_sets
+// sets (a decision over more than SAI_FUSED_SRC sources may take a row's sets in several launches; the other
+// words of the row are left alone).
+template <int MAXP, typename GetCounts>
 __device__ __forceinline__ void eval_site(int n_pops, const int32_t* ploidy, GetCounts get, int n_sets,
                                           const EvalSets& es, const PredTable* lds_table, int64_t tile, int lane, bool live, int64_t n_sites,
                                           double* tgt_freq, uint64_t* planes, int64_t plane_stride, double* adj_freq,
-                                          bool sparse_freq, bool with_inv) {
+                                          bool sparse_freq, bool with_inv, int set0 = 0, int n_row_sets = -1) {
   const int64_t site = tile * kTile + lane;
-  double f[kMaxPops];
+  const int row_sets = n_row_sets < 0 ? n_sets : n_row_sets;
+  double f[MAXP];
   bool valid = live;
 #pragma unroll
-  for (int p = 0; p < kMaxPops; ++p) {
+  for (int p = 0; p < MAXP; ++p) {
     if (p < n_pops) {
       const uint2 c = get(p);
       const int64_t den = static_cast<int64_t>(c.y) * ploidy[p];
@@ -205,16 +233,16 @@ __device__ __forceinline__ void eval_site(int n_pops, const int32_t* ploidy, Get
   auto emit = [&](int s, bool cond, bool inverted) {
     const uint64_t bc = __ballot(cond);
     any |= bc;
-    row_lo = write_lane(static_cast<uint32_t>(bc), 1 + s, row_lo);
-    row_hi = write_lane(static_cast<uint32_t>(bc >> 32), 1 + s, row_hi);
+    row_lo = write_lane(static_cast<uint32_t>(bc), 1 + set0 + s, row_lo);
+    row_hi = write_lane(static_cast<uint32_t>(bc >> 32), 1 + set0 + s, row_hi);
     if (with_inv) {  // uniform
       const uint64_t bi = __ballot(inverted);
-      row_lo = write_lane(static_cast<uint32_t>(bi), 1 + n_sets + s, row_lo);
-      row_hi = write_lane(static_cast<uint32_t>(bi >> 32), 1 + n_sets + s, row_hi);
+      row_lo = write_lane(static_cast<uint32_t>(bi), 1 + row_sets + set0 + s, row_lo);
+      row_hi = write_lane(static_cast<uint32_t>(bi >> 32), 1 + row_sets + set0 + s, row_hi);
     }
     if (adj_freq && live) {
-      adj_freq[(static_cast<int64_t>(s) * 2 + 0) * n_sites + site] = inverted ? 1.0 - f[0] : f[0];
-      adj_freq[(static_cast<int64_t>(s) * 2 + 1) * n_sites + site] = inverted ? 1.0 - f[1] : f[1];
+      adj_freq[(static_cast<int64_t>(set0 + s) * 2 + 0) * n_sites + site] = inverted ? 1.0 - f[0] : f[0];
+      adj_freq[(static_cast<int64_t>(set0 + s) * 2 + 1) * n_sites + site] = inverted ? 1.0 - f[1] : f[1];
     }
   };
   if (es.use_table) {  // uniform
@@ -238,7 +266,7 @@ __device__ __forceinline__ void eval_site(int n_pops, const int32_t* ploidy, Get
         cur_slot = slot;
         v = 1.0 - f[0];
 #pragma unroll
-        for (int p = 0; p < kMaxPops; ++p) v = cur_slot == p ? f[p] : v;
+        for (int p = 0; p < MAXP; ++p) v = cur_slot == p ? f[p] : v;
       }
       bool holds;  // one compare per comparison, chosen by a scalar branch; its lane mask selects the bit
       switch (ob) {
@@ -264,18 +292,18 @@ __device__ __forceinline__ void eval_site(int n_pops, const int32_t* ploidy, Get
       }
       m = next;
     }
-  } else {
+  } else if constexpr (MAXP == kMaxPops) {  // the set-by-set form: a streaming pass's at most SAI_FUSED_SRC sources
     for (int s = 0; s < n_sets; ++s) {
-      const sai_params& ps = es.sets[s];
+      const DevSet& ps = es.sets[s];
       bool hit_y = true, hit_m = true;
 #pragma unroll
-      for (int k = 0; k < SAI_MAX_SRC; ++k) {
+      for (int k = 0; k < SAI_FUSED_SRC; ++k) {
         if (k < n_src) {
           hit_y = hit_y && cmp_op(ps.op[k], f[2 + k], ps.y[k]);
           hit_m = hit_m && cmp_op(ps.op[k], f[2 + k], ps.one_minus_y[k]);
         }
       }
-      const bool anc = ps.anc_allele_available != 0;
+      const bool anc = ps.anc != 0;
       const bool inverted = !anc && hit_m && valid;
       const bool hit = anc ? hit_y : (hit_y || hit_m);
       const double rf = inverted ? 1.0 - f[0] : f[0];
@@ -286,8 +314,9 @@ __device__ __forceinline__ void eval_site(int n_pops, const int32_t* ploidy, Get
   row_hi = write_lane(static_cast<uint32_t>(any >> 32), 0, row_hi);
   // non-temporal stores: measured on MI355X, plain stores in the middle of the genotype stream cost
   // twice as much of the pass as streaming ones
-  if (lane < 1 + (with_inv ? 2 : 1) * n_sets)
-    __builtin_nontemporal_store((static_cast<uint64_t>(row_hi) << 32) | row_lo, planes + tile * plane_stride + lane);
+  const bool my_word = lane == 0 || (lane >= 1 + set0 && lane < 1 + set0 + n_sets) ||
+                       (with_inv && lane >= 1 + row_sets + set0 && lane < 1 + row_sets + set0 + n_sets);
+  if (my_word) __builtin_nontemporal_store((static_cast<uint64_t>(row_hi) << 32) | row_lo, planes + tile * plane_stride + lane);
   // The windows stage reads tgt_freq only where a set's condition bit is up (about 1 site in 1000; one in
   // three for C5's loosest sets), and dense f64 stores in the middle of the genotype stream cost ~10 % of
   // the pass: SAI_FREQ_CANDIDATES stores those sites' values only, packed at the start of the tile's slots.

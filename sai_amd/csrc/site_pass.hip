@@ -8,9 +8,12 @@ namespace {
 struct FlagArgs {
   int64_t n_sites;
   int32_t n_pops;
-  int16_t n_sets;
+  int16_t n_sets;      // sets of THIS launch
   int16_t with_inv;
-  int32_t ploidy[kMaxPops];
+  int16_t set0;        // ... which are sets set0 .. set0 + n_sets - 1 of a row of n_row_sets sets
+  int16_t n_row_sets;
+  int32_t pad;
+  int32_t ploidy[kBigPops];
   const uint2* counts;
   double* tgt_freq;
   uint64_t* planes;
@@ -20,7 +23,10 @@ struct FlagArgs {
 };
 static_assert(sizeof(FlagArgs) <= 4096, "kernel arguments exceed the kernarg segment");
 
-// one wavefront per tile (four per workgroup): lane = site inside the tile
+// one wavefront per tile (four per workgroup): lane = site inside the tile.  MAXP = kMaxPops: the usual build;
+// kBigPops: up to SAI_MAX_SRC sources (table form only; its launcher takes as many sets per launch as the
+// table holds).
+template <int MAXP>
 __global__ __launch_bounds__(256) void site_flags_kernel(FlagArgs a) {
   __shared__ PredTable table;
   stage_pred_table(a.es, &table);
@@ -28,11 +34,11 @@ __global__ __launch_bounds__(256) void site_flags_kernel(FlagArgs a) {
   const int64_t site = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
   if ((site & ~int64_t{63}) >= a.n_sites) return;  // whole wavefronts beyond the last tile: there is no row for them
   const bool live = site < a.n_sites;              // the last tile's spare lanes vote 0
-  eval_site(
+  eval_site<MAXP>(
       a.n_pops, a.ploidy,
       [&](int p) { return live ? a.counts[static_cast<int64_t>(p) * a.n_sites + site] : make_uint2(0u, 0u); }, a.n_sets,
       a.es, &table, site >> 6, static_cast<int>(threadIdx.x & 63), live, a.n_sites, a.tgt_freq, a.planes, a.plane_stride,
-      a.adj_freq, false, a.with_inv != 0);
+      a.adj_freq, false, a.with_inv != 0, a.set0, a.n_row_sets);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -114,7 +120,7 @@ __global__ __launch_bounds__(64, MULTI ? 4 : 5) void site_counts_kernel(CountsAr
     }
     if (FUSED) {
       wave_lds_fence();
-      eval_site(
+      eval_site<kMaxPops>(
           a.n_pops, fa.ploidy, [&](int p) { return stash[p][lane]; }, fa.n_sets, fa.es, table, tile, lane,
           tile * kTile + lane < a.n_sites, a.n_sites, fa.tgt_freq, fa.planes, fa.plane_stride, nullptr,
           fa.sparse_freq != 0, fa.with_inv != 0);
@@ -235,7 +241,7 @@ int sai_site_flags(sai_ctx* ctx, int64_t n_sites, int32_t n_pops, const int32_t*
                    uint64_t* planes, int64_t plane_stride, double* adj_freq, void* stream) {
   if (int rc = enter(ctx)) return rc;
   if (n_sites < 0 || n_sites >= 0x7FFFFFFFll) return fail(SAI_ERR_ARG, "n_sites out of range");
-  if (n_pops < 2 || n_pops > kMaxPops) return fail(SAI_ERR_ARG, "n_pops must be 2..%d (ref, tgt, sources)", kMaxPops);
+  if (n_pops < 2 || n_pops > kBigPops) return fail(SAI_ERR_ARG, "n_pops must be 2..%d (ref, tgt, sources)", kBigPops);
   if (!ploidy_host) return fail(SAI_ERR_ARG, "ploidy_host is NULL");
   if (int rc = check_sets(n_sets, sets_host, n_pops - 2)) return rc;
   if (n_sites == 0) return SAI_OK;
@@ -245,8 +251,8 @@ int sai_site_flags(sai_ctx* ctx, int64_t n_sites, int32_t n_pops, const int32_t*
   std::memset(&a, 0, sizeof(a));
   a.n_sites = n_sites;
   a.n_pops = n_pops;
-  a.n_sets = static_cast<int16_t>(n_sets);
   a.with_inv = sets_with_inverted(n_sets, sets_host);
+  a.n_row_sets = static_cast<int16_t>(n_sets);
   for (int p = 0; p < n_pops; ++p) {
     if (ploidy_host[p] <= 0) return fail(SAI_ERR_ARG, "ploidy[%d] must be positive", p);
     a.ploidy[p] = ploidy_host[p];
@@ -256,10 +262,28 @@ int sai_site_flags(sai_ctx* ctx, int64_t n_sites, int32_t n_pops, const int32_t*
   a.planes = planes;
   a.plane_stride = plane_stride;
   a.adj_freq = adj_freq;
-  fill_eval_sets(a.es, n_sets, sets_host, n_pops - 2);
   const unsigned grid = static_cast<unsigned>((n_sites + 255) / 256);
-  hipLaunchKernelGGL(site_flags_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), a);
-  return check_launch("site_flags");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (n_pops <= kMaxPops) {
+    a.n_sets = static_cast<int16_t>(n_sets);
+    fill_eval_sets(a.es, n_sets, sets_host, n_pops - 2);
+    hipLaunchKernelGGL(site_flags_kernel<kMaxPops>, dim3(grid), dim3(256), 0, st, a);
+    return check_launch("site_flags");
+  }
+  // more than SAI_FUSED_SRC sources (stat_utils.py:114-119 loops over any number): the table form only, as many
+  // sets of the row per launch as the table's 32 comparisons hold (one set of 14 sources needs at most 30)
+  for (int s0 = 0; s0 < n_sets;) {
+    int k = n_sets - s0;
+    while (k > 1 && !fill_eval_sets(a.es, k, sets_host + s0, n_pops - 2, true)) --k;
+    if (k == 1 && !fill_eval_sets(a.es, 1, sets_host + s0, n_pops - 2, true))
+      return fail(SAI_ERR_UNSUPPORTED, "set %d: more distinct comparisons than one launch evaluates", s0);
+    a.set0 = static_cast<int16_t>(s0);
+    a.n_sets = static_cast<int16_t>(k);
+    hipLaunchKernelGGL(site_flags_kernel<kBigPops>, dim3(grid), dim3(256), 0, st, a);
+    if (int rc = check_launch("site_flags")) return rc;
+    s0 += k;
+  }
+  return SAI_OK;
 }
 
 }  // extern "C"

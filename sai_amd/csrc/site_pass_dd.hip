@@ -197,7 +197,7 @@ __global__ __launch_bounds__(64, NS <= 2 ? 3 : 2) void site_counts_dd_kernel(Cou
     }
     if (FUSED) {
       wave_lds_fence();
-      eval_site(
+      eval_site<kMaxPops>(
           a.n_pops, fa.ploidy, [&](int p) { return stash[p][lane]; }, fa.n_sets, fa.es, table, tile, lane,
           tile * kTile + lane < a.n_sites, a.n_sites, fa.tgt_freq, fa.planes, fa.plane_stride, nullptr,
           fa.sparse_freq != 0, fa.with_inv != 0);

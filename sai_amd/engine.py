@@ -209,7 +209,11 @@ class Plan:
     def add_site_counts(self, pops, counts) -> None:
         e = self.eng
         self._keep.append(counts)
-        _ffi.check(e.lib.sai_plan_add_site_counts(self._h, pops[0].n_sites, len(pops), self._pops(pops, None, False), e._ptr(counts)))
+        per_call = 2 + _ffi.SAI_FUSED_SRC  # populations a streaming pass takes: more go in groups
+        for g0 in range(0, len(pops), per_call):
+            part = pops[g0 : g0 + per_call]
+            _ffi.check(e.lib.sai_plan_add_site_counts(self._h, part[0].n_sites, len(part), self._pops(part, None, False),
+                                                      e._ptr(counts[g0 : g0 + len(part)])))  # fmt: skip
 
     def add_site_pass(self, pops, ploidies, sets, out, counts=None, freq_mode="dense", packed2=False, dd=None) -> None:
         """``Engine.site_pass`` / ``site_pass_packed2`` (``packed2=True``; ``sets == []`` = counts only);
@@ -567,14 +571,17 @@ class Engine:
         n_sites = pops[0].n_sites
         if any(p.n_sites != n_sites for p in pops):
             raise ValueError("all populations of one call must cover the same sites")
-        arr = (_ffi.SaiPop * len(pops))()
-        for i, p in enumerate(pops):
-            arr[i].tiles = p.tiles.data_ptr() if p.tiles.numel() else 0
-            arr[i].n_ind = p.n_ind
-            arr[i].ploidy = 1
         if out is None:
             out = self._empty((len(pops), n_sites, 2), torch.int32)
-        _ffi.check(self.lib.sai_site_counts(self.ctx, n_sites, len(pops), arr, self._ptr(out), self._stream()))
+        per_call = 2 + _ffi.SAI_FUSED_SRC  # populations a streaming pass takes: more go in groups
+        for g0 in range(0, len(pops), per_call):
+            part = pops[g0 : g0 + per_call]
+            arr = (_ffi.SaiPop * len(part))()
+            for i, p in enumerate(part):
+                arr[i].tiles = p.tiles.data_ptr() if p.tiles.numel() else 0
+                arr[i].n_ind = p.n_ind
+                arr[i].ploidy = 1
+            _ffi.check(self.lib.sai_site_counts(self.ctx, n_sites, len(part), arr, self._ptr(out[g0 : g0 + len(part)]), self._stream()))
         return out
 
     def alloc_planes(self, n_sites: int, n_sets: int):
@@ -819,6 +826,39 @@ class Engine:
             )
         )  # fmt: skip
         return stats
+
+    def fourpop_windows(self, counts, ploidies: Sequence[int], n_src: int, has_outgroup: bool, lo, hi):
+        """fd, df, Danc, Dplus per (window, source) for ANY number of sources: ``counts`` = int32 [P][n_sites][2] in
+        the order ref, tgt, sources..., (outgroup).  Every source is a statistic of its own (fd_statistic.py:63-88),
+        so the sources go through ``site_freqs`` / ``window_fourpop`` SAI_FUSED_SRC at a time."""
+        torch = _torch()
+        parts = []
+        tail = [2 + n_src] if has_outgroup else []
+        for s0 in range(0, n_src, _ffi.SAI_FUSED_SRC):
+            s1 = min(s0 + _ffi.SAI_FUSED_SRC, n_src)
+            rows = [0, 1, *range(2 + s0, 2 + s1), *tail]
+            sel = counts if rows == list(range(int(counts.shape[0]))) else counts[torch.tensor(rows, device=counts.device)]
+            freqs = self.site_freqs(sel, [ploidies[r] for r in rows])
+            parts.append(self.window_fourpop(freqs, s1 - s0, has_outgroup, lo, hi))
+        return parts[0] if len(parts) == 1 else torch.cat(parts, dim=1)
+
+    def single_window_unfused(self, pops: Sequence[TiledPop], ploidies: Sequence[int], prm: _ffi.SaiParams):
+        """``single_window`` for more than SAI_FUSED_SRC source populations: counts in groups, the stand-alone
+        per-site decision (which takes up to SAI_MAX_SRC sources), the window statistics over [0, n_sites)."""
+        torch = _torch()
+        n_sites = pops[0].n_sites
+        rec = _ffi.SaiWindowRecord()
+        if n_sites == 0:
+            rec.q = float("nan")
+            return rec, np.zeros(0, np.int64), np.zeros(0, np.int64)
+        counts = self.site_counts(pops)
+        tgt_freq, planes, _ = self.site_flags(counts, ploidies, [prm])
+        lo = torch.zeros(1, dtype=torch.int32, device=self.device)
+        hi = torch.full((1,), n_sites, dtype=torch.int32, device=self.device)
+        res = self.window_stats(tgt_freq, planes, [prm], lo, hi, pos=None, cap_hint=max(n_sites, 1))
+        r = res.records[0, 0]
+        rec.n_sites, rec.u_count, rec.n_cond, rec.n_cdd_q, rec.q = int(r["n_sites"]), int(r["u_count"]), int(r["n_cond"]), int(r["n_cdd_q"]), float(r["q"])
+        return rec, res.u_list(0, 0).astype(np.int64), res.q_list(0, 0).astype(np.int64)
 
     def pattern_sum(self, ref_freq, tgt_freq, src_freq, out_freq, pattern_bits: int) -> float:
         """np.sum over the sites of the per-site pattern product (calc_pattern_sum's arithmetic) of

@@ -288,7 +288,7 @@ class FeaturePreprocessor(DataPreprocessor):
         def counts_of(keys):
             """int32 [len(keys)][n_sites][2]; every block is reduced at most once."""
             todo = [k for k in dict.fromkeys(keys) if k not in counts_rows]
-            max_pops = 2 + _ffi.SAI_MAX_SRC
+            max_pops = 2 + _ffi.SAI_FUSED_SRC
             for i in range(0, len(todo), max_pops):
                 part = todo[i : i + max_pops]
                 c = eng.site_counts([tiled[k] for k in part])
@@ -345,7 +345,8 @@ class FeaturePreprocessor(DataPreprocessor):
                     sink(cb)
                 continue
             if (sink is not None and uq_names and not shared and not four_names and not want_dd and al.segments is None
-                    and al.uniq is None and al.file_order is None and len(win) >= self.PART_MIN_WINDOWS):  # fmt: skip
+                    and al.uniq is None and al.file_order is None and len(win) >= self.PART_MIN_WINDOWS
+                    and n_eff <= _ffi.SAI_FUSED_SRC):  # fmt: skip
                 self._score_in_parts(eng, wg, cb, al, tiled, ploidy, n_eff, sets, set_of, sink, batch)
                 continue
             batch.combos.append(cb)
@@ -420,8 +421,7 @@ class FeaturePreprocessor(DataPreprocessor):
                     pl4.append(pc.get_ploidy("outgroup", out_pop))
                 for p in pl4:
                     _check_ploidy(p)
-                freqs = eng.site_freqs(counts_of(keys), pl4)
-                cb.four = eng.window_fourpop(freqs, len(src_comb), out_pop is not None, lo, hi).cpu().numpy()
+                cb.four = eng.fourpop_windows(counts_of(keys), pl4, len(src_comb), out_pop is not None, lo, hi).cpu().numpy()
             if dd_terms is not None:  # the terms came with the pass: only the window sums are left
                 ref_t, tgt_t = tiled[("ref", ref_pop)], tiled[("tgt", tgt_pop)]
                 cols, row = [], 0

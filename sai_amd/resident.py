@@ -194,7 +194,9 @@ class ResidentScorer:
         if counts_in is not None and (counts_out is not None or layout != "int8"):
             raise ValueError("counts_in excludes counts_out and the packed2 layout")
         self.have_counts = counts_in is not None
-        self.fused = n_s <= _ffi.SAI_FUSED_SETS and not self.have_counts
+        # one fused launch serves at most SAI_FUSED_SETS sets and SAI_FUSED_SRC source populations; beyond that the
+        # counts (in groups of populations) and the stand-alone per-site decision
+        self.fused = n_s <= _ffi.SAI_FUSED_SETS and not self.have_counts and len(block.pops) <= 2 + _ffi.SAI_FUSED_SRC
         if dd_out is not None and (not self.fused or layout != "int8"):
             raise ValueError("DD rides along the fused int8 pass only")
         self.dd_out = dd_out
@@ -263,7 +265,7 @@ class ResidentScorer:
             raise ValueError("rebind needs a block of the same number of sites and as many parameter sets")
         if (block.segments is None) != (self.block.segments is None) or (block.segments is not None and block.segments != self.block.segments):
             raise ValueError("rebind needs the same chromosome pieces")
-        if dd_out is not None and (counts_in is not None or self.n_sets > _ffi.SAI_FUSED_SETS):
+        if dd_out is not None and (counts_in is not None or self.n_sets > _ffi.SAI_FUSED_SETS or len(block.pops) > 2 + _ffi.SAI_FUSED_SRC):
             raise ValueError("DD rides along the fused int8 pass only")
         signature = self._binding_signature(block, sets, counts_in, lists_as_indices, dd_out)
         if signature == getattr(self, "_bound", None):
@@ -275,7 +277,7 @@ class ResidentScorer:
         self._bound = signature
         self.block, self.sets = block, list(sets)
         self.have_counts = counts_in is not None
-        self.fused = self.n_sets <= _ffi.SAI_FUSED_SETS and not self.have_counts
+        self.fused = self.n_sets <= _ffi.SAI_FUSED_SETS and not self.have_counts and len(block.pops) <= 2 + _ffi.SAI_FUSED_SRC
         self.dd_out = dd_out
         self.counts = counts_in
         if self.counts is None and not self.fused:

@@ -70,7 +70,10 @@ def run_single_window(stat, w, x, quantile, y_list, anc_allele_available):
         both.update(hint)
     prm = _ffi.make_params(w, both["x"], both["quantile"], y_list, anc_allele_available, n_src=n_eff)
     pops = eng.tile_many(mats)
-    rec, idx_u, idx_q = eng.single_window(pops, ploidy[: 2 + n_eff], prm)
+    if n_eff <= _ffi.SAI_FUSED_SRC:
+        rec, idx_u, idx_q = eng.single_window(pops, ploidy[: 2 + n_eff], prm)
+    else:  # more sources than a streaming pass takes (the reference loops over any number, stat_utils.py:114-119)
+        rec, idx_u, idx_q = eng.single_window_unfused(pops, ploidy[: 2 + n_eff], prm)
     out = ({"n_sites": rec.n_sites, "u_count": rec.u_count, "n_cond": rec.n_cond, "n_cdd_q": rec.n_cdd_q, "q": rec.q}, idx_u, idx_q)
     if scope is not None:
         scope["results"][key] = (both, out)

@@ -41,10 +41,9 @@ def evaluate_fourpop(stat: GenericStatistic) -> np.ndarray:
     if any(p.n_sites != n_sites for p in pops):
         raise ValueError("genotype matrices must have the same number of sites")
     counts = eng.site_counts(pops)
-    freqs = eng.site_freqs(counts, ploidy)
     lo = torch.zeros(1, dtype=torch.int32, device=eng.device)
     hi = torch.full((1,), n_sites, dtype=torch.int32, device=eng.device)
-    return eng.window_fourpop(freqs, n_src, stat.out_gts is not None, lo, hi)[0].cpu().numpy()
+    return eng.fourpop_windows(counts, ploidy, n_src, stat.out_gts is not None, lo, hi)[0].cpu().numpy()
 
 
 class _FourPopStatistic(GenericStatistic):

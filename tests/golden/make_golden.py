@@ -843,3 +843,74 @@ def make_sitesets():
 
 if __name__ == "__main__" and os.path.isdir(REF):
     make_sitesets()
+
+
+# ---------------------------------------------------------------------------
+# 11. more than six source populations (stat_utils.py:114-119, 141-152 loop over any number): seeded
+#     chromosomes with seven to ten sources through the reference's WindowGenerator + FeaturePreprocessor
+#     (output text), and single windows through UStatistic / QStatistic
+# ---------------------------------------------------------------------------
+
+MANY_SOURCE_SEEDS = [900, 901, 902, 903, 904, 905]
+
+
+def make_many_sources():
+    sys.path.insert(0, str(OUT))
+    from itertools import combinations
+
+    from seeded import many_sources_scenario
+    from sai.configs import PloidyConfig, StatConfig
+    from sai.generators import WindowGenerator
+    from sai.preprocessors import FeaturePreprocessor
+    from sai.stats import QStatistic, UStatistic
+    from sai.utils import split_genome
+    from sai.utils.genomic_dataclasses import ChromosomeData
+
+    out = []
+    for seed in MANY_SOURCE_SEEDS:
+        sc = many_sources_scenario(seed)
+        pos = sc["pos"]
+        wg = object.__new__(WindowGenerator)
+        wg.win_len, wg.win_step, wg.chr_name, wg.ploidy_config = sc["win"], sc["step"], "7", PloidyConfig(sc["pl"])
+        for g in ("ref", "tgt", "src"):
+            setattr(wg, f"{g}_data", {k: ChromosomeData(POS=pos.copy(), REF=None, ALT=None, GT=v.copy()) for k, v in sc["gts"][g].items()})
+            setattr(wg, f"{g}_samples", {k: [] for k in sc["gts"][g]})
+        if sc["gts"]["outgroup"]:
+            wg.out_data = {k: ChromosomeData(POS=pos.copy(), REF=None, ALT=None, GT=v.copy()) for k, v in sc["gts"]["outgroup"].items()}
+            wg.out_samples = {k: [] for k in sc["gts"]["outgroup"]}
+        else:
+            wg.out_data = wg.out_samples = None
+        wg.num_src = len(sc["gts"]["src"])
+        wg.src_combinations = list(combinations(wg.src_samples.keys(), wg.num_src))
+        wg.tgt_windows = {t: split_genome(pos=wg.tgt_data[t].POS, window_size=sc["win"], step_size=sc["step"], start=None)
+                          for t in wg.tgt_samples}
+        stat_config = StatConfig(json.loads(json.dumps(sc["stats"])))
+        with tempfile.TemporaryDirectory() as td:
+            tsv = os.path.join(td, "o.tsv")
+            fp = FeaturePreprocessor(output_file=tsv, stat_config=stat_config, anc_allele_available=sc["anc"])
+            items = []
+            for item in wg.get():
+                items.extend(fp.run(**item))
+            fp.process_items(items)
+            text = {"tsv": open(tsv).read()}
+            for k in ("U", "Q"):
+                text[k] = open(os.path.join(td, f"o.{k}.log")).read()
+        # the whole chromosome as ONE window through the statistic classes (the per-window plugin route)
+        t0 = next(iter(sc["gts"]["tgt"]))
+        kw = dict(ref_gts=sc["gts"]["ref"]["R0"], tgt_gts=sc["gts"]["tgt"][t0], src_gts_list=list(sc["gts"]["src"].values()),
+                  ref_ploidy=2, tgt_ploidy=sc["pl"]["tgt"][t0], src_ploidy_list=list(sc["pl"]["src"].values()))
+        up = stat_config.get_parameters("U")
+        qp = stat_config.get_parameters("Q")
+        u = UStatistic(**kw).compute(pos=pos, w=up["ref"]["R0"], x=up["tgt"][t0], y_list=list(up["src"].values()),
+                                     anc_allele_available=sc["anc"])
+        q = QStatistic(**kw).compute(pos=pos, w=qp["ref"]["R0"], quantile=qp["tgt"][t0], y_list=list(qp["src"].values()),
+                                     anc_allele_available=sc["anc"])
+        assert any(it["U"] > 0 for it in items if isinstance(it["U"], int)), seed  # some window passes all the sources' conditions
+        out.append(dict(seed=seed, n_src=wg.num_src, n_items=len(items), text=text,
+                        whole=dict(tgt=t0, U=u["value"], U_cdd_pos=ints(u["cdd_pos"]), Q=hx(q["value"]), Q_cdd_pos=ints(q["cdd_pos"]))))
+        print("many sources", seed, wg.num_src, "sources", len(items), "items", list(sc["stats"]))
+    (OUT / "many_sources.json").write_text(json.dumps(out, separators=(",", ":")) + "\n")
+
+
+if __name__ == "__main__" and os.path.isdir(REF):
+    make_many_sources()

@@ -76,6 +76,61 @@ def fuzz_scenario(seed):
     return dict(pos=pos, gts=gts, pl=pl, stats=stats, win=win, step=step, start=start, end=end, anc=anc, with_out=with_out)
 
 
+def many_sources_scenario(seed):
+    """``fuzz_scenario``'s shape with SEVEN to TEN source populations (the reference loops over any number of
+    them, stat_utils.py:114-119, 141-152): one or two target populations, optional outgroup, ploidy 1-3, missing
+    calls, both polarity modes, thresholds that let some windows through all the sources' conditions."""
+    rng = np.random.default_rng(seed)
+    n_sites = int(rng.integers(600, 1800))
+    pos = np.cumsum(rng.integers(1, 60, n_sites)).astype(np.int32)
+    n_src = int(rng.integers(7, 11))
+    n_tgt = int(rng.integers(1, 3))
+    with_out = bool(seed % 2)
+    anc = True if with_out else bool(rng.random() < 0.5)
+    p = rng.random(n_sites) ** 3
+    intro = rng.random(n_sites) < 0.12  # sites every source carries (and the reference population lacks)
+
+    def pop(n_ind, ploidy, role):
+        pp = p.copy()
+        if role == "ref":
+            pp[intro] = 0.0
+        elif role == "src":
+            pp[intro] = 1.0
+        g = rng.binomial(ploidy, np.broadcast_to(pp[:, None], (n_sites, n_ind))).astype(np.int64)
+        g[rng.random(g.shape) < float(rng.choice([0.0, 0.01]))] = -ploidy
+        return g
+
+    pl = {"ref": {"R0": 2}, "tgt": {}, "src": {}}
+    gts = {"ref": {"R0": pop(int(rng.integers(5, 30)), 2, "ref")}, "tgt": {}, "src": {}, "outgroup": {}}
+    for i in range(n_tgt):
+        ploidy = int(rng.integers(1, 4))
+        pl["tgt"][f"T{i}"] = ploidy
+        gts["tgt"][f"T{i}"] = pop(int(rng.integers(3, 25)), ploidy, "tgt")
+    for i in range(n_src):
+        ploidy = int(rng.integers(1, 4))
+        pl["src"][f"S{i}"] = ploidy
+        gts["src"][f"S{i}"] = pop(int(rng.integers(1, 4)), ploidy, "src")
+    if with_out:
+        pl["outgroup"] = {"O": 2}
+        gts["outgroup"]["O"] = pop(int(rng.integers(1, 6)), 2, "out")
+
+    def uq():
+        return {
+            "ref": {"R0": float(rng.choice([0.1, 0.3]))},
+            "tgt": {k: float(rng.choice([0.0, 0.2, 0.9])) for k in pl["tgt"]},
+            "src": {k: str(rng.choice(["=1", ">=0.5", ">0", "<=1", ">=0.75"])) for k in pl["src"]},
+        }
+
+    stats = {"U": uq(), "Q": uq()}
+    if anc:
+        for name in ("fd", "Dplus", "DD"):
+            if rng.random() < 0.8:
+                stats[name] = True
+    win = int(rng.integers(1500, 6000))
+    step = int(rng.integers(500, win + 1))
+    return dict(pos=pos, gts=gts, pl=pl, stats=stats, win=win, step=step, start=None, end=None, anc=anc, with_out=with_out)
+
+
 def siteset_scenario(kind, seed):
     """Populations whose site sets differ and / or repeat a position (what the reference's
     WindowGenerator resolves per window with intersect1d + isin, window_generator.py:193-231).

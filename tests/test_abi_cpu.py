@@ -38,7 +38,7 @@ def test_header_and_binding_agree(lib):
     assert lib.sai_abi_version() == _ffi.SAI_ABI_VERSION
     assert lib.sai_build_arch() == b"gfx950"
     assert C.sizeof(_ffi.SaiWindowRecord) == 24
-    assert C.sizeof(_ffi.SaiParams) == 152
+    assert C.sizeof(_ffi.SaiParams) == 32 + _ffi.SAI_MAX_SRC * 20 == 312  # op (4) + y (8) + one_minus_y (8) per source
     assert C.sizeof(_ffi.SaiPop) == 16
 
 
@@ -99,8 +99,10 @@ def test_params_packing():
     assert (p.w, p.x, p.quantile, p.n_src, p.anc_allele_available) == (0.01, 0.5, 0.95, 2, 0)
     assert list(p.op)[:2] == [0, 4]
     assert p.one_minus_y[0] == 1 - 0.9 and p.one_minus_y[0] != 0.1  # the f64 mirror, not the decimal one
+    seven = _ffi.make_params(0.1, 0.1, 0.5, [("=", 1.0)] * 7, True)  # more than a streaming pass takes: counts in groups + site_flags
+    assert seven.n_src == 7 > _ffi.SAI_FUSED_SRC and list(seven.y)[:8] == [1.0] * 7 + [0.0]
     with pytest.raises(ValueError):
-        _ffi.make_params(0.1, 0.1, 0.5, [("=", 1.0)] * 7, True)
+        _ffi.make_params(0.1, 0.1, 0.5, [("=", 1.0)] * (_ffi.SAI_MAX_SRC + 1), True)
 
 
 @pytest.mark.parametrize(

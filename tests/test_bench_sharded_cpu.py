@@ -427,9 +427,16 @@ def test_static_traffic_and_one_gpu_base_of_the_full_size_job(monkeypatch):
     args = argparse.Namespace(traffic="auto", sites=0, chroms=0, scaling="strong", layout="int8", anc="true")
     whole, src = bench.static_traffic(wl, args, 1, 110_000_000)
     share, src8 = bench.static_traffic(wl, args, 8, 13_752_000)
-    assert whole > 2.2e11 and "not measured in this run" in src
-    assert share == int(whole * 13_752_000 / 110_000_000) and "rank 0's share" in src8
+    if whole is None:  # the stored counters are another tree's: said so, not handed out
+        assert "other sources" in src and share is None
+    else:
+        assert whole > 2.2e11 and "not measured in this run" in src
+        assert share == int(whole * 13_752_000 / 110_000_000) and "rank 0's share" in src8
     assert bench.static_traffic(wl, argparse.Namespace(**{**vars(args), "sites": 1000}), 8, 10) == (None, None)
+    monkeypatch.setattr(bench, "source_digest", lambda: "f" * 16)
+    none, why = bench.static_traffic(wl, args, 1, 110_000_000)
+    assert none is None and "other sources" in why
+    monkeypatch.undo()
     base = bench.one_gpu_base(wl, args)
     assert base["workload_id"] == "c4"
     if base["value"] is not None:

@@ -629,6 +629,91 @@ def test_pipeline_fuzz_against_oracle(seed, tmp_path):
             assert (tmp_path / f"o.{k}.log").read_text() == O.log_header_line(k) + ref_text[k]
 
 
+# ---- more than six source populations (stat_utils.py:114-119 loops over any number) ------------
+
+from seeded import many_sources_scenario  # noqa: E402
+from test_oracle_golden import MANY_SOURCES  # noqa: E402
+
+
+@pytest.mark.parametrize("rec", MANY_SOURCES, ids=[f"{r['seed']}-{r['n_src']}src" for r in MANY_SOURCES])
+def test_many_sources_equal_the_reference(rec, tmp_path):
+    """Seven to ten source populations: more than a streaming pass takes per call, so the counts come in groups and
+    the per-site decision from the stand-alone kernel built for 2 + SAI_MAX_SRC populations (several launches per
+    row when the sets' comparisons do not fit one table).  The batched route writes the reference's text; U and Q
+    of the whole chromosome through the statistic classes are the reference's (VERDICT r4 #8a)."""
+    from oracle import sai_oracle as O
+    from sai_amd.configs import PloidyConfig, StatConfig
+    from sai_amd.generators import WindowGenerator
+    from sai_amd.preprocessors import FeaturePreprocessor
+    from sai_amd.sai import write_headers
+    from sai_amd.stats import QStatistic, UStatistic
+    from sai_amd.utils import ChromosomeData
+
+    sc = many_sources_scenario(rec["seed"])
+    pos = sc["pos"]
+    data = {grp: {k: ChromosomeData(pos, None, None, v.astype(np.int8)) for k, v in sc["gts"][grp].items()} for grp in sc["gts"]}
+    pc = PloidyConfig(sc["pl"])
+    wg = WindowGenerator.from_arrays("7", data["ref"], data["tgt"], data["src"], sc["win"], sc["step"], pc,
+                                     out_data=data["outgroup"] or None)  # fmt: skip
+    stat_config = StatConfig(json.loads(json.dumps(sc["stats"])))
+    names = list(sc["stats"].keys())
+    for tag in ("items", "native"):
+        out = tmp_path / f"{tag}.tsv"
+        fp = FeaturePreprocessor(str(out), stat_config, anc_allele_available=sc["anc"])
+        write_headers(str(out), stat_config, pc)
+        if tag == "items":
+            items = fp.run_windows(wg)
+            assert len(items) == rec["n_items"]
+            fp.process_items(items)
+        else:
+            fp.score_and_write(wg)
+        assert out.read_text() == O.header_line(names, list(sc["pl"]["src"])) + rec["text"]["tsv"]
+        for k in ("U", "Q"):
+            assert (tmp_path / f"{tag}.{k}.log").read_text() == O.log_header_line(k) + rec["text"][k]
+    t0 = rec["whole"]["tgt"]
+    kw = dict(ref_gts=sc["gts"]["ref"]["R0"], tgt_gts=sc["gts"]["tgt"][t0], src_gts_list=list(sc["gts"]["src"].values()),
+              ref_ploidy=2, tgt_ploidy=sc["pl"]["tgt"][t0], src_ploidy_list=list(sc["pl"]["src"].values()))  # fmt: skip
+    up, qp = stat_config.get_parameters("U"), stat_config.get_parameters("Q")
+    u = UStatistic(**kw).compute(pos=pos, w=up["ref"]["R0"], x=up["tgt"][t0], y_list=list(up["src"].values()), anc_allele_available=sc["anc"])
+    q = QStatistic(**kw).compute(pos=pos, w=qp["ref"]["R0"], quantile=qp["tgt"][t0], y_list=list(qp["src"].values()),
+                                 anc_allele_available=sc["anc"])  # fmt: skip
+    assert u["value"] == rec["whole"]["U"] and np.asarray(u["cdd_pos"]).astype(np.int64).tolist() == rec["whole"]["U_cdd_pos"]
+    assert same_f64(q["value"], unhex(rec["whole"]["Q"])) and np.asarray(q["cdd_pos"]).astype(np.int64).tolist() == rec["whole"]["Q_cdd_pos"]
+
+
+def test_a_row_of_sets_over_many_sources_in_several_launches(_gpu):
+    """Twenty sets over twelve sources whose comparisons differ: one table (32 comparisons) holds a few of them, so
+    sai_site_flags evaluates the row in several launches, each writing only its own words -- against one launch per
+    set into rows of one set, both polarity modes."""
+    import torch
+
+    from sai_amd import _ffi
+    from sai_amd.engine import Engine
+
+    eng = Engine.get(0)
+    rng = np.random.default_rng(12)
+    n_sites, n_src = 700, 12
+    mats = [rng.integers(0, 3, size=(n_sites, n)).astype(np.int8) for n in (20, 15, *([2] * n_src))]
+    pops = eng.tile_many(mats)
+    counts = eng.site_counts(pops)
+    assert counts.shape[0] == 14
+    ops = ["=", "<", ">", "<=", ">="]
+    grid = [0.0, 0.25, 0.5, 0.75, 1.0]
+    sets = [_ffi.make_params(0.9, 0.1, 0.5, [(str(rng.choice(ops)), float(rng.choice(grid))) for _ in range(n_src)], bool(s % 3))
+            for s in range(20)]  # fmt: skip
+    tgt_freq, planes, adj = eng.site_flags(counts, [2] * 14, sets, want_adj=True)
+    got = eng.flag_bytes(planes, n_sites, sets)
+    assert int((got & 1).sum()) > 0
+    for s, prm in enumerate(sets):
+        f1, p1, a1 = eng.site_flags(counts, [2] * 14, [prm], want_adj=True)
+        one = eng.flag_bytes(p1, n_sites, [prm])
+        keep = 1 if prm.anc_allele_available else 5  # a row without inverted words reports no inversions
+        assert torch.equal(got[s] & keep, one[0] & keep), s
+        assert torch.equal(adj[s].nan_to_num(-1.0), a1[0].nan_to_num(-1.0)) and torch.equal(tgt_freq.nan_to_num(-1.0), f1.nan_to_num(-1.0))
+    with pytest.raises(ValueError, match="at most 14 source"):
+        _ffi.make_params(0.5, 0.5, 0.5, [("=", 1.0)] * 15, True)
+
+
 # ---- populations with different site sets / repeated positions (window_generator.py:193-231) ----
 
 from test_oracle_golden import SITESETS, siteset_inputs  # noqa: E402

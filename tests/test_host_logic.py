@@ -308,8 +308,10 @@ def test_score_config_errors_without_gpu(in_repo_root, tmp_path):
 def test_score_takes_the_preloaded_blocks_only_when_the_chunk_holds_them(in_repo_root, tmp_path, monkeypatch):
     """Host logic of ``score``'s one-pass order for a plain-text file (sai._scan_while_reading), with the
     GPU reader stood in for: the scan's span lays out the chunk; the blocks read meanwhile are handed to
-    ``run_compact`` when every kept position lies inside the chunk, not otherwise; a read that failed is
-    repeated in the usual order; a chromosome the scan does not find is ChunkGenerator's error."""
+    ``run_and_write`` (the one chunk of a one-process run: scored and written in one call) when every kept
+    position lies inside the chunk, not otherwise; a read that failed is repeated in the usual order; a
+    chromosome the scan does not find is ChunkGenerator's error; a chromosome cut into several chunks (the HBM
+    budget) goes chunk by chunk through ``run_compact`` and is written at the end."""
     from sai_amd import sai as sai_mod
     from sai_amd.preprocessors import ChunkPreprocessor
 
@@ -317,7 +319,10 @@ def test_score_takes_the_preloaded_blocks_only_when_the_chunk_holds_them(in_repo
     monkeypatch.setattr(sai_mod, "_reads_in_one_pass", lambda vcf: True)
     monkeypatch.setattr(ChunkPreprocessor, "write_results", lambda self, batches: calls.append(("write", len(batches))))
     monkeypatch.setattr(ChunkPreprocessor, "run_compact",
-                        lambda self, chr_name, start, end, preloaded=None: calls.append(("run", start, end, preloaded)) or "batch")  # fmt: skip
+                        lambda self, chr_name, start, end, preloaded=None: calls.append(("compact", start, end, preloaded)) or "batch")  # fmt: skip
+    monkeypatch.setattr(ChunkPreprocessor, "run_and_write",
+                        lambda self, chr_name, start, end, preloaded=None: calls.append(("run", start, end, preloaded)))  # fmt: skip
+    monkeypatch.delenv("SAI_AMD_HBM_BUDGET_BYTES", raising=False)
     kw = dict(vcf_file="tests/data/test.data.vcf", win_len=10000, win_step=5000, anc_allele_file=None,
               output_file=str(tmp_path / "o.tsv"), config="tests/data/test.uq.config.yaml", num_workers=1)  # fmt: skip
 
@@ -333,13 +338,18 @@ def test_score_takes_the_preloaded_blocks_only_when_the_chunk_holds_them(in_repo
         calls.clear()
         monkeypatch.setattr(ChunkPreprocessor, "preload", preload_with(span))
         sai_mod.score(chr_name="21", **kw)
-        assert calls == [("run", 1, 55000, want), ("write", 1)], span  # chr 21: 2309 .. 48989 -> windows 1 .. 55000
+        assert calls == [("run", 1, 55000, want)], span  # chr 21: 2309 .. 48989 -> windows 1 .. 55000
     with pytest.raises(ValueError, match="Chromosome 9 not found in VCF"):
         sai_mod.score(chr_name="9", **kw)
     monkeypatch.setattr(sai_mod, "_reads_in_one_pass", lambda vcf: False)  # compressed file / no GPU: scan, then read
     calls.clear()
     sai_mod.score(chr_name="21", **kw)
-    assert calls == [("run", 1, 55000, None), ("write", 1)]
+    assert calls == [("run", 1, 55000, None)]
+    monkeypatch.setenv("SAI_AMD_HBM_BUDGET_BYTES", "700")  # 5 509 bytes of text = 1 377 resident bytes: two chunks
+    calls.clear()
+    sai_mod.score(chr_name="21", **kw)
+    assert [c[0] for c in calls] == ["compact", "compact", "write"] and calls[-1] == ("write", 2)
+    assert calls[0][1] == 1 and calls[1][2] == 55000 and calls[0][2] + 1 - 10000 + 5000 == calls[1][1]  # window-aligned cut
 
 
 def test_cli_parser(in_repo_root):

@@ -326,6 +326,40 @@ def test_pipeline_fuzz_text_equals_reference(rec):
         assert "".join(O.log_lines(items, k)) == rec["text"][k]
 
 
+# ---- more than six source populations (make_golden.py section 11) ------------------------------
+
+from seeded import many_sources_scenario  # noqa: E402
+
+MANY_SOURCES = load_golden("many_sources.json")
+
+
+@pytest.mark.parametrize("rec", MANY_SOURCES, ids=[f"{r['seed']}-{r['n_src']}src" for r in MANY_SOURCES])
+def test_many_sources_text_equals_reference(rec):
+    """Seven to ten source populations (the reference loops over any number, stat_utils.py:114-119, 141-152):
+    the oracle's chunk driver writes the reference's text, and its U / Q of the whole chromosome as one window
+    are the reference's."""
+    sc = many_sources_scenario(rec["seed"])
+    assert len(sc["gts"]["src"]) == rec["n_src"] >= 7
+    pos = sc["pos"]
+    ostats = {n: (_validated({n: p})[n] if n in ("U", "Q") else p) for n, p in sc["stats"].items()}
+    odata = {grp: {k: O.Chrom(pos, v) for k, v in sc["gts"][grp].items()} for grp in sc["gts"]}
+    items = O.run_chunk("7", odata["ref"], odata["tgt"], odata["src"], sc["win"], sc["step"], ostats, sc["pl"], sc["anc"],
+                        out_data=odata["outgroup"] or None)  # fmt: skip
+    assert len(items) == rec["n_items"]
+    names = list(sc["stats"].keys())
+    assert "".join(O.score_lines(items, names)) == rec["text"]["tsv"]
+    for k in ("U", "Q"):
+        assert "".join(O.log_lines(items, k)) == rec["text"][k]
+    t0 = rec["whole"]["tgt"]
+    kw = dict(ref_gts=sc["gts"]["ref"]["R0"], tgt_gts=sc["gts"]["tgt"][t0], src_gts_list=list(sc["gts"]["src"].values()),
+              ref_ploidy=2, tgt_ploidy=sc["pl"]["tgt"][t0], src_ploidy_list=list(sc["pl"]["src"].values()), pos=pos,
+              anc_allele_available=sc["anc"])  # fmt: skip
+    u = O.u_stat(w=ostats["U"]["ref"]["R0"], x=ostats["U"]["tgt"][t0], y_list=list(ostats["U"]["src"].values()), **kw)
+    q = O.q_stat(w=ostats["Q"]["ref"]["R0"], quantile=ostats["Q"]["tgt"][t0], y_list=list(ostats["Q"]["src"].values()), **kw)
+    assert u["value"] == rec["whole"]["U"] and np.asarray(u["cdd_pos"]).astype(np.int64).tolist() == rec["whole"]["U_cdd_pos"]
+    assert same_f64(q["value"], unhex(rec["whole"]["Q"])) and np.asarray(q["cdd_pos"]).astype(np.int64).tolist() == rec["whole"]["Q_cdd_pos"]
+
+
 # ---- populations with different site sets / repeated positions (make_golden.py section 10) ----
 
 SITESETS = load_golden("sitesets.json")

@@ -8,6 +8,9 @@ import csv, glob, json, shutil, sys
 from collections import defaultdict
 from pathlib import Path
 
+sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+import bench  # noqa: E402  (source_digest: which tree a stored figure belongs to)
+
 tag = sys.argv[1] if len(sys.argv) > 1 else "r02_c3"
 workload_key = sys.argv[2] if len(sys.argv) > 2 else "c3"  # bench.py's workload id (+ ":packed2")
 # launches before the timed region: the set-up pass that fixes the row layout + the warm-up steps
@@ -16,6 +19,19 @@ dominant = sys.argv[4] if len(sys.argv) > 4 else "site_counts"
 src = Path("gpurun_out") / f"prof_{tag}"
 dst = Path("profiles")
 dst.mkdir(exist_ok=True)
+
+# One tree, one evidence set: the bench lines the three passes printed name the digest of the sources
+# they ran on; a set measured on other sources than this tree's is refused -- nothing is written.
+lines = {}
+for name in ("trace.log", "pmc_fetch.log", "pmc_write.log"):
+    got = [l for l in (src / name).read_text().splitlines() if l.startswith('{"metric"')] if (src / name).exists() else []
+    if got:
+        lines[name] = json.loads(got[-1])
+digests = {name: line["config"].get("source_digest") for name, line in lines.items()}
+here = bench.source_digest()
+if not lines or any(d != here for d in digests.values()):
+    sys.exit(f"summarize_profile: {src} was measured on sources {digests or 'unknown'} but this tree is {here}: "
+             "profile the frozen tree again (tools/profile.sh); nothing written")
 
 
 def short(name):
@@ -69,15 +85,22 @@ if dominant in pmc:
     ws = pmc[dominant].get("WRITE_SIZE", (0, 0.0))[1]
     rec[workload_key] = {
         "source": f"profiles/{tag}_pmc_summary.csv",
+        "source_digest": here,
         "site_counts_fetch_size_kib_raw": fs,
         "site_counts_write_size_kib": ws,
         "site_counts_hbm_bytes_per_launch": int(fs * 1024 * 2 + ws * 1024),
     }
     tfile.write_text(json.dumps(rec, indent=1) + "\n")
-for name in ("trace.log", "pmc_fetch.log", "pmc_write.log"):
-    lines = [l for l in (src / name).read_text().splitlines() if l.startswith('{"metric"')]
-    if lines:
-        (dst / f"{tag}_bench_under_{name.split('.')[0]}.json").write_text(lines[-1] + "\n")
+for name, line in lines.items():
+    (dst / f"{tag}_bench_under_{name.split('.')[0]}.json").write_text(json.dumps(line) + "\n")
+# which tree and which box every file of this set is from
+mfile = dst / "manifest.json"
+manifest = json.loads(mfile.read_text()) if mfile.exists() else {}
+first = lines["trace.log"]
+for f in sorted(dst.glob(f"{tag}_*")):
+    manifest[f.name] = {"source_digest": here, "box_stream_read_probe_gbps": first["roofline"].get("stream_read_probe_gbps"),
+                        "command": f"tools/profile.sh {tag} (bench.py --workload {first['config']['workload_id']} --steps 10 --warmup 2 under rocprofv3)"}
+mfile.write_text(json.dumps(manifest, indent=1, sort_keys=True) + "\n")
 print(open(dst / f"{tag}_kernel_durations.csv").read())
 print(open(dst / f"{tag}_pmc_summary.csv").read())
 print(tfile.read_text())
