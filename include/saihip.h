@@ -170,7 +170,7 @@ int64_t sai_plane_words(int64_t n_sites, int32_t n_sets);
  * (dense 8-byte stores interleaved with the genotype stream cost about 10 % of the pass on MI355X,
  * a tile's candidates in slots of their own a fifth of that for sets as loose as C5's).
  * Streams: a launch of many multi-wavefront workgroups (sai_window_stats, sai_site_flags, any large kernel)
- * that waits in THIS pass's stream behind the running pass costs the pass ~6 % (profiles/r04_lone_pass.txt);
+ * that waits in THIS pass's stream behind the running pass costs the pass ~6 % (profiles/history/r04_lone_pass.txt);
  * enqueue what follows on a second stream behind an event wait. */
 int sai_site_pass(sai_ctx* ctx, int64_t n_sites, int32_t n_pops, const sai_pop* pops,
                   uint32_t* counts, int32_t n_sets, const sai_params* sets_host, int32_t freq_mode,

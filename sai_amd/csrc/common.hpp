@@ -102,8 +102,8 @@ inline unsigned stream_grid(const sai_ctx* ctx, int64_t n_tiles, int waves_per_c
   return static_cast<unsigned>(n_tiles < max_grid ? n_tiles : max_grid);
 }
 
-// Waves per CU of the int8 / packed2 site pass (same-box sweeps: profiles/r04_waves_per_cu.txt,
-// profiles/r04_shape_sweep.txt, profiles/r05_c5_grid.txt).  The pass is HBM-bound from 8 waves per CU on when its
+// Waves per CU of the int8 / packed2 site pass (same-box sweeps: profiles/history/r04_waves_per_cu.txt,
+// profiles/history/r04_shape_sweep.txt, profiles/r05_c5_grid.txt).  The pass is HBM-bound from 8 waves per CU on when its
 // populations are wide, so the grid is chosen for what runs NEXT to it (the windows stage of the step before, on
 // a second stream) and for the pass's own tail:
 //  * with many parameter sets (C5's 18) every tile ends in the sets' evaluation, during which a wave loads

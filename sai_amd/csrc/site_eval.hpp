@@ -246,11 +246,13 @@ __device__ __forceinline__ void eval_site(int n_pops, const int32_t* ploidy, Get
     }
   };
   if (es.use_table) {  // uniform
-    // The table is read from the workgroup's LDS copy (stage_pred_table), not from the kernel arguments: next to
-    // the windows stage of the step before, a scalar load per comparison and set -- each waited for -- made a
-    // C5 pass 8 % slower than the set-by-set form, alone 2 % faster (profiles/r05_eval_cost.txt); LDS answers in
-    // the same time whatever else the chip is doing.  Every lane reads the same address; the values are made
-    // wave-uniform again with v_readfirstlane so that compares take them as scalars and branches stay scalar.
+    // The table is read from the workgroup's LDS copy (stage_pred_table), not with a scalar load per comparison and
+    // set from the kernel arguments: those loads are waited for one by one and answer as fast as the scalar cache
+    // happens to (it is shared with whatever runs next to the pass); LDS answers in the same time whatever else
+    // the chip is doing.  Every lane reads the same address; the values are made wave-uniform again with
+    // v_readfirstlane so that compares take them as scalars and branches stay scalar.  Alone an 18-set pass is
+    // 2 % faster than with the set-by-set form below (profiles/r05_eval_cost.txt; the stand-alone site_flags
+    // kernel 0.24 against 0.56 ms); what decides the pipelined step is the pass's grid (profiles/r05_c5_grid.txt).
     const PredTable& t = *lds_table;
     uint32_t miss = ~0u;  // bit i DOWN = comparison i holds at this site
     const int n_preds = __builtin_amdgcn_readfirstlane(t.n_preds);

@@ -107,7 +107,7 @@ __global__ __launch_bounds__(256) void window_bounds_kernel(const int32_t* __res
 //   window_lists   the same two forms: candidate lists in ascending site order
 // Round 3 ran one wavefront per (window, set) and a second workgroup kernel for the heavy pairs, all
 // reading global memory: C5's 18 sets x 2x window overlap x 64-byte lines re-read ~190 MB of planes
-// and frequencies as 1.36 GB per step (profiles/r03g_c5_pmc_summary.csv), under the next step's
+// and frequencies as 1.36 GB per step (profiles/history/r03g_c5_pmc_summary.csv), under the next step's
 // genotype stream.
 // ------------------------------------------------------------------------------------------
 

@@ -945,7 +945,7 @@ class Engine:
         the one contiguous byte buffer ``head``, so a single copy brings them to the host.  ``joined``: the
         two candidate lists lie right behind ``head`` in the same allocation (a seventh entry is the whole of
         it): ONE copy then brings records and lists -- every copy of the runtime's starts ~12 us after the
-        kernel before it has ended (profiles/r04_score_windows_call.txt)."""
+        kernel before it has ended (profiles/history/r04_score_windows_call.txt)."""
         torch = _torch()
         n_rec = n_sets * n_windows
         rec_bytes, off_bytes = n_rec * RECORD_DTYPE.itemsize, n_rec * 16  # 24 B records keep 8-byte alignment

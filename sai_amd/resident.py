@@ -216,7 +216,7 @@ class ResidentScorer:
         # the windows stage always runs on a second stream.  Pipelined form: under the next site pass.  Plain
         # form: a kernel queued BEHIND a running site pass on the pass's own stream slows the pass down (C3, one
         # box: 2.92 ms with nothing or only a copy behind it, 3.09 with window_bounds, 3.10 with the whole stage;
-        # profiles/r04_lone_pass.txt), so the stage waits for the pass on its own stream instead: a lone
+        # profiles/history/r04_lone_pass.txt), so the stage waits for the pass on its own stream instead: a lone
         # step + results takes 3.02 instead of 3.19 ms
         self.side = torch.cuda.Stream(device=dev, priority=-1)  # small kernels first
         self._plain_done = [torch.cuda.Event() for _ in range(n_buf)]

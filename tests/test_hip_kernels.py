@@ -589,6 +589,46 @@ def test_randomized_stage_shapes_against_oracle(eng):
     assert seen_heavy > 0 and seen_shared > 0
 
 
+@pytest.mark.parametrize("n_src", [1, 2, 3, 6])
+def test_predicate_table_and_set_by_set_decision_agree(eng, monkeypatch, n_src):
+    """The per-site decision from the predicate table (every distinct comparison once, site_eval.hpp) against the
+    set-by-set form (SAI_NO_PRED_TABLE=1; also what a call with more than 32 distinct comparisons gets): the same
+    planes and stored frequencies from the fused pass and from site_flags, for sweeps like C5's and for random sets
+    with all five operators, repeated and unique thresholds, both polarity modes mixed in one row."""
+    import torch
+
+    from sai_amd import _ffi
+
+    rng = np.random.default_rng(50 + n_src)
+    n_sites = 3000
+    ploidy = [2, 3] + [int(rng.integers(1, 4)) for _ in range(n_src)]
+    sizes = [40, 30] + [int(rng.integers(1, 4)) for _ in range(n_src)]
+    mats = [np.where(rng.random((n_sites, n)) < 0.03, -pl, rng.binomial(pl, rng.random(n_sites)[:, None] ** 2, size=(n_sites, n))).astype(np.int8)
+            for n, pl in zip(sizes, ploidy)]  # fmt: skip
+    pops = eng.tile_many(mats)
+    ops = ["=", "<", ">", "<=", ">="]
+    grid = [0.0, 0.25, 1 / 3, 0.5, 2 / 3, 0.75, 1.0]
+    for trial in range(6):
+        n_sets = int(rng.integers(1, 21))
+        few = trial % 2 == 0  # a sweep over a small grid (few distinct comparisons) / every threshold its own
+        sets = [_ffi.make_params(float(rng.choice([0.05, 0.3, 0.6]) if few else rng.random()), 0.2, 0.9,
+                                 [(str(rng.choice(ops)), float(rng.choice(grid)) if few else float(rng.random())) for _ in range(n_src)],
+                                 bool(rng.random() < 0.5)) for _ in range(n_sets)]  # fmt: skip
+        got = {}
+        for form in ("table", "sets"):
+            if form == "sets":
+                monkeypatch.setenv("SAI_NO_PRED_TABLE", "1")
+            else:
+                monkeypatch.delenv("SAI_NO_PRED_TABLE", raising=False)
+            counts = eng.site_counts(pops)
+            f1, p1, a1 = eng.site_flags(counts, ploidy, sets, want_adj=True)
+            f2, p2 = eng.site_pass(pops, ploidy, sets, freq_mode="candidates")
+            got[form] = (f1.nan_to_num(-1.0), p1, a1.nan_to_num(-1.0), eng.site_tgt_freq(p2, f2, n_sites).nan_to_num(-1.0), p2)
+        for a, b in zip(got["table"], got["sets"]):
+            assert torch.equal(a, b), (trial, n_sets)
+    monkeypatch.delenv("SAI_NO_PRED_TABLE", raising=False)
+
+
 @pytest.mark.parametrize("n_sets,polarised", [(20, "none"), (20, "all"), (27, "first chunk only"), (27, "second chunk only"), (45, "mixed")])
 def test_rows_of_many_sets_and_both_polarity_modes(eng, n_sets, polarised):
     """A full row (20 sets: 1 + 20 condition words, + 20 inverted words when a set lacks ancestral alleles)
