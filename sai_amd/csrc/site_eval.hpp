@@ -47,6 +47,7 @@ constexpr int kPlanesPerSet = SAI_PLANES_PER_SET;  // row words RESERVED per set
 // The arithmetic per comparison is the reference's: one f64 compare of the same two doubles.
 // ------------------------------------------------------------------------------------------
 constexpr int kMaxPreds = 32;  // with the masks below the table stays under 1 KiB of LDS next to the 4 KiB of parked counts
+constexpr int kTableFromSets = 4;  // parameter sets from which a call's decision is taken from the table
 constexpr int kMirrorRefSlot = kBigPops;  // any slot beyond a kernel's populations reads as 1 - ref_freq
 
 struct PredEntry {
@@ -125,7 +126,10 @@ inline bool fill_eval_sets(EvalSets& es, int32_t n_sets, const sai_params* sets,
     index_of(0, 1, ps.w);
     if (!ps.anc_allele_available) index_of(kMirrorRefSlot, 1, ps.w);
   }
-  fits = (fits || table_only) && n_raw <= kMaxPreds;
+  // one to three sets: the set-by-set form is as fast or faster (its few scalar loads against the table's LDS round
+  // trips per tile: site_flags 0.104 against 0.122 ms for one set, 0.172 against 0.147 for four -- profiles/r05_eval_cost.txt;
+  // a packed2 tile is over in a quarter of an int8 tile's time and feels it)
+  fits = ((fits && n_sets >= kTableFromSets) || table_only) && n_raw <= kMaxPreds;
   if (!fits) {
     if (table_only) return false;
     for (int s = 0; s < n_sets; ++s) {

@@ -84,6 +84,30 @@ def _rows_per_statistic(res, set_of):
     return WindowResults(res.records[idx], res.offsets[idx], res.cdd_u, res.cdd_q, shared_lists=True)
 
 
+def _merge_window_ranges(parts):
+    """WindowResults of consecutive window ranges of ONE scorer configuration -> the results over all the windows:
+    records side by side, every set's lists range after range, offsets = running sums of the counts in (set, window)
+    order -- the layout a single pass over all windows leaves (engine.WindowResults)."""
+    from ..engine import WindowResults
+
+    rec = np.concatenate([p.records for p in parts], axis=1)
+    n_sets, n_w = rec.shape
+    flat = {}
+    for col, field, name in ((0, "u_count", "cdd_u"), (1, "n_cdd_q", "cdd_q")):
+        pieces = []
+        for s in range(n_sets):
+            for p in parts:
+                n = int(p.records[s][field].sum())
+                a = int(p.offsets[s, 0, col]) if p.records.shape[1] else 0
+                pieces.append(getattr(p, name)[a : a + n])
+        flat[name] = np.concatenate(pieces) if pieces else getattr(parts[0], name)[:0]
+    off = np.zeros((n_sets, n_w, 2), dtype=np.int64)
+    for col, field in ((0, "u_count"), (1, "n_cdd_q")):
+        counts = rec[field].reshape(-1).astype(np.int64)
+        off[:, :, col] = (np.cumsum(counts) - counts).reshape(n_sets, n_w)
+    return WindowResults(rec, off, flat["cdd_u"], flat["cdd_q"])
+
+
 def _file_order_semantics(res, uq_names, lo, hi, pos_sorted, file_order) -> None:
     """What the reference reports when the positions of a region do not ascend (an unsorted VCF): its
     window matrices keep the FILE order of the rows (``GT.compress`` of a mask, window_generator.py:217-231)
@@ -496,12 +520,30 @@ class FeaturePreprocessor(DataPreprocessor):
         running = plan[1]
         for scorer, _, _ in running:
             scorer.step()
+        # Rows are written part by part only when that is cheap: with long candidate lists (a loose sweep: tens of
+        # entries per window) the writer's calls cost more apiece than the passes they would hide behind (C5's first
+        # set: 4.0 ms in three calls, 1.6 in one -- profiles/r05_score_parts.txt), so the parts are then put together
+        # and written once.  The first part's lists decide.
+        held, streaming = [], None
         for scorer, w0, w1 in running:
+            raw = scorer.results(grow=True)
+            if streaming is None:
+                streaming = (raw.cdd_u.size + raw.cdd_q.size) <= self.PART_MAX_LIST_ENTRIES_PER_WINDOW * (w1 - w0)
+            if not streaming:
+                held.append(raw)
+                continue
             part = ComboBatch(cb.ref_pop, cb.tgt_pop, cb.src_comb, cb.out_pop, win[w0:w1], None, list(cb.uq_names), pos_dtype=cb.pos_dtype)
-            part.uq = _rows_per_statistic(scorer.results(grow=True), set_of)
+            part.uq = _rows_per_statistic(raw, set_of)
             part.nsnps = part.uq.records[0]["n_sites"].astype(np.int32)
             batch.combos.append(part)
             sink(part)
+        if held:
+            cb.uq = _rows_per_statistic(_merge_window_ranges(held), set_of)
+            cb.nsnps = cb.uq.records[0]["n_sites"].astype(np.int32)
+            batch.combos.append(cb)
+            sink(cb)
+
+    PART_MAX_LIST_ENTRIES_PER_WINDOW = 8
 
     def items_from_batch(self, batch: WindowBatch, combos=None) -> list[dict[str, Any]]:
         """The reference's item dictionaries (feature_preprocessor.py:113-191) of a batch, in
