@@ -97,7 +97,9 @@ for name, line in lines.items():
 mfile = dst / "manifest.json"
 manifest = json.loads(mfile.read_text()) if mfile.exists() else {}
 first = lines["trace.log"]
-for f in sorted(dst.glob(f"{tag}_*")):
+mine = [dst / f"{tag}_{n}" for n in ("kernel_stats.csv", "kernel_durations.csv", "pmc_summary.csv", "bench_under_trace.json",
+                                       "bench_under_pmc_fetch.json", "bench_under_pmc_write.json")]
+for f in (m for m in mine if m.exists()):
     manifest[f.name] = {"source_digest": here, "box_stream_read_probe_gbps": first["roofline"].get("stream_read_probe_gbps"),
                         "command": f"tools/profile.sh {tag} (bench.py --workload {first['config']['workload_id']} --steps 10 --warmup 2 under rocprofv3)"}
 mfile.write_text(json.dumps(manifest, indent=1, sort_keys=True) + "\n")
