@@ -668,8 +668,8 @@ class FeaturePreprocessor(DataPreprocessor):
             logs[i] = _ffi.SaiLogRows(counts.ctypes.data, counts.strides[0], offs.ctypes.data, 1,
                                       None if lists is None or lists.size == 0 else lists.ctypes.data,
                                       4 if lists is None else lists.dtype.itemsize, files[1 + i].fileno())  # fmt: skip
-        _ffi.check(lib.sai_write_window_rows(str(chr_name).encode(), pops.encode(), n_w, win.ctypes.data_as(C.c_void_p),
-                                             nsnps.ctypes.data_as(C.c_void_p), len(cols), arr, files[0].fileno(),
+        _ffi.check(lib.sai_write_window_rows(str(chr_name).encode(), pops.encode(), n_w, C.c_void_p(win.ctypes.data),
+                                             C.c_void_p(nsnps.ctypes.data), len(cols), arr, files[0].fileno(),
                                              len(log_keys), logs, None), lib)  # fmt: skip
 
     def write_batches(self, batches) -> None:
