@@ -118,10 +118,19 @@ __global__ __launch_bounds__(64, MULTI ? 4 : 5) void site_counts_kernel(CountsAr
         uint32_t both[16];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          both[4 * j + 0] = (lo[j] & 0xFFFFu) | ((ms[j] & 0xFFu) << 20);
-          both[4 * j + 1] = (hi[j] & 0xFFFFu) | (((ms[j] >> 8) & 0xFFu) << 20);
-          both[4 * j + 2] = (lo[j] >> 16) | (((ms[j] >> 16) & 0xFFu) << 20);
-          both[4 * j + 3] = (hi[j] >> 16) | ((ms[j] >> 24) << 20);
+          both[4 * j + 0] = lo[j] & 0xFFFFu;
+          both[4 * j + 1] = hi[j] & 0xFFFFu;
+          both[4 * j + 2] = lo[j] >> 16;
+          both[4 * j + 3] = hi[j] >> 16;
+        }
+        if (__ballot((ms[0] | ms[1] | ms[2] | ms[3]) != 0u) != 0ull) {  // wave-uniform: some lane met a missing call
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            both[4 * j + 0] |= (ms[j] & 0xFFu) << 20;
+            both[4 * j + 1] |= ((ms[j] >> 8) & 0xFFu) << 20;
+            both[4 * j + 2] |= ((ms[j] >> 16) & 0xFFu) << 20;
+            both[4 * j + 3] |= (ms[j] >> 24) << 20;
+          }
         }
         reduce_scatter_step<16, 32>(both, lane);
         reduce_scatter_step<8, 16>(both, lane);

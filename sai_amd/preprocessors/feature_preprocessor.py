@@ -269,6 +269,7 @@ class FeaturePreprocessor(DataPreprocessor):
 
     PARTS = 3  # window ranges a large region is scored in when its rows are written as they arrive (3: 3.58 ms for C3 on one box, 4: 3.70-3.97, 6: 4.18, one: 4.08-4.12 -- profiles/r05_score_parts.txt)
     PART_MIN_WINDOWS = 2048
+    PART_FRACTIONS = None  # where the ranges end, as fractions of the windows (PARTS - 1 of them); None: equal ranges but a last one of 0.6 of their size
 
     def score_windows(self, wg, sink=None) -> WindowBatch:
         """The GPU part of ``run_windows``: every population block of the region is uploaded once
@@ -487,7 +488,7 @@ class FeaturePreprocessor(DataPreprocessor):
         # the parts of a (generator, combination, parameter sets) are laid out once: a later call on the same
         # generator -- the same region scored again -- finds its scorers bound and only enqueues their passes
         plans = wg.__dict__.setdefault("_part_plans", {})
-        plan_key = (cb.tgt_pop, cb.ref_pop, tuple(cb.src_comb), self.PARTS)
+        plan_key = (cb.tgt_pop, cb.ref_pop, tuple(cb.src_comb), self.PARTS, self.PART_FRACTIONS)
         signature = ResidentScorer._binding_signature(ResidentBlock([tiled[k] for k in keys], ploidy[: 2 + n_eff], wg.device_positions(eng, pos)),
                                                       sets, None, False)  # fmt: skip
         plan = plans.get(plan_key)
@@ -496,7 +497,8 @@ class FeaturePreprocessor(DataPreprocessor):
             scorers = wg.__dict__.setdefault("_scorers", {})
             # the last part is the smallest: its rows are written after the GPU has finished
             n_w = len(win)
-            cuts = [0] + [int(round(n_w * f)) for f in np.cumsum([1.0 / (self.PARTS - 0.4)] * (self.PARTS - 1))] + [n_w]
+            fractions = self.PART_FRACTIONS or np.cumsum([1.0 / (self.PARTS - 0.4)] * (self.PARTS - 1))
+            cuts = [0] + [int(round(n_w * f)) for f in fractions] + [n_w]
             ranges = [(a, b) for a, b in zip(cuts, cuts[1:]) if b > a] if self.PARTS > 1 else split_index_ranges(n_w, 1)
             built = []
             for k, (w0, w1) in enumerate(ranges):
@@ -509,7 +511,7 @@ class FeaturePreprocessor(DataPreprocessor):
                 pops = [TiledPop(tiled[key].tiles[t0 * tiled[key].n_ind * tile : t1 * tiled[key].n_ind * tile], b - a, tiled[key].n_ind)
                         for key in keys]  # fmt: skip
                 block = ResidentBlock(pops, ploidy[: 2 + n_eff], pos_dev[a:b])
-                key = (cb.tgt_pop, n_sites, len(sets), "part", k, self.PARTS)
+                key = (cb.tgt_pop, n_sites, len(sets), "part", k, self.PARTS, self.PART_FRACTIONS)
                 scorer = scorers.get(key)
                 if scorer is None or scorer.block.n_sites != block.n_sites or scorer.n_windows != w1 - w0:
                     scorer = scorers[key] = ResidentScorer(eng, block, win[w0:w1], sets, cap_u=1 << 16, cap_q=1 << 16, fetch_lists=1 << 16)

@@ -64,6 +64,24 @@ def test_site_counts_exact(eng, n_ind):
         assert np.array_equal(counts[p, :, 1], c)
 
 
+@pytest.mark.parametrize("top,rate", [(2, 0.0), (63, 0.0), (64, 0.0), (2, 2e-4), (63, 2e-4), (127, 2e-3)])
+def test_site_counts_groups_with_and_without_missing_calls(eng, top, rate):
+    """The stream loop adds four rows bytewise when a group holds no missing call and no dosage of 64 or more, and goes
+    call by call otherwise (stream_loops.hpp acc_group): dosages up to the limit of either way, missing calls and large
+    dosages rare enough that both kinds of group meet in one tile, full and partial groups, one load and many."""
+    rng = np.random.default_rng(top * 1000 + int(rate * 1e6))
+    n_sites = 700
+    for n_ind in (3, 16, 50, 64, 67, 200, 1000):
+        g = rng.integers(0, top + 1, size=(n_sites, n_ind)).astype(np.int8)
+        g[0] = top  # every call at the top of the range: the bytewise sums at their limit
+        if rate:
+            hit = rng.random(g.shape) < rate
+            g[hit] = rng.choice(np.array([-1, -128, -2, 127, 64, 100], dtype=np.int8), size=int(hit.sum()))
+        counts = eng.site_counts([eng.tile(g)]).cpu().numpy().astype(np.int64)
+        s, c = counts_numpy(g.astype(np.int64))
+        assert np.array_equal(counts[0, :, 0], s) and np.array_equal(counts[0, :, 1], c), (n_ind, top, rate)
+
+
 STATS = load_golden("stats_cases.json")
 
 

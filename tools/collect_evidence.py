@@ -4,7 +4,7 @@
 Every bench line names the digest of the sources it ran on (bench.source_digest); a file measured on other sources
 than this tree's is refused.  The manifest lists, per kept file, that digest, the box (its stream-read probe) and the
 command -- what tests/test_profiles_cpu.py checks."""
-import csv, glob, json, shutil, subprocess, sys
+import csv, glob, json, os, shutil, subprocess, sys
 from pathlib import Path
 
 ROOT = Path(__file__).resolve().parents[1]
@@ -33,7 +33,8 @@ for f in sorted(SRC.glob("bench_*.json")):
         sys.exit(f"{f}: measured on sources {got}, this tree is {here}: run tools/evidence.sh on the frozen tree again")
     name = f.stem[len("bench_"):]
     probes[name] = line["roofline"].get("stream_read_probe_gbps")
-    flags = {"c3": "", "c3_noanc": " --anc false", "c3_packed2": " --layout packed2", "c4": " --workload c4 --steps 20 --cpu-sites 0"}.get(name, f" --workload {name}")
+    base = name[: -len("_second_box")] if name.endswith("_second_box") else name  # (tools/evidence.sh second_box: another gpurun call, another box)
+    flags = {"c3": "", "c3_noanc": " --anc false", "c3_packed2": " --layout packed2", "c4": " --workload c4 --steps 20 --cpu-sites 0"}.get(base, f" --workload {base}")
     keep(f"r05_bench_{name}.json", json.dumps(line), probes[name], f"python bench.py{flags}")
 box = probes.get("c3")
 for src, dst, cmd, head in (
@@ -50,7 +51,7 @@ for src, dst, cmd, head in (
     if (SRC / src).exists():
         body = "\n".join(l for l in (SRC / src).read_text().splitlines() if "amdgpu.ids" not in l and "Warning" not in l and l.strip())
         keep(dst, head + body, box, cmd)
-stats = glob.glob(str(SRC / "widened_trace" / "*" / "*_kernel_stats.csv"))
+stats = sorted(glob.glob(str(SRC / "widened_trace" / "*" / "*_kernel_stats.csv")), key=os.path.getmtime)[-1:]  # (an earlier run's files may lie beside)
 if stats:
     keep("r05_widened_kernel_stats.csv", open(stats[0]).read(), box, "rocprofv3 --kernel-trace --stats -- python3 tools/widened_perf.py")
 if (SRC / "rehearse_n2_on_one_gpu.json").exists() and (SRC / "rehearse_n2_on_one_gpu.json").read_text().strip():
@@ -76,7 +77,7 @@ for tag, key, dom in (("r05_c3", "c3", "site_counts"), ("r05_c3_noanc", "c3:noan
 # the SQ counters of the c2x22 pass (what its waves spend their cycles on)
 manifest = json.loads(mfile.read_text())
 for pas in ("pmc_sq", "pmc_sq2"):
-    files = glob.glob(str(ROOT / "gpurun_out" / "prof_r05_c2x22" / pas / "*" / "*_counter_collection.csv"))
+    files = sorted(glob.glob(str(ROOT / "gpurun_out" / "prof_r05_c2x22" / pas / "*" / "*_counter_collection.csv")), key=os.path.getmtime)[-1:]
     if files:
         acc = {}
         for r in csv.DictReader(open(files[0])):

@@ -4,6 +4,7 @@
 # gpurun_out/ into profiles/r05_* and refuses anything that was measured on other sources than the tree's.
 #   bash tools/evidence.sh benches    the un-profiled bench lines of every workload + the small tools' logs
 #   bash tools/evidence.sh profiles   rocprofv3 kernel trace + the two PMC passes of c2, c2x22, c3 (+ noanc, packed2), c5
+#   bash tools/evidence.sh second_box c3 / c5 / c2x22 lines from another call (another box of the pool)
 #   bash tools/evidence.sh c4         the whole-genome job on one GPU: bench line, profile, N = 2 rehearsal on the one GPU
 set -o pipefail
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -31,6 +32,9 @@ benches)
 profiles)
   bash tools/profile.sh r05_c3 c3 && bash tools/profile.sh r05_c3_noanc c3 --anc false && bash tools/profile.sh r05_c3_packed2 c3 --layout packed2 \
     && bash tools/profile.sh r05_c2 c2 && SAI_PROFILE_SQ=1 bash tools/profile.sh r05_c2x22 c2x22 && bash tools/profile.sh r05_c5 c5
+  ;;
+second_box)  # the headline lines once more in another call: the pool's boxes differ by 3-4 % on the same code
+  bench c3_second_box && bench c5_second_box --workload c5 && bench c2x22_second_box --workload c2x22
   ;;
 c4)
   bench c4 --workload c4 --steps 20 --cpu-sites 0

@@ -43,10 +43,17 @@ def short(name):
     return name.split("<")[0].split("(")[0].strip()[-60:] or name[:60]
 
 
-shutil.copy(glob.glob(str(src / "trace/*/*_kernel_stats.csv"))[0], dst / f"{tag}_kernel_stats.csv")
+def newest(pattern):
+    """The newest file of a pass: an output folder may still hold an earlier run's files under another pid."""
+    import os
+
+    return sorted(glob.glob(str(pattern)), key=os.path.getmtime)[-1:]
+
+
+shutil.copy(newest(src / "trace/*/*_kernel_stats.csv")[0], dst / f"{tag}_kernel_stats.csv")
 # durations per kernel, all calls and timed calls (after the warm-up steps)
 per = defaultdict(list)
-for r in csv.DictReader(open(glob.glob(str(src / "trace/*/*_kernel_trace.csv"))[0])):
+for r in csv.DictReader(open(newest(src / "trace/*/*_kernel_trace.csv")[0])):
     per[short(r["Kernel_Name"])].append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
 rows = []
 for k, v in per.items():
@@ -62,7 +69,7 @@ with open(dst / f"{tag}_kernel_durations.csv", "w") as f:
 # PMC passes
 pmc = defaultdict(dict)
 for pas, counter in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
-    files = glob.glob(str(src / pas / "*/*_counter_collection.csv"))
+    files = newest(src / pas / "*/*_counter_collection.csv")
     if not files:
         continue
     acc = defaultdict(list)
