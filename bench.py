@@ -980,6 +980,9 @@ def main(argv=None, device=None) -> None:
                 "traffic_source": traffic_source,
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "avg_launch_ms": round(avg_ms, 4),
+                # the launches one by one: a mean can hide a few slow ones (a fresh process's first passes)
+                "launch_ms_min_median_max": [round(v, 4) for v in (min(site_ms), sorted(site_ms)[len(site_ms) // 2], max(site_ms))] if site_ms else None,
+                "launches_over_1p1_median": int(sum(1 for v in site_ms if v > 1.1 * sorted(site_ms)[len(site_ms) // 2])) if site_ms else None,
                 "rank": 0,
                 "stream_read_probe_gbps": round(stream_read, 1),
                 "frac_of_stream_read_probe": round(achieved / stream_read, 4),

@@ -14,18 +14,16 @@ namespace {
 // negative number).  v_sad_u8 adds up the absolute differences of the four bytes of two words -- but a loaded
 // word holds four SITES of one individual.  So the four words that the four loads in flight hold for the same
 // four sites (four individuals) are transposed in registers (eight v_perm_b32) into one word per site with
-// four individuals in it, and with every byte biased to unsigned (x ^ 0x80: u = g + 128, s' = s + 128) ONE
-// instruction per site-word serves each sum, accumulating in 32 bits (no field ever needs widening, so any
-// population size is served):
-//     RAW'  += sad(T, 0)             sum_b u_b
-//     ABS   += sad(T, 0x80808080)    sum_b |g_b|        -> alt_sum = (ABS + sum g) / 2   (stat_utils.py:48)
-//     C128  += sad(T & 0x80808080, 0) 128 [g_b >= 0]     -> n_called                       (stat_utils.py:46)
-//     DD_a  += sad(T, s'_a x 4)      sum_b |s_a - g_b|
-// -- 7 + 2 NS operations per word of four genotypes where the packed 16-bit form of dd.hip needs 4 + 8 NS on top
-// of the counts' 11.  Rows that do not exist (the last batch of four row groups is padded) are loaded as zero
-// words, i.e. as called dosages of 0, and what P such rows add to a site's sums is taken off afterwards:
-// 128 P from RAW', P from the called count, P |s_a| from DD_a, nothing from ABS.  All integers are exact
-// (u32 arithmetic wraps; every result is below 255 * 2^24 < 2^32).
+// four individuals in it, every byte biased to unsigned (x ^ 0x80: u = g + 128, s' = s + 128), and ONE
+// instruction per site-word and source individual accumulates  DD_a += sad(T, s'_a x 4)  in 32 bits (any
+// population size).  The source's byte replicated four times is made once per tile.  The COUNTS of the same loads
+// are the site pass's own (stream_loops.hpp: a group without a missing call and without a dosage of 64 or more is
+// added up bytewise) -- until the middle of round 5 they were three more SADs per site-word (sum u, sum |g|,
+// 128 [g >= 0]).  12 + 4 NS operations per word of four genotypes for the DD terms (NS = 2: 20 per load and
+// lane + 9-11 for the counts; the SAD-only form: 44; the packed-16-bit form of dd.hip: 66 on top of the counts).
+// Rows that do not exist (the last batch of four row groups is padded) are loaded as zero words, i.e. as called
+// dosages of 0: they add nothing to the counts, and the P |s_a| they add to DD_a are taken off afterwards.  All
+// integers are exact (u32 arithmetic; every result is below 255 * 2^24 < 2^32).
 // ------------------------------------------------------------------------------------------
 
 constexpr int kDdRows = SAI_DD_FUSED_ROWS;
@@ -45,13 +43,6 @@ struct DdArgs {
 };
 static_assert(sizeof(CountsArgs) + sizeof(FusedArgs) + sizeof(DdArgs) <= 4096, "kernel arguments exceed the kernarg segment");
 
-// sums per site of this lane's 16 sites; NS = 0: the counts only (sources, outgroup)
-template <int NS>
-struct SadAcc {
-  uint32_t raw[16], abs_[16], c128[16];
-  uint32_t dd[NS > 0 ? NS : 1][16];
-};
-
 // bytes b of four words -> four words of one byte position each: t[b] = {w0.b, w1.b, w2.b, w3.b}
 __device__ __forceinline__ void transpose_bytes(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, uint32_t (&t)[4]) {
   const uint32_t a_lo = __builtin_amdgcn_perm(w1, w0, 0x05010400u);  // w0.b0 w1.b0 w0.b1 w1.b1
@@ -64,9 +55,9 @@ __device__ __forceinline__ void transpose_bytes(uint32_t w0, uint32_t w1, uint32
   t[3] = __builtin_amdgcn_perm(b_hi, a_hi, 0x07060302u);
 }
 
-// four row groups (the four loads in flight) of this lane's 16 sites; sv[k][j] = biased word j of source row k
+// DD's terms of four row groups (the four loads in flight) of this lane's 16 sites; sv[k][j] = biased word j of source row k
 template <int NS>
-__device__ __forceinline__ void sad_batch(const u32x4 (&v)[4], SadAcc<NS>& a, const uint32_t (&sv)[NS > 0 ? NS : 1][4]) {
+__device__ __forceinline__ void dd_batch(const u32x4 (&v)[4], uint32_t (&dd)[NS][16], const uint32_t (&sv)[NS][4]) {
   const uint32_t w[4][4] = {{v[0].x, v[0].y, v[0].z, v[0].w}, {v[1].x, v[1].y, v[1].z, v[1].w},
                             {v[2].x, v[2].y, v[2].z, v[2].w}, {v[3].x, v[3].y, v[3].z, v[3].w}};
 #pragma unroll
@@ -74,17 +65,13 @@ __device__ __forceinline__ void sad_batch(const u32x4 (&v)[4], SadAcc<NS>& a, co
     uint32_t t[4];
     transpose_bytes(w[0][j] ^ 0x80808080u, w[1][j] ^ 0x80808080u, w[2][j] ^ 0x80808080u, w[3][j] ^ 0x80808080u, t);
 #pragma unroll
-    for (int b = 0; b < 4; ++b) {
-      const int s = 4 * j + b;
-      a.raw[s] = __builtin_amdgcn_sad_u8(t[b], 0u, a.raw[s]);
-      a.abs_[s] = __builtin_amdgcn_sad_u8(t[b], 0x80808080u, a.abs_[s]);
-      a.c128[s] = __builtin_amdgcn_sad_u8(t[b] & 0x80808080u, 0u, a.c128[s]);
+    for (int b = 0; b < 4; ++b)
 #pragma unroll
       for (int k = 0; k < NS; ++k) {
-        const uint32_t rep = __builtin_amdgcn_perm(0u, sv[k][j], 0x01010101u * static_cast<uint32_t>(b));  // byte b x 4
-        a.dd[k][s] = __builtin_amdgcn_sad_u8(t[b], rep, a.dd[k][s]);
+        // byte b of the source's word, four times (a value per tile: the compiler keeps it in a register where it has one)
+        const uint32_t rep = __builtin_amdgcn_perm(0u, sv[k][j], 0x01010101u * static_cast<uint32_t>(b));
+        dd[k][4 * j + b] = __builtin_amdgcn_sad_u8(t[b], rep, dd[k][4 * j + b]);
       }
-    }
   }
 }
 
@@ -97,59 +84,103 @@ __device__ __forceinline__ uint32_t butterfly(uint32_t (&sum32)[16], int lane) {
   return sum32[0];
 }
 
-// One population of a tile: streams its rows four groups at a time and leaves this lane's site with
-// {alt_sum, n_called} and, for NS > 0, the NS terms of DD (`ad`).  `pad_rows` comes back as the number of zero
-// rows the sums of a site include.
+// A chunk's packed fields -> {alt_sum, missing} of this lane's site: one butterfly for both (a chunk is at most
+// kChunkIters + kUnroll iterations: the alt sum stays below 2^20, the missing count below 2^12 -- site_pass.hip)
+__device__ __forceinline__ uint2 close_chunk(const uint32_t (&lo)[4], const uint32_t (&hi)[4], const uint32_t (&ms)[4], int lane) {
+  static_assert(16 * (kChunkIters + kUnroll) * 255 < (1 << 20) && 16 * (kChunkIters + kUnroll) < (1 << 12), "packed butterfly fields overflow");
+  uint32_t both[16];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    both[4 * j + 0] = lo[j] & 0xFFFFu;
+    both[4 * j + 1] = hi[j] & 0xFFFFu;
+    both[4 * j + 2] = lo[j] >> 16;
+    both[4 * j + 3] = hi[j] >> 16;
+  }
+  if (__ballot((ms[0] | ms[1] | ms[2] | ms[3]) != 0u) != 0ull) {  // wave-uniform: some lane met a missing call
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      both[4 * j + 0] |= (ms[j] & 0xFFu) << 20;
+      both[4 * j + 1] |= ((ms[j] >> 8) & 0xFFu) << 20;
+      both[4 * j + 2] |= ((ms[j] >> 16) & 0xFFu) << 20;
+      both[4 * j + 3] |= (ms[j] >> 24) << 20;
+    }
+  }
+  const uint32_t v = butterfly(both, lane);
+  return make_uint2(v & 0xFFFFFu, v >> 20);
+}
+
+// A population whose counts only are needed (sources, outgroup): the site pass's loop, any size -- a population of
+// more than 3 968 individuals closes its chunks one by one (a butterfly per 248 wave loads) instead of widening
+// 32 partial sums per lane.
+__device__ __forceinline__ uint2 count_population(const u32x4* base, int n_ind, int lane) {
+  const int n_full = n_ind >> 4, n_iter = (n_ind + 15) >> 4;
+  uint32_t sum = 0, miss = 0;
+  int it = 0;
+  while (it < n_iter) {
+    uint32_t lo[4] = {0, 0, 0, 0}, hi[4] = {0, 0, 0, 0}, ms[4] = {0, 0, 0, 0};
+    accumulate_rows(base, it, min(n_full, it + kChunkIters), n_full, n_iter, n_ind, lane >> 2, lo, hi, ms);
+    const uint2 c = close_chunk(lo, hi, ms, lane);
+    sum += c.x;
+    miss += c.y;
+  }
+  return make_uint2(sum, static_cast<uint32_t>(n_ind) - miss);
+}
+
+// ref or tgt of a tile: streams its rows four groups at a time and leaves this lane's site with {alt_sum, n_called}
+// and the NS terms of DD (`ad`).  s_abs[k] = |s_k| at this lane's site.
 template <int NS>
-__device__ __forceinline__ uint2 sad_population(const u32x4* base, int n_ind, int lane, const uint32_t (&sv)[NS > 0 ? NS : 1][4],
-                                                const uint32_t (&s_own)[NS > 0 ? NS : 1], uint32_t (&ad)[NS > 0 ? NS : 1]) {
+__device__ __forceinline__ uint2 dd_population(const u32x4* base, int n_ind, int lane, const uint32_t (&sv)[NS][4],
+                                               const uint32_t (&s_abs)[NS], uint32_t (&ad)[NS]) {
   const int r = lane >> 2;
   const int n_full = n_ind >> 4;         // iterations in which all 16 rows exist
   const int n_iter = (n_ind + 15) >> 4;  // plus at most one partial iteration
-  SadAcc<NS> acc;
+  uint32_t dd[NS][16];
 #pragma unroll
-  for (int s = 0; s < 16; ++s) {
-    acc.raw[s] = acc.abs_[s] = acc.c128[s] = 0;
+  for (int s = 0; s < 16; ++s)
 #pragma unroll
-    for (int k = 0; k < NS; ++k) acc.dd[k][s] = 0;
-  }
-  int it = 0;
-  for (; it + kUnroll <= n_full; it += kUnroll) {
-    u32x4 v[kUnroll];
+    for (int k = 0; k < NS; ++k) dd[k][s] = 0;
+  uint32_t sum = 0, miss = 0;
+  int it = 0, slots = 0;
+  while (it < n_iter) {  // chunks the 16-/8-bit fields of the counts can absorb
+    uint32_t lo[4] = {0, 0, 0, 0}, hi[4] = {0, 0, 0, 0}, ms[4] = {0, 0, 0, 0};
+    const int chunk_end = min(n_iter, it + kChunkIters);
+    const int full_end = min(n_full, chunk_end);
+    for (; it + kUnroll <= full_end; it += kUnroll) {
+      u32x4 v[kUnroll];
 #pragma unroll
-    for (int u = 0; u < kUnroll; ++u) v[u] = __builtin_nontemporal_load(base + (it + u) * 64);
-    sad_batch<NS>(v, acc, sv);
-  }
-  int slots = it;
-  if (it < n_iter) {  // the last one to four groups as ONE batch of clamped loads; rows that do not exist become zero words
-    u32x4 v[kUnroll];
-#pragma unroll
-    for (int u = 0; u < kUnroll; ++u) {
-      const int row = min(it + u, n_iter - 1) * 16 + r;
-      v[u] = __builtin_nontemporal_load(base + (min(row, n_ind - 1) - r) * 4);
+      for (int u = 0; u < kUnroll; ++u) v[u] = __builtin_nontemporal_load(base + (it + u) * 64);
+      acc_group(v, lo, hi, ms);
+      dd_batch<NS>(v, dd, sv);
     }
+    slots = it;
+    if (chunk_end == n_iter && it < n_iter) {  // the last one to four groups as ONE batch of clamped loads; rows that do not exist become zero words
+      u32x4 v[kUnroll];
 #pragma unroll
-    for (int u = 0; u < kUnroll; ++u)
-      if (!((it + u < n_iter) && ((it + u) * 16 + r < n_ind))) v[u] = u32x4{0u, 0u, 0u, 0u};
-    sad_batch<NS>(v, acc, sv);
-    slots += kUnroll;
-  }
-  const uint32_t n = static_cast<uint32_t>(n_ind);
-  const uint32_t pad_rows = 16u * static_cast<uint32_t>(slots) - n;
-  const uint32_t raw = butterfly(acc.raw, lane);                  // sum u over the real rows + 128 pad_rows
-  const uint32_t abs_sum = butterfly(acc.abs_, lane);             // sum |g|
-  const uint32_t called = butterfly(acc.c128, lane) / 128u - pad_rows;
-  const uint32_t g_sum = raw - 128u * (n + pad_rows);             // sum g (two's complement when negative)
+      for (int u = 0; u < kUnroll; ++u) {
+        const int row = min(it + u, n_iter - 1) * 16 + r;
+        v[u] = __builtin_nontemporal_load(base + (min(row, n_ind - 1) - r) * 4);
+      }
 #pragma unroll
-  for (int k = 0; k < NS; ++k) {
-    const uint32_t s_abs = s_own[k] >= 128u ? s_own[k] - 128u : 128u - s_own[k];  // |s| of this lane's site
-    ad[k] = butterfly(acc.dd[k], lane) - pad_rows * s_abs;
+      for (int u = 0; u < kUnroll; ++u)
+        if (!((it + u < n_iter) && ((it + u) * 16 + r < n_ind))) v[u] = u32x4{0u, 0u, 0u, 0u};
+      acc_group(v, lo, hi, ms);
+      dd_batch<NS>(v, dd, sv);
+      slots = it + kUnroll;
+      it = n_iter;
+    }
+    const uint2 c = close_chunk(lo, hi, ms, lane);  // (a butterfly per 248 wave loads for populations of more than 3 968 individuals)
+    sum += c.x;
+    miss += c.y;
   }
-  return make_uint2((abs_sum + g_sum) >> 1, called);
+  const uint32_t pad_rows = 16u * static_cast<uint32_t>(slots) - static_cast<uint32_t>(n_ind);
+#pragma unroll
+  for (int k = 0; k < NS; ++k) ad[k] = butterfly(dd[k], lane) - pad_rows * s_abs[k];
+  return make_uint2(sum, static_cast<uint32_t>(n_ind) - miss);
 }
 
-// NS source individuals ride along.  Registers: the 48 sums of the counts + 16 per source individual + the
-// loads in flight -- three waves per SIMD for one or two source individuals, two for three or four.
+// NS source individuals ride along.  Registers: the counts' 32 partial sums and 12 fields + 32 per source individual
+// (16 sums, 16 replicated bytes) + the loads in flight -- three waves per SIMD for one or two source individuals,
+// two for three or four.
 template <int NS, bool FUSED>
 __global__ __launch_bounds__(64, NS <= 2 ? 3 : 2) void site_counts_dd_kernel(CountsArgs a, FusedArgs fa, DdArgs d) {
   __shared__ uint2 stash[FUSED ? kMaxPops : 1][FUSED ? 64 : 1];
@@ -162,13 +193,14 @@ __global__ __launch_bounds__(64, NS <= 2 ? 3 : 2) void site_counts_dd_kernel(Cou
   for (int64_t tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
     const int lane = threadIdx.x;
     const int my_site = (lane & 3) * 16 + (lane >> 2);  // the site this lane holds after the butterfly
-    // this lane's 16 sites of every source individual, biased; and the byte of its own site
-    uint32_t sv[NS][4], s_own[NS];
+    // this lane's 16 sites of every source individual, biased; and |s| of its own site
+    uint32_t sv[NS][4], s_abs[NS];
 #pragma unroll
     for (int k = 0; k < NS; ++k) {
       const int8_t* row = d.row[k].tiles + tile * d.row[k].tile_bytes + d.row[k].row_off;
       const u32x4 v = *(reinterpret_cast<const u32x4*>(row) + (lane & 3));
-      s_own[k] = static_cast<uint32_t>(static_cast<uint8_t>(row[my_site])) ^ 0x80u;
+      const int own = row[my_site];
+      s_abs[k] = static_cast<uint32_t>(own < 0 ? -own : own);
       sv[k][0] = v.x ^ 0x80808080u;
       sv[k][1] = v.y ^ 0x80808080u;
       sv[k][2] = v.z ^ 0x80808080u;
@@ -182,15 +214,13 @@ __global__ __launch_bounds__(64, NS <= 2 ? 3 : 2) void site_counts_dd_kernel(Cou
       uint2 cnt;
       if (p < 2) {  // ref, tgt: counts and DD terms from the same loads
         uint32_t ad[NS];
-        cnt = sad_population<NS>(base, n_ind, lane, sv, s_own, ad);
+        cnt = dd_population<NS>(base, n_ind, lane, sv, s_abs, ad);
 #pragma unroll
         for (int k = 0; k < NS; ++k)
           if (site < a.n_sites)
             __builtin_nontemporal_store(ad[k], d.out + (static_cast<int64_t>(p) * d.n_rows + k) * a.n_sites + site);
       } else {  // sources, outgroup: the counts
-        const uint32_t none[1][4] = {{0u, 0u, 0u, 0u}}, none_own[1] = {0u};
-        uint32_t unused[1];
-        cnt = sad_population<0>(base, n_ind, lane, none, none_own, unused);
+        cnt = count_population(base, n_ind, lane);
       }
       if (a.counts && site < a.n_sites) store_counts_nt(a.counts + static_cast<int64_t>(p) * a.n_sites + site, cnt);
       if (FUSED) stash[p][my_site] = cnt;
