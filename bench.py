@@ -509,7 +509,7 @@ def one_gpu_base(wl, args) -> dict:
     number stays visible under `stale`."""
     rec = {"workload_id": wl.name, "command": f"python bench.py --workload {wl.name}", "value": None, "unit": "windows/s"}
     f = ROOT / "profiles" / "one_gpu_base.json"
-    reduced = bool(args.sites or args.chroms or args.scaling != "strong" or args.layout != "int8")
+    reduced = bool(args.sites or args.chroms or args.scaling != "strong" or args.layout != "int8" or getattr(args, "missing_per_million", 0))
     if reduced:
         rec["note"] = "reduced / non-default job: run the same arguments with --gpus 1 for the base"
     elif f.exists():
@@ -722,6 +722,9 @@ def main(argv=None, device=None) -> None:
                     "workload's size, still sharded by contiguous window ranges")
     ap.add_argument("--sites", type=float, default=0, help="sites per chromosome (0 = the workload's own size)")
     ap.add_argument("--chroms", type=int, default=0, help="number of chromosomes (0 = the workload's own)")
+    ap.add_argument("--missing-per-million", type=int, default=0,
+                    help="missing calls per million genotypes in the synthetic populations (0 = none, the metric's job: the reference's "
+                    "reader drops sites with missing calls by default); a side measurement of the stream loop's call-by-call form")
     ap.add_argument("--layout", choices=["int8", "packed2"], default="int8",
                     help="int8 = the SoA int8 block the metric is defined on (default); packed2 = the optional "
                     "2-bit layout (4x fewer genotype bytes; reported with its own algorithmic bytes)")
@@ -768,6 +771,9 @@ def main(argv=None, device=None) -> None:
     wl = make_workload(name, args.sites, args.chroms, args.scaling, world)
     if hasattr(device, "adapt_workload"):
         device.adapt_workload(wl)
+    if args.missing_per_million:
+        wl.missing_per_million = int(args.missing_per_million)
+        wl.description += f"; {wl.missing_per_million} missing calls per million genotypes (NOT the metric's job)"
     if args.anc == "false":
         for spec in wl.specs:
             spec["anc"] = False
@@ -946,6 +952,7 @@ def main(argv=None, device=None) -> None:
                 "n_sites_per_chromosome": wl.n_sites,
                 "parameter_sets": n_sets,
                 "anc_allele_available": args.anc == "true",
+                "missing_per_million": int(args.missing_per_million),
                 "windows_total": total_windows,
                 "windows_rank0": scorer.n_windows,
                 "sites_rank0": n_sites_rank0,
@@ -995,7 +1002,7 @@ def main(argv=None, device=None) -> None:
             "product_windows_per_s": score_path.get("value") if isinstance(score_path, dict) else None,
             "score_path": score_path,
         }
-        reduced = bool(args.sites or args.chroms)
+        reduced = bool(args.sites or args.chroms or args.missing_per_million)
         # never under a profiler: its preloaded library has initialised the GPU in every process of the tree, and a
         # nested rocprofv3 would exec its target from such a process (refused on this pool, for good reason)
         profiled = "rocprof" in os.environ.get("LD_PRELOAD", "").lower() or any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ)
