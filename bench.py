@@ -492,7 +492,7 @@ def source_digest() -> str:
 
     h = hashlib.sha256()
     files = sorted((ROOT / "sai_amd" / "csrc").glob("*")) + [ROOT / "include" / "saihip.h"] + [
-        ROOT / "sai_amd" / f for f in ("engine.py", "resident.py", "sharding.py", "_ffi.py")]  # fmt: skip
+        ROOT / "sai_amd" / f for f in ("engine.py", "resident.py", "sharding.py", "placement.py", "_ffi.py")]  # fmt: skip
     for f in files:
         if f.is_file():
             h.update(f.name.encode() + b"\0" + f.read_bytes())
@@ -970,6 +970,9 @@ def main(argv=None, device=None) -> None:
                 "one_gpu_base": one_gpu_base(wl, args) if world > 1 else None,
                 "per_rank": rank_figures,
                 "source_digest": source_digest(),
+                # where the big populations of rank 0's block lie relative to each other (sai_amd/placement.py): the passes
+                # over the placements it tried, in ms, and whether a population was moved; part of the set-up
+                "placement": (getattr(block, "extra", None) or {}).get("placement"),
                 "setup_s": round(t_setup, 2),
                 "u_sum": int(res.records["u_count"].sum()),
                 "q_finite": int(np.isfinite(res.records["q"]).sum()),

@@ -254,6 +254,7 @@ class WindowGenerator(DataGenerator):
         from ..engine import TiledPop
 
         cache = self.__dict__.setdefault("_device_blocks", {})
+        fresh = False
         groups = [("ref", self.ref_data), ("tgt", self.tgt_data), ("src", self.src_data)]
         if self.out_data:
             groups.append(("outgroup", self.out_data))
@@ -261,6 +262,17 @@ class WindowGenerator(DataGenerator):
             for pop, cd in data.items():
                 if (group, pop) not in cache:
                     cache[(group, pop)] = cd.GT if isinstance(cd.GT, TiledPop) else eng.tile(cd.GT)
+                    fresh = True
+        if fresh:  # big populations are settled next to the largest one once (placement.py): same bytes, maybe elsewhere
+            from ..placement import settle_block
+
+            keys = list(cache)
+            owner = {(group, pop): cd for group, data in groups for pop, cd in data.items()}
+            for key, pop in zip(keys, settle_block(eng, [cache[k] for k in keys])):
+                if pop is not cache[key]:
+                    cache[key] = pop
+                    if isinstance(owner[key].GT, TiledPop):  # a resident population: the moved copy is the population now
+                        owner[key].GT = pop
         return cache
 
     def device_positions(self, eng, pos: np.ndarray):

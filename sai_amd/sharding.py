@@ -179,11 +179,15 @@ def build_synth_shard(eng, wl: SynthWorkload, rank: int, world: int):
             eng.synth_population(wl.seed, int(wl.chroms[pc.chrom_index]), a, n, stream, n_ind, wl.ploidy,
                                  wl.missing_per_million, out=tiles[t0 * n_ind * TILE : (t0 + nt) * n_ind * TILE])  # fmt: skip
         pops.append(TiledPop(tiles, n_tiles * TILE, n_ind))
+    from .placement import settle_block
+
+    placement: dict = {}
+    pops = settle_block(eng, pops, placement)  # the same bytes, possibly in another allocation (placement.py)
     pos_host = np.zeros(n_tiles * TILE, dtype=np.int32)
     for pc, a, n, t0 in zip(lay.pieces, lay.site0, lay.n_sites, lay.tile0):
         pos_host[t0 * TILE : t0 * TILE + n] = all_pos[pc.chrom_index][a : a + n]
     pos = torch.from_numpy(pos_host).to(eng.device)
-    block = ResidentBlock(pops, [wl.ploidy] * len(pops), pos, segments=lay.segments)
+    block = ResidentBlock(pops, [wl.ploidy] * len(pops), pos, segments=lay.segments, extra={"placement": placement})
     return block, lay, counts
 
 

@@ -1,0 +1,84 @@
+"""sai_amd/placement.py: the decision between two placements (CPU), and -- on the GPU -- that a population moved
+into another allocation holds the same bytes and scores to the same records."""
+
+import numpy as np
+import pytest
+
+
+def test_worth_moving_needs_more_than_a_levels_own_spread():
+    from sai_amd.placement import GAIN, worth_moving
+
+    assert worth_moving(3.00, 2.85) and worth_moving(3.07, 2.96)  # the levels measured at C3
+    assert not worth_moving(2.85, 3.00) and not worth_moving(2.85, 2.84) and not worth_moving(3.00, 2.99)
+    edge = 3.0 * (1.0 - GAIN)
+    assert worth_moving(3.0, edge - 1e-9) and not worth_moving(3.0, edge + 1e-9)
+
+
+def test_settle_block_leaves_small_blocks_and_the_switch_alone(monkeypatch):
+    from types import SimpleNamespace
+
+    from sai_amd import placement
+
+    class Tiles:
+        def __init__(self, n):
+            self.n = n
+
+        def numel(self):
+            return self.n
+
+    small = [SimpleNamespace(tiles=Tiles(1 << 20), n_sites=64, n_ind=1) for _ in range(3)]
+    report = {}
+    assert placement.settle_block(None, small, report) == small and report == {"enabled": True}  # no engine is touched
+    monkeypatch.setenv("SAI_AMD_PLACEMENT", "0")
+    big = [SimpleNamespace(tiles=Tiles(2 << 30), n_sites=64, n_ind=1) for _ in range(2)]
+    assert placement.settle_block(None, big) == big
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("times,moved,chosen", [
+    ([3.00, 2.85], ["other"], 2.85),  # the first copy of the other population is of the anchor's kind
+    ([2.85, 3.00], [], 2.85),  # ... or shows that the pair as it is was
+    ([3.00, 2.99, 3.01, 2.86], ["other"], 2.86),
+    # no copy of the other helps: the anchor is of a kind of its own; its second copy next to the third copy of the other
+    ([3.00, 3.01, 2.99, 3.02] + [3.00, 3.01, 2.99, 3.00] + [3.01, 3.00, 2.84], ["anchor", "other"], 2.84),
+    ([3.00, 3.01, 2.99, 3.02] + [2.85], ["anchor"], 2.85),
+    ([2.85, 2.86, 2.84, 2.85] + [2.86, 2.85, 2.84, 2.86] * 3, [], 2.85),  # fast as it is: a hundredth is not worth a move
+])  # fmt: skip
+def test_a_moved_population_is_the_same_population(monkeypatch, times, moved, chosen):
+    import torch
+
+    from sai_amd import _ffi, placement
+    from sai_amd.engine import Engine
+    from sai_amd.resident import ResidentScorer, synth_block
+
+    eng = Engine.get()
+    block = synth_block(eng, 77, 1, 20_000, 300, 280, [2], missing_per_million=2000)
+    script = list(times)
+    real_ms = placement._PairTimer.ms
+
+    def scripted(self, a, b, passes=placement.PASSES):
+        real_ms(self, a, b, 1)  # the pass runs over the pair it is asked about
+        return script.pop(0)
+
+    monkeypatch.setattr(placement._PairTimer, "ms", scripted)
+    report = {}
+    ref2, tgt2 = placement.settle_pair(eng, block.pops[0], block.pops[1], report=report)
+    log = report["pairs"][0]
+    assert not script and log["ms"] == times and log["moved"] == moved and log["ms_chosen"] == chosen
+    assert (tgt2 is block.pops[1]) == ("other" not in moved) and (ref2 is block.pops[0]) == ("anchor" not in moved)
+    for now, was in ((ref2, block.pops[0]), (tgt2, block.pops[1])):
+        assert (now.n_ind, now.n_sites) == (was.n_ind, was.n_sites) and torch.equal(now.tiles, was.tiles)
+        assert (now.tiles.data_ptr() == was.tiles.data_ptr()) == (now is was)
+
+    pos = block.pos.cpu().numpy()
+    windows = [(int(pos[a]), int(pos[min(a + 900, len(pos) - 1)])) for a in range(0, len(pos) - 1, 450)]
+    sets = [_ffi.make_params(0.3, 0.5, 0.9, [("=", 1.0)], True)]
+    got = []
+    for pops in (block.pops, [ref2, tgt2, block.pops[2]]):
+        import dataclasses
+
+        sc = ResidentScorer(eng, dataclasses.replace(block, pops=list(pops)), windows, sets)
+        sc.step()
+        got.append(sc.results())
+    assert got[0].records.tobytes() == got[1].records.tobytes()
+    assert np.array_equal(got[0].cdd_u, got[1].cdd_u) and np.array_equal(got[0].cdd_q, got[1].cdd_q)
