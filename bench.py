@@ -441,7 +441,9 @@ def measure_traffic(argv: list, kernel: str, timeout_s: float = 90.0):
             out = os.path.join(tmp, counter)
             cmd = [prof, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", out, "--", *child]
             try:  # its own session: a run that overstays is ended together with the program it profiles
-                proc = subprocess.Popen(cmd, cwd="/tmp", env={**os.environ, "TMPDIR": "/tmp"}, stdout=subprocess.DEVNULL,
+                # SAI_AMD_PLACEMENT=0: the passes placement.py times while a block is built are launches of the same
+                # kernel over two of the three populations -- they would be averaged into the bytes per launch
+                proc = subprocess.Popen(cmd, cwd="/tmp", env={**os.environ, "TMPDIR": "/tmp", "SAI_AMD_PLACEMENT": "0"}, stdout=subprocess.DEVNULL,
                                         stderr=subprocess.DEVNULL, start_new_session=True)  # fmt: skip
             except OSError as exc:
                 return None, f"rocprofv3 --pmc {counter}: {type(exc).__name__}"
