@@ -82,3 +82,60 @@ def test_a_moved_population_is_the_same_population(monkeypatch, times, moved, ch
         got.append(sc.results())
     assert got[0].records.tobytes() == got[1].records.tobytes()
     assert np.array_equal(got[0].cdd_u, got[1].cdd_u) and np.array_equal(got[0].cdd_q, got[1].cdd_q)
+
+
+@pytest.mark.gpu
+def test_score_writes_the_same_files_from_settled_blocks(monkeypatch, tmp_path):
+    """What ``score`` runs on: WindowGenerator.device_blocks settles the big populations once per generator; a
+    population that moved IS the generator's population from then on, and the files are the ones an unsettled run
+    writes."""
+    import torch
+
+    from sai_amd import placement
+    from sai_amd.configs import PloidyConfig, StatConfig
+    from sai_amd.engine import Engine
+    from sai_amd.generators import WindowGenerator
+    from sai_amd.preprocessors import FeaturePreprocessor
+    from sai_amd.sai import write_headers
+
+    eng = Engine.get(0)
+    n_sites, seed = 120_000, 4242
+    sizes = {"ref": 150, "tgt": 90, "src": 2}
+    stats = StatConfig({"U": {"ref": {"ref": 0.05}, "tgt": {"tgt": 0.3}, "src": {"src": "=1"}},
+                        "Q": {"ref": {"ref": 0.05}, "tgt": {"tgt": 0.9}, "src": {"src": "=1"}}})  # fmt: skip
+    ploidies = PloidyConfig({"ref": {"ref": 2}, "tgt": {"tgt": 2}, "src": {"src": 2}})
+    monkeypatch.setattr(placement, "MIN_BYTES", 1 << 20)  # ref and tgt count as big, src does not
+    calls = []
+    real_ms = placement._PairTimer.ms
+
+    def first_copy_is_faster(self, a, b, passes=placement.PASSES):
+        real_ms(self, a, b, 1)
+        calls.append((a.n_ind, b.n_ind))
+        return 3.0 if len(calls) == 1 else 2.85
+
+    outs = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("SAI_AMD_PLACEMENT", mode)
+        monkeypatch.setattr(placement._PairTimer, "ms", first_copy_is_faster)
+        eng.__dict__.pop("_settled_pairs", None)
+        pops = {k: eng.synth_population(seed, 1, 0, n_sites, i, n, 2, 3000) for i, (k, n) in enumerate(sizes.items())}
+        was = {k: p.tiles.data_ptr() for k, p in pops.items()}
+        pos_dev = eng.synth_positions(seed, 1, n_sites)
+        wg = WindowGenerator.from_resident("7", pos_dev.cpu().numpy(), pos_dev, {"ref": pops["ref"]}, {"tgt": pops["tgt"]},
+                                           {"src": pops["src"]}, 5000, 2500, ploidies)  # fmt: skip
+        out = tmp_path / f"placement{mode}.tsv"
+        fp = FeaturePreprocessor(str(out), stats, anc_allele_available=True)
+        write_headers(str(out), stats, ploidies)
+        fp.score_and_write(wg)
+        fp.score_and_write(wg)  # the second call finds the blocks settled
+        torch.cuda.synchronize()
+        outs[mode] = [out.read_bytes(), out.with_suffix(".U.log").read_bytes(), out.with_suffix(".Q.log").read_bytes()]
+        now = {k[1]: p.tiles.data_ptr() for k, p in wg.device_blocks(eng).items()}
+        if mode == "0":
+            assert not calls and now == was
+        else:
+            assert calls == [(150, 90), (150, 90)]  # the pair as built, one copy of tgt: clearly of the fast kind
+            assert now["ref"] == was["ref"] and now["src"] == was["src"] and now["tgt"] != was["tgt"]
+            assert wg.tgt_data["tgt"].GT.tiles.data_ptr() == now["tgt"]  # the copy is the population now
+            assert torch.equal(wg.tgt_data["tgt"].GT.tiles, pops["tgt"].tiles)
+    assert outs["0"] == outs["1"] and outs["0"][1].count(b":") > 5

@@ -65,7 +65,7 @@ tfile = DST / "traffic.json"
 if tfile.exists():
     old = json.loads(tfile.read_text())
     tfile.write_text(json.dumps({k: v for k, v in old.items() if v.get("source_digest") == here}, indent=1) + "\n")
-NOTES = {"r05_c5_grid.txt", "r05_dd_pass.txt", "r05_score_parts.txt"}  # experiment logs of trees on the way (their headers say so)
+NOTES = {"r05_c5_grid.txt", "r05_dd_pass.txt", "r05_score_parts.txt", "r05_placement.txt"}  # experiment logs of trees on the way (their headers say so)
 manifest = {k: v for k, v in manifest.items() if v["source_digest"] == here and (DST / k).exists() and k not in NOTES}
 mfile.write_text(json.dumps(manifest, indent=1, sort_keys=True) + "\n")
 # the rocprofv3 runs: kernel trace + PMC passes -> summaries, traffic.json, manifest (tools/summarize_profile.py refuses other trees)
@@ -82,7 +82,9 @@ for pas in ("pmc_sq", "pmc_sq2"):
         acc = {}
         for r in csv.DictReader(open(files[0])):
             if "site_counts" in r["Kernel_Name"]:
-                acc.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+                acc.setdefault(r["Counter_Name"], []).append((int(r.get("Dispatch_Id") or 0), float(r["Counter_Value"])))
+        # the bench's own 13 launches (set-up, 2 warm-up, 10 timed): the passes placement.py times come before them
+        acc = {k: [x[1] for x in sorted(v)][-13:] for k, v in acc.items()}
         rows = "\n".join(f"{k},{len(v)},{sum(v) / len(v):.1f}" for k, v in sorted(acc.items()))
         manifest_name = f"r05_c2x22_{pas}.csv"
         (DST / manifest_name).write_text("counter,launches,avg_per_site_counts_launch\n" + rows + "\n")

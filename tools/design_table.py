@@ -20,7 +20,7 @@ for key, label in rows:
     under = "—"
     if dur.exists():
         for row in csv.DictReader(open(dur)):
-            if row["kernel"].startswith("site_counts"):
+            if row["kernel"] == r["kernel"]:  # the line's dominant kernel (a packed2 run also holds placement.py's int8 passes)
                 under = f"{float(row['avg_us_timed_steps']) / 1e3:.3f} / {float(row['min_us']) / 1e3:.3f} ms"
                 break
     traffic = f"{r['traffic'] / 1e9:.3f} GB ÷ {r['algorithmic_bytes_per_launch'] / 1e9:.3f} GB = {r['traffic'] / r['algorithmic_bytes_per_launch']:.4f}" if r.get("traffic") else "—"
