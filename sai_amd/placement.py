@@ -105,7 +105,11 @@ def settle_pair(eng, anchor, other, timer: Optional[_PairTimer] = None, tries: i
         if _free_bytes(eng) < pop.tiles.numel() + KEEP_FREE:
             log["stopped"] = "no room for another copy"
             return False
-        fresh = TiledPop(torch.empty_like(pop.tiles), pop.n_sites, pop.n_ind)
+        try:
+            fresh = TiledPop(torch.empty_like(pop.tiles), pop.n_sites, pop.n_ind)
+        except torch.cuda.OutOfMemoryError:  # another process took the room in between (several ranks on one card)
+            log["stopped"] = "no room for another copy"
+            return False
         fresh.tiles.copy_(pop.tiles)
         of.append(fresh)
         return True

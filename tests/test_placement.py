@@ -139,3 +139,32 @@ def test_score_writes_the_same_files_from_settled_blocks(monkeypatch, tmp_path):
             assert wg.tgt_data["tgt"].GT.tiles.data_ptr() == now["tgt"]  # the copy is the population now
             assert torch.equal(wg.tgt_data["tgt"].GT.tiles, pops["tgt"].tiles)
     assert outs["0"] == outs["1"] and outs["0"][1].count(b":") > 5
+
+
+@pytest.mark.gpu
+def test_no_room_for_a_copy_leaves_the_pair_as_it_is(monkeypatch):
+    """A card shared with other processes (several ranks rehearsed on one GPU) can run out between the look at the
+    free memory and the allocation: the search stops, the block is used as built."""
+    import torch
+
+    from sai_amd import placement
+    from sai_amd.engine import Engine
+    from sai_amd.resident import synth_block
+
+    eng = Engine.get()
+    block = synth_block(eng, 78, 1, 10_000, 100, 90, [2])
+
+    def no_room(*a, **k):
+        raise torch.cuda.OutOfMemoryError("HIP out of memory (simulated)")
+
+    monkeypatch.setattr(torch, "empty_like", no_room)
+    report = {}
+    ref2, tgt2 = placement.settle_pair(eng, block.pops[0], block.pops[1], report=report)
+    assert ref2 is block.pops[0] and tgt2 is block.pops[1]
+    log = report["pairs"][0]
+    assert log["stopped"] == "no room for another copy" and log["moved"] == [] and len(log["ms"]) == 1
+    monkeypatch.undo()
+    monkeypatch.setattr(placement, "KEEP_FREE", 1 << 60)  # ... or the look at the free memory says so already
+    report = {}
+    assert placement.settle_pair(eng, block.pops[0], block.pops[1], report=report) == (block.pops[0], block.pops[1])
+    assert report["pairs"][0]["stopped"] == "no room for another copy"
