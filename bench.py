@@ -528,6 +528,11 @@ def one_gpu_base(wl, args) -> dict:
 RANK_RECORD_BYTES = 1024
 
 
+def _placement_ms(block):
+    pairs = ((getattr(block, "extra", None) or {}).get("placement") or {}).get("pairs") or []
+    return [[p["ms"][0], p["ms_chosen"], "+".join(p["moved"]) or "as built"] for p in pairs if p.get("ms")] or None
+
+
 def per_rank_figures(dist_on: bool, cdev, mine: dict) -> list:
     """One record per rank, all_gathered after the timed region (outside it) as JSON in fixed-size byte
     rows: the rank's own wall time per step, its site-pass average (HIP events), what its per-pass gather
@@ -864,6 +869,8 @@ def main(argv=None, device=None) -> None:
             "gather_avg_ms_host_call": avg(out["gather_host_ms"]), "gathers_timed": len(out["gather_host_ms"]),
             "windows": scorer.n_windows if scorer is not None else 0,
             "sites": block.n_real_sites if block is not None else 0, "setup_s": round(t_setup, 2),
+            # the placement search of this rank's block (sai_amd/placement.py): the pass over the pair as built and as chosen, ms
+            "placement_ms": _placement_ms(block),
             **(device.identity() if hasattr(device, "identity") else {})}  # fmt: skip
     rank_figures = per_rank_figures(dist_on, cdev, mine)
     collective = collective_record(backend, rank_figures) if dist_on else None
