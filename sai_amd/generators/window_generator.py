@@ -268,7 +268,11 @@ class WindowGenerator(DataGenerator):
 
             keys = list(cache)
             owner = {(group, pop): cd for group, data in groups for pop, cd in data.items()}
-            for key, pop in zip(keys, settle_block(eng, [cache[k] for k in keys])):
+            arena: list = []
+            settled = settle_block(eng, [cache[k] for k in keys], arena=arena)
+            if arena:  # memory of another class than the populations': where the scorers of this region write (placement.py)
+                self.__dict__["_output_arena"] = arena[0]
+            for key, pop in zip(keys, settled):
                 if pop is not cache[key]:
                     cache[key] = pop
                     if isinstance(owner[key].GT, TiledPop):  # a resident population: the moved copy is the population now
@@ -285,7 +289,7 @@ class WindowGenerator(DataGenerator):
         return torch.as_tensor(np.ascontiguousarray(pos, dtype=np.int32)).to(eng.device)
 
     def __getstate__(self):  # device handles never travel with a pickled generator
-        return {k: v for k, v in self.__dict__.items() if k not in ("_device_blocks", "_device_pos", "_aligned", "_scorers", "_win_arrays", "_part_plans")}
+        return {k: v for k, v in self.__dict__.items() if k not in ("_device_blocks", "_device_pos", "_aligned", "_scorers", "_win_arrays", "_part_plans", "_output_arena")}
 
     @staticmethod
     def window_range(pos: np.ndarray, start: int, end: int) -> tuple[int, int]:

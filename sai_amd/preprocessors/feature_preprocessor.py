@@ -403,7 +403,8 @@ class FeaturePreprocessor(DataPreprocessor):
                         counts_rows.setdefault(k, c[j])
             if uq_names:
                 block = ResidentBlock([tiled[k] for k in uq_keys], ploidy[: 2 + n_eff], pos_dev,
-                                      segments=None if segs is None else [tuple(map(int, sg)) for sg in segs])  # fmt: skip
+                                      segments=None if segs is None else [tuple(map(int, sg)) for sg in segs],
+                                      extra={"output_arena": wg.__dict__.get("_output_arena") if tiled is shared_tiled else None})  # fmt: skip
                 # one scorer per (window grid, block length, number of sets) serves every combination of the
                 # region -- and the next call on the same generator: only its launch sequences are re-recorded
                 key = (tgt_pop, n_sites, len(sets)) if segs is None else (tgt_pop, n_sites, len(sets), tuple(al.keys))
@@ -510,7 +511,9 @@ class FeaturePreprocessor(DataPreprocessor):
                 a, b = t0 * tile, min(t1 * tile, n_sites)
                 pops = [TiledPop(tiled[key].tiles[t0 * tiled[key].n_ind * tile : t1 * tiled[key].n_ind * tile], b - a, tiled[key].n_ind)
                         for key in keys]  # fmt: skip
-                block = ResidentBlock(pops, ploidy[: 2 + n_eff], pos_dev[a:b])
+                # (the arena belongs to the settled blocks of the generator, not to re-tiled row selections)
+                block = ResidentBlock(pops, ploidy[: 2 + n_eff], pos_dev[a:b],
+                                      extra={"output_arena": wg.__dict__.get("_output_arena") if tiled is wg.__dict__.get("_device_blocks") else None})  # fmt: skip
                 key = (cb.tgt_pop, n_sites, len(sets), "part", k, self.PARTS, self.PART_FRACTIONS)
                 scorer = scorers.get(key)
                 if scorer is None or scorer.block.n_sites != block.n_sites or scorer.n_windows != w1 - w0:

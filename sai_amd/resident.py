@@ -210,9 +210,26 @@ class ResidentScorer:
         # pass k+2 without waiting for it (with two sets a short pass -- C2: 75 us -- left the main
         # stream idle whenever the stage under it ran longer than the pass)
         n_buf = 3 if self.overlap else 1
-        # the fused pass writes tgt_freq only at candidate sites (all the windows stage reads)
-        self._tgt_freq = [torch.full((n,), float("nan"), dtype=torch.float64, device=dev) for _ in range(n_buf)]
-        self._flags = [eng.alloc_planes(n, n_s) for _ in range(n_buf)]  # flag planes [tiles][3 * sets]
+        # the fused pass writes tgt_freq only at candidate sites (all the windows stage reads).  What the pass writes lies
+        # best in memory of another class than the populations it reads (sai_amd/placement.py): in the block's output
+        # arena when the placement search found such memory and this scorer still fits into it
+        arena = (block.extra or {}).get("output_arena")
+        n_tiles = (n + _ffi.SAI_TILE_SITES - 1) // _ffi.SAI_TILE_SITES
+
+        def in_arena(nbytes: int):
+            return arena.take(nbytes) if arena is not None and nbytes > 0 else None
+
+        self._tgt_freq, self._flags = [], []
+        for _ in range(n_buf):
+            freq, planes = in_arena(8 * n), in_arena(8 * n_tiles * PLANES * n_s)
+            if freq is None or planes is None:
+                arena = None  # used up: this and the remaining sets as always
+                freq, planes = torch.full((n,), float("nan"), dtype=torch.float64, device=dev), eng.alloc_planes(n, n_s)
+            else:
+                freq = freq.view(torch.float64).fill_(float("nan"))
+                planes = planes.view(torch.int64).reshape(n_tiles, PLANES * n_s).zero_()
+            self._tgt_freq.append(freq)
+            self._flags.append(planes)  # flag planes [tiles][3 * sets]
         # the windows stage always runs on a second stream.  Pipelined form: under the next site pass.  Plain
         # form: a kernel queued BEHIND a running site pass on the pass's own stream slows the pass down (C3, one
         # box: 2.92 ms with nothing or only a copy behind it, 3.09 with window_bounds, 3.10 with the whole stage;

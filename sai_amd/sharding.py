@@ -182,12 +182,13 @@ def build_synth_shard(eng, wl: SynthWorkload, rank: int, world: int):
     from .placement import settle_block
 
     placement: dict = {}
-    pops = settle_block(eng, pops, placement)  # the same bytes, possibly in another allocation (placement.py)
+    arena: list = []
+    pops = settle_block(eng, pops, placement, arena, owned=True)  # the same bytes, possibly in another allocation (placement.py)
     pos_host = np.zeros(n_tiles * TILE, dtype=np.int32)
     for pc, a, n, t0 in zip(lay.pieces, lay.site0, lay.n_sites, lay.tile0):
         pos_host[t0 * TILE : t0 * TILE + n] = all_pos[pc.chrom_index][a : a + n]
     pos = torch.from_numpy(pos_host).to(eng.device)
-    block = ResidentBlock(pops, [wl.ploidy] * len(pops), pos, segments=lay.segments, extra={"placement": placement})
+    block = ResidentBlock(pops, [wl.ploidy] * len(pops), pos, segments=lay.segments, extra={"placement": placement, "output_arena": arena[0] if arena else None})
     return block, lay, counts
 
 

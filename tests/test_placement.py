@@ -36,13 +36,13 @@ def test_settle_block_leaves_small_blocks_and_the_switch_alone(monkeypatch):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("times,moved,chosen", [
-    ([3.00, 2.85], ["other"], 2.85),  # the first copy of the other population is of the anchor's kind
-    ([2.85, 3.00], [], 2.85),  # ... or shows that the pair as it is was
-    ([3.00, 2.99, 3.01, 2.86], ["other"], 2.86),
-    # no copy of the other helps: the anchor is of a kind of its own; its second copy next to the third copy of the other
-    ([3.00, 3.01, 2.99, 3.02] + [3.00, 3.01, 2.99, 3.00] + [3.01, 3.00, 2.84], ["anchor", "other"], 2.84),
-    ([3.00, 3.01, 2.99, 3.02] + [2.85], ["anchor"], 2.85),
-    ([2.85, 2.86, 2.84, 2.85] + [2.86, 2.85, 2.84, 2.86] * 3, [], 2.85),  # fast as it is: a hundredth is not worth a move
+    # pairs in order: as built, (anchor, F1), (F1, other), (anchor, F2), (F2, other), (F1, F2)
+    ([3.00, 2.85, 3.01, 2.86, 3.00, 2.852], ["other"], 2.85),  # both fresh pieces are of the anchor's class: the first one met
+    ([2.85, 3.00, 3.01, 2.99, 3.02, 2.86], [], 2.85),  # the pair as built was of one class
+    ([3.00, 3.01, 2.85, 3.00, 3.02, 2.99], ["anchor"], 2.85),  # F1 is of the other's class: the anchor goes there
+    ([3.00, 3.01, 2.99, 3.02, 3.00, 2.84], ["anchor", "other"], 2.84),  # three classes met: the two fresh pieces are the pair
+    ([3.07, 2.93, 3.05, 2.85, 3.06, 2.94], ["other"], 2.85),  # a piece partly in two classes (2.93) is not mistaken for the fast one
+    ([2.85, 2.86, 2.84, 2.85, 2.86, 2.85], [], 2.85),  # all of one class: a hundredth is not worth a move
 ])  # fmt: skip
 def test_a_moved_population_is_the_same_population(monkeypatch, times, moved, chosen):
     import torch
@@ -134,7 +134,7 @@ def test_score_writes_the_same_files_from_settled_blocks(monkeypatch, tmp_path):
         if mode == "0":
             assert not calls and now == was
         else:
-            assert calls == [(150, 90), (150, 90)]  # the pair as built, one copy of tgt: clearly of the fast kind
+            assert calls == [(150, 90)] * 6  # the pair as built and the five pairs with the two fresh pieces
             assert now["ref"] == was["ref"] and now["src"] == was["src"] and now["tgt"] != was["tgt"]
             assert wg.tgt_data["tgt"].GT.tiles.data_ptr() == now["tgt"]  # the copy is the population now
             assert torch.equal(wg.tgt_data["tgt"].GT.tiles, pops["tgt"].tiles)
@@ -153,11 +153,15 @@ def test_no_room_for_a_copy_leaves_the_pair_as_it_is(monkeypatch):
 
     eng = Engine.get()
     block = synth_block(eng, 78, 1, 10_000, 100, 90, [2])
+    need = block.pops[0].tiles.numel()
+    real_empty = torch.empty
 
-    def no_room(*a, **k):
-        raise torch.cuda.OutOfMemoryError("HIP out of memory (simulated)")
+    def no_room_for_a_population(*a, **k):
+        if k.get("dtype") == torch.int8 and a and tuple(a[0]) == (need,):
+            raise torch.cuda.OutOfMemoryError("HIP out of memory (simulated)")
+        return real_empty(*a, **k)
 
-    monkeypatch.setattr(torch, "empty_like", no_room)
+    monkeypatch.setattr(torch, "empty", no_room_for_a_population)
     report = {}
     ref2, tgt2 = placement.settle_pair(eng, block.pops[0], block.pops[1], report=report)
     assert ref2 is block.pops[0] and tgt2 is block.pops[1]
@@ -168,3 +172,78 @@ def test_no_room_for_a_copy_leaves_the_pair_as_it_is(monkeypatch):
     report = {}
     assert placement.settle_pair(eng, block.pops[0], block.pops[1], report=report) == (block.pops[0], block.pops[1])
     assert report["pairs"][0]["stopped"] == "no room for another copy"
+
+
+@pytest.mark.gpu
+def test_a_fixed_anchor_only_gets_new_partners(monkeypatch):
+    """Later populations of a block are settled next to an anchor that stays: fresh pieces for them alone."""
+    from sai_amd import placement
+    from sai_amd.engine import Engine
+    from sai_amd.resident import synth_block
+
+    eng = Engine.get()
+    block = synth_block(eng, 79, 1, 10_000, 100, 90, [2])
+    script = [3.00, 3.01, 2.85, 2.86]
+    monkeypatch.setattr(placement._PairTimer, "ms", lambda self, a, b, passes=placement.PASSES: script.pop(0))
+    report = {}
+    ref2, tgt2 = placement.settle_pair(eng, block.pops[0], block.pops[1], report=report, move_anchor=False)
+    log = report["pairs"][0]
+    assert ref2 is block.pops[0] and tgt2 is not block.pops[1] and log["moved"] == ["other"]
+    assert log["pairs"] == ["ao", "a1", "a2", "a3"] and log["ms_chosen"] == 2.85 and not script
+
+
+def test_output_arena_hands_out_aligned_views_front_to_back():
+    import torch
+
+    from sai_amd.placement import OutputArena
+
+    arena = OutputArena(torch.zeros(4096, dtype=torch.uint8))
+    a, b = arena.take(100), arena.take(1000)
+    assert a.numel() == 100 and b.numel() == 1000 and b.data_ptr() - a.data_ptr() == 256
+    assert arena.take(4096) is None and arena.take(2000).numel() == 2000  # what does not fit is refused, the rest stays usable
+    a.fill_(7)
+    assert int(arena.tensor[:100].sum()) == 700 and int(arena.tensor[100:].sum()) == 0
+
+
+@pytest.mark.gpu
+def test_a_piece_of_another_class_becomes_the_output_arena_and_the_scorer_writes_there(monkeypatch):
+    import dataclasses
+
+    import torch
+
+    from sai_amd import _ffi, placement
+    from sai_amd.engine import Engine
+    from sai_amd.resident import ResidentScorer, synth_block
+
+    eng = Engine.get()
+    torch.cuda.empty_cache()  # the arena is carved from the piece that was released last: nothing else of its size may wait in the cache
+    block = synth_block(eng, 80, 1, 200_000, 120, 100, [2], missing_per_million=1000)
+    # as built fast; F1 of another class (slow next to both); F2 of the pair's class
+    script = [2.85, 3.00, 3.01, 2.86, 2.85, 3.00]
+    real_ms = placement._PairTimer.ms
+    monkeypatch.setattr(placement._PairTimer, "ms", lambda self, a, b, passes=placement.PASSES: (real_ms(self, a, b, 1), script.pop(0))[1])
+    report, arena = {}, []
+    need = placement.ARENA_BYTES_PER_SITE * block.n_sites
+    ref2, tgt2 = placement.settle_pair(eng, block.pops[0], block.pops[1], report=report, arena=arena, arena_bytes=need)
+    log = report["pairs"][0]
+    assert (ref2, tgt2) == (block.pops[0], block.pops[1]) and log["moved"] == [] and log.get("arena") == "piece 1"
+    assert len(arena) == 1 and arena[0].tensor.numel() == need and arena[0].used == 0
+
+    pos = block.pos.cpu().numpy()
+    windows = [(int(pos[a]), int(pos[min(a + 3000, len(pos) - 1)])) for a in range(0, len(pos) - 1, 1500)]
+    sets = [_ffi.make_params(0.3, 0.5, 0.9, [("=", 1.0)], True), _ffi.make_params(0.5, 0.2, 0.5, [(">=", 0.5)], False)]
+    got = []
+    for extra in ({}, {"output_arena": arena[0]}):
+        for overlap in (False, True):
+            sc = ResidentScorer(eng, dataclasses.replace(block, extra=extra), windows, sets, overlap=overlap)
+            sc.step()
+            sc.step()
+            sc.flush()
+            got.append(sc.results())
+            lo, hi = arena[0].tensor.data_ptr(), arena[0].tensor.data_ptr() + need
+            inside = [lo <= t.data_ptr() < hi for t in sc._tgt_freq + sc._flags]
+            assert all(inside) if extra else not any(inside)  # one plus three buffer sets of this size fit into the arena
+    assert arena[0].used > 0
+    for other in got[1:]:
+        assert other.records.tobytes() == got[0].records.tobytes()
+        assert np.array_equal(other.cdd_u, got[0].cdd_u) and np.array_equal(other.cdd_q, got[0].cdd_q)

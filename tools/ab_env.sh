@@ -7,7 +7,7 @@ for v in $VALS; do
   for wl in $WLS; do
     env $VAR=$v python bench.py --workload $wl --steps 40 --cpu-sites 0 --score-path off --traffic off "$@" 2>/dev/null | python -c "
 import json,sys
-d=json.loads(sys.stdin.read()); print('$VAR=$v', '$wl', 'step', d['ms_per_step'], 'site', d['roofline']['avg_launch_ms'], d['roofline']['frac'], d['config']['u_sum'], d['config']['cdd_q_entries'], 'placement', [(q['ms'][0], q['ms_chosen']) for q in ((d['config'].get('placement') or {}).get('pairs') or [])])"
+d=json.loads(sys.stdin.read()); print('$VAR=$v', '$wl', 'step', d['ms_per_step'], 'site', d['roofline']['avg_launch_ms'], d['roofline']['frac'], d['config']['u_sum'], d['config']['cdd_q_entries'], 'placement', [(q['ms'][0], q['ms_chosen'], q.get('arena')) for q in ((d['config'].get('placement') or {}).get('pairs') or [])])"
   done
 done
 done

@@ -113,6 +113,22 @@ def main() -> None:
         print(f"{name}, ms (and minus the scorer's pass):")
         for i in range(K):
             print(f"{i:4d}  " + " ".join("      -      " if i == j else f"{mat[i][j]:6.3f}({mat[i][j] - m[i][j]:+.3f})" for j in range(K)), flush=True)
+    # is a pair slow everywhere?  Tenths of the sites of the worst and the best pair, slice k of ref with slice k of tgt
+    # (the pass over views, as FeaturePreprocessor._score_in_parts takes them), then slice 0 of ref with every slice of tgt
+    n_tiles = ref.n_sites // 64
+    per = n_tiles // 10
+
+    def view(i, k, n_ind):
+        t = arrays[i][k * per * n_ind * 64 : (k + 1) * per * n_ind * 64]
+        return TiledPop(t, per * 64, n_ind)
+
+    for tag, (_, i, j) in (("worst", cells[-1]), ("best", cells[0])):
+        tms = _PairTimer(eng, per * 64)
+        gb = per * 64 * (ref.n_ind + tgt.n_ind) / 1e9
+        same = [gb / tms.ms(view(i, k, ref.n_ind), view(j, k, tgt.n_ind), 3) * 1e3 for k in range(10)]
+        cross = [gb / tms.ms(view(i, 0, ref.n_ind), view(j, k, tgt.n_ind), 3) * 1e3 for k in range(10)]
+        print(f"{tag} pair ({i},{j}) in tenths, GB/s: slice k with slice k: " + " ".join(f"{v:.0f}" for v in same), flush=True)
+        print(f"{tag} pair ({i},{j}) in tenths, GB/s: ref slice 0 with tgt slice k: " + " ".join(f"{v:.0f}" for v in cross), flush=True)
     # the product's answer (sai_amd/placement.py): the slowest pairs, settled
     from sai_amd.placement import settle_pair
 
