@@ -337,7 +337,8 @@ def score_path_rate(eng, wl, block, lay, repeats: int = 3) -> dict:
         str(wl.chroms[0]), pos_host, block.pos[:n], {"ref": _trim(block.pops[0], n)}, {"tgt": _trim(block.pops[1], n)},
         {nm: _trim(p, n) for nm, p in zip(src_names, block.pops[2:])}, wl.win_len, wl.win_step, ploidies,
     )  # fmt: skip
-    times, plain, first_calls = [], [], []
+    times, plain, first_calls, rows_of_calls = [], [], [], []
+    ROW = 12  # calls in a row per repeat: the device needs several calls after an idle stretch to return to its steady rate
     with tempfile.TemporaryDirectory() as tmp:
         out, out_items = os.path.join(tmp, "scores.tsv"), os.path.join(tmp, "items.tsv")
         fp = FeaturePreprocessor(out, stats, anc_allele_available=s0["anc"])
@@ -354,12 +355,13 @@ def score_path_rate(eng, wl, block, lay, repeats: int = 3) -> dict:
             # what `score` runs after the ingest (rows written while later windows are scored), as a run meets it:
             # one call after the other (a chromosome after a chromosome); the first timed call is reported too
             in_a_row = []
-            for _k in range(4):
+            for _k in range(ROW):
                 write_headers(out, stats, ploidies)
                 t0 = time.perf_counter()
                 fp.score_and_write(wg)
                 in_a_row.append(time.perf_counter() - t0)
             first_calls.append(in_a_row[0])
+            rows_of_calls.append(in_a_row)
             t0, t1 = 0.0, min(in_a_row)
             # the same work as two calls, nothing overlapped (round 4's form), for comparison
             write_headers(out_items, stats, ploidies)
@@ -396,6 +398,8 @@ def score_path_rate(eng, wl, block, lay, repeats: int = 3) -> dict:
         "windows": n_rows,
         "ms_total": round(total * 1e3, 2),
         "ms_first_call_after_idle": round(min(first_calls[1:]) * 1e3, 2),
+        # the k-th call of a row (best over the repeats): how the rate returns after the ~100 ms the device idled
+        "ms_by_call_in_row": [round(min(r[k] for r in rows_of_calls[1:]) * 1e3, 2) for k in range(ROW)],
         "parts": FeaturePreprocessor.PARTS,
         # the same work as score_windows + write_batches, one after the other (round 4's product path)
         "ms_as_two_calls": round(two_calls * 1e3, 2),
@@ -412,9 +416,9 @@ def score_path_rate(eng, wl, block, lay, repeats: int = 3) -> dict:
         "what": "FeaturePreprocessor.score_and_write on the resident block = what `score` runs after the ingest (U and Q as two "
         "statistics, one fused pass per window range, TSV + .U.log + .Q.log written while the later ranges are scored); "
         "ms_as_two_calls = score_windows + write_batches one after the other; item_protocol = the same batch through "
-        "items_from_batch + process_items; ms_total = the best of %d x 4 calls in a row (chromosome after chromosome), "
-        "ms_first_call_after_idle = the first of four, right after one untimed call (the device has idled ~100 ms through the item "
-        "route of the repeat before and runs its first pass ~0.2 ms slower)" % repeats,
+        "items_from_batch + process_items; ms_total = the best of %d x %d calls in a row (chromosome after chromosome; "
+        "ms_by_call_in_row = the k-th call of a row), ms_first_call_after_idle = the first of a row, right after one untimed call "
+        "(the device has idled ~100 ms through the item route of the repeat before and runs its first passes slower)" % (repeats, ROW),
     }
 
 
