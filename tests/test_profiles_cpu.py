@@ -31,7 +31,7 @@ def test_every_file_of_this_round_is_listed_with_this_trees_digest(digest):
 
 
 # experiment logs of the round that were measured on trees on the way to the final one (they say so in their headers)
-NOTES = {"r05_c5_grid.txt", "r05_dd_pass.txt", "r05_score_parts.txt", "r05_placement.txt", "r05_placement_ab.txt"}
+NOTES = {"r05_c5_grid.txt", "r05_dd_pass.txt", "r05_score_parts.txt", "r05_placement.txt", "r05_placement_ab.txt", "r05_c5_product_trace.txt"}
 
 
 def test_bench_lines_and_stored_figures_carry_the_digest(digest):

@@ -65,7 +65,7 @@ tfile = DST / "traffic.json"
 if tfile.exists():
     old = json.loads(tfile.read_text())
     tfile.write_text(json.dumps({k: v for k, v in old.items() if v.get("source_digest") == here}, indent=1) + "\n")
-NOTES = {"r05_c5_grid.txt", "r05_dd_pass.txt", "r05_score_parts.txt", "r05_placement.txt", "r05_placement_ab.txt"}  # experiment logs of trees on the way (their headers say so)
+NOTES = {"r05_c5_grid.txt", "r05_dd_pass.txt", "r05_score_parts.txt", "r05_placement.txt", "r05_placement_ab.txt", "r05_c5_product_trace.txt"}  # experiment logs of trees on the way (their headers say so)
 manifest = {k: v for k, v in manifest.items() if v["source_digest"] == here and (DST / k).exists() and k not in NOTES}
 mfile.write_text(json.dumps(manifest, indent=1, sort_keys=True) + "\n")
 # the rocprofv3 runs: kernel trace + PMC passes -> summaries, traffic.json, manifest (tools/summarize_profile.py refuses other trees)
