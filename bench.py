@@ -337,6 +337,13 @@ def score_path_rate(eng, wl, block, lay, repeats: int = 3) -> dict:
         str(wl.chroms[0]), pos_host, block.pos[:n], {"ref": _trim(block.pops[0], n)}, {"tgt": _trim(block.pops[1], n)},
         {nm: _trim(p, n) for nm, p in zip(src_names, block.pops[2:])}, wl.win_len, wl.win_step, ploidies,
     )  # fmt: skip
+    # `score` gets its blocks from WindowGenerator.device_blocks, whose placement search hands the generator an output
+    # arena (memory of another class than the populations': where the scorers of the region write, placement.py); the
+    # block of this process was settled when it was built, so its arena -- what the timed scorer has left of it -- goes
+    # to the generator by hand
+    arena = (block.extra or {}).get("output_arena")
+    if arena is not None:
+        wg.__dict__["_output_arena"] = arena
     times, plain, first_calls, rows_of_calls = [], [], [], []
     ROW = 12  # calls in a row per repeat: the device needs several calls after an idle stretch to return to its steady rate
     with tempfile.TemporaryDirectory() as tmp:
@@ -400,6 +407,9 @@ def score_path_rate(eng, wl, block, lay, repeats: int = 3) -> dict:
         "ms_first_call_after_idle": round(min(first_calls[1:]) * 1e3, 2),
         # the k-th call of a row (best over the repeats): how the rate returns after the ~100 ms the device idled
         "ms_by_call_in_row": [round(min(r[k] for r in rows_of_calls[1:]) * 1e3, 2) for k in range(ROW)],
+        # every row as measured, the untimed repeat first (it ran before any item-route leg of this function)
+        "ms_rows": [[round(v * 1e3, 2) for v in r] for r in rows_of_calls],
+        "output_arena_bytes_used": None if arena is None else [int(arena.used), int(arena.tensor.numel())],
         "parts": FeaturePreprocessor.PARTS,
         # the same work as score_windows + write_batches, one after the other (round 4's product path)
         "ms_as_two_calls": round(two_calls * 1e3, 2),
