@@ -167,6 +167,11 @@ def settle_pair(eng, anchor, other, timer: Optional[_PairTimer] = None, tries: i
         pa, po, best = "a", "o", seen[("a", "o")]
     log["moved"] = [name for name, k in (("anchor", pa), ("other", po)) if k not in ("a", "o")]
     log["ms_chosen"] = round(best, 4)
+    # an array a population has left is of another class only when ITS pair with the chosen partner was clearly slower
+    # than the chosen pair (the test the fresh pieces go through below): a move for a per cent inside one class leaves
+    # memory of the populations' own class behind -- the slow place for what the pass writes
+    log["left_away"] = [name for name, k, old in (("anchor", pa, ("a", po)), ("other", po, (pa, "o")))
+                        if k not in ("a", "o") and seen.get(old, 0.0) > best * (1.0 + AWAY)]  # fmt: skip
     if report is not None:
         report.setdefault("pairs", []).append(log)
     # the bytes go where they were chosen to lie (a fresh piece may have played the other role since)
@@ -214,8 +219,9 @@ def settle_block(eng, pops: Sequence, report: Optional[dict] = None, arena: Opti
     see the module's docstring.  Returns the list to build the block from -- the same objects where nothing moved.
     ``arena`` (a list) receives the block's ``OutputArena`` when the search met memory of another class.
     ``owned=True``: ``pops`` is a list nobody else holds (nor its populations) -- it is changed in place, and a
-    population that moved leaves its old array to the arena: that array made a slow pair with what stayed, so it is
-    of another class, and once nothing refers to it the allocator's cache hands its memory out again."""
+    population that moved leaves its old array to the arena when that array made a clearly slower pair with the chosen
+    partner -- it is of another class then -- and once nothing refers to it the allocator's cache hands its memory out
+    again (an array left for a per cent inside one class is the populations' own class: no arena from it)."""
     if not owned:
         pops = list(pops)
     if report is not None:
@@ -230,6 +236,7 @@ def settle_block(eng, pops: Sequence, report: Optional[dict] = None, arena: Opti
     # pairs this engine has settled already (a block handed from one generator to the next, the same region scored
     # again): known by where the two arrays lie -- memory that comes back from the allocator's cache is still where it was
     done = eng.__dict__.setdefault("_settled_pairs", set())
+    rep = report if report is not None else {}  # (settle_pair's log of a pair is read here too)
     timer = None
     anchor_is_fixed = False
     for i in big[1:]:
@@ -240,9 +247,11 @@ def settle_block(eng, pops: Sequence, report: Optional[dict] = None, arena: Opti
             want = arena is not None and not arena and not anchor_is_fixed
             arena_bytes = ARENA_BYTES_PER_SITE * pops[anchor].n_sites
             hold: list = []  # the unused fresh pieces stay out of the allocator's cache until the arena has been carved
-            new_a, new_o = settle_pair(eng, pops[anchor], pops[i], timer, report=report, move_anchor=not anchor_is_fixed,
+            new_a, new_o = settle_pair(eng, pops[anchor], pops[i], timer, report=rep, move_anchor=not anchor_is_fixed,
                                        arena=arena if want else None, arena_bytes=arena_bytes, hold=hold)  # fmt: skip
-            donors = [(p.tiles.data_ptr(), p.tiles.data_ptr() + p.tiles.numel()) for p, q in ((pops[anchor], new_a), (pops[i], new_o)) if q is not p]
+            left_away = rep["pairs"][-1]["left_away"]  # which of the arrays a population left are of another class (settle_pair)
+            donors = [(p.tiles.data_ptr(), p.tiles.data_ptr() + p.tiles.numel())
+                      for name, p, q in (("anchor", pops[anchor], new_a), ("other", pops[i], new_o)) if q is not p and name in left_away]  # fmt: skip
             device = pops[anchor].tiles.device
             pops[anchor], pops[i] = new_a, new_o
             del new_a, new_o

@@ -35,16 +35,19 @@ def test_settle_block_leaves_small_blocks_and_the_switch_alone(monkeypatch):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("times,moved,chosen", [
+@pytest.mark.parametrize("times,moved,chosen,left_away", [
     # pairs in order: as built, (anchor, F1), (F1, other), (anchor, F2), (F2, other), (F1, F2)
-    ([3.00, 2.85, 3.01, 2.86, 3.00, 2.852], ["other"], 2.85),  # both fresh pieces are of the anchor's class: the first one met
-    ([2.85, 3.00, 3.01, 2.99, 3.02, 2.86], [], 2.85),  # the pair as built was of one class
-    ([3.00, 3.01, 2.85, 3.00, 3.02, 2.99], ["anchor"], 2.85),  # F1 is of the other's class: the anchor goes there
-    ([3.00, 3.01, 2.99, 3.02, 3.00, 2.84], ["anchor", "other"], 2.84),  # three classes met: the two fresh pieces are the pair
-    ([3.07, 2.93, 3.05, 2.85, 3.06, 2.94], ["other"], 2.85),  # a piece partly in two classes (2.93) is not mistaken for the fast one
-    ([2.85, 2.86, 2.84, 2.85, 2.86, 2.85], [], 2.85),  # all of one class: a hundredth is not worth a move
+    ([3.00, 2.85, 3.01, 2.86, 3.00, 2.852], ["other"], 2.85, ["other"]),  # both fresh pieces are of the anchor's class: the first one met
+    ([2.85, 3.00, 3.01, 2.99, 3.02, 2.86], [], 2.85, []),  # the pair as built was of one class
+    ([3.00, 3.01, 2.85, 3.00, 3.02, 2.99], ["anchor"], 2.85, ["anchor"]),  # F1 is of the other's class: the anchor goes there
+    ([3.00, 3.01, 2.99, 3.02, 3.00, 2.84], ["anchor", "other"], 2.84, ["anchor", "other"]),  # three classes met: the two fresh pieces are the pair
+    ([3.07, 2.93, 3.05, 2.85, 3.06, 2.94], ["other"], 2.85, ["other"]),  # a piece partly in two classes (2.93) is not mistaken for the fast one
+    ([2.85, 2.86, 2.84, 2.85, 2.86, 2.85], [], 2.85, []),  # all of one class: a hundredth is not worth a move
+    # all of one class and a move for its per cent (profiles/r05 C5 line of the round's last set): the array left is of
+    # the populations' OWN class -- no arena from it
+    ([2.8554, 2.8259, 2.8451, 2.8276, 2.8412, 2.8357], ["other"], 2.8259, []),
 ])  # fmt: skip
-def test_a_moved_population_is_the_same_population(monkeypatch, times, moved, chosen):
+def test_a_moved_population_is_the_same_population(monkeypatch, times, moved, chosen, left_away):
     import torch
 
     from sai_amd import _ffi, placement
@@ -65,6 +68,7 @@ def test_a_moved_population_is_the_same_population(monkeypatch, times, moved, ch
     ref2, tgt2 = placement.settle_pair(eng, block.pops[0], block.pops[1], report=report)
     log = report["pairs"][0]
     assert not script and log["ms"] == times and log["moved"] == moved and log["ms_chosen"] == chosen
+    assert log["left_away"] == left_away  # which of the arrays a population left may serve as the output arena
     assert (tgt2 is block.pops[1]) == ("other" not in moved) and (ref2 is block.pops[0]) == ("anchor" not in moved)
     for now, was in ((ref2, block.pops[0]), (tgt2, block.pops[1])):
         assert (now.n_ind, now.n_sites) == (was.n_ind, was.n_sites) and torch.equal(now.tiles, was.tiles)
